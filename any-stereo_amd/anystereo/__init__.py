@@ -1,0 +1,6 @@
+"""anystereo — MI355X-native (gfx950) implementation of Any-Stereo's data-parallel hot path behind
+the reference's own Python operator API.  Hot-path arithmetic lives in
+lib/libanystereo_hip.so (C ABI: include/anystereo_hip.h); this package is the host-side mirror."""
+from . import _lib  # noqa: F401
+
+__all__ = ["_lib", "ops", "nn", "models", "harness", "corr_sampler"]

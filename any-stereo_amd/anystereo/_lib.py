@@ -1,0 +1,90 @@
+"""ctypes binding of libanystereo_hip.so (C ABI: include/anystereo_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails the product path
+raises.  (The CPU oracle lives under /oracle and is test infrastructure only.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+AS_MAX_LEVELS = 4
+AS_MAX_SRCS = 4
+AS_F32, AS_F16, AS_F64 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanystereo_hip.so")
+
+_vp, _i, _fp = C.c_void_p, C.c_int, C.c_void_p
+_pp = C.POINTER(C.c_void_p)
+
+
+class ConvDesc(C.Structure):
+    """as_conv_desc (include/anystereo_hip.h)."""
+    _fields_ = [
+        ("src", C.c_void_p * AS_MAX_SRCS), ("src_c", C.c_int * AS_MAX_SRCS), ("n_src", C.c_int),
+        ("wpack", C.c_void_p), ("bias", C.c_void_p), ("add", C.c_void_p),
+        ("add_ctot", C.c_int), ("add_coff", C.c_int),
+        ("h", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
+        ("out_ctot", C.c_int), ("out_coff", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("KS", C.c_int),
+        ("act", C.c_int), ("epilogue", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/anystereo_hip.h declares
+SIGNATURES = {
+    "as_last_error_string": (C.c_char_p, []),
+    "as_abi_version": (_i, []),
+    "as_device_count": (_i, []),
+    "as_corr_sampler_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_corr_sampler_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_corr_build_pyramid": (_i, [_vp, _vp, _pp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_geo_pyramid": (_i, [_vp, _pp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_geo_corr_lookup_fwd": (_i, [_pp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_geo_corr_lookup_bwd": (_i, [_vp, _vp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_gwc_volume_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_disparity_regression": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
+    "as_conv_pack_size": (C.c_int64, [_i, _i, _i]),
+    "as_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_pool2x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_interp_bilinear_ac": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_structure_feature": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_convex_upsample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (once) and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libanystereo_hip.so not found at {LIB_PATH}: build it with `python any-stereo_amd/build.py` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().as_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError(f"anystereo HIP call {what} failed (code {rc}): {msg}")
+
+
+def ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return C.cast(arr, _pp), arr  # keep `arr` alive for the duration of the call

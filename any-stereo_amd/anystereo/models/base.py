@@ -1,0 +1,118 @@
+"""Shared skeleton of the two Any-Stereo models (continuous_IGEVstereo.py:91-305,
+prune_raft_stereo.py:92-297): context net -> [volume build] -> iters x (lookup -> multi-level
+ConvGRU -> disp += delta) -> LIIF convex upsampling at arbitrary query coordinates.
+
+The CNN backbones run on PyTorch-ROCm; every operator of SURVEY.md §8(a) is dispatched to
+libanystereo_hip.so through `anystereo.ops`.  The small `_hot_*` hooks exist so the test oracle
+(/oracle, CPU) can substitute its own restatement of the same operators on the same module tree;
+the product never imports the oracle.
+"""
+from __future__ import annotations
+
+import argparse
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..nn import functional as AF
+from ..nn.liif import liif_out_multi_scale_Training
+from ..nn.update import BasicMultiUpdateBlock
+
+
+def default_args(model: str = "continuous_IGEVStereo", **over) -> argparse.Namespace:
+    """Training-script defaults that fix every shape (SURVEY.md Appendix C;
+    train_continuous_IGEV.py:284-369, train_continuous_Raft.py:298-385) with `multi_training` on
+    (the only functional arbitrary-scale branch)."""
+    igev = "IGEV" in model
+    d = dict(
+        model=model, hidden_dims=[128, 128, 128], n_gru_layers=3, n_downsample=2, corr_radius=4,
+        corr_levels=2 if igev else 4, slow_fast_gru=False, max_disp=192 if igev else 700, agg_type="type5",
+        unfold_similarity="with_v2ISU", lsp_width=3, lsp_height=3, lsp_dilation=[1, 2, 4, 8],
+        mlphidden_list=[128, 64, 64], pos_dim=0, pos_enconding=False, pos_enconding_new=False, local_ensemble=False,
+        decode_cell=False, unfold=False, quater_nearest=None, require_grad=False, Raw_Mask_dim=32,
+        disparity_norm=False, disparity_norm2=False, multi_training=True, multi_input_training=False,
+        mixed_precision=False, train_iters=16, valid_iters=32, corr_implementation="reg", shared_backbone=False)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+class ContinuousStereoBase(nn.Module):
+    geo_channels = 0  # 8 for IGEV (geometry encoding volume), 0 for RAFT
+
+    # ---- construction helpers -----------------------------------------------------------------
+    def _check_args(self, args):
+        if not (args.multi_training or args.multi_input_training):
+            raise NotImplementedError(
+                "only the multi_training (arbitrary-scale LIIF) branch is built; the reference's fixed-scale branch "
+                "is dimensionally inconsistent with the default dims (SURVEY.md §0 item 8)")
+        if getattr(args, "disparity_norm", False) or getattr(args, "disparity_norm2", False):
+            raise NotImplementedError("disparity_norm options are off by default and not built")
+        if "type2" in args.agg_type:
+            raise NotImplementedError("agg_type 'type2' (three-input LIIF) is not built")
+
+    def _make_update_block(self, args):
+        return BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims, geo_channels=self.geo_channels)
+
+    def _make_liif(self, args, indim, chanels):
+        aff = {"win_w": args.lsp_width, "win_h": args.lsp_height, "dilation": args.lsp_dilation}
+        return liif_out_multi_scale_Training(
+            encoder_dim=indim, mlphidden_list=args.mlphidden_list, pos_dim=args.pos_dim, pos_enconding=args.pos_enconding,
+            pos_enconding_new=args.pos_enconding_new, local_ensemble=args.local_ensemble, decode_cell=args.decode_cell,
+            unfold=args.unfold_similarity, affinity_settings=aff, quater_nearest=args.quater_nearest,
+            require_grad=args.require_grad, number_input=len(chanels), chanels=chanels)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    # ---- hot-path hooks (HIP) ------------------------------------------------------------------
+    def _hot_update(self, net_list, inp_list, corr, disp, **flags):
+        return self.update_block(net_list, inp_list, corr, disp, **flags)
+
+    def _hot_upsample(self, disp, x, stem_2x, hr_coord, scale_vec):
+        feats = [x, stem_2x] if stem_2x is not None else [x]
+        logits = self.liif_up(feats, hr_coord, scale_vec)  # [B,9,Q]
+        hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)  # side effect of context_upsample_multiscale_train (submodule.py:366)
+        return ops.convex_upsample(disp.float().contiguous(), logits, hr_coord, scale=scale_vec, mask_is_logits=True)
+
+    # ---- reference API -------------------------------------------------------------------------
+    def upsample_disp(self, disp, hidden_layer, stem_4x, stem_2x, stem_1x, hr_coord=None, scale=1):
+        """[B,1,h,w] disparity at 1/4 res -> [B,1,Q] at the query coordinates
+        (continuous_IGEVstereo.py:192-237, prune_raft_stereo.py:200-242)."""
+        if stem_1x is not None:
+            raise NotImplementedError("stem_1x (agg_type 'type2') is not built")
+        x = torch.cat((stem_4x.float(), hidden_layer.float()), 1) if stem_4x is not None else hidden_layer.float()
+        b = disp.shape[0]
+        if torch.is_tensor(scale):
+            scale_vec = scale.reshape(-1).float().to(disp.device)
+            if scale_vec.numel() == 1 and b > 1:
+                scale_vec = scale_vec.expand(b)
+            scale_vec = scale_vec.contiguous()
+        else:
+            scale_vec = torch.full((b,), float(scale), device=disp.device, dtype=torch.float32)
+        hr = hr_coord if (hr_coord.dtype == torch.float32 and hr_coord.is_contiguous()) else hr_coord.float().contiguous()
+        return self._hot_upsample(disp, x.contiguous(), None if stem_2x is None else stem_2x.float().contiguous(), hr, scale_vec)
+
+    def _iterate(self, lookup_fn, net_list, inp_list, disp, coords, iters, test_mode, stem_4x, stem_2x, hr_coord, scale):
+        """The GRU loop shared by both models (continuous_IGEVstereo.py:284-301, prune_raft_stereo.py:276-291)."""
+        a = self.args
+        disp_preds = []
+        disp_up = None
+        for itr in range(iters):
+            disp = disp.detach()
+            geo_feat = lookup_fn(disp, coords)
+            if a.n_gru_layers == 3 and a.slow_fast_gru:
+                net_list = self._hot_update(net_list, inp_list, None, None, iter16=True, iter08=False, iter04=False, update=False)
+            if a.n_gru_layers >= 2 and a.slow_fast_gru:
+                net_list = self._hot_update(net_list, inp_list, None, None, iter16=a.n_gru_layers == 3, iter08=True,
+                                            iter04=False, update=False)
+            net_list, delta = self._hot_update(net_list, inp_list, geo_feat, disp, iter16=a.n_gru_layers == 3,
+                                               iter08=a.n_gru_layers >= 2)
+            disp = disp + delta
+            if test_mode and itr < iters - 1:
+                continue
+            disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, None, hr_coord=hr_coord, scale=scale)
+            disp_preds.append(disp_up)
+        return disp, disp_up, disp_preds

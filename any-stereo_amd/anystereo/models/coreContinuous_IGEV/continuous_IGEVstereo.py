@@ -1,0 +1,110 @@
+"""continuous_IGEVStereo — same constructor, forward() signature, return values and state_dict keys
+as models/coreContinuous_IGEV/continuous_IGEVstereo.py:91-305, with the hot path on HIP.
+
+    model = continuous_IGEVStereo(args)
+    disp_up = model(image1, image2, iters=32, hr_coord=coord[None], scale=torch.tensor([[s]]), test_mode=True)
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ...nn import blocks as B
+from ...nn import functional as AF
+from ...nn.encoders import Feature, MultiBasicEncoder
+from ...nn.geometry import Combined_Geo_Encoding_Volume
+from ..base import ContinuousStereoBase
+
+hourglass = B.hourglass
+
+
+def _stems(agg_type):
+    if "type1" in agg_type:
+        return B.plain_stem(3, 32, True), B.plain_stem(32, 48, True)
+    if "type3" in agg_type:
+        return B.HighRes_Aggregation(3, 32), B.HighRes_Aggregation(32, 48)
+    if "type4" in agg_type:
+        return B.HighRes_Aggregation_LN(3, 32), B.HighRes_Aggregation_LN(32, 48)
+    if "type5" in agg_type:
+        return B.HighRes_Aggregation_LN_GeLU(3, 32), B.HighRes_Aggregation_LN_GeLU(32, 48)
+    raise AssertionError(f"unsupported agg_type {agg_type!r}")
+
+
+class continuous_IGEVStereo(ContinuousStereoBase):
+    geo_channels = 8
+    geo_block = Combined_Geo_Encoding_Volume
+
+    def __init__(self, args):
+        super().__init__()
+        self._check_args(args)
+        self.args = args
+        self.name_buff = []
+        context_dims = args.hidden_dims
+        self.max_disp = args.max_disp
+        self.multi_training = args.multi_training
+        self.multi_input_training = args.multi_input_training
+        self.cnet = MultiBasicEncoder(output_dim=[args.hidden_dims, context_dims], norm_fn="batch", downsample=args.n_downsample)
+        self.update_block = self._make_update_block(args)
+        self.context_zqr_convs = nn.ModuleList(
+            nn.Conv2d(context_dims[i], args.hidden_dims[i] * 3, 3, padding=1) for i in range(args.n_gru_layers))
+        self.agg_type = args.agg_type
+        self.feature = Feature()
+        self.stem_2, self.stem_4 = _stems(args.agg_type)
+        chanels = [48 + args.hidden_dims[2], 32]
+        self.conv = B.BasicConv_IN(96, 96, kernel_size=3, padding=1, stride=1)
+        self.desc = nn.Conv2d(96, 96, kernel_size=1, padding=0, stride=1)
+        self.liif_up = self._make_liif(args, 48 + 32 + args.hidden_dims[2], chanels)
+        self.corr_stem = B.BasicConv(8, 8, is_3d=True, kernel_size=3, stride=1, padding=1)
+        self.corr_feature_att = B.FeatureAtt(8, 96)
+        self.cost_agg = B.hourglass(8)
+        self.classifier = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
+
+    # hot-path hooks -----------------------------------------------------------------------------
+    def _hot_gwc(self, match_left, match_right):
+        return AF.build_gwc_volume(match_left, match_right, self.args.max_disp // 4, 8)
+
+    def _hot_init_disp(self, cost):
+        return AF.softmax_disparity_regression(cost)
+
+    def _hot_lookup_fn(self, match_left, match_right, gev):
+        return self.geo_block(match_left.float(), match_right.float(), gev.float(), radius=self.args.corr_radius,
+                              num_levels=self.args.corr_levels)
+
+    def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
+        """Estimate disparity between a pair of frames (images are 0..255 float)."""
+        a = self.args
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda):
+            features_left = self.feature(image1)
+            features_right = self.feature(image2)
+            stem_2x = self.stem_2(image1)
+            stem_2y = self.stem_2(image2)
+            stem_4x = self.stem_4(stem_2x)
+            stem_4y = self.stem_4(stem_2y)
+            features_left[0] = torch.cat((features_left[0], stem_4x), 1)
+            features_right[0] = torch.cat((features_right[0], stem_4y), 1)
+            match_left = self.desc(self.conv(features_left[0]))
+            match_right = self.desc(self.conv(features_right[0]))
+            gwc_volume = self._hot_gwc(match_left, match_right)
+            gwc_volume = self.corr_stem(gwc_volume)
+            gwc_volume = self.corr_feature_att(gwc_volume, features_left[0])
+            geo_encoding_volume = self.cost_agg(gwc_volume, features_left)
+            init_disp = self._hot_init_disp(self.classifier(geo_encoding_volume).squeeze(1))
+            del gwc_volume
+            cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
+            net_list = [torch.tanh(x[0]) for x in cnet_list]
+            inp_list = [torch.relu(x[1]) for x in cnet_list]
+            ctx_list = [conv(i) for i, conv in zip(inp_list, self.context_zqr_convs)]
+        net_list = [n.float() for n in net_list]
+        # cz, cr, cq stay VIEWS of one [B,3*hidden,h,w] tensor: the GRU kernels index it in place
+        inp_list = [list(c.float().split(split_size=c.shape[1] // 3, dim=1)) for c in ctx_list]
+
+        geo_fn = self._hot_lookup_fn(match_left, match_right, geo_encoding_volume)
+        b, c, h, w = match_left.shape
+        coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+        disp, disp_up, disp_preds = self._iterate(geo_fn, net_list, inp_list, init_disp.float(), coords, iters, test_mode,
+                                                  stem_4x, stem_2x, hr_coord, scale)
+        if test_mode:
+            return disp_up
+        return init_disp.squeeze(1), disp_preds

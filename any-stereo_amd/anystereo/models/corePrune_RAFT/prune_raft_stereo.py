@@ -1,0 +1,88 @@
+"""continuous_RaftStereo — same constructor, forward() signature, return values and state_dict keys as
+models/corePrune_RAFT/prune_raft_stereo.py:92-297, with the hot path on HIP (no geometry encoding
+volume: correlation pyramid of 4 levels, zero initial disparity)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ...nn import blocks as B
+from ...nn.encoders import BasicEncoder, MultiBasicEncoder
+from ...nn.geometry import CorrBlock1D
+from ..base import ContinuousStereoBase
+
+
+def _stems(agg_type):
+    if "IGEV" in agg_type:
+        return B.plain_stem(3, 32, False), B.plain_stem(32, 48, False)
+    if "type1" in agg_type:
+        return B.plain_stem(3, 32, True), B.plain_stem(32, 48, True)
+    if "type3" in agg_type:
+        return B.HighRes_Aggregation(3, 32), B.HighRes_Aggregation(32, 48)
+    if "type4" in agg_type:
+        return B.HighRes_Aggregation_LN(3, 32), B.HighRes_Aggregation_LN(32, 48)
+    if "type5" in agg_type:
+        return B.HighRes_Aggregation_LN_GeLU(3, 32), B.HighRes_Aggregation_LN_GeLU(32, 48)
+    return None, None
+
+
+class continuous_RaftStereo(ContinuousStereoBase):
+    geo_channels = 0
+    corr_block = CorrBlock1D
+
+    def __init__(self, args):
+        super().__init__()
+        self._check_args(args)
+        self.args = args
+        self.multi_training = args.multi_training
+        self.multi_input_training = args.multi_input_training
+        self.agg_type = args.agg_type
+        context_dims = args.hidden_dims
+        self.cnet = MultiBasicEncoder(output_dim=[args.hidden_dims, context_dims], norm_fn="batch", downsample=args.n_downsample)
+        self.update_block = self._make_update_block(args)
+        self.context_zqr_convs = nn.ModuleList(
+            nn.Conv2d(context_dims[i], args.hidden_dims[i] * 3, 3, padding=1) for i in range(args.n_gru_layers))
+        self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=args.n_downsample)
+        s2, s4 = _stems(args.agg_type)
+        if s2 is not None:
+            self.stem_2, self.stem_4 = s2, s4
+            indim, chanels = 48 + 32, [48 + args.hidden_dims[2], 32]
+            if "IGEV" in args.agg_type:
+                # the reference leaves `chanels` undefined on this branch (prune_raft_stereo.py:110-121)
+                chanels = [48 + args.hidden_dims[2], 32]
+        else:
+            indim, chanels = 0, [args.hidden_dims[2]]
+        self._has_stems = s2 is not None
+        self.liif_up = self._make_liif(args, indim + args.hidden_dims[2], chanels)
+
+    def _hot_lookup_fn(self, match_left, match_right):
+        return self.corr_block(match_left.float(), match_right.float(), radius=self.args.corr_radius,
+                               num_levels=self.args.corr_levels)
+
+    def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=False):
+        a = self.args
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda):
+            match_left, match_right = self.fnet([image1, image2])
+            cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
+            net_list = [torch.tanh(x[0]) for x in cnet_list]
+            inp_list = [torch.relu(x[1]) for x in cnet_list]
+            ctx_list = [conv(i) for i, conv in zip(inp_list, self.context_zqr_convs)]
+            if self._has_stems:
+                stem_2x = self.stem_2(image1)
+                stem_4x = self.stem_4(stem_2x)
+            else:
+                stem_4x = stem_2x = None
+        net_list = [n.float() for n in net_list]
+        inp_list = [list(c.float().split(split_size=c.shape[1] // 3, dim=1)) for c in ctx_list]
+
+        corr_fn = self._hot_lookup_fn(match_left, match_right)
+        b, c, h, w = match_left.shape
+        coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+        disp0 = match_left.new_zeros((b, 1, h, w), dtype=torch.float32)
+        disp, disp_up, disp_preds = self._iterate(corr_fn, net_list, inp_list, disp0, coords, iters, test_mode,
+                                                  stem_4x, stem_2x, hr_coord, scale)
+        if test_mode:
+            return (disp, disp_up) if output_raw else disp_up
+        return disp_preds

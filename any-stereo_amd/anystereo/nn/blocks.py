@@ -1,0 +1,226 @@
+"""Backbone building blocks that stay on PyTorch-ROCm / MIOpen (SURVEY.md §2 rows 9-10:
+out of the hot-path scope by north_star's own wording).  They exist so that the two
+models run end to end and so that `state_dict` keys equal the reference's
+(models/coreContinuous_IGEV/submodule.py:6-252, extractor.py:10-361).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _conv_nd(is_3d: bool, deconv: bool):
+    if is_3d:
+        return nn.ConvTranspose3d if deconv else nn.Conv3d
+    return nn.ConvTranspose2d if deconv else nn.Conv2d
+
+
+class _ConvNormAct(nn.Module):
+    """conv (no bias) -> norm -> LeakyReLU(0.01); `norm_attr` fixes the state_dict key
+    ('bn' for BasicConv, 'IN' for BasicConv_IN; submodule.py:6-33, :76-103)."""
+
+    norm_attr = "bn"
+
+    def __init__(self, cin, cout, deconv=False, is_3d=False, norm=True, relu=True, **kw):
+        super().__init__()
+        self.relu = relu
+        self.use_norm = norm
+        self.conv = _conv_nd(is_3d, deconv)(cin, cout, bias=False, **kw)
+        setattr(self, self.norm_attr, self._make_norm(cout, is_3d))
+
+    def _make_norm(self, c, is_3d):
+        raise NotImplementedError
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.use_norm:
+            x = getattr(self, self.norm_attr)(x)
+        return F.leaky_relu(x, 0.01) if self.relu else x
+
+
+class BasicConv(_ConvNormAct):
+    norm_attr = "bn"
+
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, bn=True, relu=True, **kw):
+        super().__init__(in_channels, out_channels, deconv, is_3d, bn, relu, **kw)
+
+    def _make_norm(self, c, is_3d):
+        return nn.BatchNorm3d(c) if is_3d else nn.BatchNorm2d(c)
+
+
+class BasicConv_IN(_ConvNormAct):
+    norm_attr = "IN"
+
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, IN=True, relu=True, **kw):
+        super().__init__(in_channels, out_channels, deconv, is_3d, IN, relu, **kw)
+
+    def _make_norm(self, c, is_3d):
+        return nn.InstanceNorm3d(c) if is_3d else nn.InstanceNorm2d(c)
+
+
+class _Up2x(nn.Module):
+    """stride-2 (de)conv, resize-to-skip if shapes differ, concat or add skip, 3x3 conv
+    (submodule.py:36-73 Conv2x, :106-144 Conv2x_IN)."""
+
+    block = BasicConv
+
+    def __init__(self, cin, cout, deconv=False, is_3d=False, concat=True, keep_concat=True, norm=True,
+                 relu=True, keep_dispc=False):
+        super().__init__()
+        self.concat = concat
+        self.is_3d = is_3d
+        if deconv and is_3d and keep_dispc:
+            k, s, p = (1, 4, 4), (1, 2, 2), (0, 1, 1)
+        else:
+            k = (4, 4, 4) if (deconv and is_3d) else (4 if deconv else 3)
+            s, p = 2, 1
+        self.conv1 = self.block(cin, cout, deconv, is_3d, True, True, kernel_size=k, stride=s, padding=p)
+        if concat:
+            self.conv2 = self.block(cout * 2, cout * (2 if keep_concat else 1), False, is_3d, norm, relu,
+                                    kernel_size=3, stride=1, padding=1)
+        else:
+            self.conv2 = self.block(cout, cout, False, is_3d, norm, relu, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x, rem):
+        x = self.conv1(x)
+        if x.shape != rem.shape:
+            x = F.interpolate(x, size=rem.shape[-2:], mode="nearest")
+        x = torch.cat((x, rem), 1) if self.concat else x + rem
+        return self.conv2(x)
+
+
+class Conv2x(_Up2x):
+    block = BasicConv
+
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, concat=True, keep_concat=True,
+                 bn=True, relu=True, keep_dispc=False):
+        super().__init__(in_channels, out_channels, deconv, is_3d, concat, keep_concat, bn, relu, keep_dispc)
+
+
+class Conv2x_IN(_Up2x):
+    block = BasicConv_IN
+
+    def __init__(self, in_channels, out_channels, deconv=False, is_3d=False, concat=True, keep_concat=True,
+                 IN=True, relu=True, keep_dispc=False):
+        super().__init__(in_channels, out_channels, deconv, is_3d, concat, keep_concat, IN, relu, keep_dispc)
+
+
+class LayerNorm2d(nn.Module):
+    """Per-pixel LayerNorm over channels of an NCHW tensor (submodule.py:148-187).
+    Plain autograd (the reference's hand-written backward is mathematically the same)."""
+
+    def __init__(self, channels, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.eps = eps
+
+    def forward(self, x):
+        mu = x.mean(1, keepdim=True)
+        var = (x - mu).pow(2).mean(1, keepdim=True)
+        y = (x - mu) / (var + self.eps).sqrt()
+        return self.weight.view(1, -1, 1, 1) * y + self.bias.view(1, -1, 1, 1)
+
+
+class _HighResAgg(nn.Module):
+    """PixelUnshuffle(2) -> conv-IN-LeakyReLU -> simplified channel attention -> conv -> norm -> act
+    (submodule.py:190-252: HighRes_Aggregation / _LN / _LN_GeLU differ in the head only)."""
+
+    def __init__(self, input_dim, output_dim, head_norm, head_act):
+        super().__init__()
+        self.embeding = nn.Sequential(
+            nn.PixelUnshuffle(2),
+            BasicConv_IN(input_dim * 4, output_dim, kernel_size=3, stride=1, padding=1))
+        self.sca = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(output_dim, output_dim, 1, bias=True))
+        self.head = nn.Sequential(nn.Conv2d(output_dim, output_dim, 3, 1, 1, bias=False), head_norm, head_act)
+
+    def forward(self, x):
+        x = self.embeding(x)
+        x = x * self.sca(x)
+        return self.head(x)
+
+
+class HighRes_Aggregation(_HighResAgg):
+    def __init__(self, input_dim, output_dim):
+        super().__init__(input_dim, output_dim, nn.InstanceNorm2d(output_dim), nn.ReLU())
+
+
+class HighRes_Aggregation_LN(_HighResAgg):
+    def __init__(self, input_dim, output_dim):
+        super().__init__(input_dim, output_dim, LayerNorm2d(output_dim), nn.ReLU())
+
+
+class HighRes_Aggregation_LN_GeLU(_HighResAgg):
+    def __init__(self, input_dim, output_dim):
+        super().__init__(input_dim, output_dim, LayerNorm2d(output_dim), nn.GELU())
+
+
+def plain_stem(cin, cout, unshuffle: bool):
+    """The 'type1' (PixelUnshuffle) and 'IGEV' (stride-2) stems
+    (continuous_IGEVstereo.py:105-118, prune_raft_stereo.py:110-134)."""
+    if unshuffle:
+        return nn.Sequential(nn.PixelUnshuffle(2),
+                             BasicConv_IN(cin * 4, cout, kernel_size=3, stride=1, padding=1),
+                             nn.Conv2d(cout, cout, 3, 1, 1, bias=False), nn.InstanceNorm2d(cout), nn.ReLU())
+    return nn.Sequential(BasicConv_IN(cin, cout, kernel_size=3, stride=2, padding=1),
+                         nn.Conv2d(cout, cout, 3, 1, 1, bias=False), nn.InstanceNorm2d(cout), nn.ReLU())
+
+
+class FeatureAtt(nn.Module):
+    """Sigmoid channel gate of the cost volume from 2-D features (submodule.py:328-341)."""
+
+    def __init__(self, cv_chan, feat_chan):
+        super().__init__()
+        self.feat_att = nn.Sequential(BasicConv(feat_chan, feat_chan // 2, kernel_size=1, stride=1, padding=0),
+                                      nn.Conv2d(feat_chan // 2, cv_chan, 1))
+
+    def forward(self, cv, feat):
+        return torch.sigmoid(self.feat_att(feat).unsqueeze(2)) * cv
+
+
+class hourglass(nn.Module):
+    """3-D cost aggregation U-Net with feature attention (continuous_IGEVstereo.py:22-89)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        c = in_channels
+
+        def down(ci, co):
+            return nn.Sequential(
+                BasicConv(ci, co, is_3d=True, bn=True, relu=True, kernel_size=3, padding=1, stride=2, dilation=1),
+                BasicConv(co, co, is_3d=True, bn=True, relu=True, kernel_size=3, padding=1, stride=1, dilation=1))
+
+        def up(ci, co, bn=True, relu=True):
+            return BasicConv(ci, co, deconv=True, is_3d=True, bn=bn, relu=relu, kernel_size=(4, 4, 4),
+                             padding=(1, 1, 1), stride=(2, 2, 2))
+
+        def agg(ci, co):
+            return nn.Sequential(
+                BasicConv(ci, co, is_3d=True, kernel_size=1, padding=0, stride=1),
+                BasicConv(co, co, is_3d=True, kernel_size=3, padding=1, stride=1),
+                BasicConv(co, co, is_3d=True, kernel_size=3, padding=1, stride=1))
+
+        self.conv1 = down(c, c * 2)
+        self.conv2 = down(c * 2, c * 4)
+        self.conv3 = down(c * 4, c * 6)
+        self.conv3_up = up(c * 6, c * 4)
+        self.conv2_up = up(c * 4, c * 2)
+        self.conv1_up = up(c * 2, 8, bn=False, relu=False)
+        self.agg_0 = agg(c * 8, c * 4)
+        self.agg_1 = agg(c * 4, c * 2)
+        self.feature_att_8 = FeatureAtt(c * 2, 64)
+        self.feature_att_16 = FeatureAtt(c * 4, 192)
+        self.feature_att_32 = FeatureAtt(c * 6, 160)
+        self.feature_att_up_16 = FeatureAtt(c * 4, 192)
+        self.feature_att_up_8 = FeatureAtt(c * 2, 64)
+
+    def forward(self, x, features):
+        c1 = self.feature_att_8(self.conv1(x), features[1])
+        c2 = self.feature_att_16(self.conv2(c1), features[2])
+        c3 = self.feature_att_32(self.conv3(c2), features[3])
+        c2 = self.agg_0(torch.cat((self.conv3_up(c3), c2), dim=1))
+        c2 = self.feature_att_up_16(c2, features[2])
+        c1 = self.agg_1(torch.cat((self.conv2_up(c2), c1), dim=1))
+        c1 = self.feature_att_up_8(c1, features[1])
+        return self.conv1_up(c1)

@@ -1,0 +1,239 @@
+"""Feature / context encoders — PyTorch-ROCm (MIOpen), not hand-written: north_star keeps
+"the feature/context CNN backbones" on the host framework.
+
+State-dict keys follow models/coreContinuous_IGEV/extractor.py so reference checkpoints load:
+ResidualBlock :10-62, BasicEncoder :126-198, MultiBasicEncoder :200-304, Feature :327-361.
+`timm` is not available offline, so the MobileNetV2-100 trunk the reference takes from
+`timm.create_model('mobilenetv2_100', features_only=True)` (extractor.py:331) is restated here
+with timm's module names (conv_stem / bn1 / blocks[i][j].conv_pw|bn1|conv_dw|bn2|conv_pwl|bn3).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .blocks import BasicConv_IN, Conv2x_IN
+
+
+def _norm(kind: str, c: int, groups: int | None = None):
+    if kind == "group":
+        return nn.GroupNorm(num_groups=groups if groups is not None else c // 8, num_channels=c)
+    if kind == "batch":
+        return nn.BatchNorm2d(c)
+    if kind == "instance":
+        return nn.InstanceNorm2d(c)
+    if kind == "none":
+        return nn.Sequential()
+    raise ValueError(kind)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_planes, planes, norm_fn="group", stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1 = _norm(norm_fn, planes, planes // 8)
+        self.norm2 = _norm(norm_fn, planes, planes // 8)
+        if stride == 1 and in_planes == planes:
+            self.downsample = None
+        else:
+            # norm3 is registered twice (as .norm3 and as .downsample.1), as in the reference
+            self.norm3 = _norm(norm_fn, planes, planes // 8)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+def _init_encoder(mod: nn.Module):
+    for m in mod.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 1)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+class _Trunk(nn.Module):
+    """7x7 stem + three 2-block residual stages shared by both encoders."""
+
+    def __init__(self, norm_fn, downsample):
+        super().__init__()
+        self.norm_fn = norm_fn
+        self.downsample = downsample
+        self.norm1 = _norm(norm_fn, 64, 8)
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=1 + (downsample > 2), padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.in_planes = 64
+        self.layer1 = self._make_layer(64, 1)
+        self.layer2 = self._make_layer(96, 1 + (downsample > 1))
+        self.layer3 = self._make_layer(128, 1 + (downsample > 0))
+
+    def _make_layer(self, dim, stride=1):
+        seq = nn.Sequential(ResidualBlock(self.in_planes, dim, self.norm_fn, stride),
+                            ResidualBlock(dim, dim, self.norm_fn, 1))
+        self.in_planes = dim
+        return seq
+
+    def trunk(self, x):
+        x = self.relu1(self.norm1(self.conv1(x)))
+        return self.layer3(self.layer2(self.layer1(x)))
+
+
+class BasicEncoder(_Trunk):
+    """RAFT-Stereo feature net: both images batched through the trunk, 1x1 to output_dim."""
+
+    def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0, downsample=3):
+        super().__init__(norm_fn, downsample)
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        _init_encoder(self)
+
+    def forward(self, x, dual_inp=False):
+        is_list = isinstance(x, (tuple, list))
+        if is_list:
+            n = x[0].shape[0]
+            x = torch.cat(x, dim=0)
+        x = self.conv2(self.trunk(x))
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        return x.split(n, dim=0) if is_list else x
+
+
+class MultiBasicEncoder(_Trunk):
+    """Context net: per scale (1/4, 1/8, 1/16) one head per entry of output_dim
+    ([hidden_dims, context_dims]); returns lists of [hidden, context] per scale."""
+
+    def __init__(self, output_dim=[128], norm_fn="batch", dropout=0.0, downsample=3):
+        super().__init__(norm_fn, downsample)
+        self.layer4 = self._make_layer(128, 2)
+        self.layer5 = self._make_layer(128, 2)
+        self.outputs04 = nn.ModuleList(
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, 1), nn.Conv2d(128, d[2], 3, padding=1)) for d in output_dim)
+        self.outputs08 = nn.ModuleList(
+            nn.Sequential(ResidualBlock(128, 128, norm_fn, 1), nn.Conv2d(128, d[1], 3, padding=1)) for d in output_dim)
+        self.outputs16 = nn.ModuleList(nn.Conv2d(128, d[0], 3, padding=1) for d in output_dim)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        _init_encoder(self)
+
+    def forward(self, x, dual_inp=False, num_layers=3):
+        x = self.trunk(x)
+        if dual_inp:
+            v = x
+            x = x[: x.shape[0] // 2]
+        tail = (v,) if dual_inp else ()
+        o04 = [f(x) for f in self.outputs04]
+        if num_layers == 1:
+            return (o04,) + tail
+        y = self.layer4(x)
+        o08 = [f(y) for f in self.outputs08]
+        if num_layers == 2:
+            return (o04, o08) + tail
+        z = self.layer5(y)
+        o16 = [f(z) for f in self.outputs16]
+        return (o04, o08, o16) + tail
+
+
+# ---- MobileNetV2-100 trunk with timm's naming ---------------------------------------------
+
+
+class _DSConv(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(cin, cin, 3, stride, 1, groups=cin, bias=False)
+        self.bn1 = nn.BatchNorm2d(cin)
+        self.conv_pw = nn.Conv2d(cin, cout, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.res = stride == 1 and cin == cout
+
+    def forward(self, x):
+        y = nn.functional.relu6(self.bn1(self.conv_dw(x)))
+        y = self.bn2(self.conv_pw(y))
+        return x + y if self.res else y
+
+
+class _InvRes(nn.Module):
+    def __init__(self, cin, cout, stride, expand=6):
+        super().__init__()
+        mid = cin * expand
+        self.conv_pw = nn.Conv2d(cin, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.conv_dw = nn.Conv2d(mid, mid, 3, stride, 1, groups=mid, bias=False)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.conv_pwl = nn.Conv2d(mid, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.res = stride == 1 and cin == cout
+
+    def forward(self, x):
+        y = nn.functional.relu6(self.bn1(self.conv_pw(x)))
+        y = nn.functional.relu6(self.bn2(self.conv_dw(y)))
+        y = self.bn3(self.conv_pwl(y))
+        return x + y if self.res else y
+
+
+class MobileNetV2Trunk(nn.Module):
+    """conv_stem/bn1/act1/blocks[0..6] of mobilenetv2_100 (what extractor.py:332-342 slices)."""
+
+    CFG = [("ds", 1, 1, 16), ("ir", 2, 2, 24), ("ir", 3, 2, 32), ("ir", 4, 2, 64), ("ir", 3, 1, 96),
+           ("ir", 3, 2, 160), ("ir", 1, 1, 320)]
+
+    def __init__(self):
+        super().__init__()
+        self.conv_stem = nn.Conv2d(3, 32, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.act1 = nn.ReLU6()
+        stages, cin = [], 32
+        for kind, reps, stride, cout in self.CFG:
+            blk = []
+            for j in range(reps):
+                s = stride if j == 0 else 1
+                blk.append(_DSConv(cin, cout, s) if kind == "ds" else _InvRes(cin, cout, s))
+                cin = cout
+            stages.append(nn.Sequential(*blk))
+        self.blocks = nn.Sequential(*stages)
+
+
+def default_backbone_factory():
+    return MobileNetV2Trunk()
+
+
+class Feature(nn.Module):
+    """MobileNetV2 encoder + Conv2x_IN decoder -> [x4 (48ch), x8 (64), x16 (192), x32 (160)]
+    (extractor.py:327-361).  `backbone_factory` stands in for timm.create_model."""
+
+    backbone_factory = staticmethod(default_backbone_factory)
+
+    def __init__(self):
+        super().__init__()
+        model = type(self).backbone_factory()
+        chans = [16, 24, 32, 96, 160]
+        self.conv_stem, self.bn1, self.act1 = model.conv_stem, model.bn1, model.act1
+        b = model.blocks
+        self.block0 = nn.Sequential(*b[0:1])
+        self.block1 = nn.Sequential(*b[1:2])
+        self.block2 = nn.Sequential(*b[2:3])
+        self.block3 = nn.Sequential(*b[3:5])
+        self.block4 = nn.Sequential(*b[5:6])
+        self.deconv32_16 = Conv2x_IN(chans[4], chans[3], deconv=True, concat=True)
+        self.deconv16_8 = Conv2x_IN(chans[3] * 2, chans[2], deconv=True, concat=True)
+        self.deconv8_4 = Conv2x_IN(chans[2] * 2, chans[1], deconv=True, concat=True)
+        self.conv4 = BasicConv_IN(chans[1] * 2, chans[1] * 2, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        x = self.act1(self.bn1(self.conv_stem(x)))
+        x2 = self.block0(x)
+        x4 = self.block1(x2)
+        x8 = self.block2(x4)
+        x16 = self.block3(x8)
+        x32 = self.block4(x16)
+        x16 = self.deconv32_16(x32, x16)
+        x8 = self.deconv16_8(x16, x8)
+        x4 = self.conv4(self.deconv8_4(x8, x4))
+        return [x4, x8, x16, x32]

@@ -1,0 +1,36 @@
+"""Hot-path free functions of models/coreContinuous_IGEV/submodule.py, HIP-backed, same signatures:
+groupwise_correlation/build_gwc_volume :253-271, disparity_regression :321-325,
+context_upsample_multiscale_train :357-372."""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """[B,C,H,W] x2 -> [B,num_groups,maxdisp,H,W] group-wise correlation volume."""
+    if torch.is_grad_enabled() and (refimg_fea.requires_grad or targetimg_fea.requires_grad):
+        raise NotImplementedError("anystereo: build_gwc_volume backward is not built yet (inference path)")
+    return ops.gwc_volume(refimg_fea.float().contiguous(), targetimg_fea.float().contiguous(), maxdisp, num_groups)
+
+
+def disparity_regression(x, maxdisp):
+    """sum_d d * x[:, d] for a probability volume x [B,D,H,W] -> [B,1,H,W]."""
+    assert x.dim() == 4 and x.shape[1] == maxdisp
+    return ops.disparity_regression(x.float().contiguous(), apply_softmax=False)
+
+
+def softmax_disparity_regression(cost):
+    """Fused F.softmax(cost, 1) + disparity_regression (continuous_IGEVstereo.py:267-268)."""
+    return ops.disparity_regression(cost.float().contiguous(), apply_softmax=True)
+
+
+def context_upsample_multiscale_train(disp_low, up_weights, hr_coord):
+    """Convex 3x3 upsampling at arbitrary query coordinates -> [B,Q].
+    disp_low [B,1,h,w] (already scaled), up_weights [B,9,Q] (already softmaxed), hr_coord [B,Q,2].
+    Like the reference (submodule.py:366) this clamps `hr_coord` IN PLACE."""
+    hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)
+    out = ops.convex_upsample(disp_low.float().contiguous(), up_weights.float().contiguous(),
+                              hr_coord.float().contiguous(), scale=None, mask_is_logits=False)
+    return out[:, 0]

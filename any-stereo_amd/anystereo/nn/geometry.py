@@ -1,0 +1,83 @@
+"""Correlation / geometry-encoding volumes and their per-iteration lookup — HIP-backed mirror of
+models/coreContinuous_IGEV/geometry.py:6-72 and models/corePrune_RAFT/geometry.py:6-55.
+
+Same constructor and call signatures as the reference classes:
+    fn = Combined_Geo_Encoding_Volume(fmap1, fmap2, geo_volume, num_levels=2, radius=4)
+    feat = fn(disp [B,1,h,w], coords [B,h,w,1])      -> [B, L*9*(G+1), h, w] float32 contiguous
+Differences that do not change results: the all-pairs product and every pooled level are produced
+by one kernel (as_corr_build_pyramid); the geometry volume is stored [B,h,w,D,G] instead of
+[B*h*w,G,1,D]; `coords` is accepted for signature parity but must be the pixel-column grid the
+reference always passes (continuous_IGEVstereo.py:280) — it is regenerated in-kernel.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+
+
+def _needs_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+class _LookupFn(torch.autograd.Function):
+    """Lookup with gradients flowing to the pyramid levels only (disp arrives detached,
+    continuous_IGEVstereo.py:285)."""
+
+    @staticmethod
+    def forward(ctx, disp, radius, n_geo, *levels):
+        geo, corr = list(levels[:n_geo]), list(levels[n_geo:])
+        ctx.radius, ctx.n_geo = radius, n_geo
+        ctx.geo_shapes = [tuple(t.shape) for t in geo]
+        ctx.corr_shapes = [tuple(t.shape) for t in corr]
+        ctx.save_for_backward(disp)
+        return ops.geo_corr_lookup(geo, corr, disp, radius)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (disp,) = ctx.saved_tensors
+        d_geo, d_corr = ops.geo_corr_lookup_backward(disp, d_out.contiguous(), ctx.geo_shapes, ctx.corr_shapes, ctx.radius)
+        return (None, None, None, *d_geo, *d_corr)
+
+
+class Combined_Geo_Encoding_Volume:
+    def __init__(self, init_fmap1, init_fmap2, geo_volume, num_levels=2, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        f1 = init_fmap1.float().contiguous()
+        f2 = init_fmap2.float().contiguous()
+        if _needs_grad(f1, f2, geo_volume):
+            raise NotImplementedError("anystereo: backward of the volume build is not implemented yet (inference path)")
+        self.init_corr_pyramid = ops.corr_build_pyramid(f1, f2, num_levels)
+        self.geo_volume_pyramid = (ops.geo_pyramid(geo_volume.float().contiguous(), num_levels)
+                                   if geo_volume is not None else [])
+
+    def __call__(self, disp, coords=None):
+        disp = disp.float().contiguous()
+        if coords is not None:
+            b, _, h, w = disp.shape
+            if tuple(coords.shape) != (b, h, w, 1):
+                raise RuntimeError(f"lookup: coords must be [B,h,w,1] = {(b, h, w, 1)}, got {tuple(coords.shape)}")
+        levels = list(self.geo_volume_pyramid) + list(self.init_corr_pyramid)
+        if _needs_grad(*levels):
+            return _LookupFn.apply(disp, self.radius, len(self.geo_volume_pyramid), *levels)
+        return ops.geo_corr_lookup(self.geo_volume_pyramid, self.init_corr_pyramid, disp, self.radius)
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """All-pairs correlation only -> [B,h,w1,1,w2] (geometry.py:63-72)."""
+        lv = ops.corr_build_pyramid(fmap1.float().contiguous(), fmap2.float().contiguous(), 1)[0]
+        b, h, w1, w2 = lv.shape
+        return lv.view(b, h, w1, 1, w2)
+
+
+class CorrBlock1D(Combined_Geo_Encoding_Volume):
+    """RAFT-Stereo style 1-D correlation pyramid (corePrune_RAFT/geometry.py:6-55)."""
+
+    def __init__(self, init_fmap1, init_fmap2, num_levels=2, radius=4, mask_invalid=False):
+        # mask_invalid is a no-op in the reference as well (`corr == torch.tril(corr)` discards its result, :53-54)
+        super().__init__(init_fmap1, init_fmap2, None, num_levels=num_levels, radius=radius)
+
+    @staticmethod
+    def corr(fmap1, fmap2, mask_invalid=False):
+        return Combined_Geo_Encoding_Volume.corr(fmap1, fmap2)

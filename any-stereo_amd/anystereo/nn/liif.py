@@ -1,0 +1,141 @@
+"""LIIF-style continuous implicit upsampler — HIP-backed mirror of the live branches of
+models/*/liif.py (MLP :9-25, make_coord :32-45, liif_feat_multiscale_train :108-137,
+AffinityFeature :417-446, StructureFeature 'with_v2ISU' :496-499,
+liif_out_multi_scale_Training :575-678).
+
+Only the default-configuration branch is implemented (unfold_similarity='with_v2ISU', pos_dim=0,
+no positional encoding / cell decode / local ensemble / quarter-nearest); any other option raises
+at construction (SURVEY.md §2 row 5 lists them as out of scope).
+
+Data layout: the per-query latent is built CHANNEL-major, latent[B, 228, Q], so that
+  * the gather kernel's stores are coalesced along Q,
+  * the MLP is a chain of 1x1 convs on the fp32-MFMA implicit-GEMM kernel, and
+  * the last layer's output already is the reference's return layout [B, 9, Q].
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+
+
+def make_coord(shape, ranges=None, flatten=True):
+    """Cell-centre coordinates of a grid (liif.py:32-45); same fp32 evaluation order as the reference."""
+    seqs = []
+    for i, n in enumerate(shape):
+        v0, v1 = (-1, 1) if ranges is None else ranges[i]
+        r = (v1 - v0) / (2 * n)
+        seqs.append(v0 + r + (2 * r) * torch.arange(n).float())
+    ret = torch.stack(torch.meshgrid(*seqs, indexing="ij"), dim=-1)
+    return ret.view(-1, ret.shape[-1]) if flatten else ret
+
+
+class MLP(nn.Module):
+    """Linear/ReLU stack with the reference's parameter names (`layers.0.weight`, `layers.2.weight`, ...)."""
+
+    def __init__(self, in_dim, out_dim, hidden_list):
+        super().__init__()
+        layers, last = [], in_dim
+        for hdim in hidden_list:
+            layers += [nn.Linear(last, hdim), nn.ReLU()]
+            last = hdim
+        layers.append(nn.Linear(last, out_dim))
+        self.layers = nn.Sequential(*layers)
+        self._packs = [ops.PackedConv() for m in self.layers if isinstance(m, nn.Linear)]
+
+    def forward_cm(self, x_cm: torch.Tensor) -> torch.Tensor:
+        """x_cm [B, in_dim, Q] channel-major -> [B, out_dim, Q]."""
+        b, c, q = x_cm.shape
+        x = x_cm.view(b, c, 1, q)
+        lin = [m for m in self.layers if isinstance(m, nn.Linear)]
+        for i, (m, pk) in enumerate(zip(lin, self._packs)):
+            act = L.ACT_RELU if i + 1 < len(lin) else L.ACT_NONE
+            x = ops.conv2d([x], pk.get([m.weight], [m.bias]), act=act)
+        return x.view(b, -1, q)
+
+    def forward(self, x):
+        """Reference contract: [..., in_dim] -> [..., out_dim] (liif.py:22-25)."""
+        shape = x.shape[:-1]
+        flat = x.reshape(1, -1, x.shape[-1]).float()
+        y = self.forward_cm(flat.permute(0, 2, 1).contiguous())
+        return y.permute(0, 2, 1).reshape(*shape, -1)
+
+
+class AffinityFeature(nn.Module):
+    """3x3 cosine affinity (liif.py:417-446); dilation 1 only (the 'with_v2ISU' branch uses Affi1)."""
+
+    def __init__(self, win_h, win_w, dilation, cut):
+        super().__init__()
+        if (win_h, win_w, dilation) != (3, 3, 1):
+            raise NotImplementedError("AffinityFeature: only the 3x3, dilation-1 window of the default config is built")
+        self.win_w, self.win_h, self.dilation, self.cut = win_w, win_h, dilation, 0
+
+    def forward(self, feature):
+        x = feature.float().contiguous()
+        return ops.structure_feature(x)[:, x.shape[1]:]
+
+
+class StructureFeature(nn.Module):
+    """cat(x, Affi1(x.detach())) — the 'with_v2ISU' branch (liif.py:496-499)."""
+
+    def __init__(self, affinity_settings, unfold, input_chanels):
+        super().__init__()
+        if unfold != "with_v2ISU":
+            raise NotImplementedError(f"StructureFeature: unfold_similarity={unfold!r} is not built (default: 'with_v2ISU')")
+        self.win_w, self.win_h = affinity_settings["win_w"], affinity_settings["win_h"]
+        self.dilation, self.unfold = affinity_settings["dilation"], unfold
+        self.Affi1 = AffinityFeature(self.win_h, self.win_w, self.dilation[0], 0)
+
+    def forward(self, x):
+        return ops.structure_feature(x.float().contiguous())
+
+
+def liif_feat_multiscale_train(feat, coords, scale=None, local=False, cell=False):
+    """(rel_coord [B,Q,2], q_feat [B,Q,C], None) — reference contract of liif.py:108-137."""
+    if local or cell:
+        raise NotImplementedError("local ensemble / cell decoding are not built (off in the default config)")
+    feat = feat.float().contiguous()
+    coords = coords.float().contiguous()
+    b, c = feat.shape[:2]
+    q = coords.shape[1]
+    lat = torch.empty((b, c + 2, q), device=feat.device, dtype=torch.float32)
+    ops.liif_gather(feat, coords, lat, 0)
+    lat = lat.permute(0, 2, 1)
+    return lat[..., c:], lat[..., :c], None
+
+
+class liif_out_multi_scale_Training(nn.Module):
+    def __init__(self, pos_dim=24, encoder_dim=256, mlphidden_list=[128, 64, 64], pos_enconding=False,
+                 pos_enconding_new=False, local_ensemble=False, decode_cell=False, unfold=False, affinity_settings=None,
+                 quater_nearest=None, require_grad=True, number_input=3, chanels=0):
+        super().__init__()
+        unsupported = {"pos_dim": pos_dim != 0, "pos_enconding": pos_enconding, "pos_enconding_new": pos_enconding_new,
+                       "local_ensemble": local_ensemble, "decode_cell": decode_cell,
+                       "quater_nearest": quater_nearest is not None, "unfold": unfold != "with_v2ISU"}
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"liif_out_multi_scale_Training: non-default options {bad} are not built")
+        self.local_ensemble, self.decode_cell, self.unfold = local_ensemble, decode_cell, unfold
+        self.pos_enconding, self.pos_enconding_new, self.quater_nearest = pos_enconding, pos_enconding_new, quater_nearest
+        self.encoder_dim = encoder_dim
+        self.pos_dim = 2
+        self.outputdim = 9
+        in_c = affinity_settings["win_h"] * affinity_settings["win_w"] - 1
+        self.to_sf_l2 = nn.ModuleList(StructureFeature(affinity_settings, unfold, input_chanels=c) for c in chanels)
+        imnet_in_dim = encoder_dim + in_c * number_input + self.pos_dim * number_input
+        self.imnet = MLP(imnet_in_dim, self.outputdim, hidden_list=mlphidden_list)
+
+    def forward(self, feats, coord, scale=None):
+        """feats: list of [B,C_i,H_i,W_i]; coord [B,Q,2] (row, col) -> mask logits [B,9,Q] (liif.py:644-678)."""
+        coord = coord.float().contiguous()
+        b, q = coord.shape[:2]
+        sfs = [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
+        ctot = sum(s.shape[1] + 2 for s in sfs)
+        latent = torch.empty((b, ctot, q), device=coord.device, dtype=torch.float32)
+        off = 0
+        for s in sfs:
+            ops.liif_gather(s, coord, latent, off)
+            off += s.shape[1] + 2
+        return self.imnet.forward_cm(latent)

@@ -1,0 +1,160 @@
+"""Iterative update operator — HIP-backed mirror of models/*/update.py:16-136.
+
+Module / parameter names equal the reference's (`update_block.gru04.convz.weight`,
+`update_block.encoder.convc1.bias`, ...) so checkpoints load unchanged; `forward` signatures are
+the reference's.  The nn.Conv2d children only *hold* the parameters: the arithmetic runs in
+libanystereo_hip.so (fp32-MFMA implicit GEMM, conv.hip):
+
+  * ConvGRU: convz‖convr run as ONE conv (Cout = 2*hidden) over the un-materialised concat
+    [h, x...], the epilogue emits z and r⊙h; convq consumes [r⊙h, x...] and its epilogue emits
+    (1-z)·h + z·tanh(·)   — 2 launches instead of 3 convs + 2 cats + 6 pointwise kernels.
+  * BasicMotionEncoder: convc2 / convd2 write into the two halves of one buffer (no cat),
+    the 7x7 1-channel conv and the 256->1 head conv use direct kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+
+
+def _f(t):
+    return t.float().contiguous()
+
+
+def _no_grad_only(*ts):
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts):
+        raise NotImplementedError(
+            "anystereo: the HIP update block implements the inference path; backward kernels are not built yet "
+            "(run under torch.no_grad())")
+
+
+class DispHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, output_dim, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self._p1 = ops.PackedConv()
+        self._p2 = ops.PackedConv()
+
+    def forward(self, x):
+        _no_grad_only(x, self.conv1.weight)
+        t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
+        if self.conv2.out_channels == 1:
+            return ops.conv3x3_to1(t, _f(self.conv2.weight.detach()), _f(self.conv2.bias.detach()))
+        return ops.conv2d([t], self._p2.get([self.conv2.weight], [self.conv2.bias]))
+
+
+class FlowHead(DispHead):
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=2):
+        super().__init__(input_dim, hidden_dim, output_dim)
+
+
+def _context_window(cz, cr, cq):
+    """cz, cr, cq are normally the three 128-channel views of ONE context tensor
+    (`conv(i).split(...)`, continuous_IGEVstereo.py:273); find that tensor so the kernels index it
+    in place.  Otherwise fall back to a single concatenation."""
+    base = cz._base
+    if (base is not None and cr._base is base and cq._base is base and base.is_contiguous() and base.dim() == 4
+            and base.dtype == torch.float32):
+        plane = base.shape[2] * base.shape[3]
+        c = cz.shape[1]
+        o0 = base.storage_offset()
+        offs = [(t.storage_offset() - o0) for t in (cz, cr, cq)]
+        if (offs[0] % plane == 0 and offs[1] == offs[0] + c * plane and offs[2] == offs[1] + c * plane
+                and all(t.stride() == base.stride() for t in (cz, cr, cq))):
+            return base, offs[0] // plane
+    cat = torch.cat([cz, cr, cq], dim=1).float().contiguous()
+    return cat, 0
+
+
+class ConvGRU(nn.Module):
+    def __init__(self, hidden_dim, input_dim, kernel_size=3):
+        super().__init__()
+        pad = kernel_size // 2
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
+        self._pzr = ops.PackedConv()
+        self._pq = ops.PackedConv()
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        _no_grad_only(h, cz, self.convz.weight, *x_list)
+        h = _f(h)
+        xs = [_f(x) for x in x_list]
+        ctx, coff = _context_window(cz, cr, cq)
+        hid = h.shape[1]
+        pzr = self._pzr.get([self.convz.weight, self.convr.weight], [self.convz.bias, self.convr.bias])
+        pq = self._pq.get([self.convq.weight], [self.convq.bias])
+        z, rh = ops.conv2d([h] + xs, pzr, add=ctx, add_coff=coff, epilogue=L.EPI_GRU_ZR, h=h)
+        return ops.conv2d([rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z)
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, args, geo_channels=8):
+        super().__init__()
+        self.args = args
+        # geo_channels: 8 (IGEV, coreContinuous_IGEV/update.py:77) or 0 (RAFT, corePrune_RAFT/update.py:77)
+        cor_planes = args.corr_levels * (2 * args.corr_radius + 1) * (geo_channels + 1)
+        self.convc1 = nn.Conv2d(cor_planes, 64, 1, padding=0)
+        self.convc2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.convd1 = nn.Conv2d(1, 64, 7, padding=3)
+        self.convd2 = nn.Conv2d(64, 64, 3, padding=1)
+        self.conv = nn.Conv2d(64 + 64, 128 - 1, 3, padding=1)
+        self._pc1, self._pc2, self._pd2, self._pc = (ops.PackedConv() for _ in range(4))
+
+    def forward(self, disp, corr):
+        _no_grad_only(disp, corr, self.convc1.weight)
+        disp, corr = _f(disp), _f(corr)
+        b, _, h, w = disp.shape
+        cor = ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
+        cd = torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
+        ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out=cd, out_coff=0)
+        d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()))
+        ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out=cd, out_coff=64)
+        out = torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
+        ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out=out, out_coff=0)
+        out[:, 127:128].copy_(disp)
+        return out
+
+
+def pool2x(x):
+    return ops.pool2x(_f(x))
+
+
+def interp(x, dest):
+    return ops.interp(_f(x), dest.shape[2], dest.shape[3])
+
+
+class BasicMultiUpdateBlock(nn.Module):
+    def __init__(self, args, hidden_dims=[], geo_channels=8):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args, geo_channels)
+        encoder_output_dim = 128
+        self.gru04 = ConvGRU(hidden_dims[2], encoder_output_dim + hidden_dims[1] * (args.n_gru_layers > 1))
+        self.gru08 = ConvGRU(hidden_dims[1], hidden_dims[0] * (args.n_gru_layers == 3) + hidden_dims[2])
+        self.gru16 = ConvGRU(hidden_dims[0], hidden_dims[1])
+        self.disp_head = DispHead(hidden_dims[2], hidden_dim=256, output_dim=1)
+
+    def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+        if iter16:
+            net[2] = self.gru16(net[2], *(inp[2]), pool2x(net[1]))
+        if iter08:
+            if self.args.n_gru_layers > 2:
+                net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+            else:
+                net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]))
+        if iter04:
+            motion_features = self.encoder(disp, corr)
+            if self.args.n_gru_layers > 1:
+                net[0] = self.gru04(net[0], *(inp[0]), motion_features, interp(net[1], net[0]))
+            else:
+                net[0] = self.gru04(net[0], *(inp[0]), motion_features)
+        if not update:
+            return net
+        delta_disp = self.disp_head(net[0])
+        return net, delta_disp

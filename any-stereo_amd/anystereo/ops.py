@@ -1,0 +1,383 @@
+"""Host-side operator layer: torch tensors in, device pointers out to the C ABI.
+
+PyTorch is plumbing here (device memory through the caching allocator, the current HIP stream);
+all arithmetic of the hot path happens in libanystereo_hip.so.  Every op demands CUDA (=HIP)
+fp32 contiguous tensors and raises RuntimeError otherwise — no silent fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (HIP) tensor — the anystereo hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# correlation volume / pyramids / lookup
+# ------------------------------------------------------------------------------------------------
+
+
+def corr_build_pyramid(f1: torch.Tensor, f2: torch.Tensor, num_levels: int) -> List[torch.Tensor]:
+    """[B,C,H,W1],[B,C,H,W2] -> levels [B,H,W1,W2>>i] (geometry.py:63-72,:27-29)."""
+    _req(f1, "fmap1"), _req(f2, "fmap2")
+    if f1.dim() != 4 or f2.dim() != 4 or f1.shape[:3] != f2.shape[:3]:
+        raise RuntimeError(f"corr_build_pyramid: incompatible shapes {tuple(f1.shape)} / {tuple(f2.shape)}")
+    b, c, h, w1 = f1.shape
+    w2 = f2.shape[3]
+    lv = [torch.empty((b, h, w1, w2 >> i), device=f1.device, dtype=torch.float32) for i in range(num_levels)]
+    pp, keep = L.ptr_array([t.data_ptr() for t in lv])
+    with torch.cuda.device(f1.device):
+        L.check(L.load().as_corr_build_pyramid(_p(f1), _p(f2), pp, b, c, h, w1, w2, num_levels, _stream()),
+                "corr_build_pyramid")
+    return lv
+
+
+def geo_pyramid(gev: torch.Tensor, num_levels: int) -> List[torch.Tensor]:
+    """[B,G,D,H,W] -> levels [B,H,W,D>>i,G] (geometry.py:17-25)."""
+    _req(gev, "geo_volume")
+    if gev.dim() != 5:
+        raise RuntimeError(f"geo_pyramid: expected [B,G,D,H,W], got {tuple(gev.shape)}")
+    b, g, d, h, w = gev.shape
+    lv = [torch.empty((b, h, w, d >> i, g), device=gev.device, dtype=torch.float32) for i in range(num_levels)]
+    pp, keep = L.ptr_array([t.data_ptr() for t in lv])
+    with torch.cuda.device(gev.device):
+        L.check(L.load().as_geo_pyramid(_p(gev), pp, b, g, d, h, w, num_levels, _stream()), "geo_pyramid")
+    return lv
+
+
+def geo_corr_lookup(geo: Optional[Sequence[torch.Tensor]], corr: Sequence[torch.Tensor], disp: torch.Tensor,
+                    radius: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused pyramid lookup -> [B, L*(2r+1)*(G+1), H, W] (geometry.py:34-60)."""
+    _req(disp, "disp")
+    nl = len(corr)
+    b, one, h, w = disp.shape
+    if one != 1:
+        raise RuntimeError(f"geo_corr_lookup: disp must be [B,1,H,W], got {tuple(disp.shape)}")
+    for i, t in enumerate(corr):
+        _req(t, f"corr[{i}]")
+    w2 = corr[0].shape[3]
+    for i, t in enumerate(corr):
+        if tuple(t.shape) != (b, h, w, w2 >> i):
+            raise RuntimeError(f"geo_corr_lookup: corr[{i}] has shape {tuple(t.shape)}, expected {(b, h, w, w2 >> i)}")
+    g = d = 0
+    if geo:
+        if len(geo) != nl:
+            raise RuntimeError("geo_corr_lookup: geo and corr pyramids differ in depth")
+        d, g = geo[0].shape[3], geo[0].shape[4]
+        for i, t in enumerate(geo):
+            _req(t, f"geo[{i}]")
+            if tuple(t.shape) != (b, h, w, d >> i, g):
+                raise RuntimeError(f"geo_corr_lookup: geo[{i}] has shape {tuple(t.shape)}, expected {(b, h, w, d >> i, g)}")
+    ch = nl * (2 * radius + 1) * (g + 1)
+    if out is None:
+        out = torch.empty((b, ch, h, w), device=disp.device, dtype=torch.float32)
+    else:
+        _req(out, "out")
+        if tuple(out.shape) != (b, ch, h, w):
+            raise RuntimeError("geo_corr_lookup: bad out shape")
+    gp, k1 = L.ptr_array([t.data_ptr() for t in geo]) if geo else (None, None)
+    cp, k2 = L.ptr_array([t.data_ptr() for t in corr])
+    with torch.cuda.device(disp.device):
+        L.check(L.load().as_geo_corr_lookup_fwd(gp, cp, _p(disp), _p(out), b, h, w, w2, d, g, nl, radius, _stream()),
+                "geo_corr_lookup_fwd")
+    return out
+
+
+def geo_corr_lookup_backward(disp, d_out, geo_shapes, corr_shapes, radius):
+    """Gradients w.r.t. the pyramid levels (transpose of the lookup)."""
+    _req(disp, "disp"), _req(d_out, "d_out")
+    b, _, h, w = disp.shape
+    nl = len(corr_shapes)
+    d_corr = [torch.zeros(s, device=disp.device, dtype=torch.float32) for s in corr_shapes]
+    d_geo = [torch.zeros(s, device=disp.device, dtype=torch.float32) for s in geo_shapes] if geo_shapes else []
+    g = d = 0
+    if d_geo:
+        d, g = geo_shapes[0][3], geo_shapes[0][4]
+    w2 = corr_shapes[0][3]
+    gp, k1 = L.ptr_array([t.data_ptr() for t in d_geo]) if d_geo else (None, None)
+    cp, k2 = L.ptr_array([t.data_ptr() for t in d_corr])
+    with torch.cuda.device(disp.device):
+        L.check(L.load().as_geo_corr_lookup_bwd(_p(disp), _p(d_out), gp, cp, b, h, w, w2, d, g, nl, radius, _stream()),
+                "geo_corr_lookup_bwd")
+    return d_geo, d_corr
+
+
+_DT = {torch.float32: L.AS_F32, torch.float16: L.AS_F16, torch.float64: L.AS_F64}
+
+
+def corr_sampler_forward(volume: torch.Tensor, coords: torch.Tensor, radius: int) -> torch.Tensor:
+    """`corr_sampler.forward` contract (sampler/sampler.cpp:24-32) -> corr [N,2r+1,H1,W1]."""
+    if volume.dtype not in _DT:
+        raise RuntimeError(f"corr_sampler: unsupported volume dtype {volume.dtype}")
+    _req(volume, "volume", volume.dtype), _req(coords, "coords")
+    if volume.dim() != 4 or coords.dim() != 4 or coords.shape[1] not in (1, 2):
+        raise RuntimeError("corr_sampler: volume must be [N,H1,W1,W2] and coords [N,2,H1,W1]")
+    n, h1, w1, w2 = volume.shape
+    if (coords.shape[0], coords.shape[2], coords.shape[3]) != (n, h1, w1):
+        raise RuntimeError("corr_sampler: coords shape does not match volume")
+    out = torch.empty((n, 2 * radius + 1, h1, w1), device=volume.device, dtype=volume.dtype)
+    with torch.cuda.device(volume.device):
+        L.check(L.load().as_corr_sampler_fwd(_p(volume), _p(coords), _p(out), n, h1, w1, w2, radius,
+                                             coords.shape[1], _DT[volume.dtype], _stream()), "corr_sampler_fwd")
+    return out
+
+
+def corr_sampler_backward(volume: torch.Tensor, coords: torch.Tensor, corr_grad: torch.Tensor, radius: int) -> torch.Tensor:
+    """`corr_sampler.backward` contract (sampler/sampler.cpp:34-45) -> volume_grad."""
+    if volume.dtype not in _DT:
+        raise RuntimeError(f"corr_sampler: unsupported volume dtype {volume.dtype}")
+    _req(volume, "volume", volume.dtype), _req(coords, "coords"), _req(corr_grad, "corr_grad", volume.dtype)
+    n, h1, w1, w2 = volume.shape
+    if tuple(corr_grad.shape) != (n, 2 * radius + 1, h1, w1):
+        raise RuntimeError("corr_sampler: corr_grad shape mismatch")
+    grad = torch.empty_like(volume)
+    with torch.cuda.device(volume.device):
+        L.check(L.load().as_corr_sampler_bwd(_p(coords), _p(corr_grad), _p(grad), n, h1, w1, w2, radius,
+                                             coords.shape[1], _DT[volume.dtype], _stream()), "corr_sampler_bwd")
+    return grad
+
+
+def gwc_volume(fl: torch.Tensor, fr: torch.Tensor, maxdisp: int, groups: int) -> torch.Tensor:
+    """build_gwc_volume (submodule.py:261-271) -> [B,G,D,H,W]."""
+    _req(fl, "refimg_fea"), _req(fr, "targetimg_fea")
+    if fl.shape != fr.shape or fl.dim() != 4:
+        raise RuntimeError("gwc_volume: feature maps must share a [B,C,H,W] shape")
+    b, c, h, w = fl.shape
+    out = torch.empty((b, groups, maxdisp, h, w), device=fl.device, dtype=torch.float32)
+    with torch.cuda.device(fl.device):
+        L.check(L.load().as_gwc_volume_fwd(_p(fl), _p(fr), _p(out), b, c, h, w, maxdisp, groups, _stream()), "gwc_volume_fwd")
+    return out
+
+
+def disparity_regression(cost: torch.Tensor, apply_softmax: bool) -> torch.Tensor:
+    """(softmax over D then) sum_d d*p (continuous_IGEVstereo.py:267-268, submodule.py:321-325) -> [B,1,H,W]."""
+    _req(cost, "cost")
+    b, d, h, w = cost.shape
+    out = torch.empty((b, 1, h, w), device=cost.device, dtype=torch.float32)
+    with torch.cuda.device(cost.device):
+        L.check(L.load().as_disparity_regression(_p(cost), _p(out), b, d, h, w, 1 if apply_softmax else 0, _stream()),
+                "disparity_regression")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutions (update block, MLP)
+# ------------------------------------------------------------------------------------------------
+
+
+class PackedConv:
+    """Weights of one (possibly channel-concatenated) conv re-laid out for the implicit-GEMM kernel.
+
+    `weights` are nn.Conv2d weights [Cout_i, Cin, K, K] (or nn.Linear [Cout_i, Cin]) concatenated
+    along Cout; the pack is rebuilt whenever a weight's version counter, storage or device changes,
+    so optimiser steps and load_state_dict are picked up."""
+
+    def __init__(self):
+        self._key = None
+        self.wpack = None
+        self.bias = None
+        self.cin = self.cout = self.ks = 0
+
+    def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+        key = tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
+            tuple((None if b is None else (b.data_ptr(), b._version)) for b in biases)
+        if key != self._key:
+            ws = [w.detach().reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1))) for w in weights]
+            w = torch.cat(ws, dim=0).contiguous().float() if len(ws) > 1 else ws[0].contiguous().float()
+            _req(w, "conv weight")
+            cout, cin, ks, ks2 = w.shape
+            if ks != ks2:
+                raise RuntimeError("PackedConv: non-square kernel")
+            n = L.load().as_conv_pack_size(cin, cout, ks)
+            if n <= 0:
+                raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}")
+            wp = torch.empty(n, device=w.device, dtype=torch.float32)
+            with torch.cuda.device(w.device):
+                L.check(L.load().as_conv_pack_weights(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights")
+            if all(b is None for b in biases):
+                bias = None
+            else:
+                bias = torch.cat([(torch.zeros(wi.shape[0], device=w.device) if bi is None else bi.detach().float())
+                                  for wi, bi in zip(weights, biases)]).contiguous()
+            self.wpack, self.bias, self.cin, self.cout, self.ks, self._key = wp, bias, cin, cout, ks, key
+        return self
+
+
+def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE, add: Optional[torch.Tensor] = None,
+           add_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0, epilogue: int = L.EPI_LINEAR,
+           h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None):
+    """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue."""
+    b, _, hh, ww = srcs[0].shape
+    d = L.ConvDesc()
+    cin = 0
+    if len(srcs) > L.AS_MAX_SRCS:
+        raise RuntimeError(f"conv2d: at most {L.AS_MAX_SRCS} sources")
+    for i, s in enumerate(srcs):
+        _req(s, f"src[{i}]")
+        if s.shape[0] != b or tuple(s.shape[2:]) != (hh, ww):
+            raise RuntimeError(f"conv2d: src[{i}] shape {tuple(s.shape)} does not match {(b, '*', hh, ww)}")
+        d.src[i] = s.data_ptr()
+        d.src_c[i] = s.shape[1]
+        cin += s.shape[1]
+    if cin != pack.cin:
+        raise RuntimeError(f"conv2d: sources hold {cin} channels but the weights expect {pack.cin}")
+    d.n_src = len(srcs)
+    d.wpack = pack.wpack.data_ptr()
+    d.bias = 0 if pack.bias is None else pack.bias.data_ptr()
+    cout = pack.cout
+    if add is not None:
+        _req(add, "add")
+        if add.shape[0] != b or tuple(add.shape[2:]) != (hh, ww):
+            raise RuntimeError("conv2d: add shape mismatch")
+        d.add, d.add_ctot, d.add_coff = add.data_ptr(), add.shape[1], add_coff
+    dev = srcs[0].device
+    if epilogue == L.EPI_LINEAR:
+        if out is None:
+            out = torch.empty((b, cout, hh, ww), device=dev, dtype=torch.float32)
+        _req(out, "out")
+        d.out, d.out_ctot, d.out_coff = out.data_ptr(), out.shape[1], out_coff
+    elif epilogue == L.EPI_GRU_ZR:
+        ch = cout // 2
+        _req(h, "h")
+        if out is None:
+            out = torch.empty((b, ch, hh, ww), device=dev, dtype=torch.float32)
+        if out2 is None:
+            out2 = torch.empty((b, ch, hh, ww), device=dev, dtype=torch.float32)
+        _req(out, "out"), _req(out2, "out2")
+        for t in (h, out, out2):
+            if tuple(t.shape) != (b, ch, hh, ww):
+                raise RuntimeError("conv2d(GRU_ZR): h/out/out2 must be [B,Cout/2,H,W]")
+        d.h, d.out, d.out2 = h.data_ptr(), out.data_ptr(), out2.data_ptr()
+    else:
+        _req(h, "h"), _req(z, "z")
+        if out is None:
+            out = torch.empty((b, cout, hh, ww), device=dev, dtype=torch.float32)
+        _req(out, "out")
+        for t in (h, z, out):
+            if tuple(t.shape) != (b, cout, hh, ww):
+                raise RuntimeError("conv2d(GRU_Q): h/z/out must be [B,Cout,H,W]")
+        d.h, d.z, d.out = h.data_ptr(), z.data_ptr(), out.data_ptr()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KS = b, hh, ww, cin, cout, pack.ks
+    d.act, d.epilogue = act, epilogue
+    with torch.cuda.device(dev):
+        L.check(L.load().as_conv2d(C.byref(d), _stream()), "conv2d")
+    return (out, out2) if epilogue == L.EPI_GRU_ZR else out
+
+
+def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0):
+    """relu(conv7x7(x [B,1,H,W]) + bias) into channels [out_coff, out_coff+Cout) of `out` (update.py:81,87)."""
+    _req(x, "x"), _req(weight, "weight")
+    b, one, h, w = x.shape
+    cout = weight.shape[0]
+    if one != 1 or tuple(weight.shape[1:]) != (1, 7, 7):
+        raise RuntimeError("conv7x7_c1_relu: expects x [B,1,H,W] and weight [Cout,1,7,7]")
+    if out is None:
+        out = torch.empty((b, cout, h, w), device=x.device, dtype=torch.float32)
+    _req(out, "out")
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(weight), _p(bias), _p(out), b, h, w, cout, out.shape[1], out_coff, _stream()),
+                "conv7x7_c1_relu")
+    return out
+
+
+def conv3x3_to1(x, weight, bias):
+    """conv3x3(x [B,Cin,H,W]) + bias -> [B,1,H,W] (DispHead.conv2, update.py:19,24)."""
+    _req(x, "x"), _req(weight, "weight")
+    b, cin, h, w = x.shape
+    if tuple(weight.shape) != (1, cin, 3, 3):
+        raise RuntimeError("conv3x3_to1: weight must be [1,Cin,3,3]")
+    out = torch.empty((b, 1, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_conv3x3_to1(_p(x), _p(weight), _p(bias), _p(out), b, cin, h, w, _stream()), "conv3x3_to1")
+    return out
+
+
+def pool2x(x):
+    """avg_pool2d(x, 3, stride=2, padding=1) (update.py:94-95)."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_pool2x(_p(x), _p(out), b, c, h, w, _stream()), "pool2x")
+    return out
+
+
+def interp(x, ho: int, wo: int):
+    """F.interpolate(x, (ho, wo), mode='bilinear', align_corners=True) (update.py:100-102)."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    out = torch.empty((b, c, ho, wo), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_interp_bilinear_ac(_p(x), _p(out), b, c, h, w, ho, wo, _stream()), "interp_bilinear_ac")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# LIIF upsampler stages
+# ------------------------------------------------------------------------------------------------
+
+
+def structure_feature(x: torch.Tensor) -> torch.Tensor:
+    """cat(x, cosine affinity to the 8 neighbours) -> [B,C+8,H,W] (liif.py:432-446, :496-499)."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    out = torch.empty((b, c + 8, h, w), device=x.device, dtype=torch.float32)
+    ws = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_structure_feature(_p(x), _p(out), _p(ws), b, c, h, w, _stream()), "structure_feature")
+    return out
+
+
+def liif_gather(feat: torch.Tensor, coord: torch.Tensor, latent: torch.Tensor, lat_coff: int) -> None:
+    """Nearest gather + relative coordinates into channels [lat_coff, lat_coff+C+2) of latent [B,Ctot,Q]
+    (liif.py:108-137)."""
+    _req(feat, "feat"), _req(coord, "coord"), _req(latent, "latent")
+    b, c, h, w = feat.shape
+    q = coord.shape[1]
+    if tuple(coord.shape) != (b, q, 2) or latent.shape[0] != b or latent.shape[2] != q:
+        raise RuntimeError("liif_gather: coord must be [B,Q,2] and latent [B,Ctot,Q]")
+    with torch.cuda.device(feat.device):
+        L.check(L.load().as_liif_gather(_p(feat), _p(coord), _p(latent), b, c, h, w, q, latent.shape[1], lat_coff, _stream()),
+                "liif_gather")
+
+
+def convex_upsample(disp, mask, coord, scale=None, mask_is_logits=False):
+    """(softmax(mask) ·) disp[3x3 nbr of the nearest low-res pixel] -> [B,1,Q]; with `scale` [B] the
+    disparity is multiplied by 4*scale_b on the fly
+    (continuous_IGEVstereo.py:204,212-214; submodule.py:357-372)."""
+    _req(disp, "disp"), _req(mask, "mask"), _req(coord, "coord")
+    b, one, h, w = disp.shape
+    q = coord.shape[1]
+    if one != 1 or tuple(mask.shape) != (b, 9, q) or tuple(coord.shape) != (b, q, 2):
+        raise RuntimeError("convex_upsample: shape mismatch")
+    if scale is not None:
+        _req(scale, "scale")
+        if scale.numel() != b:
+            raise RuntimeError("convex_upsample: scale must hold one value per batch element")
+    out = torch.empty((b, 1, q), device=disp.device, dtype=torch.float32)
+    with torch.cuda.device(disp.device):
+        L.check(L.load().as_convex_upsample(_p(disp), _p(scale), _p(mask), _p(coord), _p(out), b, h, w, q,
+                                            1 if mask_is_logits else 0, _stream()), "convex_upsample")
+    return out

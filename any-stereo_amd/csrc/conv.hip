@@ -1,0 +1,474 @@
+// a6/a7/a9/a15: implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
+// fp32 fma chains => results track the reference's fp32 convs to rounding order), with the GRU
+// gate arithmetic fused into the epilogue; plus the two degenerate shapes as direct VALU kernels
+// and the pool2x / interp resamplers (a8).
+//
+// GEMM view:  D[co][pixel] = sum_k Wp[k][co] * X[k][pixel],  k = (tap, channel).
+//   MFMA A operand = weights  (A[i=co][k]  : lane&31 -> co,    lane>>5 -> k parity)
+//   MFMA B operand = patch    (B[k][j=pix] : lane&31 -> pixel, lane>>5 -> k parity)
+//   C/D: col j = lane&31 = pixel  => every epilogue load/store is a 128-B run along x in NCHW.
+// Per channel chunk the block stages an input halo patch [KC][TH+KS-1][TW+KS-1] and the packed
+// weight slab [KS*KS*KC][BN] in LDS; inside a chunk k is ordered (tap, channel) so the two k
+// parities of a lane differ by one channel stride and every ds_read address is
+// lane_base + compile-time immediate.  The channel concat of the reference (torch.cat([h, x...]))
+// is never materialised: a chunk's channels are read from whichever source tensor owns them.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct ConvParams {
+  const float* src[AS_MAX_SRCS];
+  int src_c[AS_MAX_SRCS];
+  int src_end[AS_MAX_SRCS];  // exclusive prefix end of each source's channel range
+  int n_src;
+  const float* wpack;
+  const float* bias;
+  const float* add;
+  int add_ctot, add_coff;
+  const float* h;
+  const float* z;
+  float* out;
+  float* out2;
+  int out_ctot, out_coff;
+  int B, H, W, Cin, Cout, Cout_pad, act;
+  int tiles_x, tiles_y, n_tiles, chunks;
+};
+
+template <int KS> struct ConvCfg;
+template <> struct ConvCfg<3> { static constexpr int KC = 8; };
+template <> struct ConvCfg<1> { static constexpr int KC = 32; };
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case AS_ACT_RELU: return fmaxf(v, 0.f);
+    case AS_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case AS_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// KS: 1 or 3.  TW: tile width in pixels (tile = (128/TW) rows x TW cols; KS==1 uses TW=128 on the
+// flattened H*W plane).  BN: output channels per block (128: waves 2(pix) x 2(co); 64/32: 4 x 1).
+template <int KS, int TW, int BN, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+  constexpr int KC = ConvCfg<KS>::KC;
+  constexpr int TH = 128 / TW;
+  constexpr int PAD = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int PATCH = PH * PW;
+  constexpr int KROWS = KC * KS * KS;
+  constexpr int CTW = (BN >= 64) ? 2 : 1;   // co tiles per wave
+  constexpr int PTW = (BN == 128) ? 2 : 1;  // pixel tiles per wave
+  __shared__ float patch_s[KC * PATCH];
+  __shared__ __attribute__((aligned(16))) float w_s[KROWS * BN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  int id = blockIdx.x;
+  const int nt = id % p.n_tiles;
+  id /= p.n_tiles;
+  const int tx = id % p.tiles_x;
+  id /= p.tiles_x;
+  const int ty = id % p.tiles_y;
+  const int b = id / p.tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int n0 = nt * BN;
+  const long long plane = (long long)p.H * p.W;
+
+  // wave -> (pixel tiles, co tiles)
+  int pt0, ct0;
+  if (BN == 128) { pt0 = (wave & 1) * 2; ct0 = (wave >> 1) * 2; }
+  else { pt0 = wave; ct0 = 0; }
+
+  int poff[PTW];  // LDS offset of this lane's pixel inside the patch (tap (0,0))
+#pragma unroll
+  for (int i = 0; i < PTW; ++i) {
+    const int m = (pt0 + i) * 32 + l31;
+    poff[i] = half * PATCH + (m / TW) * PW + (m % TW);
+  }
+  const int woff = half * BN + ct0 * 32 + l31;
+
+  f32x16 acc[CTW][PTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c)
+#pragma unroll
+    for (int q = 0; q < PTW; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
+
+  for (int chunk = 0; chunk < p.chunks; ++chunk) {
+    __syncthreads();
+    // ---- stage the input halo patch (zero outside the image / beyond Cin) ----
+    for (int idx = tid; idx < KC * PATCH; idx += 256) {
+      const int c = idx / PATCH;
+      const int r = idx - c * PATCH;
+      const int py = r / PW, px = r - py * PW;
+      const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+      const int cg = chunk * KC + c;
+      float v = 0.f;
+      if (cg < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        int s = 0, base = 0;
+#pragma unroll
+        for (int i = 0; i < AS_MAX_SRCS - 1; ++i)
+          if (i + 1 < p.n_src && cg >= p.src_end[i]) { s = i + 1; base = p.src_end[i]; }
+        v = p.src[s][((long long)b * p.src_c[s] + (cg - base)) * plane + (long long)gy * p.W + gx];
+      }
+      patch_s[idx] = v;
+    }
+    // ---- stage the weight slab rows [chunk*KROWS, +KROWS) x cols [n0, n0+BN) ----
+    {
+      const float4* wsrc = reinterpret_cast<const float4*>(p.wpack + ((long long)chunk * KROWS) * p.Cout_pad + n0);
+      const int rstride4 = p.Cout_pad >> 2;
+      for (int idx = tid; idx < KROWS * (BN / 4); idx += 256) {
+        const int row = idx / (BN / 4);
+        const int c4 = idx - row * (BN / 4);
+        reinterpret_cast<float4*>(w_s)[idx] = wsrc[(long long)row * rstride4 + c4];
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the chunk: k = (tap, channel pair) ----
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+      for (int cc = 0; cc < KC / 2; ++cc) {
+        float a[CTW], bv[PTW];
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) a[c] = w_s[woff + (tap * KC + 2 * cc) * BN + c * 32];
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) bv[q] = patch_s[poff[q] + (2 * cc) * PATCH + ky * PW + kx];
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+          for (int q = 0; q < PTW; ++q)
+            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bv[q], acc[c][q], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int q = 0; q < PTW; ++q) {
+    const int m = (pt0 + q) * 32 + l31;
+    const int gy = y0 + m / TW, gx = x0 + m % TW;
+    if (gy >= p.H || gx >= p.W) continue;
+    const long long pixoff = (long long)gy * p.W + gx;
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = n0 + (ct0 + c) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= p.Cout) continue;
+        float v = acc[c][q][r];
+        if (p.bias) v += p.bias[co];
+        if (p.add) v += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pixoff];
+        if (EPI == AS_EPI_LINEAR) {
+          p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pixoff] = act_apply(v, p.act);
+        } else if (EPI == AS_EPI_GRU_ZR) {
+          const int ch = p.Cout >> 1;
+          const float g = 1.f / (1.f + expf(-v));
+          if (co < ch) {
+            p.out[((long long)b * ch + co) * plane + pixoff] = g;
+          } else {
+            const long long o = ((long long)b * ch + (co - ch)) * plane + pixoff;
+            p.out2[o] = g * p.h[o];
+          }
+        } else {  // AS_EPI_GRU_Q
+          const long long o = ((long long)b * p.Cout + co) * plane + pixoff;
+          const float zz = p.z[o];
+          p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(v);
+        }
+      }
+    }
+  }
+}
+
+// weight [Cout,Cin,KS,KS] -> wpack [chunks][tap][KC][Cout_pad]  (zero padded)
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                                    int Cout_pad, int KS, int KC, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int co = (int)(idx % Cout_pad);
+  long long t = idx / Cout_pad;
+  const int cl = (int)(t % KC);
+  t /= KC;
+  const int tap = (int)(t % (KS * KS));
+  const int chunk = (int)(t / (KS * KS));
+  const int ci = chunk * KC + cl;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) v = w[((long long)co * Cin + ci) * KS * KS + tap];
+  wp[idx] = v;
+}
+
+// ---- direct kernels --------------------------------------------------------------------------
+
+// 7x7, 1 -> Cout, + bias, ReLU  (convd1, update.py:81,87).  16x16 pixel tile, the 49-tap window of
+// a pixel lives in registers, weights are wave-uniform (scalar loads).
+__global__ __launch_bounds__(256) void conv7x7_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int H, int W, int Cout, int out_ctot, int out_coff) {
+  __shared__ float patch[22 * 22];
+  const int b = blockIdx.z;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
+  const long long plane = (long long)H * W;
+  const float* xp = x + (long long)b * plane;
+  for (int idx = threadIdx.x; idx < 22 * 22; idx += 256) {
+    const int py = idx / 22, px = idx - py * 22;
+    const int gy = y0 - 3 + py, gx = x0 - 3 + px;
+    patch[idx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xp[(long long)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  float win[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) win[t] = patch[(ly + t / 7) * 22 + lx + t % 7];
+  const int gy = y0 + ly, gx = x0 + lx;
+  const bool ok = gy < H && gx < W;
+  float* o = out + ((long long)b * out_ctot + out_coff) * plane + (long long)gy * W + gx;
+  for (int co = 0; co < Cout; ++co) {
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 49; ++t) acc += win[t] * w[co * 49 + t];
+    acc += bias ? bias[co] : 0.f;
+    if (ok) o[(long long)co * plane] = fmaxf(acc, 0.f);
+  }
+}
+
+// 3x3, Cin -> 1, + bias (DispHead.conv2, update.py:19,24).  64 pixels of a row x 4 channel slices.
+__global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int Cin, int H, int W) {
+  __shared__ float red[4][64];
+  const int lx = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int gx = blockIdx.x * 64 + lx, gy = blockIdx.y, b = blockIdx.z;
+  const long long plane = (long long)H * W;
+  const int c0 = slice * ((Cin + 3) / 4), c1 = min(Cin, c0 + (Cin + 3) / 4);
+  float acc = 0.f;
+  if (gx < W) {
+    for (int c = c0; c < c1; ++c) {
+      const float* xp = x + ((long long)b * Cin + c) * plane;
+      const float* wc = w + c * 9;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = gy + ky - 1;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = gx + kx - 1;
+          const float v = (xx >= 0 && xx < W) ? xp[(long long)yy * W + xx] : 0.f;
+          acc += v * wc[ky * 3 + kx];
+        }
+      }
+    }
+  }
+  red[slice][lx] = acc;
+  __syncthreads();
+  if (slice == 0 && gx < W)
+    out[(long long)b * plane + (long long)gy * W + gx] = ((red[0][lx] + red[1][lx]) + (red[2][lx] + red[3][lx])) + (bias ? bias[0] : 0.f);
+}
+
+// pool2x: 3x3 mean, stride 2, zero pad 1, divisor 9 (update.py:94-95)
+__global__ __launch_bounds__(256) void pool2x_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
+                                                     int Ho, int Wo, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int xo = (int)(idx % Wo);
+  long long t = idx / Wo;
+  const int yo = (int)(t % Ho);
+  const long long bc = t / Ho;
+  const float* xp = x + bc * H * W;
+  float s = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = 2 * yo - 1 + dy;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int xx = 2 * xo - 1 + dx;
+      if (xx >= 0 && xx < W) s += xp[(long long)yy * W + xx];
+    }
+  }
+  out[idx] = s / 9.f;
+}
+
+// interp: bilinear, align_corners=True (update.py:100-102)
+__global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
+                                                     int Ho, int Wo, float sy, float sx, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int xo = (int)(idx % Wo);
+  long long t = idx / Wo;
+  const int yo = (int)(t % Ho);
+  const long long bc = t / Ho;
+  const float fy = sy * (float)yo, fx = sx * (float)xo;
+  const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ty = fy - (float)y0, tx = fx - (float)x0;
+  const float* xp = x + bc * H * W;
+  const float top = (1.f - tx) * xp[(long long)y0 * W + x0] + tx * xp[(long long)y0 * W + x1];
+  const float bot = (1.f - tx) * xp[(long long)y1 * W + x0] + tx * xp[(long long)y1 * W + x1];
+  out[idx] = (1.f - ty) * top + ty * bot;
+}
+
+template <int KS, int TW, int BN>
+int launch_conv(const ConvParams& p, int epi, hipStream_t s) {
+  const dim3 grid((unsigned)((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles));
+  if (epi == AS_EPI_LINEAR) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, BN, AS_EPI_LINEAR>), grid, dim3(256), 0, s, p);
+  else if (BN == 128 && epi == AS_EPI_GRU_ZR) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, 128, AS_EPI_GRU_ZR>), grid, dim3(256), 0, s, p);
+  else if (BN == 128 && epi == AS_EPI_GRU_Q) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, 128, AS_EPI_GRU_Q>), grid, dim3(256), 0, s, p);
+  else return as::fail(AS_ERR_BAD_ARG, "conv2d: GRU epilogues need Cout %% 128 == 0");
+  return as::check_launch("conv2d");
+}
+
+int conv_kc(int KS) { return KS == 3 ? ConvCfg<3>::KC : ConvCfg<1>::KC; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t as_conv_pack_size(int Cin, int Cout, int KS) {
+  if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return -1;
+  const int KC = conv_kc(KS);
+  const int64_t chunks = (Cin + KC - 1) / KC, cpad = ((Cout + 31) / 32) * 32;
+  return chunks * KS * KS * KC * cpad;
+}
+
+int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, int KS, void* stream) {
+  AS_REQUIRE(weight && wpack, AS_ERR_BAD_ARG, "conv_pack: null pointer");
+  const int64_t total = as_conv_pack_size(Cin, Cout, KS);
+  AS_REQUIRE(total > 0, AS_ERR_BAD_ARG, "conv_pack: unsupported Cin=%d Cout=%d KS=%d", Cin, Cout, KS);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream),
+                     weight, wpack, Cin, Cout, ((Cout + 31) / 32) * 32, KS, conv_kc(KS), (long long)total);
+  return as::check_launch("conv_pack_weights");
+}
+
+int as_conv2d(const as_conv_desc* d, void* stream) {
+  AS_REQUIRE(d, AS_ERR_BAD_ARG, "conv2d: null descriptor");
+  AS_REQUIRE(d->KS == 1 || d->KS == 3, AS_ERR_BAD_ARG, "conv2d: KS=%d (supported: 1, 3)", d->KS);
+  AS_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, AS_ERR_BAD_ARG, "conv2d: non-positive size");
+  AS_REQUIRE(d->n_src >= 1 && d->n_src <= AS_MAX_SRCS, AS_ERR_BAD_ARG, "conv2d: n_src=%d", d->n_src);
+  AS_REQUIRE(d->wpack && d->out, AS_ERR_BAD_ARG, "conv2d: null wpack/out");
+  AS_REQUIRE((reinterpret_cast<uintptr_t>(d->wpack) & 15) == 0, AS_ERR_BAD_ARG, "conv2d: wpack not 16-B aligned");
+  ConvParams p{};
+  int csum = 0;
+  for (int i = 0; i < d->n_src; ++i) {
+    AS_REQUIRE(d->src[i] && d->src_c[i] > 0, AS_ERR_BAD_ARG, "conv2d: source %d null or empty", i);
+    p.src[i] = d->src[i];
+    p.src_c[i] = d->src_c[i];
+    csum += d->src_c[i];
+    p.src_end[i] = csum;
+  }
+  AS_REQUIRE(csum == d->Cin, AS_ERR_BAD_SHAPE, "conv2d: sources hold %d channels, Cin=%d", csum, d->Cin);
+  p.n_src = d->n_src;
+  p.wpack = d->wpack; p.bias = d->bias; p.add = d->add;
+  p.add_ctot = d->add_ctot; p.add_coff = d->add_coff;
+  AS_REQUIRE(!d->add || (d->add_coff >= 0 && d->add_coff + d->Cout <= d->add_ctot), AS_ERR_BAD_SHAPE, "conv2d: add channel window [%d,%d) outside %d", d->add_coff, d->add_coff + d->Cout, d->add_ctot);
+  p.h = d->h; p.z = d->z; p.out = d->out; p.out2 = d->out2;
+  p.B = d->B; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
+  p.Cout_pad = ((d->Cout + 31) / 32) * 32;
+  const int epi = d->epilogue;
+  if (epi == AS_EPI_LINEAR) {
+    p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
+    p.out_coff = d->out_coff;
+    AS_REQUIRE(p.out_coff >= 0 && p.out_coff + d->Cout <= p.out_ctot, AS_ERR_BAD_SHAPE, "conv2d: out channel window outside out_ctot");
+    AS_REQUIRE(d->act >= AS_ACT_NONE && d->act <= AS_ACT_TANH, AS_ERR_BAD_ARG, "conv2d: act=%d", d->act);
+  } else if (epi == AS_EPI_GRU_ZR) {
+    AS_REQUIRE(d->h && d->out2 && (d->Cout % 2) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and even Cout");
+  } else if (epi == AS_EPI_GRU_Q) {
+    AS_REQUIRE(d->h && d->z, AS_ERR_BAD_ARG, "conv2d(GRU_Q): needs h and z");
+  } else {
+    return as::fail(AS_ERR_BAD_ARG, "conv2d: epilogue=%d", epi);
+  }
+  const int KC = conv_kc(d->KS);
+  p.chunks = (d->Cin + KC - 1) / KC;
+  const int bn = (p.Cout_pad % 128 == 0) ? 128 : (p.Cout_pad % 64 == 0 ? 64 : 32);
+  AS_REQUIRE(epi == AS_EPI_LINEAR || bn == 128, AS_ERR_BAD_SHAPE, "conv2d: GRU epilogues need Cout %% 128 == 0 (Cout=%d)", d->Cout);
+  p.n_tiles = p.Cout_pad / bn;
+  hipStream_t s = as::as_stream(stream);
+  long long nblk;
+  if (d->KS == 1) {
+    // no halo: run on the flattened H*W plane
+    AS_REQUIRE((long long)d->H * d->W < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: plane too large");
+    p.H = 1;
+    p.W = d->H * d->W;
+    p.tiles_x = as::cdiv(p.W, 128);
+    p.tiles_y = 1;
+    nblk = (long long)p.B * p.tiles_x * p.n_tiles;
+    AS_REQUIRE(nblk < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+    if (bn == 128) return launch_conv<1, 128, 128>(p, epi, s);
+    if (bn == 64) return launch_conv<1, 128, 64>(p, epi, s);
+    return launch_conv<1, 128, 32>(p, epi, s);
+  }
+  p.H = d->H;
+  p.W = d->W;
+  // pick the tile shape (TH x TW = 128 pixels) that wastes the fewest pixels on this image
+  int best_tw = 32;
+  long long best = -1;
+  for (int tw = 32; tw >= 8; tw >>= 1) {
+    const int th = 128 / tw;
+    const long long area = (long long)as::cdiv(p.W, tw) * tw * as::cdiv(p.H, th) * th;
+    if (best < 0 || area < best) { best = area; best_tw = tw; }
+  }
+  const int th = 128 / best_tw;
+  p.tiles_x = as::cdiv(p.W, best_tw);
+  p.tiles_y = as::cdiv(p.H, th);
+  nblk = (long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles;
+  AS_REQUIRE(nblk < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+  if (best_tw == 32) {
+    if (bn == 128) return launch_conv<3, 32, 128>(p, epi, s);
+    if (bn == 64) return launch_conv<3, 32, 64>(p, epi, s);
+    return launch_conv<3, 32, 32>(p, epi, s);
+  } else if (best_tw == 16) {
+    if (bn == 128) return launch_conv<3, 16, 128>(p, epi, s);
+    if (bn == 64) return launch_conv<3, 16, 64>(p, epi, s);
+    return launch_conv<3, 16, 32>(p, epi, s);
+  }
+  if (bn == 128) return launch_conv<3, 8, 128>(p, epi, s);
+  if (bn == 64) return launch_conv<3, 8, 64>(p, epi, s);
+  return launch_conv<3, 8, 32>(p, epi, s);
+}
+
+int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out, int B, int H, int W,
+                       int Cout, int out_ctot, int out_coff, void* stream) {
+  AS_REQUIRE(x && weight && out, AS_ERR_BAD_ARG, "conv7x7_c1: null pointer");
+  AS_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, AS_ERR_BAD_ARG, "conv7x7_c1: non-positive size");
+  AS_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctot, AS_ERR_BAD_SHAPE, "conv7x7_c1: out channel window outside out_ctot");
+  AS_REQUIRE(B <= 65535 && as::cdiv(H, 16) <= 65535, AS_ERR_BAD_SHAPE, "conv7x7_c1: grid too large");
+  dim3 grid((unsigned)as::cdiv(W, 16), (unsigned)as::cdiv(H, 16), (unsigned)B);
+  hipLaunchKernelGGL(conv7x7_c1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, out_ctot, out_coff);
+  return as::check_launch("conv7x7_c1_relu");
+}
+
+int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float* out, int B, int Cin, int H, int W, void* stream) {
+  AS_REQUIRE(x && weight && out, AS_ERR_BAD_ARG, "conv3x3_to1: null pointer");
+  AS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0, AS_ERR_BAD_ARG, "conv3x3_to1: non-positive size");
+  AS_REQUIRE(B <= 65535 && H <= 65535, AS_ERR_BAD_SHAPE, "conv3x3_to1: grid too large");
+  dim3 grid((unsigned)as::cdiv(W, 64), (unsigned)H, (unsigned)B);
+  hipLaunchKernelGGL(conv3x3_to1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, Cin, H, W);
+  return as::check_launch("conv3x3_to1");
+}
+
+int as_pool2x(const float* x, float* out, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(x && out, AS_ERR_BAD_ARG, "pool2x: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "pool2x: non-positive size");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)B * C * Ho * Wo;
+  hipLaunchKernelGGL(pool2x_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x, out, H, W, Ho, Wo, total);
+  return as::check_launch("pool2x");
+}
+
+int as_interp_bilinear_ac(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
+  AS_REQUIRE(x && out, AS_ERR_BAD_ARG, "interp: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, AS_ERR_BAD_ARG, "interp: non-positive size");
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long long total = (long long)B * C * Ho * Wo;
+  hipLaunchKernelGGL(interp_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x, out, H, W, Ho, Wo, sy, sx, total);
+  return as::check_launch("interp_bilinear_ac");
+}
+
+}  // extern "C"

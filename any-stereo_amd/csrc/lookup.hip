@@ -1,0 +1,352 @@
+// a3: fused multi-level geometry/correlation pyramid lookup (forward + backward), and
+// a18: the `corr_sampler` forward/backward contract as first-class HIP.
+//
+// HBM-bound gathers.  Mapping: one lane per 1/4-res pixel (consecutive lanes = consecutive x, so
+// every store of the NCHW output is a 256-B coalesced wave store); blockIdx.y enumerates the
+// independent (level, channel-quad | corr) tasks of a pixel so that a 960x540 frame (32 640
+// pixels) still launches ~3000 waves.  A pixel's (2r+2)-tap window is loaded into registers
+// once (one float4 per tap covers 4 geo channels in the [B,H,W,D,G] layout) and reused by
+// all 2r+1 interpolated taps: compulsory traffic only, no zero-init pass on the output.
+#include "common.h"
+
+namespace {
+
+struct LookupParams {
+  const float* geo[AS_MAX_LEVELS];
+  const float* corr[AS_MAX_LEVELS];
+  float* dgeo[AS_MAX_LEVELS];
+  float* dcorr[AS_MAX_LEVELS];
+  const float* disp;
+  const float* dout;
+  float* out;
+  int B, H, W, W2, D, G, L, radius;
+  int HW, CH;
+  long long P;
+};
+
+// position of tap k (kk = k - R) given the level-scaled base; returns window slot selection.
+//   xk = xbase + kk (one fp32 add, as the reference's `dx + disp/2**i`, geometry.py:43,52)
+//   result = (1-t)*w[k] + t*w[k+1], except when the add rounded xk up to the next integer
+//   (then floor(xk) = i0+kk+1, t = 0 and the sample is exactly w[k+1]).
+__device__ __forceinline__ void tap_weights(float xbase, int i0, int kk, float& t, bool& bump) {
+  const float xk = xbase + (float)kk;
+  const float fk = floorf(xk);
+  t = xk - fk;
+  bump = ((int)fk != i0 + kk);
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void lookup_fwd_kernel(LookupParams p) {
+  constexpr int K = 2 * R + 1;
+  constexpr int NW = 2 * R + 2;
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.P) return;
+  const int gq = p.G >> 2;
+  const int tpl = gq + 1;
+  const int level = blockIdx.y / tpl;
+  const int sub = blockIdx.y - level * tpl;
+  const int b = (int)(pix / p.HW);
+  const int rem = (int)(pix - (long long)b * p.HW);
+  const int x = rem % p.W;
+  const float ds = ldexpf(p.disp[pix], -level);  // disp / 2**i (exact)
+  float* outp = p.out + ((long long)b * p.CH + (long long)level * K * (p.G + 1)) * p.HW + rem;
+
+  if (sub < gq) {
+    const int Dl = p.D >> level;
+    const int i0 = (int)floorf(ds);
+    const float4* row = reinterpret_cast<const float4*>(p.geo[level] + (pix * Dl) * p.G + 4 * sub);
+    const int gstride = p.G >> 2;  // float4 units between consecutive disparities
+    float4 w[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int dd = i0 - R + j;
+      w[j] = (dd >= 0 && dd < Dl) ? row[(long long)dd * gstride] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float* o = outp + (long long)(4 * sub) * K * p.HW;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t;
+      bool bump;
+      tap_weights(ds, i0, k - R, t, bump);
+      const float a = bump ? 0.f : 1.f - t, c = bump ? 1.f : t;
+      const float4 v = make_float4(a * w[k].x + c * w[k + 1].x, a * w[k].y + c * w[k + 1].y,
+                                   a * w[k].z + c * w[k + 1].z, a * w[k].w + c * w[k + 1].w);
+      o[(long long)(0 * K + k) * p.HW] = v.x;
+      o[(long long)(1 * K + k) * p.HW] = v.y;
+      o[(long long)(2 * K + k) * p.HW] = v.z;
+      o[(long long)(3 * K + k) * p.HW] = v.w;
+    }
+  } else {
+    const int Wl = p.W2 >> level;
+    const float xs = ldexpf((float)x, -level);
+    const float xb = xs - ds;  // coords/2**i - disp/2**i
+    const int i0 = (int)floorf(xb);
+    const float* row = p.corr[level] + pix * Wl;
+    float w[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int dd = i0 - R + j;
+      w[j] = (dd >= 0 && dd < Wl) ? row[dd] : 0.f;
+    }
+    float* o = outp + (long long)p.G * K * p.HW;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t;
+      bool bump;
+      tap_weights(xb, i0, k - R, t, bump);
+      const float a = bump ? 0.f : 1.f - t, c = bump ? 1.f : t;
+      o[(long long)k * p.HW] = a * w[k] + c * w[k + 1];
+    }
+  }
+}
+
+// Backward w.r.t. the volumes: the transpose of the above.  Each (pixel, task) owns a private
+// window of its pixel's row, so the accumulated window is written with plain stores into the
+// caller-zeroed gradient (no atomics; same property as sampler_kernel.cu:63-104).
+template <int R>
+__global__ __launch_bounds__(256) void lookup_bwd_kernel(LookupParams p) {
+  constexpr int K = 2 * R + 1;
+  constexpr int NW = 2 * R + 2;
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.P) return;
+  const int gq = p.G >> 2;
+  const int tpl = gq + 1;
+  const int level = blockIdx.y / tpl;
+  const int sub = blockIdx.y - level * tpl;
+  const int b = (int)(pix / p.HW);
+  const int rem = (int)(pix - (long long)b * p.HW);
+  const int x = rem % p.W;
+  const float ds = ldexpf(p.disp[pix], -level);
+  const float* gp = p.dout + ((long long)b * p.CH + (long long)level * K * (p.G + 1)) * p.HW + rem;
+
+  if (sub < gq) {
+    const int Dl = p.D >> level;
+    const int i0 = (int)floorf(ds);
+    float4 w[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* g = gp + (long long)(4 * sub) * K * p.HW;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t;
+      bool bump;
+      tap_weights(ds, i0, k - R, t, bump);
+      const float a = bump ? 0.f : 1.f - t, c = bump ? 1.f : t;
+      const float gx = g[(long long)(0 * K + k) * p.HW], gy = g[(long long)(1 * K + k) * p.HW];
+      const float gz = g[(long long)(2 * K + k) * p.HW], gw = g[(long long)(3 * K + k) * p.HW];
+      w[k].x += a * gx; w[k].y += a * gy; w[k].z += a * gz; w[k].w += a * gw;
+      w[k + 1].x += c * gx; w[k + 1].y += c * gy; w[k + 1].z += c * gz; w[k + 1].w += c * gw;
+    }
+    float4* row = reinterpret_cast<float4*>(p.dgeo[level] + (pix * Dl) * p.G + 4 * sub);
+    const int gstride = p.G >> 2;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int dd = i0 - R + j;
+      if (dd >= 0 && dd < Dl) row[(long long)dd * gstride] = w[j];
+    }
+  } else {
+    const int Wl = p.W2 >> level;
+    const float xb = ldexpf((float)x, -level) - ds;
+    const int i0 = (int)floorf(xb);
+    float w[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w[j] = 0.f;
+    const float* g = gp + (long long)p.G * K * p.HW;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t;
+      bool bump;
+      tap_weights(xb, i0, k - R, t, bump);
+      const float a = bump ? 0.f : 1.f - t, c = bump ? 1.f : t;
+      const float gv = g[(long long)k * p.HW];
+      w[k] += a * gv;
+      w[k + 1] += c * gv;
+    }
+    float* row = p.dcorr[level] + pix * Wl;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int dd = i0 - R + j;
+      if (dd >= 0 && dd < Wl) row[dd] = w[j];
+    }
+  }
+}
+
+// ---- corr_sampler (a18) ------------------------------------------------------------------------
+// One lane per (n,y,x); runtime radius; the window is streamed with a running `prev` value so
+// each volume element is loaded once:  out[k] = s[k]*(1-dx) + s[k+1]*dx  (sampler_kernel.cu:45-59,
+// products and sums rounded in the volume dtype exactly as `scalar_t(dx)` arithmetic does).
+template <typename T>
+__global__ __launch_bounds__(256) void sampler_fwd_kernel(const T* __restrict__ vol, const float* __restrict__ coords,
+                                                          T* __restrict__ out, int H1, int W1, int W2, int r,
+                                                          int cch, long long P) {
+#pragma clang fp contract(off)
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const int hw = H1 * W1;
+  const int n = (int)(pix / hw);
+  const int rem = (int)(pix - (long long)n * hw);
+  const float x0 = coords[(long long)n * cch * hw + rem];
+  const float fl = floorf(x0);
+  const T dx = (T)(x0 - fl);
+  const T omdx = (T)(1.0f - (x0 - fl));
+  const int i0 = (int)fl - r;
+  const T* row = vol + pix * W2;
+  const int rd = 2 * r + 1;
+  T* o = out + (long long)n * rd * hw + rem;
+  T prev = (T)0;
+  for (int i = 0; i <= rd; ++i) {
+    const int x1 = i0 + i;
+    const T s = (x1 >= 0 && x1 < W2) ? row[x1] : (T)0;
+    if (i > 0) o[(long long)(i - 1) * hw] = prev * omdx + s * dx;
+    prev = s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sampler_bwd_kernel(const float* __restrict__ coords, const T* __restrict__ cg,
+                                                          T* __restrict__ vg, int H1, int W1, int W2, int r, int cch,
+                                                          long long P) {
+#pragma clang fp contract(off)
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const int hw = H1 * W1;
+  const int n = (int)(pix / hw);
+  const int rem = (int)(pix - (long long)n * hw);
+  const float x0 = coords[(long long)n * cch * hw + rem];
+  const float fl = floorf(x0);
+  const T dx = (T)(x0 - fl);
+  const T omdx = (T)(1.0f - (x0 - fl));
+  const int i0 = (int)fl - r;
+  T* row = vg + pix * W2;
+  const int rd = 2 * r + 1;
+  const T* g = cg + (long long)n * rd * hw + rem;
+  // the whole row is written (zeros outside the window): volume_grad needs no memset
+  T gprev = (T)0;
+  int lo = i0 < 0 ? 0 : i0;
+  int hi = i0 + rd;  // inclusive last window index
+  if (hi > W2 - 1) hi = W2 - 1;
+  for (int x1 = 0; x1 < (lo < W2 ? lo : W2); ++x1) row[x1] = (T)0;
+  for (int i = 0; i <= rd; ++i) {
+    const int x1 = i0 + i;
+    const T gcur = (i < rd) ? g[(long long)i * hw] : (T)0;
+    // sampler_kernel.cu:95-101: g = corr_grad[i-1]*dx (i>0)  +  corr_grad[i]*(1-dx) (i<rd)
+    T acc = (T)0;
+    if (i > 0) acc = acc + gprev * dx;
+    if (i < rd) acc = acc + gcur * omdx;
+    if (x1 >= 0 && x1 < W2) row[x1] = acc;
+    gprev = gcur;
+  }
+  for (int x1 = (hi + 1 > 0 ? hi + 1 : 0); x1 < W2; ++x1) row[x1] = (T)0;
+}
+
+int fill_common(LookupParams& p, int B, int H, int W, int W2, int D, int G, int L, int radius) {
+  AS_REQUIRE(B > 0 && H > 0 && W > 0 && W2 > 0, AS_ERR_BAD_ARG, "lookup: non-positive size B=%d H=%d W=%d W2=%d", B, H, W, W2);
+  AS_REQUIRE(L >= 1 && L <= AS_MAX_LEVELS, AS_ERR_BAD_ARG, "lookup: L=%d outside [1,%d]", L, AS_MAX_LEVELS);
+  AS_REQUIRE(G >= 0 && (G % 4) == 0, AS_ERR_BAD_ARG, "lookup: G=%d must be a multiple of 4 (float4 channel quads)", G);
+  AS_REQUIRE(G == 0 || D > 0, AS_ERR_BAD_ARG, "lookup: D=%d", D);
+  AS_REQUIRE(radius >= 1 && radius <= 4, AS_ERR_BAD_ARG, "lookup: radius=%d outside the supported [1,4]", radius);
+  AS_REQUIRE((W2 >> (L - 1)) >= 1 && (G == 0 || (D >> (L - 1)) >= 1), AS_ERR_BAD_SHAPE,
+             "lookup: level %d of the pyramid is empty (W2=%d D=%d)", L - 1, W2, D);
+  AS_REQUIRE((long long)B * H * W * (long long)(2 * radius + 1) * L * (G + 1) < (1ll << 40), AS_ERR_BAD_SHAPE, "lookup: too large");
+  p.B = B; p.H = H; p.W = W; p.W2 = W2; p.D = D; p.G = G; p.L = L; p.radius = radius;
+  p.HW = H * W;
+  p.CH = L * (2 * radius + 1) * (G + 1);
+  p.P = (long long)B * H * W;
+  return AS_OK;
+}
+
+}  // namespace
+
+#define LAUNCH_LOOKUP(KERNEL, p, stream)                                                     \
+  do {                                                                                      \
+    dim3 grid((unsigned)as::cdiv64((p).P, 256), (unsigned)((p).L * (((p).G >> 2) + 1)));     \
+    switch ((p).radius) {                                                                    \
+      case 1: hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, as::as_stream(stream), p); break; \
+      case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), 0, as::as_stream(stream), p); break; \
+      case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(256), 0, as::as_stream(stream), p); break; \
+      default: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, as::as_stream(stream), p); break; \
+    }                                                                                       \
+  } while (0)
+
+extern "C" {
+
+int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, const float* disp, float* out,
+                           int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream) {
+  LookupParams p{};
+  int rc = fill_common(p, B, H, W, W2, D, G, L, radius);
+  if (rc != AS_OK) return rc;
+  AS_REQUIRE(corr && disp && out && (G == 0 || geo), AS_ERR_BAD_ARG, "lookup_fwd: null pointer");
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(corr[i] && (G == 0 || geo[i]), AS_ERR_BAD_ARG, "lookup_fwd: null level %d", i);
+    p.corr[i] = corr[i];
+    p.geo[i] = G ? geo[i] : nullptr;
+    AS_REQUIRE(G == 0 || (reinterpret_cast<uintptr_t>(geo[i]) & 15) == 0, AS_ERR_BAD_ARG, "lookup_fwd: geo[%d] not 16-B aligned", i);
+  }
+  p.disp = disp;
+  p.out = out;
+  LAUNCH_LOOKUP(lookup_fwd_kernel, p, stream);
+  return as::check_launch("geo_corr_lookup_fwd");
+}
+
+int as_geo_corr_lookup_bwd(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr,
+                           int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream) {
+  LookupParams p{};
+  int rc = fill_common(p, B, H, W, W2, D, G, L, radius);
+  if (rc != AS_OK) return rc;
+  AS_REQUIRE(d_corr && disp && d_out && (G == 0 || d_geo), AS_ERR_BAD_ARG, "lookup_bwd: null pointer");
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(d_corr[i] && (G == 0 || d_geo[i]), AS_ERR_BAD_ARG, "lookup_bwd: null level %d", i);
+    p.dcorr[i] = d_corr[i];
+    p.dgeo[i] = G ? d_geo[i] : nullptr;
+    AS_REQUIRE(G == 0 || (reinterpret_cast<uintptr_t>(d_geo[i]) & 15) == 0, AS_ERR_BAD_ARG, "lookup_bwd: d_geo[%d] not 16-B aligned", i);
+  }
+  p.disp = disp;
+  p.dout = d_out;
+  LAUNCH_LOOKUP(lookup_bwd_kernel, p, stream);
+  return as::check_launch("geo_corr_lookup_bwd");
+}
+
+static int sampler_check(const void* a, const void* b, const void* c, int N, int H1, int W1, int W2, int radius,
+                         int cch, int dtype) {
+  AS_REQUIRE(a && b && c, AS_ERR_BAD_ARG, "corr_sampler: null pointer");
+  AS_REQUIRE(N > 0 && H1 > 0 && W1 > 0 && W2 > 0, AS_ERR_BAD_ARG, "corr_sampler: non-positive size");
+  AS_REQUIRE(radius >= 0 && radius <= 64, AS_ERR_BAD_ARG, "corr_sampler: radius=%d", radius);
+  AS_REQUIRE(cch == 1 || cch == 2, AS_ERR_BAD_ARG, "corr_sampler: coords must have 1 or 2 channels, got %d", cch);
+  AS_REQUIRE(dtype == AS_F32 || dtype == AS_F16 || dtype == AS_F64, AS_ERR_BAD_ARG, "corr_sampler: dtype code %d", dtype);
+  AS_REQUIRE((long long)N * H1 * W1 * (long long)W2 < (1ll << 40), AS_ERR_BAD_SHAPE, "corr_sampler: too large");
+  return AS_OK;
+}
+
+int as_corr_sampler_fwd(const void* volume, const float* coords, void* out, int N, int H1, int W1, int W2, int radius,
+                        int coords_channels, int dtype, void* stream) {
+  int rc = sampler_check(volume, coords, out, N, H1, W1, W2, radius, coords_channels, dtype);
+  if (rc != AS_OK) return rc;
+  const long long P = (long long)N * H1 * W1;
+  dim3 grid((unsigned)as::cdiv64(P, 256));
+  hipStream_t s = as::as_stream(stream);
+  if (dtype == AS_F32)
+    hipLaunchKernelGGL(sampler_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)volume, coords, (float*)out, H1, W1, W2, radius, coords_channels, P);
+  else if (dtype == AS_F16)
+    hipLaunchKernelGGL(sampler_fwd_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)volume, coords, (_Float16*)out, H1, W1, W2, radius, coords_channels, P);
+  else
+    hipLaunchKernelGGL(sampler_fwd_kernel<double>, grid, dim3(256), 0, s, (const double*)volume, coords, (double*)out, H1, W1, W2, radius, coords_channels, P);
+  return as::check_launch("corr_sampler_fwd");
+}
+
+int as_corr_sampler_bwd(const float* coords, const void* corr_grad, void* volume_grad, int N, int H1, int W1, int W2,
+                        int radius, int coords_channels, int dtype, void* stream) {
+  int rc = sampler_check(coords, corr_grad, volume_grad, N, H1, W1, W2, radius, coords_channels, dtype);
+  if (rc != AS_OK) return rc;
+  const long long P = (long long)N * H1 * W1;
+  dim3 grid((unsigned)as::cdiv64(P, 256));
+  hipStream_t s = as::as_stream(stream);
+  if (dtype == AS_F32)
+    hipLaunchKernelGGL(sampler_bwd_kernel<float>, grid, dim3(256), 0, s, coords, (const float*)corr_grad, (float*)volume_grad, H1, W1, W2, radius, coords_channels, P);
+  else if (dtype == AS_F16)
+    hipLaunchKernelGGL(sampler_bwd_kernel<_Float16>, grid, dim3(256), 0, s, coords, (const _Float16*)corr_grad, (_Float16*)volume_grad, H1, W1, W2, radius, coords_channels, P);
+  else
+    hipLaunchKernelGGL(sampler_bwd_kernel<double>, grid, dim3(256), 0, s, coords, (const double*)corr_grad, (double*)volume_grad, H1, W1, W2, radius, coords_channels, P);
+  return as::check_launch("corr_sampler_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+// a1+a2: all-pairs correlation with the pooled pyramid fused into the epilogue (fp32 MFMA),
+// a2:    geometry-encoding-volume pyramid (transpose to the disparity-major lookup layout + pooling),
+// a4:    group-wise correlation volume,  a5: softmax + disparity regression.
+//
+// All four are one-shot (once per stereo pair) and HBM-bound: each input element is read once per
+// consumer tile (re-reads are L1/L2 hits) and every output element is written exactly once.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ------------------------------------------------------------------------------------------------
+// corr[b,y,x1,x2] = sum_c f1[b,c,y,x1] f2[b,c,y,x2]  — one (b,y) row is a (W1 x C)·(C x W2) GEMM.
+// v_mfma_f32_32x32x2_f32: A[i=x1][k=c] and B[k=c][j=x2] are both "index = lane&31, k = lane>>5", and in
+// NCHW a lane's element for both operands is f[b, c, y, x] with x contiguous across lanes, so the
+// fragments are loaded straight from global memory as 128-B coalesced runs (no LDS round trip).
+// C/D layout: col j = lane&31 = x2 (contiguous in the output row), row i = x1 from the register
+// index, so pooled level l (mean of 2^l adjacent x2) is a butterfly over lanes xor 1,2,4 and the
+// whole pyramid is written from registers: the level-0 volume is never re-read.
+// ------------------------------------------------------------------------------------------------
+struct CorrParams {
+  const float* f1;
+  const float* f2;
+  float* lvl[AS_MAX_LEVELS];
+  int B, C, H, W1, W2, L;
+  int MT, NT;  // 32-wide tiles along x1 / x2
+};
+
+constexpr int kNG = 4;  // N-tiles accumulated per pass (4 x 16 accumulator registers)
+
+__global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int row = blockIdx.x;  // b*H + y
+  const int b = row / p.H;
+  const int y = row - b * p.H;
+  const int mt = blockIdx.y * 4 + wave;
+  if (mt >= p.MT) return;
+  const long long cs1 = (long long)p.H * p.W1;  // channel stride
+  const long long cs2 = (long long)p.H * p.W2;
+  const int x1 = mt * 32 + l31;
+  const bool ok1 = x1 < p.W1;
+  const float* a_ptr = p.f1 + ((long long)b * p.C + half) * cs1 + (long long)y * p.W1 + (ok1 ? x1 : 0);
+  const float* b_base = p.f2 + ((long long)b * p.C + half) * cs2 + (long long)y * p.W2;
+  const int ksteps = (p.C + 1) >> 1;
+
+  for (int nt0 = 0; nt0 < p.NT; nt0 += kNG) {
+    f32x16 acc[kNG];
+#pragma unroll
+    for (int j = 0; j < kNG; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    int xc[kNG];
+    bool okc[kNG];
+#pragma unroll
+    for (int j = 0; j < kNG; ++j) {
+      xc[j] = (nt0 + j) * 32 + l31;
+      okc[j] = xc[j] < p.W2;
+      if (!okc[j]) xc[j] = 0;
+    }
+#pragma unroll 4
+    for (int kk = 0; kk < ksteps; ++kk) {
+      const bool okk = (2 * kk + half) < p.C;
+      const float a = (ok1 && okk) ? a_ptr[(long long)(2 * kk) * cs1] : 0.f;
+      const float* bp = b_base + (long long)(2 * kk) * cs2;
+#pragma unroll
+      for (int j = 0; j < kNG; ++j) {
+        const float bv = (okc[j] && okk) ? bp[xc[j]] : 0.f;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+      }
+    }
+    // epilogue: level 0 + pooled levels
+    const long long rowbase = (long long)row * p.W1;
+#pragma unroll
+    for (int j = 0; j < kNG; ++j) {
+      const int x2 = (nt0 + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int xr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool okr = xr < p.W1;
+        float v = acc[j][r];
+        if (okr && x2 < p.W2) p.lvl[0][(rowbase + xr) * p.W2 + x2] = v;
+        // butterfly: after step s the lanes with (l31 & (2^s - 1)) == 0 hold the level-s value
+#pragma unroll
+        for (int s = 1; s < AS_MAX_LEVELS; ++s) {
+          if (s < p.L) {
+            v = (v + __shfl_xor(v, 1 << (s - 1))) * 0.5f;
+            const int wl = p.W2 >> s;
+            const int xs = x2 >> s;
+            if (okr && (l31 & ((1 << s) - 1)) == 0 && xs < wl) p.lvl[s][(rowbase + xr) * wl + xs] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gev [B,G,D,H,W] -> level i [B,H,W,D>>i,G].  32 consecutive pixels of a row per block; the
+// (g,d) x pixel tile is transposed through LDS so that both the read (x-contiguous) and the write
+// (one pixel's D*G run = 1.5 KB contiguous) are coalesced.
+// ------------------------------------------------------------------------------------------------
+struct GeoParams {
+  const float* gev;
+  float* lvl[AS_MAX_LEVELS];
+  int B, G, D, H, W, L;
+};
+
+__device__ __forceinline__ float geo_pooled(const float* tile, int g, int d, int level, int D, int px) {
+  // mean over the 2^level raw disparities [d<<level, (d+1)<<level) of channel g, as repeated pair means
+  // ((a+b)/2 of (a+b)/2 ...) — bitwise what repeated avg_pool2d computes.
+  float v[8];
+  const int n = 1 << level;
+  for (int i = 0; i < n; ++i) v[i] = tile[(g * D + (d << level) + i) * 33 + px];
+  for (int s = n; s > 1; s >>= 1)
+    for (int i = 0; i < (s >> 1); ++i) v[i] = (v[2 * i] + v[2 * i + 1]) * 0.5f;
+  return v[0];
+}
+
+__global__ __launch_bounds__(256) void geo_pyramid_kernel(GeoParams p) {
+  extern __shared__ float tile[];  // [G*D][33]
+  const int xt = blockIdx.x;
+  const int row = blockIdx.y;  // b*H + y
+  const int b = row / p.H;
+  const int y = row - b * p.H;
+  const int x0 = xt * 32;
+  const int GD = p.G * p.D;
+  const long long plane = (long long)p.H * p.W;
+  const float* src = p.gev + (long long)b * GD * plane + (long long)y * p.W + x0;
+  for (int idx = threadIdx.x; idx < GD * 32; idx += 256) {
+    const int gd = idx >> 5, px = idx & 31;
+    tile[gd * 33 + px] = (x0 + px < p.W) ? src[(long long)gd * plane + px] : 0.f;
+  }
+  __syncthreads();
+  const int npx = min(32, p.W - x0);
+  const long long pix0 = (long long)row * p.W + x0;
+  for (int lv = 0; lv < p.L; ++lv) {
+    const int Dl = p.D >> lv;
+    const int per = Dl * p.G;
+    float* dst = p.lvl[lv] + pix0 * per;
+    for (int idx = threadIdx.x; idx < npx * per; idx += 256) {
+      const int px = idx / per;
+      const int rem = idx - px * per;
+      const int d = rem / p.G, g = rem - d * p.G;
+      dst[idx] = geo_pooled(tile, g, d, lv, p.D, px);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4  vol[b,g,d,y,x] = mean_{c in group g} fl[b,c,y,x] * fr[b,c,y,x-d]  (0 for x<d).
+// Block = 64 consecutive x of one row; fl tile and fr tile(+D-1 halo) staged in LDS once, each
+// of the 4 waves owns a quarter of the disparities and keeps its accumulators in registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGwcMaxDpt = 16;
+
+template <int DPT>
+__global__ __launch_bounds__(256) void gwc_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
+                                                  float* __restrict__ out, int B, int C, int H, int W, int D, int G) {
+  extern __shared__ float sm[];
+  const int FW = 64 + D - 1;
+  float* fl_s = sm;             // [C][64]
+  float* fr_s = sm + C * 64;    // [C][FW], local index = (x - x0) - d + (D-1)
+  const int row = blockIdx.y;
+  const int b = row / H;
+  const int y = row - b * H;
+  const int x0 = blockIdx.x * 64;
+  const long long plane = (long long)H * W;
+  const float* flp = fl + (long long)b * C * plane + (long long)y * W;
+  const float* frp = fr + (long long)b * C * plane + (long long)y * W;
+  for (int idx = threadIdx.x; idx < C * 64; idx += 256) {
+    const int c = idx >> 6, lx = idx & 63;
+    fl_s[idx] = (x0 + lx < W) ? flp[(long long)c * plane + x0 + lx] : 0.f;
+  }
+  for (int idx = threadIdx.x; idx < C * FW; idx += 256) {
+    const int c = idx / FW, j = idx - c * FW;
+    const int xs = x0 + j - (D - 1);
+    fr_s[idx] = (xs >= 0 && xs < W) ? frp[(long long)c * plane + xs] : 0.f;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 63;
+  const int dg = threadIdx.x >> 6;
+  const int dpt = (D + 3) >> 2;
+  const int d0 = dg * dpt;
+  const int cg = C / G;
+  const float inv = 1.0f / (float)cg;
+  const int x = x0 + lx;
+  for (int g = 0; g < G; ++g) {
+    float acc[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) acc[i] = 0.f;
+    for (int c = 0; c < cg; ++c) {
+      const float a = fl_s[(g * cg + c) * 64 + lx];
+      const float* r = fr_s + (g * cg + c) * FW + lx + (D - 1) - d0;
+#pragma unroll
+      for (int i = 0; i < DPT; ++i)
+        if (i < dpt && d0 + i < D) acc[i] += a * r[-i];
+    }
+    if (x < W) {
+#pragma unroll
+      for (int i = 0; i < DPT; ++i) {
+        const int d = d0 + i;
+        if (i < dpt && d < D) out[(((long long)b * G + g) * D + d) * plane + (long long)y * W + x] = acc[i] * inv;
+      }
+    }
+  }
+}
+
+// a5  out[b,0,y,x] = sum_d d * softmax_d(cost[b,:,y,x])
+__global__ __launch_bounds__(256) void softmax_dispreg_kernel(const float* __restrict__ cost, float* __restrict__ out,
+                                                              int D, long long plane, long long P, int softmax) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const long long b = pix / plane;
+  const long long rem = pix - b * plane;
+  const float* c = cost + b * D * plane + rem;
+  if (!softmax) {
+    float acc = 0.f;
+    for (int d = 0; d < D; ++d) acc += c[(long long)d * plane] * (float)d;
+    out[pix] = acc;
+    return;
+  }
+  float m = -INFINITY;
+  for (int d = 0; d < D; ++d) m = fmaxf(m, c[(long long)d * plane]);
+  float s = 0.f, sd = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float e = expf(c[(long long)d * plane] - m);
+    s += e;
+    sd += e * (float)d;
+  }
+  out[pix] = sd / s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels, int B, int C, int H, int W1, int W2,
+                          int L, void* stream) {
+  AS_REQUIRE(f1 && f2 && levels, AS_ERR_BAD_ARG, "corr_build: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W1 > 0 && W2 > 0, AS_ERR_BAD_ARG, "corr_build: non-positive size");
+  AS_REQUIRE(L >= 1 && L <= AS_MAX_LEVELS, AS_ERR_BAD_ARG, "corr_build: L=%d outside [1,%d]", L, AS_MAX_LEVELS);
+  AS_REQUIRE((W2 >> (L - 1)) >= 1, AS_ERR_BAD_SHAPE, "corr_build: W2=%d too small for %d levels", W2, L);
+  AS_REQUIRE((long long)B * H < 2147483647ll && (long long)B * H * W1 * (long long)W2 < (1ll << 40), AS_ERR_BAD_SHAPE, "corr_build: too large");
+  CorrParams p{};
+  p.f1 = f1; p.f2 = f2; p.B = B; p.C = C; p.H = H; p.W1 = W1; p.W2 = W2; p.L = L;
+  p.MT = as::cdiv(W1, 32);
+  p.NT = as::cdiv(W2, 32);
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(levels[i], AS_ERR_BAD_ARG, "corr_build: null level %d", i);
+    p.lvl[i] = levels[i];
+  }
+  dim3 grid((unsigned)(B * H), (unsigned)as::cdiv(p.MT, 4));
+  hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("corr_build_pyramid");
+}
+
+int as_geo_pyramid(const float* gev, float* const* levels, int B, int G, int D, int H, int W, int L, void* stream) {
+  AS_REQUIRE(gev && levels, AS_ERR_BAD_ARG, "geo_pyramid: null pointer");
+  AS_REQUIRE(B > 0 && G > 0 && D > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "geo_pyramid: non-positive size");
+  AS_REQUIRE(L >= 1 && L <= AS_MAX_LEVELS && (D >> (L - 1)) >= 1, AS_ERR_BAD_ARG, "geo_pyramid: L=%d D=%d", L, D);
+  const size_t lds = (size_t)G * D * 33 * sizeof(float);
+  AS_REQUIRE(lds <= 160 * 1024, AS_ERR_BAD_SHAPE, "geo_pyramid: G*D=%d needs %zu B of LDS (> 160 KiB)", G * D, lds);
+  AS_REQUIRE((long long)B * H <= 65535, AS_ERR_BAD_SHAPE, "geo_pyramid: B*H=%lld exceeds grid.y", (long long)B * H);
+  GeoParams p{};
+  p.gev = gev; p.B = B; p.G = G; p.D = D; p.H = H; p.W = W; p.L = L;
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(levels[i], AS_ERR_BAD_ARG, "geo_pyramid: null level %d", i);
+    p.lvl[i] = levels[i];
+  }
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)geo_pyramid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((unsigned)as::cdiv(W, 32), (unsigned)(B * H));
+  hipLaunchKernelGGL(geo_pyramid_kernel, grid, dim3(256), lds, as::as_stream(stream), p);
+  return as::check_launch("geo_pyramid");
+}
+
+int as_gwc_volume_fwd(const float* fl, const float* fr, float* out, int B, int C, int H, int W, int D, int G, void* stream) {
+  AS_REQUIRE(fl && fr && out, AS_ERR_BAD_ARG, "gwc: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0 && G > 0, AS_ERR_BAD_ARG, "gwc: non-positive size");
+  AS_REQUIRE(C % G == 0, AS_ERR_BAD_SHAPE, "gwc: C=%d not divisible by G=%d", C, G);
+  AS_REQUIRE(D <= 4 * kGwcMaxDpt, AS_ERR_BAD_SHAPE, "gwc: D=%d above the supported %d", D, 4 * kGwcMaxDpt);
+  AS_REQUIRE((long long)B * H <= 65535, AS_ERR_BAD_SHAPE, "gwc: B*H=%lld exceeds grid.y", (long long)B * H);
+  const size_t lds = (size_t)C * (64 + 64 + D - 1) * sizeof(float);
+  AS_REQUIRE(lds <= 160 * 1024, AS_ERR_BAD_SHAPE, "gwc: C=%d D=%d needs %zu B of LDS (> 160 KiB)", C, D, lds);
+  dim3 grid((unsigned)as::cdiv(W, 64), (unsigned)(B * H));
+  const int dpt = (D + 3) / 4;
+  if (dpt <= 12) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gwc_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gwc_kernel<12>, grid, dim3(256), lds, as::as_stream(stream), fl, fr, out, B, C, H, W, D, G);
+  } else {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gwc_kernel<kGwcMaxDpt>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gwc_kernel<kGwcMaxDpt>, grid, dim3(256), lds, as::as_stream(stream), fl, fr, out, B, C, H, W, D, G);
+  }
+  return as::check_launch("gwc_volume_fwd");
+}
+
+int as_disparity_regression(const float* cost, float* out, int B, int D, int H, int W, int apply_softmax, void* stream) {
+  AS_REQUIRE(cost && out, AS_ERR_BAD_ARG, "dispreg: null pointer");
+  AS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "dispreg: non-positive size");
+  const long long plane = (long long)H * W, P = plane * B;
+  hipLaunchKernelGGL(softmax_dispreg_kernel, dim3((unsigned)as::cdiv64(P, 256)), dim3(256), 0, as::as_stream(stream), cost, out, D, plane, P, apply_softmax);
+  return as::check_launch("disparity_regression");
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+/*
+ * anystereo_hip.h — C ABI of libanystereo_hip.so, the MI355X (gfx950) implementation of
+ * Any-Stereo's data-parallel hot path.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes + a stream; no torch / C++ types cross this boundary.
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated otherwise; tensors are dense,
+ *     row-major in the index order written in the comment.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Launchers never
+ *     allocate, synchronise or touch global state, so they are re-entrant and safe under
+ *     hipStreamBeginCapture (hipGraph).
+ *   - return value: AS_OK (0) or a negative AS_ERR_* code; as_last_error_string() describes the
+ *     last failure on the calling thread.  Shapes are validated on the host BEFORE any launch
+ *     (the reference performs no shape checks: sampler/sampler.cpp:20-22 checks device+contiguity only).
+ *   - outputs are caller-allocated and fully overwritten (no zero-init requirement; the reference
+ *     allocates zeros and accumulates, sampler/sampler_kernel.cu:122-124,148).
+ *
+ * "replaces" = the reference interface (file:line under /root/reference) each entry point stands in for.
+ */
+#ifndef ANYSTEREO_HIP_H
+#define ANYSTEREO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AS_OK 0
+#define AS_ERR_BAD_ARG (-1)    /* null pointer / non-positive size / unsupported combination */
+#define AS_ERR_BAD_SHAPE (-2)  /* sizes inconsistent with each other or above the supported maximum */
+#define AS_ERR_LAUNCH (-3)     /* hipGetLastError() != hipSuccess after the launch */
+#define AS_ERR_NO_DEVICE (-4)
+
+#define AS_MAX_LEVELS 4
+#define AS_MAX_SRCS 4
+
+/* dtype codes for as_corr_sampler_* (the reference dispatches f64/f32/f16: sampler_kernel.cu:126) */
+#define AS_F32 0
+#define AS_F16 1
+#define AS_F64 2
+
+/* activation / epilogue codes for as_conv2d */
+#define AS_ACT_NONE 0
+#define AS_ACT_RELU 1
+#define AS_ACT_SIGMOID 2
+#define AS_ACT_TANH 3
+#define AS_EPI_LINEAR 0 /* out = act(acc + bias + add)                                            */
+#define AS_EPI_GRU_ZR 1 /* co <  Cout/2: z  = sigmoid(acc+bias+add)        -> out  [B,Cout/2,H,W]
+                           co >= Cout/2: rh = sigmoid(acc+bias+add) * h    -> out2 [B,Cout/2,H,W]  */
+#define AS_EPI_GRU_Q 2  /* out = (1-z)*h + z*tanh(acc+bias+add)            (update.py:39-40)      */
+
+const char* as_last_error_string(void);
+int as_abi_version(void);        /* bumped on any signature change */
+int as_device_count(void);       /* hipGetDeviceCount; 0 on a CPU-only host */
+
+/* ---------------------------------------------------------------------------------------------
+ * a18  corr_sampler — replaces sampler/sampler.cpp:24-45 (`corr_sampler.forward/backward`),
+ *      kernels sampler/sampler_kernel.cu:19-60 and :63-104.
+ *   volume [N,H1,W1,W2] (dtype), coords [N,2,H1,W1] fp32 (channel 0 = x; channel 1 is never read —
+ *   the reference reads it only for an unused `dy`, :40-43), out/corr_grad [N,2r+1,H1,W1] (dtype),
+ *   volume_grad [N,H1,W1,W2] (dtype).  coords_channels is 1 or 2 (batch stride of coords).
+ * ------------------------------------------------------------------------------------------- */
+int as_corr_sampler_fwd(const void* volume, const float* coords, void* out,
+                        int N, int H1, int W1, int W2, int radius, int coords_channels, int dtype, void* stream);
+int as_corr_sampler_bwd(const float* coords, const void* corr_grad, void* volume_grad,
+                        int N, int H1, int W1, int W2, int radius, int coords_channels, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1+a2  all-pairs correlation + pooled pyramid in one pass — replaces
+ *   Combined_Geo_Encoding_Volume.corr + the init_corr pyramid (coreContinuous_IGEV/geometry.py:63-72,:27-29)
+ *   and CorrBlock1D (corePrune_RAFT/geometry.py:46-55,:17-19).
+ *   f1 [B,C,H,W1], f2 [B,C,H,W2]; levels[i] [B,H,W1,W2>>i] for i < L (1..AS_MAX_LEVELS).
+ * ------------------------------------------------------------------------------------------- */
+int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels,
+                          int B, int C, int H, int W1, int W2, int L, void* stream);
+
+/* a2 (geo half): gev [B,G,D,H,W] -> levels[i] [B,H,W,D>>i,G] (disparity-major, channel-minor so a
+ * (2r+2)-tap window of all G channels is one contiguous run) — replaces geometry.py:17-25.       */
+int as_geo_pyramid(const float* gev, float* const* levels, int B, int G, int D, int H, int W, int L, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3  fused multi-level lookup — replaces Combined_Geo_Encoding_Volume.__call__ (geometry.py:34-60),
+ *   CorrBlock1D.__call__ (corePrune_RAFT/geometry.py:24-43) and bilinear_sampler (utils.py:59-73).
+ *   geo[i] as produced by as_geo_pyramid (G may be 0 and geo NULL: RAFT), corr[i] as produced by
+ *   as_corr_build_pyramid, disp [B,1,H,W]; out [B, L*(2r+1)*(G+1), H, W].  The x coordinate grid
+ *   (`coords`, continuous_IGEVstereo.py:280) is the pixel column and is generated in-kernel.
+ * ------------------------------------------------------------------------------------------- */
+int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, const float* disp, float* out,
+                           int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
+/* backward of the above w.r.t. the volumes (disp is detached by the caller, continuous_IGEVstereo.py:285):
+ * d_geo[i], d_corr[i] must be ZERO-FILLED by the caller; rows are pixel-private so no atomics are used. */
+int as_geo_corr_lookup_bwd(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr,
+                           int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a4  group-wise correlation volume — replaces build_gwc_volume / groupwise_correlation
+ *   (coreContinuous_IGEV/submodule.py:253-271).  fl, fr [B,C,H,W]; out [B,G,D,H,W]; C % G == 0.
+ * a5  (softmax over D +) disparity regression — replaces F.softmax(...)+disparity_regression
+ *   (continuous_IGEVstereo.py:267-268, submodule.py:321-325).  cost [B,D,H,W] -> out [B,1,H,W];
+ *   apply_softmax != 0: cost holds logits (fused path); 0: cost is already a probability volume.
+ * ------------------------------------------------------------------------------------------- */
+int as_gwc_volume_fwd(const float* fl, const float* fr, float* out, int B, int C, int H, int W, int D, int G, void* stream);
+int as_disparity_regression(const float* cost, float* out, int B, int D, int H, int W, int apply_softmax, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6/a7/a9/a15  implicit-GEMM convolution on fp32 MFMA with fused epilogues — replaces the nn.Conv2d
+ *   calls of BasicMotionEncoder (update.py:84-92), ConvGRU (update.py:33-41), DispHead (update.py:23-24)
+ *   and the nn.Linear stack of MLP (liif.py:22-25; a Linear over [B*Q,C] is a 1x1 conv over [B,C,1,Q]).
+ *   stride 1, "same" zero padding (pad = K/2), square odd kernel KS in {1,3}.
+ *   The input is the channel concatenation of n_src tensors src[s] [B,src_c[s],H,W] (torch.cat-free).
+ *   wpack: weights re-laid out by as_conv_pack_weights.  bias [Cout] or NULL.  add [B,Cout,H,W] or NULL
+ *   (the GRU context terms cz/cr/cq).  See AS_EPI_* for out/out2/h/z.  out_ctot/out_coff write the
+ *   result into channels [out_coff, out_coff+Cout) of a [B,out_ctot,H,W] tensor (cat-free producers).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src[AS_MAX_SRCS];
+  int src_c[AS_MAX_SRCS];
+  int n_src;
+  const float* wpack;
+  const float* bias;
+  const float* add;   /* [B, add_ctot, H, W], channels [add_coff, add_coff+Cout) are used */
+  int add_ctot, add_coff;
+  const float* h;     /* AS_EPI_GRU_ZR / AS_EPI_GRU_Q: hidden state [B,Cout(/2),H,W] */
+  const float* z;     /* AS_EPI_GRU_Q */
+  float* out;
+  float* out2;        /* AS_EPI_GRU_ZR */
+  int out_ctot, out_coff;
+  int B, H, W, Cin, Cout, KS;
+  int act, epilogue;
+} as_conv_desc;
+int as_conv2d(const as_conv_desc* d, void* stream);
+/* weight [Cout,Cin,KS,KS] (nn.Conv2d layout) -> wpack; returns the element count needed when wpack==NULL */
+int64_t as_conv_pack_size(int Cin, int Cout, int KS);
+int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, int KS, void* stream);
+
+/* direct (VALU) convolutions for the two shapes where an MFMA tile would be mostly padding:
+ *   convd1: 7x7, 1 -> Cout, +bias, ReLU   (update.py:81,87);   conv2 of DispHead: 3x3, Cin -> 1, +bias (update.py:19,24) */
+int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out,
+                       int B, int H, int W, int Cout, int out_ctot, int out_coff, void* stream);
+int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float* out,
+                   int B, int Cin, int H, int W, void* stream);
+
+/* a8  pool2x = avg_pool2d(3,stride 2,pad 1) (update.py:94-95); interp = bilinear align_corners=True
+ *     resize (update.py:100-102).  x [B,C,H,W] -> out [B,C,Ho,Wo].                                */
+int as_pool2x(const float* x, float* out, int B, int C, int H, int W, void* stream);
+int as_interp_bilinear_ac(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a12/a13  cosine affinity to the 8 neighbours, written straight into channels [C, C+8) of the
+ *   concatenated structure feature — replaces AffinityFeature.forward (liif.py:432-446) and the
+ *   'with_v2ISU' branch of StructureFeature.forward (liif.py:496-499).
+ *   x [B,C,H,W] -> out [B,C+8,H,W] (channels [0,C) = x copied, [C,C+8) = affinity); ws = caller-provided
+ *   [B,H,W] scratch that receives the clamped per-pixel L2 norm.
+ * a14  nearest gather + relative coordinate — replaces liif_feat_multiscale_train (liif.py:108-137).
+ *   feat [B,C,H,W], coord [B,Q,2] (row,col) -> latent[B, lat_ctot, Q] channels [lat_coff, lat_coff+C+2)
+ *   = [q_feat (C), rel_row, rel_col]   (channel-major so the MLP runs as a 1x1 conv over Q).
+ * a16/a17  (softmax over the 9 mask logits +) convex combination of the 3x3 neighbourhood of the nearest
+ *   low-res pixel — replaces F.softmax + context_upsample_multiscale_train
+ *   (continuous_IGEVstereo.py:204,212-214; submodule.py:357-372).
+ *   disp [B,1,H,W]; mask [B,9,Q]; coord [B,Q,2] -> out [B,1,Q].
+ *   mask_is_logits != 0: softmax is applied to mask first.  scale != NULL ([B]): the disparity is the
+ *   UNscaled 1/4-res field and is multiplied by 4*scale_b on the fly (continuous_IGEVstereo.py:204);
+ *   scale == NULL: disp is used as given (the reference function's own contract).
+ * ------------------------------------------------------------------------------------------- */
+int as_structure_feature(const float* x, float* out, float* ws /* [B,H,W] scratch */, int B, int C, int H, int W, void* stream);
+int as_liif_gather(const float* feat, const float* coord, float* latent,
+                   int B, int C, int H, int W, int Q, int lat_ctot, int lat_coff, void* stream);
+int as_convex_upsample(const float* disp, const float* scale, const float* mask, const float* coord,
+                       float* out, int B, int H, int W, int Q, int mask_is_logits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANYSTEREO_HIP_H */

@@ -1,0 +1,179 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE (read-only) in the
+build container and running its own functions on deterministic inputs.
+
+    python tests/golden/make_golden.py            # needs /root/reference; writes tests/golden/*.npz
+
+The reference ships no tests or golden vectors, so these files are the parity pin of
+the oracle (oracle/ops.py, oracle/model.py) and, through it, of the HIP path.  Only inputs and
+reference OUTPUTS are stored — no reference source travels.  Import recipe: SURVEY.md Appendix B
+(five in-memory shims, no edits to the reference).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "any-stereo_amd"))
+
+from anystereo.harness.synthetic import det_uniform, fill_module_deterministic, synthetic_pair  # noqa: E402
+from anystereo.models.base import default_args  # noqa: E402
+from anystereo.nn.encoders import MobileNetV2Trunk  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    for n in ("opt_einsum", "timm"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["opt_einsum"].contract = torch.einsum
+    # timm is unavailable offline: the same MobileNetV2 trunk is injected on both sides
+    sys.modules["timm"].create_model = lambda *a, **k: MobileNetV2Trunk()
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [REF + "/models"]
+    sys.modules["models"] = pkg
+    import models.coreContinuous_IGEV.submodule as _s
+    a = types.ModuleType("models.coreContinuous_A2A4IGEV")
+    a.__path__ = []
+    sys.modules["models.coreContinuous_A2A4IGEV"] = a
+    sys.modules["models.coreContinuous_A2A4IGEV.submodule"] = _s
+    torch.Tensor.cuda = lambda self, *a, **k: self  # liif.py hard-codes .cuda()
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def main():
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+    import_reference()
+    import models.coreContinuous_IGEV.geometry as rgeo
+    import models.corePrune_RAFT.geometry as rgeo_raft
+    import models.coreContinuous_IGEV.submodule as rsub
+    import models.coreContinuous_IGEV.update as rupd
+    import models.corePrune_RAFT.update as rupd_raft
+    import models.coreContinuous_IGEV.liif as rliif
+    from models.coreContinuous_IGEV.continuous_IGEVstereo import continuous_IGEVStereo as RefIGEV
+    from models.corePrune_RAFT.prune_raft_stereo import continuous_RaftStereo as RefRAFT
+
+    # ---- G1/G2/G3: correlation, pyramids, lookup (IGEV: L=2,G=8; RAFT: L=4,G=0) ------------------
+    for tag, (b, c, h, w, w2) in {"even": (2, 96, 3, 20, 20), "odd": (1, 96, 2, 21, 21)}.items():
+        f1 = det_uniform((b, c, h, w), 11)
+        f2 = det_uniform((b, c, h, w2), 12)
+        gev = det_uniform((b, 8, 48, h, w), 13)
+        fn = rgeo.Combined_Geo_Encoding_Volume(f1, f2, gev, num_levels=2, radius=4)
+        # disparities hitting both zero-pad edges, exact integers and x.5 positions
+        disp = det_uniform((b, 1, h, w), 14, -6.0, w + 6.0)
+        disp[:, :, 0, 0:4] = torch.tensor([0.0, 3.0, 7.5, -0.5])
+        disp[:, :, -1, -3:] = torch.tensor([float(w - 1), 47.0, 48.5])
+        coords = torch.arange(w).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+        out = fn(disp.clone(), coords)
+        save(f"lookup_igev_{tag}", f1=f1, f2=f2, gev=gev, disp=disp,
+             corr0=fn.init_corr_pyramid[0].reshape(b, h, w, w2), corr1=fn.init_corr_pyramid[1].reshape(b, h, w, w2 // 2),
+             geo0=fn.geo_volume_pyramid[0].reshape(b, h, w, 8, 48), geo1=fn.geo_volume_pyramid[1].reshape(b, h, w, 8, 24),
+             out=out)
+    b, c, h, w = 1, 256, 2, 37
+    f1 = det_uniform((b, c, h, w), 21)
+    f2 = det_uniform((b, c, h, w), 22)
+    fn = rgeo_raft.CorrBlock1D(f1, f2, num_levels=4, radius=4)
+    disp = det_uniform((b, 1, h, w), 23, -5.0, w + 5.0)
+    coords = torch.arange(w).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+    out = fn(disp.clone(), coords)
+    save("lookup_raft", f1=f1, f2=f2, disp=disp, out=out,
+         **{f"corr{i}": fn.init_corr_pyramid[i].reshape(b, h, w, w >> i) for i in range(4)})
+
+    # ---- G4/A5: gwc volume, disparity regression ------------------------------------------------
+    fl = det_uniform((1, 96, 3, 60), 31)
+    fr = det_uniform((1, 96, 3, 60), 32)
+    vol = rsub.build_gwc_volume(fl, fr, 48, 8)
+    cost = det_uniform((2, 48, 3, 5), 33, -4.0, 4.0)
+    prob = torch.softmax(cost, dim=1)
+    save("gwc_dispreg", fl=fl, fr=fr, vol=vol, cost=cost, init_disp=rsub.disparity_regression(prob, 48))
+
+    # ---- G5: update block (IGEV and RAFT encoders) ------------------------------------------------
+    for tag, mod, model_name in (("igev", rupd, "continuous_IGEVStereo"), ("raft", rupd_raft, "continuous_RAFTStereo")):
+        args = default_args(model_name)
+        ub = mod.BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims).eval()
+        fill_module_deterministic(ub, base_seed=5)
+        h, w = 8, 12
+        net = [torch.tanh(det_uniform((1, 128, h >> i, w >> i), 40 + i, -2, 2)) for i in range(3)]
+        ctx = [det_uniform((1, 384, h >> i, w >> i), 50 + i) for i in range(3)]
+        inp = [list(c.split(128, dim=1)) for c in ctx]
+        cor_planes = ub.encoder.convc1.in_channels
+        corr = det_uniform((1, cor_planes, h, w), 60, -3, 3)
+        disp = det_uniform((1, 1, h, w), 61, 0, 12)
+        mf = ub.encoder(disp, corr)
+        g16 = ub.gru16(net[2], *inp[2], rupd.pool2x(net[1]))
+        net_out, delta = ub([n.clone() for n in net], inp, corr, disp)
+        net_lo = ub([n.clone() for n in net], inp, iter16=True, iter08=True, iter04=False, update=False)
+        save(f"update_{tag}", net0=net[0], net1=net[1], net2=net[2], ctx0=ctx[0], ctx1=ctx[1], ctx2=ctx[2], corr=corr,
+             disp=disp, motion=mf, gru16=g16, out0=net_out[0], out1=net_out[1], out2=net_out[2], delta=delta,
+             lo1=net_lo[1], lo2=net_lo[2], pool=rupd.pool2x(net[0]), interp=rupd.interp(net[2], net[1]),
+             head=ub.disp_head(net[0]))
+
+    # ---- G6: LIIF pieces --------------------------------------------------------------------------
+    feat = det_uniform((2, 20, 5, 7), 71)
+    aff = rliif.AffinityFeature(3, 3, 1, 0)(feat)
+    liif = {}
+    for s in (1.0, 1.5, 2.0, 2.95):
+        hh, ww = round(5 * 4 * s), round(7 * 4 * s)
+        coord = rliif.make_coord([hh, ww]).unsqueeze(0).repeat(2, 1, 1)
+        coord[:, 0] = torch.tensor([-1.0, 1.0])       # exactly on the clamp boundary
+        coord[:, 1] = torch.tensor([1.0, -1.0])
+        rel, qf, _ = rliif.liif_feat_multiscale_train(feat, coord.clone(), torch.tensor([[s]]))
+        key = str(s).replace(".", "p")
+        liif[f"coord_{key}"], liif[f"rel_{key}"], liif[f"qfeat_{key}"] = coord, rel, qf
+    args = default_args("continuous_IGEVStereo")
+    aff_set = {"win_w": 3, "win_h": 3, "dilation": [1, 2, 4, 8]}
+    up = rliif.liif_out_multi_scale_Training(encoder_dim=208, mlphidden_list=[128, 64, 64], pos_dim=0, unfold="with_v2ISU",
+                                             affinity_settings=aff_set, number_input=2, chanels=[176, 32]).eval()
+    fill_module_deterministic(up, base_seed=7, gain=2.0)
+    x4 = det_uniform((1, 176, 4, 6), 81)
+    x2 = det_uniform((1, 32, 8, 12), 82)
+    coord = rliif.make_coord([24, 36]).unsqueeze(0)  # scale 1.5 over the 16x24 full-res grid
+    mask = up([x4, x2], coord.clone(), torch.tensor([[1.5]]))
+    dlow = det_uniform((1, 1, 4, 6), 83, 0, 20)
+    sm = torch.softmax(mask, dim=1)
+    cu = rsub.context_upsample_multiscale_train(dlow * 4.0 * 1.5, sm, coord.clone())
+    save("liif", feat=feat, aff=aff, x4=x4, x2=x2, coord=coord, mask=mask, dlow=dlow, convex=cu, **liif)
+
+    # ---- G7: whole models, tiny -------------------------------------------------------------------
+    for name, Ref, (H, W) in (("igev", RefIGEV, (64, 128)), ("raft", RefRAFT, (64, 96))):
+        args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
+        model = Ref(args).eval()
+        fill_module_deterministic(model, base_seed=1)
+        img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+        outs = {}
+        for s in (1.0, 1.5):
+            coord = rliif.make_coord([round(H * s), round(W * s)]).unsqueeze(0)
+            sc = torch.tensor([[s]])
+            up_test = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            key = str(s).replace(".", "p")
+            outs[f"test_{key}"] = up_test
+        coord = rliif.make_coord([H, W]).unsqueeze(0)
+        res = model(img1, img2, iters=3, test_mode=False, hr_coord=coord.clone(), scale=torch.tensor([[1.0]]))
+        preds = res[1] if name == "igev" else res
+        if name == "igev":
+            outs["init_disp"] = res[0]
+        for i, p in enumerate(preds):
+            outs[f"pred_{i}"] = p
+        save(f"model_{name}", H=H, W=W, **outs)
+        print(name, "disp_up range", float(up_test.min()), float(up_test.max()))
+
+
+if __name__ == "__main__":
+    argparse.ArgumentParser().parse_args()
+    main()
