@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..harness.timing import scope
 from ..nn import functional as AF
 from ..nn.liif import liif_out_multi_scale_Training
 from ..nn.update import BasicMultiUpdateBlock
@@ -75,7 +76,8 @@ class ContinuousStereoBase(nn.Module):
         feats = [x, stem_2x] if stem_2x is not None else [x]
         logits = self.liif_up(feats, hr_coord, scale_vec)  # [B,9,Q]
         hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)  # side effect of context_upsample_multiscale_train (submodule.py:366)
-        return ops.convex_upsample(disp.float().contiguous(), logits, hr_coord, scale=scale_vec, mask_is_logits=True)
+        with scope("convex_upsample"):
+            return ops.convex_upsample(disp.float().contiguous(), logits, hr_coord, scale=scale_vec, mask_is_logits=True)
 
     # ---- reference API -------------------------------------------------------------------------
     def upsample_disp(self, disp, hidden_layer, stem_4x, stem_2x, stem_1x, hr_coord=None, scale=1):

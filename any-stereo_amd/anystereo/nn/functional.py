@@ -6,13 +6,15 @@ from __future__ import annotations
 import torch
 
 from .. import ops
+from ..harness.timing import scope
 
 
 def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
     """[B,C,H,W] x2 -> [B,num_groups,maxdisp,H,W] group-wise correlation volume."""
     if torch.is_grad_enabled() and (refimg_fea.requires_grad or targetimg_fea.requires_grad):
         raise NotImplementedError("anystereo: build_gwc_volume backward is not built yet (inference path)")
-    return ops.gwc_volume(refimg_fea.float().contiguous(), targetimg_fea.float().contiguous(), maxdisp, num_groups)
+    with scope("gwc_volume"):
+        return ops.gwc_volume(refimg_fea.float().contiguous(), targetimg_fea.float().contiguous(), maxdisp, num_groups)
 
 
 def disparity_regression(x, maxdisp):
@@ -23,7 +25,8 @@ def disparity_regression(x, maxdisp):
 
 def softmax_disparity_regression(cost):
     """Fused F.softmax(cost, 1) + disparity_regression (continuous_IGEVstereo.py:267-268)."""
-    return ops.disparity_regression(cost.float().contiguous(), apply_softmax=True)
+    with scope("disparity_regression"):
+        return ops.disparity_regression(cost.float().contiguous(), apply_softmax=True)
 
 
 def context_upsample_multiscale_train(disp_low, up_weights, hr_coord):

@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 
 from .. import ops
+from ..harness.timing import scope
 
 
 def _needs_grad(*ts) -> bool:
@@ -48,9 +49,12 @@ class Combined_Geo_Encoding_Volume:
         f2 = init_fmap2.float().contiguous()
         if _needs_grad(f1, f2, geo_volume):
             raise NotImplementedError("anystereo: backward of the volume build is not implemented yet (inference path)")
-        self.init_corr_pyramid = ops.corr_build_pyramid(f1, f2, num_levels)
-        self.geo_volume_pyramid = (ops.geo_pyramid(geo_volume.float().contiguous(), num_levels)
-                                   if geo_volume is not None else [])
+        with scope("corr_build"):
+            self.init_corr_pyramid = ops.corr_build_pyramid(f1, f2, num_levels)
+        self.geo_volume_pyramid = []
+        if geo_volume is not None:
+            with scope("geo_pyramid"):
+                self.geo_volume_pyramid = ops.geo_pyramid(geo_volume.float().contiguous(), num_levels)
 
     def __call__(self, disp, coords=None):
         disp = disp.float().contiguous()
@@ -61,7 +65,8 @@ class Combined_Geo_Encoding_Volume:
         levels = list(self.geo_volume_pyramid) + list(self.init_corr_pyramid)
         if _needs_grad(*levels):
             return _LookupFn.apply(disp, self.radius, len(self.geo_volume_pyramid), *levels)
-        return ops.geo_corr_lookup(self.geo_volume_pyramid, self.init_corr_pyramid, disp, self.radius)
+        with scope("lookup"):
+            return ops.geo_corr_lookup(self.geo_volume_pyramid, self.init_corr_pyramid, disp, self.radius)
 
     @staticmethod
     def corr(fmap1, fmap2):

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
+from ..harness.timing import scope
 
 
 def make_coord(shape, ranges=None, flatten=True):
@@ -131,11 +132,14 @@ class liif_out_multi_scale_Training(nn.Module):
         """feats: list of [B,C_i,H_i,W_i]; coord [B,Q,2] (row, col) -> mask logits [B,9,Q] (liif.py:644-678)."""
         coord = coord.float().contiguous()
         b, q = coord.shape[:2]
-        sfs = [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
+        with scope("structure_feature"):
+            sfs = [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
         ctot = sum(s.shape[1] + 2 for s in sfs)
         latent = torch.empty((b, ctot, q), device=coord.device, dtype=torch.float32)
         off = 0
-        for s in sfs:
-            ops.liif_gather(s, coord, latent, off)
-            off += s.shape[1] + 2
-        return self.imnet.forward_cm(latent)
+        with scope("liif_gather"):
+            for s in sfs:
+                ops.liif_gather(s, coord, latent, off)
+                off += s.shape[1] + 2
+        with scope("liif_mlp"):
+            return self.imnet.forward_cm(latent)

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
+from ..harness.timing import scope
 
 
 def _f(t):
@@ -42,9 +43,11 @@ class DispHead(nn.Module):
 
     def forward(self, x):
         _no_grad_only(x, self.conv1.weight)
-        t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
+        with scope("disp_head_conv1"):
+            t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
         if self.conv2.out_channels == 1:
-            return ops.conv3x3_to1(t, _f(self.conv2.weight.detach()), _f(self.conv2.bias.detach()))
+            with scope("disp_head_conv2"):
+                return ops.conv3x3_to1(t, _f(self.conv2.weight.detach()), _f(self.conv2.bias.detach()))
         return ops.conv2d([t], self._p2.get([self.conv2.weight], [self.conv2.bias]))
 
 
@@ -80,6 +83,7 @@ class ConvGRU(nn.Module):
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
         self._pzr = ops.PackedConv()
         self._pq = ops.PackedConv()
+        self.tag = "gru"  # timing label; BasicMultiUpdateBlock renames it gru04 / gru08 / gru16
 
     def forward(self, h, cz, cr, cq, *x_list):
         _no_grad_only(h, cz, self.convz.weight, *x_list)
@@ -89,8 +93,10 @@ class ConvGRU(nn.Module):
         hid = h.shape[1]
         pzr = self._pzr.get([self.convz.weight, self.convr.weight], [self.convz.bias, self.convr.bias])
         pq = self._pq.get([self.convq.weight], [self.convq.bias])
-        z, rh = ops.conv2d([h] + xs, pzr, add=ctx, add_coff=coff, epilogue=L.EPI_GRU_ZR, h=h)
-        return ops.conv2d([rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z)
+        with scope(self.tag + "_zr_conv"):
+            z, rh = ops.conv2d([h] + xs, pzr, add=ctx, add_coff=coff, epilogue=L.EPI_GRU_ZR, h=h)
+        with scope(self.tag + "_q_conv"):
+            return ops.conv2d([rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z)
 
 
 class BasicMotionEncoder(nn.Module):
@@ -110,23 +116,30 @@ class BasicMotionEncoder(nn.Module):
         _no_grad_only(disp, corr, self.convc1.weight)
         disp, corr = _f(disp), _f(corr)
         b, _, h, w = disp.shape
-        cor = ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
+        with scope("enc_convc1"):
+            cor = ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
         cd = torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
-        ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out=cd, out_coff=0)
-        d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()))
-        ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out=cd, out_coff=64)
+        with scope("enc_convc2"):
+            ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out=cd, out_coff=0)
+        with scope("enc_convd1"):
+            d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()))
+        with scope("enc_convd2"):
+            ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out=cd, out_coff=64)
         out = torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
-        ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out=out, out_coff=0)
+        with scope("enc_conv"):
+            ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out=out, out_coff=0)
         out[:, 127:128].copy_(disp)
         return out
 
 
 def pool2x(x):
-    return ops.pool2x(_f(x))
+    with scope("pool2x"):
+        return ops.pool2x(_f(x))
 
 
 def interp(x, dest):
-    return ops.interp(_f(x), dest.shape[2], dest.shape[3])
+    with scope("interp"):
+        return ops.interp(_f(x), dest.shape[2], dest.shape[3])
 
 
 class BasicMultiUpdateBlock(nn.Module):
@@ -139,6 +152,7 @@ class BasicMultiUpdateBlock(nn.Module):
         self.gru08 = ConvGRU(hidden_dims[1], hidden_dims[0] * (args.n_gru_layers == 3) + hidden_dims[2])
         self.gru16 = ConvGRU(hidden_dims[0], hidden_dims[1])
         self.disp_head = DispHead(hidden_dims[2], hidden_dim=256, output_dim=1)
+        self.gru04.tag, self.gru08.tag, self.gru16.tag = "gru04", "gru08", "gru16"
 
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         if iter16:

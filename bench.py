@@ -1,0 +1,219 @@
+"""Headline benchmark (BASELINE.json): stereo pairs/s and ms per GRU iteration of
+coreContinuous_IGEV inference on a 960x540 SceneFlow-shape synthetic pair, 32 iterations, fp32.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; every rank runs the same per-GPU workload on its own pair (independent
+units, no data-path collective: "replicas", weak scaling).  A step = one full forward pass
+(backbones on PyTorch-ROCm/MIOpen, hot path on libanystereo_hip.so) with inputs resident in HBM.
+Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline      dominant kernel (by time) measured with HIP events on its launch stream in the timed steps
+  rooflines     the same figure for every hot kernel class (north_star quotes build+lookup vs HBM)
+  cpu_baseline  the CPU oracle (oracle/model.py) timed on this host's cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "any-stereo_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=540)
+    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--iters", type=int, default=32)
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the GRU loop eagerly instead of as a captured hipGraph")
+    return ap.parse_args()
+
+
+def algorithmic(B, h, w, Q, iters, C=96, L=2, G=8, D=48, r=4):
+    """Algorithmic bytes / flops per launch."""
+    P = B * h * w
+    build_b = 4 * (2 * B * C * h * w + sum(P * (w >> i) for i in range(L)))
+    geo_b = 4 * (B * G * D * h * w + sum(P * G * (D >> i) for i in range(L)))
+    lookup_b = 4 * P * (L * (G + 1) * (2 * r + 2) + 1 + L * (G + 1) * (2 * r + 1))
+    return {
+        "corr_build": {"bound": "hbm", "bytes": build_b, "flops": 2 * C * P * w},
+        "geo_pyramid": {"bound": "hbm", "bytes": geo_b},
+        "lookup": {"bound": "hbm", "bytes": lookup_b},
+        "gwc_volume": {"bound": "hbm", "bytes": 4 * (2 * B * C * h * w + B * G * D * h * w)},
+        # 3x3 convs of gru04: zr = (3*128 -> 256), q = (3*128 -> 128)
+        "gru04_zr_conv": {"bound": "mfma", "flops": 2 * P * 384 * 9 * 256},
+        "gru04_q_conv": {"bound": "mfma", "flops": 2 * P * 384 * 9 * 128},
+        "disp_head_conv1": {"bound": "mfma", "flops": 2 * P * 128 * 9 * 256},
+        "liif_mlp": {"bound": "mfma", "flops": 2 * Q * B * (228 * 128 + 128 * 64 + 64 * 64 + 64 * 9)},
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from anystereo import _lib
+    from anystereo.harness import timing
+    from anystereo.harness.query import pad_for_multi_train
+    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
+    from anystereo.models import __models__, default_args
+
+    _lib.load()
+    args = default_args("continuous_IGEVStereo")
+    model = __models__["continuous_IGEVStereo"](args).eval()
+    fill_module_deterministic(model, base_seed=1)  # random-init weights of the named architecture (no checkpoints offline)
+    model = model.to(dev)
+
+    img1, img2 = synthetic_pair(1, a.height, a.width, shift=8, seed=1234 + rank)
+    i1, i2, coord, _ = pad_for_multi_train(img1, img2, a.scale, divis_by=32)
+    i1, i2 = i1.to(dev), i2.to(dev)
+    coord = coord.unsqueeze(0).to(dev)
+    scale = torch.tensor([[a.scale]], device=dev)
+    Q = coord.shape[1]
+    hp, wp = i1.shape[-2:]
+    use_graph = not a.no_graph
+    if hasattr(model, "enable_graph"):
+        model.enable_graph(use_graph)
+
+    def step(iters=a.iters):
+        with torch.no_grad():
+            return model(i1, i2, iters=iters, test_mode=True, hr_coord=coord, scale=scale)
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    timing.enable(True)           # HIP events around every hot-kernel launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kstats = timing.collect()
+    timing.enable(False)
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # ms per GRU iteration = (t32 - t8) / 24 on the same inputs, outside the timed region
+    def timed(iters, reps=3):
+        step(iters)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            step(iters)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+    lo = max(1, a.iters // 4)
+    ms_iter = (timed(a.iters) - timed(lo)) / (a.iters - lo) * 1e3 if a.iters > lo else None
+
+    if rank == 0:
+        alg = algorithmic(1, hp // 4, wp // 4, Q, a.iters)
+        rooflines = {}
+        for name, st in kstats.items():
+            if name not in alg or st["count"] == 0:
+                continue
+            avg_s = st["total_ms"] / st["count"] * 1e-3
+            e = alg[name]
+            if e["bound"] == "hbm":
+                ach = e["bytes"] / avg_s / 1e9
+                rooflines[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                   "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
+            else:
+                ach = e["flops"] / avg_s / 1e12
+                rooflines[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                                   "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
+        dominant = max(rooflines, key=lambda k: rooflines[k]["total_ms"]) if rooflines else None
+        cpu = None
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline(args, model, img1, img2, a)
+        line = {
+            "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",
+            "value": round(world * a.steps / dt, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"coreContinuous_IGEV inference, {a.width}x{a.height} SceneFlow-shape synthetic pair "
+                                   f"(padded {wp}x{hp}), {a.iters} GRU iters, scale {a.scale}, Q={Q} queries, 1 pair per GPU, "
+                                   f"random-init weights", "pairs_per_gpu": 1, "parallelism": f"replicas x{world}",
+                       "gru_loop": "hipGraph" if use_graph and hasattr(model, "enable_graph") else "eager"},
+            "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
+            "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
+            "rooflines": rooflines,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def cpu_baseline(args, model, img1, img2, a):
+    """The CPU oracle (same weights) timed on this host: 1 pair of the same workload; if the machine is
+    slow the GRU iteration count of the sample is reduced and the 32-iteration figure extrapolated."""
+    from anystereo.harness.query import pad_for_multi_train
+    from oracle.model import OracleIGEV
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
+    ref = OracleIGEV(args).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    i1, i2, coord, _ = pad_for_multi_train(img1, img2, a.scale, divis_by=32)
+    coord = coord.unsqueeze(0)
+    sc = torch.tensor([[a.scale]])
+
+    def run(iters):
+        t = time.perf_counter()
+        with torch.no_grad():
+            ref(i1, i2, iters=iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        return time.perf_counter() - t
+    run(1)  # warm-up (thread pools, allocator)
+    t2, t6 = run(2), run(6)
+    per_iter = max((t6 - t2) / 4, 1e-6)
+    est_full = t2 + per_iter * (a.iters - 2)
+    if est_full <= 45.0:
+        t_full = run(a.iters)
+        sample = f"1 pair, full workload ({a.iters} iters), fp32, {threads} threads"
+    else:
+        t_full = est_full
+        sample = (f"1 pair at 2 and 6 GRU iters ({t2:.1f}s, {t6:.1f}s), extrapolated to {a.iters} iters, fp32, "
+                  f"{threads} threads")
+    return {"value": round(1.0 / t_full, 5), "unit": "pairs/s", "cores": threads, "kind": "port", "sample": sample,
+            "s_per_pair": round(t_full, 3), "ms_per_gru_iter": round(per_iter * 1e3, 2)}
+
+
+if __name__ == "__main__":
+    main()

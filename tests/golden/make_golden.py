@@ -11,6 +11,7 @@ reference OUTPUTS are stored — no reference source travels.  Import recipe: SU
 from __future__ import annotations
 
 import argparse
+import json
 import os
 import sys
 import types
@@ -151,6 +152,7 @@ def main():
     save("liif", feat=feat, aff=aff, x4=x4, x2=x2, coord=coord, mask=mask, dlow=dlow, convex=cu, **liif)
 
     # ---- G7: whole models, tiny -------------------------------------------------------------------
+    sd_keys = {}
     for name, Ref, (H, W) in (("igev", RefIGEV, (64, 128)), ("raft", RefRAFT, (64, 96))):
         args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
         model = Ref(args).eval()
@@ -172,6 +174,39 @@ def main():
             outs[f"pred_{i}"] = p
         save(f"model_{name}", H=H, W=W, **outs)
         print(name, "disp_up range", float(up_test.min()), float(up_test.max()))
+        sd_keys["continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo"] = {
+            k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(sd_keys, f, indent=0, sort_keys=True)
+
+    # ---- §8(f1): query grid of pad_for_multi_train (evaluation.py:67-89) ---------------------------
+    # evaluation.py itself cannot be imported (missing tensorboardX / fvcore / a dangling model import,
+    # SURVEY.md §0 item 3), so the single function is compiled from its AST node; InputPadder.get_pad_num
+    # is undefined in the reference and is supplied with the only meaning its call site allows (item 4).
+    import ast
+    import math
+    import torch.nn.functional as F
+    from models.coreContinuous_IGEV.utils.utils import InputPadder as RefPadder
+    RefPadder.get_pad_num = lambda self: [self._pad[2], self._pad[3], self._pad[0], self._pad[1]]
+    tree = ast.parse(open(os.path.join(REF, "evaluation.py")).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "pad_for_multi_train"][0]
+    ns = {"math": math, "F": F, "torch": torch, "InputPadder": RefPadder, "make_coord": rliif.make_coord}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "evaluation.py", "exec"), ns)
+    cases = []
+    for (H, W, s, model_name) in [(540, 960, 1.0, "continuous_IGEVStereo"), (375, 1242, 2.0, "continuous_IGEVStereo"),
+                                  (100, 150, 1.5, "continuous_IGEVStereo"), (97, 131, 2.95, "continuous_RAFTStereo"),
+                                  (64, 96, 1.0, "continuous_RAFTStereo")]:
+        a = argparse.Namespace(scale_test=s, model=model_name)
+        img = torch.zeros(1, 3, H, W)
+        i1, i2, coord = ns["pad_for_multi_train"](a, img, img)
+        div = 32 if "IGEVStereo" in model_name else 16
+        padder = RefPadder((1, 3, int(math.ceil(H / s)), int(math.ceil(W / s))), divis_by=div)
+        cases.append(dict(H=H, W=W, scale=s, divis_by=div, padded=list(i1.shape[-2:]),
+                          pad_num=[int(i * s) for i in padder.get_pad_num()], coord_shape=list(coord.shape),
+                          first=coord[0].tolist(), last=coord[-1].tolist(), coord_sum=float(coord.double().sum())))
+    with open(os.path.join(HERE, "query_grid.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("wrote state_dict_keys.json, query_grid.json")
 
 
 if __name__ == "__main__":

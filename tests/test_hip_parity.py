@@ -1,0 +1,337 @@
+"""GPU (-m gpu): every HIP entry point, called through the C ABI via anystereo.ops, against the CPU
+oracle on the same seeded inputs and against the committed golden vectors of the reference.
+
+Tolerances (fp32 path; north_star's end-to-end bar is EPE delta < 1e-3):
+  * gathers / lerps / stencils: 2e-5 relative to the tensor's max magnitude (rounding order only)
+  * fp32-MFMA convolutions / GEMMs: 1e-5 * sqrt(K)-free bound, written per test (fma-chain order differs
+    from the oracle's blocked CPU GEMM)
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def U(shape, seed, lo=-1.0, hi=1.0):
+    from anystereo.harness.synthetic import det_uniform
+    return det_uniform(shape, seed, lo, hi)
+
+
+def close(a, b, rtol=2e-5, atol=1e-6, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), f"{what}: non-finite values in the HIP result"
+    err = (a - b).abs().max().item()
+    lim = atol + rtol * b.abs().max().item()
+    assert err <= lim, f"{what}: max abs err {err:.3e} > {lim:.3e}"
+
+
+def test_native_library_is_loaded():
+    from anystereo import _lib
+    lib = _lib.load()
+    assert lib.as_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libanystereo_hip.so" in f.read()
+
+
+# ---------------------------------------------------------------------------------------------
+# a1/a2/a3  volumes + lookup
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("b,c,h,w1,w2,L", [(2, 96, 3, 20, 20, 2), (1, 96, 2, 21, 21, 2), (1, 256, 2, 37, 37, 4),
+                                           (1, 96, 5, 240, 240, 2), (2, 33, 3, 70, 45, 3)])
+def test_corr_build_pyramid(b, c, h, w1, w2, L):
+    from anystereo import ops
+    f1, f2 = U((b, c, h, w1), 1), U((b, c, h, w2), 2)
+    lv = ops.corr_build_pyramid(f1.to(DEV), f2.to(DEV), L)
+    ref = O.corr_pyramid(O.all_pairs_corr(f1.double(), f2.double()), L)
+    for i in range(L):
+        close(lv[i], ref[i], rtol=1e-6, atol=2e-6 * c ** 0.5, what=f"corr level {i}")
+
+
+@pytest.mark.parametrize("b,g,d,h,w,L", [(2, 8, 48, 3, 20, 2), (1, 8, 48, 4, 70, 2), (1, 4, 17, 2, 33, 3)])
+def test_geo_pyramid(b, g, d, h, w, L):
+    from anystereo import ops
+    gev = U((b, g, d, h, w), 3)
+    lv = ops.geo_pyramid(gev.to(DEV), L)
+    ref = O.geo_pyramid(gev, L)
+    for i in range(L):
+        close(lv[i].permute(0, 1, 2, 4, 3), ref[i], 0, 1e-7, what=f"geo level {i}")
+
+
+def _lookup_case(b, h, w, g, d, L, r, seed, lo, hi):
+    from anystereo import ops
+    corr = [U((b, h, w, w >> i), seed + i, -3, 3) for i in range(L)]
+    geo = [U((b, h, w, g, d >> i), seed + 10 + i, -3, 3) for i in range(L)] if g else None
+    disp = U((b, 1, h, w), seed + 20, lo, hi)
+    disp.view(-1)[:6] = torch.tensor([0.0, 3.0, 7.5, -0.5, float(w - 1), 1e-7])
+    out = ops.geo_corr_lookup([t.permute(0, 1, 2, 4, 3).contiguous().to(DEV) for t in geo] if g else None,
+                              [t.to(DEV) for t in corr], disp.to(DEV), r)
+    ref = O.geo_corr_lookup([t.double() for t in geo] if g else None, [t.double() for t in corr], disp.double(), r)
+    return out, ref
+
+
+@pytest.mark.parametrize("b,h,w,g,d,L,r", [(2, 3, 20, 8, 48, 2, 4), (1, 5, 37, 0, 0, 4, 4), (1, 7, 70, 8, 48, 2, 4),
+                                           (1, 2, 33, 4, 16, 3, 2), (1, 3, 300, 0, 0, 1, 3)])
+def test_lookup_vs_oracle(b, h, w, g, d, L, r):
+    out, ref = _lookup_case(b, h, w, g, d, L, r, 30, -6.0, w + 6.0)
+    close(out, ref, rtol=2e-5, atol=2e-5, what="lookup")
+
+
+def test_lookup_golden(golden):
+    from anystereo import ops
+    for tag in ("even", "odd"):
+        g = golden(f"lookup_igev_{tag}")
+        corr = ops.corr_build_pyramid(g["f1"].to(DEV), g["f2"].to(DEV), 2)
+        geo = ops.geo_pyramid(g["gev"].to(DEV), 2)
+        close(corr[0], g["corr0"], 1e-5, 1e-5, "corr0")
+        close(corr[1], g["corr1"], 1e-5, 1e-5, "corr1")
+        close(geo[1].permute(0, 1, 2, 4, 3), g["geo1"], 0, 1e-7, "geo1")
+        out = ops.geo_corr_lookup(geo, corr, g["disp"].to(DEV), 4)
+        close(out, g["out"], 3e-5, 2e-5, "lookup vs reference")
+    g = golden("lookup_raft")
+    corr = ops.corr_build_pyramid(g["f1"].to(DEV), g["f2"].to(DEV), 4)
+    out = ops.geo_corr_lookup(None, corr, g["disp"].to(DEV), 4)
+    close(out, g["out"], 3e-5, 3e-5, "raft lookup vs reference")
+
+
+def test_lookup_class_api(golden):
+    """The reference's corr_block contract: obj(disp [B,1,h,w], coords [B,h,w,1]) -> [B,162,h,w]."""
+    from anystereo.models.coreContinuous_IGEV.geometry import Combined_Geo_Encoding_Volume
+    g = golden("lookup_igev_even")
+    fn = Combined_Geo_Encoding_Volume(g["f1"].to(DEV), g["f2"].to(DEV), g["gev"].to(DEV), num_levels=2, radius=4)
+    b, _, h, w = g["disp"].shape
+    coords = torch.arange(w, device=DEV).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+    out = fn(g["disp"].to(DEV), coords)
+    assert out.shape == (b, 162, h, w) and out.is_contiguous() and out.dtype == torch.float32
+    close(out, g["out"], 3e-5, 2e-5, "class api")
+
+
+def test_lookup_backward_is_transpose():
+    from anystereo import ops
+    b, h, w, g, d, L, r = 1, 3, 24, 8, 48, 2, 4
+    corr = [U((b, h, w, w >> i), 40 + i) for i in range(L)]
+    geo = [U((b, h, w, d >> i, g), 50 + i) for i in range(L)]
+    disp = U((b, 1, h, w), 60, -4.0, w + 4.0)
+    gout = U((b, L * 9 * (g + 1), h, w), 61)
+    dg, dc = ops.geo_corr_lookup_backward(disp.to(DEV), gout.to(DEV), [tuple(t.shape) for t in geo],
+                                          [tuple(t.shape) for t in corr], r)
+    cr = [t.clone().double().requires_grad_(True) for t in corr]
+    gr = [t.permute(0, 1, 2, 4, 3).clone().double().requires_grad_(True) for t in geo]
+    O.geo_corr_lookup(gr, cr, disp.double(), r).backward(gout.double())
+    for i in range(L):
+        close(dc[i], cr[i].grad, 2e-5, 1e-6, f"d_corr{i}")
+        close(dg[i].permute(0, 1, 2, 4, 3), gr[i].grad, 2e-5, 1e-6, f"d_geo{i}")
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12), (torch.float16, 8e-3)])
+def test_corr_sampler_module(dtype, tol):
+    """`corr_sampler.forward/backward` (sampler/sampler.cpp:48-51) incl. zero-pad edges, ragged W2, r != 4."""
+    from anystereo import corr_sampler
+    for (n, h1, w1, w2, r) in [(2, 3, 20, 20, 4), (1, 2, 33, 17, 3), (1, 1, 5, 1, 4)]:
+        vol = U((n, h1, w1, w2), 70, -2, 2).to(dtype)
+        coords = torch.stack([U((n, h1, w1), 71, -6.0, w2 + 6.0), torch.zeros(n, h1, w1)], dim=1)
+        coords[0, 0, 0, :3] = torch.tensor([0.0, 2.5, float(w2 - 1)])
+        (out,) = corr_sampler.forward(vol.to(DEV), coords.to(DEV), r)
+        ref = O.corr_sampler_forward(vol.double(), coords, r)
+        assert out.dtype == dtype and out.shape == (n, 2 * r + 1, h1, w1)
+        close(out, ref, tol, tol, "sampler fwd")
+        gr = U(tuple(out.shape), 72).to(dtype)
+        (vg,) = corr_sampler.backward(vol.to(DEV), coords.to(DEV), gr.to(DEV), r)
+        close(vg, O.corr_sampler_backward(vol.double(), coords, gr.double(), r), tol, tol, "sampler bwd")
+    with pytest.raises(RuntimeError):  # CHECK_INPUT semantics (sampler.cpp:20-22)
+        corr_sampler.forward(vol, coords.to(DEV), 4)
+    with pytest.raises(RuntimeError):
+        corr_sampler.forward(vol.to(DEV).transpose(1, 2), coords.to(DEV), 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# a4/a5
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("b,c,h,w,d,g", [(1, 96, 3, 60, 48, 8), (2, 96, 2, 130, 48, 8), (1, 32, 2, 20, 50, 4)])
+def test_gwc_volume(b, c, h, w, d, g):
+    from anystereo import ops
+    fl, fr = U((b, c, h, w), 80), U((b, c, h, w), 81)
+    out = ops.gwc_volume(fl.to(DEV), fr.to(DEV), d, g)
+    close(out, O.gwc_volume(fl.double(), fr.double(), d, g), 1e-6, 1e-6, "gwc")
+
+
+def test_gwc_dispreg_golden(golden):
+    from anystereo import ops
+    g = golden("gwc_dispreg")
+    close(ops.gwc_volume(g["fl"].to(DEV), g["fr"].to(DEV), 48, 8), g["vol"], 1e-5, 1e-6, "gwc vs reference")
+    close(ops.disparity_regression(g["cost"].to(DEV), True), g["init_disp"], 1e-5, 1e-5, "dispreg vs reference")
+    close(ops.disparity_regression(torch.softmax(g["cost"], 1).to(DEV), False), g["init_disp"], 1e-5, 1e-5, "dispreg(prob)")
+
+
+# ---------------------------------------------------------------------------------------------
+# a6-a10 convolutions / update block
+# ---------------------------------------------------------------------------------------------
+
+def _ref_conv(x, w, bias, pad):
+    return torch.nn.functional.conv2d(x.double(), w.double(), None if bias is None else bias.double(), padding=pad)
+
+
+@pytest.mark.parametrize("b,cins,cout,ks,h,w,act", [
+    (1, [128, 128, 128], 128, 3, 8, 12, 1), (2, [64], 64, 3, 9, 33, 1), (1, [128], 127, 3, 7, 20, 1),
+    (1, [128], 256, 3, 5, 40, 1), (1, [162], 64, 1, 6, 21, 1), (1, [36], 64, 1, 3, 50, 0),
+    (1, [228], 128, 1, 1, 300, 1), (1, [64], 9, 1, 1, 77, 0), (1, [20, 12], 40, 3, 17, 9, 2), (1, [16], 32, 3, 34, 60, 3)])
+def test_conv2d_linear(b, cins, cout, ks, h, w, act):
+    from anystereo import ops, _lib as L
+    cin = sum(cins)
+    srcs = [U((b, c, h, w), 90 + i) for i, c in enumerate(cins)]
+    wt = U((cout, cin, ks, ks), 95) * (3.0 / (cin * ks * ks)) ** 0.5
+    bias = U((cout,), 96) * 0.1
+    add = U((b, cout + 5, h, w), 97)
+    pk = ops.PackedConv().get([wt.to(DEV)], [bias.to(DEV)])
+    out = ops.conv2d([s.to(DEV) for s in srcs], pk, act=act, add=add.to(DEV), add_coff=3)
+    ref = _ref_conv(torch.cat(srcs, 1), wt, bias, ks // 2) + add[:, 3:3 + cout].double()
+    ref = [ref, torch.relu(ref), torch.sigmoid(ref), torch.tanh(ref)][act]
+    close(out, ref, 1e-5, 1e-5, "conv2d")
+    # cat-free producer: write into a channel window of a larger tensor
+    big = torch.full((b, cout + 7, h, w), 7.0, device=DEV)
+    ops.conv2d([s.to(DEV) for s in srcs], pk, act=act, add=add.to(DEV), add_coff=3, out=big, out_coff=4)
+    close(big[:, 4:4 + cout], ref, 1e-5, 1e-5, "conv2d window")
+    assert (big[:, :4] == 7.0).all() and (big[:, 4 + cout:] == 7.0).all()
+
+
+@pytest.mark.parametrize("h,w", [(8, 12), (5, 33), (17, 9)])
+def test_conv_gru_fused(h, w):
+    from anystereo.nn.update import ConvGRU
+    from anystereo.harness.synthetic import fill_module_deterministic
+    gru = ConvGRU(128, 256).to(DEV).eval()
+    fill_module_deterministic(gru, 3)
+    hh = torch.tanh(U((1, 128, h, w), 100, -2, 2))
+    ctx = U((1, 384, h, w), 101)
+    x1, x2 = U((1, 128, h, w), 102), U((1, 128, h, w), 103)
+    with torch.no_grad():
+        cz, cr, cq = ctx.to(DEV).split(128, dim=1)
+        out = gru(hh.to(DEV), cz, cr, cq, x1.to(DEV), x2.to(DEV))
+        # non-view context tensors take the concat fallback and must agree
+        out2 = gru(hh.to(DEV), cz.clone(), cr.clone(), cq.clone(), x1.to(DEV), x2.to(DEV))
+        ref = O.conv_gru(gru.cpu().double(), hh.double(), *ctx.double().split(128, dim=1), x1.double(), x2.double())
+    close(out, ref, 1e-5, 1e-5, "convgru")
+    close(out2, ref, 1e-5, 1e-5, "convgru (cat fallback)")
+
+
+def test_direct_convs_and_resamplers():
+    from anystereo import ops
+    x = U((2, 1, 19, 37), 110, 0, 30)
+    w7, b7 = U((64, 1, 7, 7), 111) * 0.2, U((64,), 112) * 0.1
+    close(ops.conv7x7_c1_relu(x.to(DEV), w7.to(DEV), b7.to(DEV)), torch.relu(_ref_conv(x, w7, b7, 3)), 1e-5, 1e-5, "conv7x7")
+    y = U((2, 256, 9, 70), 113)
+    w3, b3 = U((1, 256, 3, 3), 114) * 0.05, U((1,), 115)
+    close(ops.conv3x3_to1(y.to(DEV), w3.to(DEV), b3.to(DEV)), _ref_conv(y, w3, b3, 1), 1e-5, 1e-5, "conv3x3_to1")
+    z = U((2, 5, 9, 14), 116)
+    close(ops.pool2x(z.to(DEV)), O.pool2x(z.double()), 1e-6, 1e-6, "pool2x")
+    close(ops.pool2x(z[..., :13].contiguous().to(DEV)), O.pool2x(z[..., :13].double()), 1e-6, 1e-6, "pool2x odd")
+    close(ops.interp(z.to(DEV), 18, 27), O.interp_to(z.double(), 18, 27), 1e-5, 1e-6, "interp")
+    close(ops.interp(z.to(DEV), 17, 28), torch.nn.functional.interpolate(z, (17, 28), mode="bilinear", align_corners=True),
+          1e-5, 1e-6, "interp vs torch")
+
+
+def test_update_block_golden(golden):
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.models.base import default_args
+    from anystereo.nn.update import BasicMultiUpdateBlock
+    for tag in ("igev", "raft"):
+        g = golden(f"update_{tag}")
+        args = default_args("continuous_IGEVStereo" if tag == "igev" else "continuous_RAFTStereo")
+        ub = BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims, geo_channels=8 if tag == "igev" else 0).eval()
+        fill_module_deterministic(ub, base_seed=5)
+        ub = ub.to(DEV)
+        net = [g["net0"].to(DEV), g["net1"].to(DEV), g["net2"].to(DEV)]
+        inp = [list(g[f"ctx{i}"].to(DEV).split(128, dim=1)) for i in range(3)]
+        with torch.no_grad():
+            close(ub.encoder(g["disp"].to(DEV), g["corr"].to(DEV)), g["motion"], 2e-5, 2e-5, "motion encoder")
+            close(ub.disp_head(net[0]), g["head"], 2e-5, 2e-5, "disp head")
+            out, delta = ub([n.clone() for n in net], inp, g["corr"].to(DEV), g["disp"].to(DEV))
+            for i in range(3):
+                close(out[i], g[f"out{i}"], 2e-5, 3e-5, f"net{i}")
+            close(delta, g["delta"], 2e-5, 3e-5, "delta")
+            lo = ub([n.clone() for n in net], inp, iter16=True, iter08=True, iter04=False, update=False)
+            close(lo[1], g["lo1"], 2e-5, 3e-5, "slow-fast net1")
+
+
+# ---------------------------------------------------------------------------------------------
+# a12-a17 LIIF
+# ---------------------------------------------------------------------------------------------
+
+def test_liif_golden(golden):
+    from anystereo import ops
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn.liif import liif_out_multi_scale_Training, liif_feat_multiscale_train, AffinityFeature
+    from anystereo.nn.functional import context_upsample_multiscale_train
+    g = golden("liif")
+    close(AffinityFeature(3, 3, 1, 0)(g["feat"].to(DEV)), g["aff"], 1e-5, 2e-6, "affinity")
+    sf = ops.structure_feature(g["feat"].to(DEV))
+    close(sf[:, :20], g["feat"], 0, 0, "structure feature copy")
+    for key in ("1p0", "1p5", "2p0", "2p95"):
+        rel, qf, _ = liif_feat_multiscale_train(g["feat"].to(DEV), g[f"coord_{key}"].to(DEV))
+        close(qf, g[f"qfeat_{key}"], 0, 0, f"q_feat {key}")
+        close(rel, g[f"rel_{key}"], 0, 2e-6, f"rel {key}")
+    up = liif_out_multi_scale_Training(encoder_dim=208, mlphidden_list=[128, 64, 64], pos_dim=0, unfold="with_v2ISU",
+                                       affinity_settings={"win_w": 3, "win_h": 3, "dilation": [1, 2, 4, 8]},
+                                       number_input=2, chanels=[176, 32]).eval()
+    fill_module_deterministic(up, base_seed=7, gain=2.0)
+    up = up.to(DEV)
+    with torch.no_grad():
+        mask = up([g["x4"].to(DEV), g["x2"].to(DEV)], g["coord"].to(DEV), torch.tensor([[1.5]], device=DEV))
+    assert mask.shape == g["mask"].shape
+    close(mask, g["mask"], 2e-5, 2e-5, "liif mask logits")
+    coord = g["coord"].clone().to(DEV)
+    cu = context_upsample_multiscale_train((g["dlow"] * 4.0 * 1.5).to(DEV), torch.softmax(g["mask"], 1).to(DEV), coord)
+    close(cu, g["convex"], 1e-5, 1e-5, "convex upsample (reference contract)")
+    fused = ops.convex_upsample(g["dlow"].to(DEV), g["mask"].to(DEV), g["coord"].to(DEV),
+                                scale=torch.tensor([1.5], device=DEV), mask_is_logits=True)
+    close(fused[:, 0], g["convex"], 1e-5, 1e-5, "convex upsample (fused softmax+scale)")
+    # MLP reference contract [..., in] -> [..., out]
+    lat = U((3, 50, 228), 120)
+    with torch.no_grad():
+        close(up.imnet(lat.to(DEV)), O.mlp(up.imnet.cpu().double(), lat.double()), 2e-5, 2e-5, "MLP")
+
+
+# ---------------------------------------------------------------------------------------------
+# whole models (G7) — HIP vs the imported reference and vs the CPU oracle
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["igev", "raft"])
+def test_whole_model(name, golden):
+    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
+    from anystereo.models import __models__, default_args
+    g = golden(f"model_{name}")
+    H, W = int(g["H"]), int(g["W"])
+    key = "continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo"
+    model = __models__[key](default_args(key)).eval()
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV)
+    img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+    with torch.no_grad():
+        for s, k in ((1.0, "1p0"), (1.5, "1p5")):
+            coord = O.make_coord([round(H * s), round(W * s)]).view(1, -1, 2).to(DEV)
+            up = model(img1.to(DEV), img2.to(DEV), iters=3, test_mode=True, hr_coord=coord, scale=torch.tensor([[s]], device=DEV))
+            assert up.shape == g[f"test_{k}"].shape
+            epe = (up.cpu() - g[f"test_{k}"]).abs().mean().item()
+            assert epe < 1e-3, f"{name} scale {s}: EPE vs reference {epe:.3e} (bar 1e-3)"
+        coord = O.make_coord([H, W]).view(1, -1, 2).to(DEV)
+        res = model(img1.to(DEV), img2.to(DEV), iters=3, test_mode=False, hr_coord=coord, scale=torch.tensor([[1.0]], device=DEV))
+        preds = res[1] if name == "igev" else res
+        assert len(preds) == 3
+        for i, p in enumerate(preds):
+            assert (p.cpu() - g[f"pred_{i}"]).abs().mean().item() < 1e-3
+
+
+def test_ops_reject_cpu_tensors():
+    """No silent CPU fallback in the product path."""
+    from anystereo import ops
+    with pytest.raises(RuntimeError):
+        ops.corr_build_pyramid(torch.zeros(1, 4, 2, 8), torch.zeros(1, 4, 2, 8), 2)
+    with pytest.raises(RuntimeError):
+        ops.pool2x(torch.zeros(1, 1, 4, 4))
