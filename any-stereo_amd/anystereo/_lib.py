@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64.so.7; it MUST be the HIP runtime this library binds to, otherwise
+# stream handles taken from torch would belong to a different runtime instance (and loading /opt/rocm's
+# copy first makes torch.cuda unusable).  Importing torch first pins the shared runtime.
+import torch  # noqa: F401
+
 AS_MAX_LEVELS = 4
 AS_MAX_SRCS = 4
 AS_F32, AS_F16, AS_F64 = 0, 1, 2

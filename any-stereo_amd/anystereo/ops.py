@@ -230,6 +230,10 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
            h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None):
     """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue."""
     b, _, hh, ww = srcs[0].shape
+    kc = 8 if pack.ks == 3 else 32  # channels per K chunk of the kernel (csrc/conv.hip ConvCfg)
+    if any(s.shape[1] % kc for s in srcs[:-1]):
+        # a K chunk must not straddle two tensors: materialise the concat for odd splits (never on the model path)
+        srcs = [torch.cat(list(srcs), dim=1)]
     d = L.ConvDesc()
     cin = 0
     if len(srcs) > L.AS_MAX_SRCS:

@@ -7,16 +7,25 @@
 //   MFMA A operand = weights  (A[i=co][k]  : lane&31 -> co,    lane>>5 -> k parity)
 //   MFMA B operand = patch    (B[k][j=pix] : lane&31 -> pixel, lane>>5 -> k parity)
 //   C/D: col j = lane&31 = pixel  => every epilogue load/store is a 128-B run along x in NCHW.
+//
+// Block = 4 waves, output tile 64 co x 64 pixels (2x2 MFMA tiles).  All four waves accumulate the
+// WHOLE tile over a quarter of K each (intra-block split-K: wave w owns channel pairs w, w+4, ... of
+// every chunk), so the serial MFMA chain per wave is K/8 instead of K/2: small feature maps
+// (1/8, 1/16 resolution: tens of tiles) finish in a quarter of the time and large ones decompose into
+// thousands of equal blocks that balance over the 256 CUs.  The four partial tiles are reduced
+// through LDS, each wave then owns ONE 32x32 tile of the epilogue.
 // Per channel chunk the block stages an input halo patch [KC][TH+KS-1][TW+KS-1] and the packed
-// weight slab [KS*KS*KC][BN] in LDS; inside a chunk k is ordered (tap, channel) so the two k
-// parities of a lane differ by one channel stride and every ds_read address is
-// lane_base + compile-time immediate.  The channel concat of the reference (torch.cat([h, x...]))
-// is never materialised: a chunk's channels are read from whichever source tensor owns them.
+// weight slab [KS*KS*KC][64] in LDS, double buffered: the next chunk is fetched into registers
+// while the MFMAs of the current one run, one barrier per chunk.  Inside a chunk k is ordered
+// (tap, channel) so every ds_read address is lane_base + compile-time immediate.  The channel concat
+// of the reference (torch.cat([h, x...])) is never materialised: a chunk's channels are read from
+// whichever source tensor owns them.
 #include "common.h"
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 struct ConvParams {
   const float* src[AS_MAX_SRCS];
@@ -40,6 +49,9 @@ template <int KS> struct ConvCfg;
 template <> struct ConvCfg<3> { static constexpr int KC = 8; };
 template <> struct ConvCfg<1> { static constexpr int KC = 32; };
 
+constexpr int kBM = 64;  // pixels per block
+constexpr int kBN = 64;  // output channels per block
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
     case AS_ACT_RELU: return fmaxf(v, 0.f);
@@ -49,140 +61,205 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-// KS: 1 or 3.  TW: tile width in pixels (tile = (128/TW) rows x TW cols; KS==1 uses TW=128 on the
-// flattened H*W plane).  BN: output channels per block (128: waves 2(pix) x 2(co); 64/32: 4 x 1).
-template <int KS, int TW, int BN, int EPI>
+// KS: 1 or 3.  TW: tile width in pixels (tile = (64/TW) rows x TW cols; KS==1 uses TW=64 on the
+// flattened H*W plane).
+template <int KS, int TW, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   constexpr int KC = ConvCfg<KS>::KC;
-  constexpr int TH = 128 / TW;
+  constexpr int TH = kBM / TW;
   constexpr int PAD = KS / 2;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PATCH = PH * PW;
   constexpr int KROWS = KC * KS * KS;
-  constexpr int CTW = (BN >= 64) ? 2 : 1;   // co tiles per wave
-  constexpr int PTW = (BN == 128) ? 2 : 1;  // pixel tiles per wave
-  __shared__ float patch_s[KC * PATCH];
-  __shared__ __attribute__((aligned(16))) float w_s[KROWS * BN];
+  constexpr int PATCH_ELEMS = KC * PATCH;
+  constexpr int W_ELEMS = KROWS * kBN;
+  constexpr int STAGE = PATCH_ELEMS + W_ELEMS;            // floats per buffer (W slab first, 16-B aligned)
+  constexpr int RED = 12 * 16 * 64;                       // 12 partial tiles of 16 regs x 64 lanes
+  constexpr int LDS_FLOATS = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  constexpr int NP = (PATCH_ELEMS + 255) / 256;           // patch elements prefetched per thread
+  constexpr int NW4 = (W_ELEMS / 4 + 255) / 256;          // weight float4s prefetched per thread
+  constexpr int CPW = KC / 8;                             // channel pairs per wave per chunk
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
 
+  // block -> (co tile [slowest: one weight slab set stays L2-hot], batch, tile y, tile x)
   int id = blockIdx.x;
-  const int nt = id % p.n_tiles;
-  id /= p.n_tiles;
   const int tx = id % p.tiles_x;
   id /= p.tiles_x;
   const int ty = id % p.tiles_y;
-  const int b = id / p.tiles_y;
+  id /= p.tiles_y;
+  const int b = id % p.B;
+  const int nt = id / p.B;
   const int x0 = tx * TW, y0 = ty * TH;
-  const int n0 = nt * BN;
+  const int n0 = nt * kBN;
   const long long plane = (long long)p.H * p.W;
 
-  // wave -> (pixel tiles, co tiles)
-  int pt0, ct0;
-  if (BN == 128) { pt0 = (wave & 1) * 2; ct0 = (wave >> 1) * 2; }
-  else { pt0 = wave; ct0 = 0; }
-
-  int poff[PTW];  // LDS offset of this lane's pixel inside the patch (tap (0,0))
+  // ---- per-thread staging descriptors (chunk independent) ----
+  // Patch elements are fetched with raw buffer loads: the descriptor (chunk-uniform, in SGPRs) covers
+  // the channels of the owning source tensor from this chunk's first channel on, so elements outside
+  // the image (sentinel offset) and channels beyond Cin read as 0 by the hardware range check —
+  // no branches, no selects, every load of a chunk in flight together.
+  unsigned p_voff[NP];
 #pragma unroll
-  for (int i = 0; i < PTW; ++i) {
-    const int m = (pt0 + i) * 32 + l31;
-    poff[i] = half * PATCH + (m / TW) * PW + (m % TW);
+  for (int i = 0; i < NP; ++i) {
+    int idx = tid + i * 256;
+    const bool slot = idx < PATCH_ELEMS;
+    if (!slot) idx = PATCH_ELEMS - 1;
+    const int c = idx / PATCH;
+    const int r = idx - c * PATCH;
+    const int py = r / PW, px = r - py * PW;
+    const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+    const bool in = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    p_voff[i] = in ? (unsigned)(((long long)c * plane + (long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
   }
-  const int woff = half * BN + ct0 * 32 + l31;
+  int w_idx[NW4];
+#pragma unroll
+  for (int i = 0; i < NW4; ++i) {
+    int idx = tid + i * 256;
+    if (idx >= W_ELEMS / 4) idx = W_ELEMS / 4 - 1;
+    w_idx[i] = (idx / (kBN / 4)) * (p.Cout_pad >> 2) + (idx % (kBN / 4));
+  }
+  const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack + n0);
+  const long long wchunk4 = (long long)KROWS * (p.Cout_pad >> 2);
 
-  f32x16 acc[CTW][PTW];
+  float pre_p[NP];
+  f32x4 pre_w[NW4];
+
+  // Source tensor of a chunk: chunk-uniform (the launcher guarantees that every source but the last
+  // holds a multiple of KC channels), selected with scalar compares on the kernel arguments.
+#define AS_CONV_FETCH(CHUNK)                                                                          \
+  {                                                                                                   \
+    const int cb = (CHUNK) * KC;                                                                      \
+    const float* sp = p.src[0];                                                                       \
+    int sc = p.src_c[0], sb = 0;                                                                      \
+    if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; }      \
+    if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; }      \
+    if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; }      \
+    const float* spb = sp + ((long long)b * sc + (cb - sb)) * plane;                                   \
+    const int recs = (int)((long long)(sc - (cb - sb)) * plane * 4);                                   \
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i)                                                     \
+      pre_p[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)p_voff[i], 0, 0)); \
+    const f32x4* wc = wsrc + (long long)(CHUNK) * wchunk4;                                             \
+    _Pragma("unroll") for (int i = 0; i < NW4; ++i) pre_w[i] = wc[w_idx[i]];                           \
+  }
+#define AS_CONV_COMMIT(BUF)                                                                           \
+  {                                                                                                   \
+    float* wdst = lds + (BUF) * STAGE;                                                                \
+    float* pdst = wdst + W_ELEMS;                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NW4; ++i) {                                                  \
+      const int idx = tid + i * 256;                                                                  \
+      if (idx < W_ELEMS / 4) reinterpret_cast<f32x4*>(wdst)[idx] = pre_w[i];                           \
+    }                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                   \
+      const int idx = tid + i * 256;                                                                  \
+      if (idx < PATCH_ELEMS) pdst[idx] = pre_p[i];                                                    \
+    }                                                                                                 \
+  }
+
+  // lane bases: wave w owns channel pairs {w, w+4, ...} of each chunk
+  int poff[2];
 #pragma unroll
-  for (int c = 0; c < CTW; ++c)
+  for (int q = 0; q < 2; ++q) {
+    const int m = q * 32 + l31;
+    poff[q] = W_ELEMS + (2 * wave + half) * PATCH + (m / TW) * PW + (m % TW);
+  }
+  const int woff = (2 * wave + half) * kBN + l31;
+
+  f32x16 acc[2][2];  // [co tile][pixel tile]
 #pragma unroll
-    for (int q = 0; q < PTW; ++q)
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
 
+  AS_CONV_FETCH(0)
+  AS_CONV_COMMIT(0)
+  __syncthreads();
+
   for (int chunk = 0; chunk < p.chunks; ++chunk) {
-    __syncthreads();
-    // ---- stage the input halo patch (zero outside the image / beyond Cin) ----
-    for (int idx = tid; idx < KC * PATCH; idx += 256) {
-      const int c = idx / PATCH;
-      const int r = idx - c * PATCH;
-      const int py = r / PW, px = r - py * PW;
-      const int gy = y0 - PAD + py, gx = x0 - PAD + px;
-      const int cg = chunk * KC + c;
-      float v = 0.f;
-      if (cg < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-        int s = 0, base = 0;
-#pragma unroll
-        for (int i = 0; i < AS_MAX_SRCS - 1; ++i)
-          if (i + 1 < p.n_src && cg >= p.src_end[i]) { s = i + 1; base = p.src_end[i]; }
-        v = p.src[s][((long long)b * p.src_c[s] + (cg - base)) * plane + (long long)gy * p.W + gx];
-      }
-      patch_s[idx] = v;
-    }
-    // ---- stage the weight slab rows [chunk*KROWS, +KROWS) x cols [n0, n0+BN) ----
-    {
-      const float4* wsrc = reinterpret_cast<const float4*>(p.wpack + ((long long)chunk * KROWS) * p.Cout_pad + n0);
-      const int rstride4 = p.Cout_pad >> 2;
-      for (int idx = tid; idx < KROWS * (BN / 4); idx += 256) {
-        const int row = idx / (BN / 4);
-        const int c4 = idx - row * (BN / 4);
-        reinterpret_cast<float4*>(w_s)[idx] = wsrc[(long long)row * rstride4 + c4];
-      }
-    }
-    __syncthreads();
-    // ---- MFMA over the chunk: k = (tap, channel pair) ----
+    const int cur = chunk & 1;
+    const bool more = chunk + 1 < p.chunks;
+    if (more) AS_CONV_FETCH(chunk + 1)
+    const float* buf = lds + cur * STAGE;
 #pragma unroll
     for (int tap = 0; tap < KS * KS; ++tap) {
       const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
-      for (int cc = 0; cc < KC / 2; ++cc) {
-        float a[CTW], bv[PTW];
+      for (int j = 0; j < CPW; ++j) {
+        const int cc = 4 * j;  // + wave, folded into the lane bases
+        float a[2], bv[2];
 #pragma unroll
-        for (int c = 0; c < CTW; ++c) a[c] = w_s[woff + (tap * KC + 2 * cc) * BN + c * 32];
+        for (int c = 0; c < 2; ++c) a[c] = buf[woff + (tap * KC + 2 * cc) * kBN + c * 32];
 #pragma unroll
-        for (int q = 0; q < PTW; ++q) bv[q] = patch_s[poff[q] + (2 * cc) * PATCH + ky * PW + kx];
+        for (int q = 0; q < 2; ++q) bv[q] = buf[poff[q] + (2 * cc) * PATCH + ky * PW + kx];
 #pragma unroll
-        for (int c = 0; c < CTW; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int q = 0; q < PTW; ++q)
+          for (int q = 0; q < 2; ++q)
             acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bv[q], acc[c][q], 0, 0, 0);
       }
     }
+    if (more) AS_CONV_COMMIT(cur ^ 1)
+    __syncthreads();
+  }
+#undef AS_CONV_FETCH
+#undef AS_CONV_COMMIT
+
+  // ---- reduce the four K-partials: wave w ends up owning tile t = w (co tile w>>1, pixel tile w&1) ----
+  // slot(t, w) = t*3 + (w < t ? w : w-1), w != t.  Layout per slot: [16 regs][64 lanes] (conflict free).
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t == wave) continue;
+    const int slot = t * 3 + (wave < t ? wave : wave - 1);
+    float* dst = lds + slot * 1024 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r * 64] = acc[t >> 1][t & 1][r];
+  }
+  __syncthreads();
+  f32x16 sum;
+  {
+    // select my own tile without dynamic register indexing
+    const f32x16 own = (wave == 0) ? acc[0][0] : (wave == 1) ? acc[0][1] : (wave == 2) ? acc[1][0] : acc[1][1];
+    sum = own;
+    const float* srcp = lds + wave * 3 * 1024 + lane;
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum[r] += srcp[s * 1024 + r * 64];
   }
 
-  // ---- epilogue ----
+  // ---- epilogue for tile (co tile = wave>>1, pixel tile = wave&1) ----
+  const int m = (wave & 1) * 32 + l31;
+  const int gy = y0 + m / TW, gx = x0 + m % TW;
+  if (gy >= p.H || gx >= p.W) return;
+  const long long pixoff = (long long)gy * p.W + gx;
 #pragma unroll
-  for (int q = 0; q < PTW; ++q) {
-    const int m = (pt0 + q) * 32 + l31;
-    const int gy = y0 + m / TW, gx = x0 + m % TW;
-    if (gy >= p.H || gx >= p.W) continue;
-    const long long pixoff = (long long)gy * p.W + gx;
-#pragma unroll
-    for (int c = 0; c < CTW; ++c) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = n0 + (ct0 + c) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= p.Cout) continue;
-        float v = acc[c][q][r];
-        if (p.bias) v += p.bias[co];
-        if (p.add) v += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pixoff];
-        if (EPI == AS_EPI_LINEAR) {
-          p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pixoff] = act_apply(v, p.act);
-        } else if (EPI == AS_EPI_GRU_ZR) {
-          const int ch = p.Cout >> 1;
-          const float g = 1.f / (1.f + expf(-v));
-          if (co < ch) {
-            p.out[((long long)b * ch + co) * plane + pixoff] = g;
-          } else {
-            const long long o = ((long long)b * ch + (co - ch)) * plane + pixoff;
-            p.out2[o] = g * p.h[o];
-          }
-        } else {  // AS_EPI_GRU_Q
-          const long long o = ((long long)b * p.Cout + co) * plane + pixoff;
-          const float zz = p.z[o];
-          p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(v);
-        }
+  for (int r = 0; r < 16; ++r) {
+    const int co = n0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (co >= p.Cout) continue;
+    float v = sum[r];
+    if (p.bias) v += p.bias[co];
+    if (p.add) v += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pixoff];
+    if (EPI == AS_EPI_LINEAR) {
+      p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pixoff] = act_apply(v, p.act);
+    } else if (EPI == AS_EPI_GRU_ZR) {
+      const int ch = p.Cout >> 1;
+      const float g = 1.f / (1.f + expf(-v));
+      if (co < ch) {
+        p.out[((long long)b * ch + co) * plane + pixoff] = g;
+      } else {
+        const long long o = ((long long)b * ch + (co - ch)) * plane + pixoff;
+        p.out2[o] = g * p.h[o];
       }
+    } else {  // AS_EPI_GRU_Q
+      const long long o = ((long long)b * p.Cout + co) * plane + pixoff;
+      const float zz = p.z[o];
+      p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(v);
     }
   }
 }
@@ -314,17 +391,17 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x
   out[idx] = (1.f - ty) * top + ty * bot;
 }
 
-template <int KS, int TW, int BN>
+template <int KS, int TW>
 int launch_conv(const ConvParams& p, int epi, hipStream_t s) {
   const dim3 grid((unsigned)((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles));
-  if (epi == AS_EPI_LINEAR) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, BN, AS_EPI_LINEAR>), grid, dim3(256), 0, s, p);
-  else if (BN == 128 && epi == AS_EPI_GRU_ZR) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, 128, AS_EPI_GRU_ZR>), grid, dim3(256), 0, s, p);
-  else if (BN == 128 && epi == AS_EPI_GRU_Q) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, 128, AS_EPI_GRU_Q>), grid, dim3(256), 0, s, p);
-  else return as::fail(AS_ERR_BAD_ARG, "conv2d: GRU epilogues need Cout %% 128 == 0");
+  if (epi == AS_EPI_LINEAR) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, AS_EPI_LINEAR>), grid, dim3(256), 0, s, p);
+  else if (epi == AS_EPI_GRU_ZR) hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, AS_EPI_GRU_ZR>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_igemm_kernel<KS, TW, AS_EPI_GRU_Q>), grid, dim3(256), 0, s, p);
   return as::check_launch("conv2d");
 }
 
 int conv_kc(int KS) { return KS == 3 ? ConvCfg<3>::KC : ConvCfg<1>::KC; }
+int conv_cout_pad(int Cout) { return ((Cout + kBN - 1) / kBN) * kBN; }
 
 }  // namespace
 
@@ -333,8 +410,8 @@ extern "C" {
 int64_t as_conv_pack_size(int Cin, int Cout, int KS) {
   if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return -1;
   const int KC = conv_kc(KS);
-  const int64_t chunks = (Cin + KC - 1) / KC, cpad = ((Cout + 31) / 32) * 32;
-  return chunks * KS * KS * KC * cpad;
+  const int64_t chunks = (Cin + KC - 1) / KC;
+  return chunks * KS * KS * KC * conv_cout_pad(Cout);
 }
 
 int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, int KS, void* stream) {
@@ -342,7 +419,7 @@ int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, i
   const int64_t total = as_conv_pack_size(Cin, Cout, KS);
   AS_REQUIRE(total > 0, AS_ERR_BAD_ARG, "conv_pack: unsupported Cin=%d Cout=%d KS=%d", Cin, Cout, KS);
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream),
-                     weight, wpack, Cin, Cout, ((Cout + 31) / 32) * 32, KS, conv_kc(KS), (long long)total);
+                     weight, wpack, Cin, Cout, conv_cout_pad(Cout), KS, conv_kc(KS), (long long)total);
   return as::check_launch("conv_pack_weights");
 }
 
@@ -363,13 +440,17 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.src_end[i] = csum;
   }
   AS_REQUIRE(csum == d->Cin, AS_ERR_BAD_SHAPE, "conv2d: sources hold %d channels, Cin=%d", csum, d->Cin);
+  for (int i = 0; i + 1 < d->n_src; ++i)
+    AS_REQUIRE(d->src_c[i] % conv_kc(d->KS) == 0, AS_ERR_BAD_SHAPE,
+               "conv2d: source %d has %d channels; every source but the last must hold a multiple of %d (concatenate first)",
+               i, d->src_c[i], conv_kc(d->KS));
   p.n_src = d->n_src;
   p.wpack = d->wpack; p.bias = d->bias; p.add = d->add;
   p.add_ctot = d->add_ctot; p.add_coff = d->add_coff;
   AS_REQUIRE(!d->add || (d->add_coff >= 0 && d->add_coff + d->Cout <= d->add_ctot), AS_ERR_BAD_SHAPE, "conv2d: add channel window [%d,%d) outside %d", d->add_coff, d->add_coff + d->Cout, d->add_ctot);
   p.h = d->h; p.z = d->z; p.out = d->out; p.out2 = d->out2;
   p.B = d->B; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
-  p.Cout_pad = ((d->Cout + 31) / 32) * 32;
+  p.Cout_pad = conv_cout_pad(d->Cout);
   const int epi = d->epilogue;
   if (epi == AS_EPI_LINEAR) {
     p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
@@ -377,59 +458,48 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     AS_REQUIRE(p.out_coff >= 0 && p.out_coff + d->Cout <= p.out_ctot, AS_ERR_BAD_SHAPE, "conv2d: out channel window outside out_ctot");
     AS_REQUIRE(d->act >= AS_ACT_NONE && d->act <= AS_ACT_TANH, AS_ERR_BAD_ARG, "conv2d: act=%d", d->act);
   } else if (epi == AS_EPI_GRU_ZR) {
-    AS_REQUIRE(d->h && d->out2 && (d->Cout % 2) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and even Cout");
+    AS_REQUIRE(d->h && d->out2 && (d->Cout % (2 * kBN)) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and Cout %% 128 == 0");
   } else if (epi == AS_EPI_GRU_Q) {
     AS_REQUIRE(d->h && d->z, AS_ERR_BAD_ARG, "conv2d(GRU_Q): needs h and z");
   } else {
     return as::fail(AS_ERR_BAD_ARG, "conv2d: epilogue=%d", epi);
   }
   const int KC = conv_kc(d->KS);
+  for (int i = 0; i < d->n_src; ++i)  // 32-bit buffer offsets inside one (batch, source) tensor
+    AS_REQUIRE((long long)d->src_c[i] * d->H * d->W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE,
+               "conv2d: source %d exceeds 2 GiB per batch element", i);
   p.chunks = (d->Cin + KC - 1) / KC;
-  const int bn = (p.Cout_pad % 128 == 0) ? 128 : (p.Cout_pad % 64 == 0 ? 64 : 32);
-  AS_REQUIRE(epi == AS_EPI_LINEAR || bn == 128, AS_ERR_BAD_SHAPE, "conv2d: GRU epilogues need Cout %% 128 == 0 (Cout=%d)", d->Cout);
-  p.n_tiles = p.Cout_pad / bn;
+  p.n_tiles = p.Cout_pad / kBN;
   hipStream_t s = as::as_stream(stream);
-  long long nblk;
   if (d->KS == 1) {
     // no halo: run on the flattened H*W plane
     AS_REQUIRE((long long)d->H * d->W < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: plane too large");
     p.H = 1;
     p.W = d->H * d->W;
-    p.tiles_x = as::cdiv(p.W, 128);
+    p.tiles_x = as::cdiv(p.W, kBM);
     p.tiles_y = 1;
-    nblk = (long long)p.B * p.tiles_x * p.n_tiles;
-    AS_REQUIRE(nblk < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
-    if (bn == 128) return launch_conv<1, 128, 128>(p, epi, s);
-    if (bn == 64) return launch_conv<1, 128, 64>(p, epi, s);
-    return launch_conv<1, 128, 32>(p, epi, s);
+    AS_REQUIRE((long long)p.B * p.tiles_x * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+    return launch_conv<1, 64>(p, epi, s);
   }
   p.H = d->H;
   p.W = d->W;
-  // pick the tile shape (TH x TW = 128 pixels) that wastes the fewest pixels on this image
-  int best_tw = 32;
+  AS_REQUIRE((long long)d->H * d->W < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: plane too large");
+  // pick the tile shape (TH x TW = 64 pixels) that wastes the fewest pixels on this image;
+  // ties prefer 4x16 (64-B store runs, least halo) over 2x32 over 8x8
+  const int cand[3] = {16, 32, 8};
+  int best_tw = 16;
   long long best = -1;
-  for (int tw = 32; tw >= 8; tw >>= 1) {
-    const int th = 128 / tw;
+  for (int i = 0; i < 3; ++i) {
+    const int tw = cand[i], th = kBM / tw;
     const long long area = (long long)as::cdiv(p.W, tw) * tw * as::cdiv(p.H, th) * th;
     if (best < 0 || area < best) { best = area; best_tw = tw; }
   }
-  const int th = 128 / best_tw;
   p.tiles_x = as::cdiv(p.W, best_tw);
-  p.tiles_y = as::cdiv(p.H, th);
-  nblk = (long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles;
-  AS_REQUIRE(nblk < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
-  if (best_tw == 32) {
-    if (bn == 128) return launch_conv<3, 32, 128>(p, epi, s);
-    if (bn == 64) return launch_conv<3, 32, 64>(p, epi, s);
-    return launch_conv<3, 32, 32>(p, epi, s);
-  } else if (best_tw == 16) {
-    if (bn == 128) return launch_conv<3, 16, 128>(p, epi, s);
-    if (bn == 64) return launch_conv<3, 16, 64>(p, epi, s);
-    return launch_conv<3, 16, 32>(p, epi, s);
-  }
-  if (bn == 128) return launch_conv<3, 8, 128>(p, epi, s);
-  if (bn == 64) return launch_conv<3, 8, 64>(p, epi, s);
-  return launch_conv<3, 8, 32>(p, epi, s);
+  p.tiles_y = as::cdiv(p.H, kBM / best_tw);
+  AS_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+  if (best_tw == 32) return launch_conv<3, 32>(p, epi, s);
+  if (best_tw == 16) return launch_conv<3, 16>(p, epi, s);
+  return launch_conv<3, 8>(p, epi, s);
 }
 
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out, int B, int H, int W,

@@ -22,7 +22,11 @@ struct LookupParams {
   int B, H, W, W2, D, G, L, radius;
   int HW, CH;
   long long P;
+  int geo_bytes[AS_MAX_LEVELS];
+  int corr_bytes[AS_MAX_LEVELS];
 };
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // position of tap k (kk = k - R) given the level-scaled base; returns window slot selection.
 //   xk = xbase + kk (one fp32 add, as the reference's `dx + disp/2**i`, geometry.py:43,52)
@@ -54,13 +58,17 @@ __global__ __launch_bounds__(256) void lookup_fwd_kernel(LookupParams p) {
   if (sub < gq) {
     const int Dl = p.D >> level;
     const int i0 = (int)floorf(ds);
-    const float4* row = reinterpret_cast<const float4*>(p.geo[level] + (pix * Dl) * p.G + 4 * sub);
-    const int gstride = p.G >> 2;  // float4 units between consecutive disparities
-    float4 w[NW];
+    // raw buffer loads with a sentinel offset for taps outside [0, Dl): the hardware range check
+    // returns 0, so all 2r+2 window loads issue back to back with no branch / wait in between
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.geo[level], 0, p.geo_bytes[level], 0x00020000);
+    const unsigned rowoff = (unsigned)(((pix * Dl) * p.G + 4 * sub) * 4);
+    const unsigned dstride = (unsigned)(p.G * 4);
+    f32x4 w[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int dd = i0 - R + j;
-      w[j] = (dd >= 0 && dd < Dl) ? row[(long long)dd * gstride] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned off = (dd >= 0 && dd < Dl) ? rowoff + (unsigned)dd * dstride : 0x7FFFFFF0u;
+      w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
     }
     float* o = outp + (long long)(4 * sub) * K * p.HW;
 #pragma unroll
@@ -69,8 +77,7 @@ __global__ __launch_bounds__(256) void lookup_fwd_kernel(LookupParams p) {
       bool bump;
       tap_weights(ds, i0, k - R, t, bump);
       const float a = bump ? 0.f : 1.f - t, c = bump ? 1.f : t;
-      const float4 v = make_float4(a * w[k].x + c * w[k + 1].x, a * w[k].y + c * w[k + 1].y,
-                                   a * w[k].z + c * w[k + 1].z, a * w[k].w + c * w[k + 1].w);
+      const f32x4 v = a * w[k] + c * w[k + 1];
       o[(long long)(0 * K + k) * p.HW] = v.x;
       o[(long long)(1 * K + k) * p.HW] = v.y;
       o[(long long)(2 * K + k) * p.HW] = v.z;
@@ -81,12 +88,14 @@ __global__ __launch_bounds__(256) void lookup_fwd_kernel(LookupParams p) {
     const float xs = ldexpf((float)x, -level);
     const float xb = xs - ds;  // coords/2**i - disp/2**i
     const int i0 = (int)floorf(xb);
-    const float* row = p.corr[level] + pix * Wl;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.corr[level], 0, p.corr_bytes[level], 0x00020000);
+    const unsigned rowoff = (unsigned)(pix * Wl * 4);
     float w[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int dd = i0 - R + j;
-      w[j] = (dd >= 0 && dd < Wl) ? row[dd] : 0.f;
+      const unsigned off = (dd >= 0 && dd < Wl) ? rowoff + (unsigned)dd * 4u : 0x7FFFFFF0u;
+      w[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
     }
     float* o = outp + (long long)p.G * K * p.HW;
 #pragma unroll
@@ -281,6 +290,12 @@ int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, co
     p.corr[i] = corr[i];
     p.geo[i] = G ? geo[i] : nullptr;
     AS_REQUIRE(G == 0 || (reinterpret_cast<uintptr_t>(geo[i]) & 15) == 0, AS_ERR_BAD_ARG, "lookup_fwd: geo[%d] not 16-B aligned", i);
+  }
+  for (int i = 0; i < L; ++i) {
+    const long long cb = p.P * (W2 >> i) * 4, gb = p.P * (long long)(D >> i) * G * 4;
+    AS_REQUIRE(cb < 0x7FFFFFF0ll && gb < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "lookup_fwd: pyramid level %d exceeds 2 GiB", i);
+    p.corr_bytes[i] = (int)cb;
+    p.geo_bytes[i] = (int)gb;
   }
   p.disp = disp;
   p.out = out;

@@ -27,8 +27,18 @@ struct CorrParams {
   int MT, NT;  // 32-wide tiles along x1 / x2
 };
 
-constexpr int kNG = 4;  // N-tiles accumulated per pass (4 x 16 accumulator registers)
+constexpr int kKS = 48;  // k-steps (channel pairs) held in registers per pass: C <= 96 in one pass
 
+// Fragments come through raw buffer loads: the descriptor spans one batch element of the feature map,
+// so columns beyond W (sentinel offset) and channels beyond C read as 0 by the hardware range check —
+// no branches around loads, a whole fragment (48 loads) is in flight at once.  The B fragment of
+// N-tile j+1 is fetched while the 48 MFMAs of tile j run (one wave per SIMD at 960x540: latency must
+// be hidden inside the wave, not by occupancy).
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+
+template <bool A_RESIDENT>
 __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -39,59 +49,72 @@ __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
   const int y = row - b * p.H;
   const int mt = blockIdx.y * 4 + wave;
   if (mt >= p.MT) return;
-  const long long cs1 = (long long)p.H * p.W1;  // channel stride
+  const long long cs1 = (long long)p.H * p.W1;  // channel stride (elements)
   const long long cs2 = (long long)p.H * p.W2;
+  const __amdgpu_buffer_rsrc_t r1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.f1 + (long long)b * p.C * cs1), 0, (int)(p.C * cs1 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.f2 + (long long)b * p.C * cs2), 0, (int)(p.C * cs2 * 4), 0x00020000);
+  const unsigned kstride1 = (unsigned)(2 * cs1 * 4), kstride2 = (unsigned)(2 * cs2 * 4);
+  const unsigned kOOB = 0x7FFFFFF0u;
   const int x1 = mt * 32 + l31;
-  const bool ok1 = x1 < p.W1;
-  const float* a_ptr = p.f1 + ((long long)b * p.C + half) * cs1 + (long long)y * p.W1 + (ok1 ? x1 : 0);
-  const float* b_base = p.f2 + ((long long)b * p.C + half) * cs2 + (long long)y * p.W2;
+  const unsigned a_off = x1 < p.W1 ? (unsigned)((half * cs1 + (long long)y * p.W1 + x1) * 4) : kOOB;
+  const unsigned b_row = (unsigned)((half * cs2 + (long long)y * p.W2) * 4);
   const int ksteps = (p.C + 1) >> 1;
+  const int passes = (ksteps + kKS - 1) / kKS;
+  const long long rowbase = (long long)row * p.W1;
 
-  for (int nt0 = 0; nt0 < p.NT; nt0 += kNG) {
-    f32x16 acc[kNG];
+  float a[kKS], bq[kKS], bn[kKS];
+  if (A_RESIDENT) {
 #pragma unroll
-    for (int j = 0; j < kNG; ++j)
+    for (int k = 0; k < kKS; ++k) a[k] = bload(r1, a_off == kOOB ? kOOB : a_off + k * kstride1);
+  }
+  // prefetch B of (tile 0, pass 0)
+  {
+    const int x2 = l31;
+    const unsigned bo = x2 < p.W2 ? b_row + x2 * 4 : kOOB;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    int xc[kNG];
-    bool okc[kNG];
+    for (int k = 0; k < kKS; ++k) bq[k] = bload(r2, bo == kOOB ? kOOB : bo + k * kstride2);
+  }
+  for (int nt = 0; nt < p.NT; ++nt) {
+    f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < kNG; ++j) {
-      xc[j] = (nt0 + j) * 32 + l31;
-      okc[j] = xc[j] < p.W2;
-      if (!okc[j]) xc[j] = 0;
-    }
-#pragma unroll 4
-    for (int kk = 0; kk < ksteps; ++kk) {
-      const bool okk = (2 * kk + half) < p.C;
-      const float a = (ok1 && okk) ? a_ptr[(long long)(2 * kk) * cs1] : 0.f;
-      const float* bp = b_base + (long long)(2 * kk) * cs2;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ps = 0; ps < passes; ++ps) {
+      // next (tile, pass) in iteration order
+      int nnt = nt, nps = ps + 1;
+      if (nps == passes) { nps = 0; nnt = nt + 1; }
+      if (nnt < p.NT) {
+        const int x2 = nnt * 32 + l31;
+        const unsigned bo = x2 < p.W2 ? b_row + x2 * 4 + (unsigned)nps * kKS * kstride2 : kOOB;
 #pragma unroll
-      for (int j = 0; j < kNG; ++j) {
-        const float bv = (okc[j] && okk) ? bp[xc[j]] : 0.f;
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
+        for (int k = 0; k < kKS; ++k) bn[k] = bload(r2, bo == kOOB ? kOOB : bo + k * kstride2);
       }
+      if (!A_RESIDENT) {
+        const unsigned ao = a_off == kOOB ? kOOB : a_off + (unsigned)ps * kKS * kstride1;
+#pragma unroll
+        for (int k = 0; k < kKS; ++k) a[k] = bload(r1, ao == kOOB ? kOOB : ao + k * kstride1);
+      }
+#pragma unroll
+      for (int k = 0; k < kKS; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], bq[k], acc, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < kKS; ++k) bq[k] = bn[k];
     }
-    // epilogue: level 0 + pooled levels
-    const long long rowbase = (long long)row * p.W1;
+    // epilogue: level 0 + pooled levels (butterfly over lanes xor 1, 2, 4)
+    const int x2 = nt * 32 + l31;
 #pragma unroll
-    for (int j = 0; j < kNG; ++j) {
-      const int x2 = (nt0 + j) * 32 + l31;
+    for (int r = 0; r < 16; ++r) {
+      const int xr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool okr = xr < p.W1;
+      float v = acc[r];
+      if (okr && x2 < p.W2) p.lvl[0][(rowbase + xr) * p.W2 + x2] = v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int xr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const bool okr = xr < p.W1;
-        float v = acc[j][r];
-        if (okr && x2 < p.W2) p.lvl[0][(rowbase + xr) * p.W2 + x2] = v;
-        // butterfly: after step s the lanes with (l31 & (2^s - 1)) == 0 hold the level-s value
-#pragma unroll
-        for (int s = 1; s < AS_MAX_LEVELS; ++s) {
-          if (s < p.L) {
-            v = (v + __shfl_xor(v, 1 << (s - 1))) * 0.5f;
-            const int wl = p.W2 >> s;
-            const int xs = x2 >> s;
-            if (okr && (l31 & ((1 << s) - 1)) == 0 && xs < wl) p.lvl[s][(rowbase + xr) * wl + xs] = v;
-          }
+      for (int s = 1; s < AS_MAX_LEVELS; ++s) {
+        if (s < p.L) {
+          v = (v + __shfl_xor(v, 1 << (s - 1))) * 0.5f;
+          const int wl = p.W2 >> s;
+          const int xs = x2 >> s;
+          if (okr && (l31 & ((1 << s) - 1)) == 0 && xs < wl) p.lvl[s][(rowbase + xr) * wl + xs] = v;
         }
       }
     }
@@ -253,8 +276,11 @@ int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels
     AS_REQUIRE(levels[i], AS_ERR_BAD_ARG, "corr_build: null level %d", i);
     p.lvl[i] = levels[i];
   }
+  AS_REQUIRE((long long)C * H * W1 * 4 < 0x7FFFFFF0ll && (long long)C * H * W2 * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE,
+             "corr_build: a feature map exceeds 2 GiB per batch element");
   dim3 grid((unsigned)(B * H), (unsigned)as::cdiv(p.MT, 4));
-  hipLaunchKernelGGL(corr_build_kernel, grid, dim3(256), 0, as::as_stream(stream), p);
+  if ((C + 1) / 2 <= kKS) hipLaunchKernelGGL(corr_build_kernel<true>, grid, dim3(256), 0, as::as_stream(stream), p);
+  else hipLaunchKernelGGL(corr_build_kernel<false>, grid, dim3(256), 0, as::as_stream(stream), p);
   return as::check_launch("corr_build_pyramid");
 }
 

@@ -173,6 +173,8 @@ def main():
             "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "rooflines": rooflines,
+            "kernel_times_us": {k: {"avg": round(v["total_ms"] / max(v["count"], 1) * 1e3, 2), "n": v["count"] // a.steps}
+                                for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

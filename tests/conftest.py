@@ -22,6 +22,6 @@ def golden():
 
     def load(name):
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
-        return {k: torch.from_numpy(z[k]) for k in z.files}
+        return {k: torch.from_numpy(np.ascontiguousarray(z[k])) for k in z.files}
 
     return load
