@@ -56,6 +56,7 @@ SIGNATURES = {
     "as_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "as_pool2x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "as_interp_bilinear_ac": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_structure_feature": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -79,6 +79,50 @@ class ContinuousStereoBase(nn.Module):
         with scope("convex_upsample"):
             return ops.convex_upsample(disp.float().contiguous(), logits, hr_coord, scale=scale_vec, mask_is_logits=True)
 
+    # ---- whole-forward hipGraph ---------------------------------------------------------------
+    # A 32-iteration forward is ~2000 short launches; replaying it as ONE captured graph removes the host
+    # launch path (PyTorch dispatch + ctypes) from the critical path.  Opt-in (`enable_graph(True)`), inference
+    # only, one graph per (input shapes, iters); inputs are copied into static buffers, the result is a clone.
+    def enable_graph(self, flag: bool = True):
+        self._use_graph = bool(flag)
+        if not flag:
+            self._graphs = {}
+
+    def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
+        """Reference signature (continuous_IGEVstereo.py:239, prune_raft_stereo.py:246)."""
+        if (getattr(self, "_use_graph", False) and test_mode and not torch.is_grad_enabled() and image1.is_cuda
+                and torch.is_tensor(scale) and not output_raw and not self.training):
+            return self._forward_graphed(image1, image2, iters, hr_coord, scale)
+        return self._forward_impl(image1, image2, iters=iters, flow_init=flow_init, test_mode=test_mode,
+                                  hr_coord=hr_coord, scale=scale, output_raw=output_raw)
+
+    def _forward_graphed(self, image1, image2, iters, hr_coord, scale):
+        key = (tuple(image1.shape), tuple(hr_coord.shape), tuple(scale.shape), int(iters), image1.device.index)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        ent = graphs.get(key)
+        if ent is None:
+            st = [t.detach().clone() for t in (image1, image2, hr_coord, scale)]
+            side = torch.cuda.Stream(device=image1.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up: MIOpen solver search, weight packing, allocator
+                for _ in range(2):
+                    st[2].copy_(hr_coord)
+                    self._forward_impl(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(image1.device)
+            g = torch.cuda.CUDAGraph()
+            st[2].copy_(hr_coord)
+            with torch.cuda.graph(g):
+                out = self._forward_impl(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
+            ent = graphs[key] = (g, st, out)
+        g, st, out = ent
+        st[0].copy_(image1)
+        st[1].copy_(image2)
+        st[2].copy_(hr_coord)
+        st[3].copy_(scale)
+        g.replay()
+        return out.clone()
+
     # ---- reference API -------------------------------------------------------------------------
     def upsample_disp(self, disp, hidden_layer, stem_4x, stem_2x, stem_1x, hr_coord=None, scale=1):
         """[B,1,h,w] disparity at 1/4 res -> [B,1,Q] at the query coordinates

@@ -70,7 +70,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         return self.geo_block(match_left.float(), match_right.float(), gev.float(), radius=self.args.corr_radius,
                               num_levels=self.args.corr_levels)
 
-    def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
+    def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
         """Estimate disparity between a pair of frames (images are 0..255 float)."""
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()

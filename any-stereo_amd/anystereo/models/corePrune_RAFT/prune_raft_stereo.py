@@ -59,7 +59,7 @@ class continuous_RaftStereo(ContinuousStereoBase):
         return self.corr_block(match_left.float(), match_right.float(), radius=self.args.corr_radius,
                                num_levels=self.args.corr_levels)
 
-    def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=False):
+    def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=False):
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()

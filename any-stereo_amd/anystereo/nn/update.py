@@ -46,8 +46,11 @@ class DispHead(nn.Module):
         with scope("disp_head_conv1"):
             t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
         if self.conv2.out_channels == 1:
+            # 3x3, 256 -> 1 as (1x1, 256 -> 9 tap planes on the MFMA path) + a 9-tap shifted sum
             with scope("disp_head_conv2"):
-                return ops.conv3x3_to1(t, _f(self.conv2.weight.detach()), _f(self.conv2.bias.detach()))
+                taps = ops.conv2d([t], self._p2.get([self.conv2.weight], [None],
+                                                    transform=lambda w: w[0].permute(1, 2, 0).reshape(9, -1, 1, 1).contiguous()))
+                return ops.tap_shift_sum(taps, _f(self.conv2.bias.detach()))
         return ops.conv2d([t], self._p2.get([self.conv2.weight], [self.conv2.bias]))
 
 
@@ -154,7 +157,27 @@ class BasicMultiUpdateBlock(nn.Module):
         self.disp_head = DispHead(hidden_dims[2], hidden_dim=256, output_dim=1)
         self.gru04.tag, self.gru08.tag, self.gru16.tag = "gru04", "gru08", "gru16"
 
+    # The motion encoder (5 convs at 1/4 res) does not depend on the 1/16 and 1/8 GRUs, and those two are far
+    # too small to fill 256 CUs: run the encoder on a second HIP stream, fork/join with events (captured as
+    # parallel branches under hipGraph).  Same arithmetic, same results; set `parallel_encoder=False` to serialise.
+    parallel_encoder = True
+
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault("_streams", {})
+        if device not in streams:
+            streams[device] = torch.cuda.Stream(device=device)
+        return streams[device]
+
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
+        motion_features = None
+        side = None
+        if (self.parallel_encoder and iter04 and (iter08 or iter16) and corr is not None and corr.is_cuda
+                and not torch.is_grad_enabled()):
+            main = torch.cuda.current_stream(corr.device)
+            side = self._side_stream(corr.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                motion_features = self.encoder(disp, corr)
         if iter16:
             net[2] = self.gru16(net[2], *(inp[2]), pool2x(net[1]))
         if iter08:
@@ -163,7 +186,11 @@ class BasicMultiUpdateBlock(nn.Module):
             else:
                 net[1] = self.gru08(net[1], *(inp[1]), pool2x(net[0]))
         if iter04:
-            motion_features = self.encoder(disp, corr)
+            if side is not None:
+                main.wait_stream(side)
+                motion_features.record_stream(main)
+            else:
+                motion_features = self.encoder(disp, corr)
             if self.args.n_gru_layers > 1:
                 net[0] = self.gru04(net[0], *(inp[0]), motion_features, interp(net[1], net[0]))
             else:

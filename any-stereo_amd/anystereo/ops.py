@@ -200,11 +200,12 @@ class PackedConv:
         self.bias = None
         self.cin = self.cout = self.ks = 0
 
-    def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+    def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], transform=None):
         key = tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
             tuple((None if b is None else (b.data_ptr(), b._version)) for b in biases)
         if key != self._key:
-            ws = [w.detach().reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1))) for w in weights]
+            ws = [w.detach() if transform is None else transform(w.detach()) for w in weights]
+            ws = [w.reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1))) for w in ws]
             w = torch.cat(ws, dim=0).contiguous().float() if len(ws) > 1 else ws[0].contiguous().float()
             _req(w, "conv weight")
             cout, cin, ks, ks2 = w.shape
@@ -220,7 +221,7 @@ class PackedConv:
                 bias = None
             else:
                 bias = torch.cat([(torch.zeros(wi.shape[0], device=w.device) if bi is None else bi.detach().float())
-                                  for wi, bi in zip(weights, biases)]).contiguous()
+                                  for wi, bi in zip(ws, biases)]).contiguous()
             self.wpack, self.bias, self.cin, self.cout, self.ks, self._key = wp, bias, cin, cout, ks, key
         return self
 
@@ -315,6 +316,18 @@ def conv3x3_to1(x, weight, bias):
     out = torch.empty((b, 1, h, w), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         L.check(L.load().as_conv3x3_to1(_p(x), _p(weight), _p(bias), _p(out), b, cin, h, w, _stream()), "conv3x3_to1")
+    return out
+
+
+def tap_shift_sum(s, bias):
+    """out[b,0,y,x] = bias + sum_t s[b,t,y+ky-1,x+kx-1] (zero padded) — see as_tap_shift_sum."""
+    _req(s, "s")
+    b, nine, h, w = s.shape
+    if nine != 9:
+        raise RuntimeError("tap_shift_sum: expects [B,9,H,W]")
+    out = torch.empty((b, 1, h, w), device=s.device, dtype=torch.float32)
+    with torch.cuda.device(s.device):
+        L.check(L.load().as_tap_shift_sum(_p(s), _p(bias), _p(out), b, h, w, _stream()), "tap_shift_sum")
     return out
 
 

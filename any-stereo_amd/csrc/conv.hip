@@ -186,24 +186,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const bool more = chunk + 1 < p.chunks;
     if (more) AS_CONV_FETCH(chunk + 1)
     const float* buf = lds + cur * STAGE;
+    // software pipeline over the KS*KS*CPW k-steps of this wave: operands of step s+1 are read from LDS
+    // before the 4 MFMAs of step s issue (sched_barrier pins that order), so at 1-2 waves per SIMD the
+    // ~100-cycle ds_read latency hides under 256 cycles of MFMA instead of preceding them.
+    constexpr int NS = KS * KS * CPW;
+    float a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];
+#define AS_CONV_LDOPS(S, A, Bv)                                                            \
+  {                                                                                        \
+    constexpr int tap_ = (S) / CPW, j_ = (S) % CPW;                                         \
+    constexpr int ky_ = tap_ / KS, kx_ = tap_ % KS;                                         \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) A[c] = buf[woff + (tap_ * KC + 8 * j_) * kBN + c * 32]; \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) Bv[q] = buf[poff[q] + (8 * j_) * PATCH + ky_ * PW + kx_]; \
+  }
+    AS_CONV_LDOPS(0, a_cur, b_cur)
 #pragma unroll
-    for (int tap = 0; tap < KS * KS; ++tap) {
-      const int ky = tap / KS, kx = tap % KS;
-#pragma unroll
-      for (int j = 0; j < CPW; ++j) {
-        const int cc = 4 * j;  // + wave, folded into the lane bases
-        float a[2], bv[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) a[c] = buf[woff + (tap * KC + 2 * cc) * kBN + c * 32];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) bv[q] = buf[poff[q] + (2 * cc) * PATCH + ky * PW + kx];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-            acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bv[q], acc[c][q], 0, 0, 0);
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) {
+        // constexpr dispatch on s+1 (the loop is fully unrolled; S must be a constant expression)
+        switch (s + 1) {
+#define AS_CASE(N) case N: if constexpr (N < NS) AS_CONV_LDOPS(N, a_nxt, b_nxt) break;
+          AS_CASE(1) AS_CASE(2) AS_CASE(3) AS_CASE(4) AS_CASE(5) AS_CASE(6) AS_CASE(7) AS_CASE(8)
+          AS_CASE(9) AS_CASE(10) AS_CASE(11) AS_CASE(12) AS_CASE(13) AS_CASE(14) AS_CASE(15)
+#undef AS_CASE
+          default: break;
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[c], b_cur[q], acc[c][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) { a_cur[c] = a_nxt[c]; b_cur[c] = b_nxt[c]; }
     }
+#undef AS_CONV_LDOPS
     if (more) AS_CONV_COMMIT(cur ^ 1)
     __syncthreads();
   }
@@ -346,6 +364,26 @@ __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float* __restric
   __syncthreads();
   if (slice == 0 && gx < W)
     out[(long long)b * plane + (long long)gy * W + gx] = ((red[0][lx] + red[1][lx]) + (red[2][lx] + red[3][lx])) + (bias ? bias[0] : 0.f);
+}
+
+// out[b,0,y,x] = bias + sum_t S[b,t,y+ky-1,x+kx-1]  (t = ky*3+kx, zero outside): second half of a 3x3,
+// Cin -> 1 convolution whose per-tap channel reductions S were produced by a 1x1 MFMA conv (Cin -> 9).
+__global__ __launch_bounds__(256) void tap_shift_sum_kernel(const float* __restrict__ S, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int H, int W, long long P) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const long long plane = (long long)H * W;
+  const long long b = pix / plane;
+  const int rem = (int)(pix - b * plane);
+  const int y = rem / W, x = rem - y * W;
+  const float* sp = S + b * 9 * plane;
+  float acc = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += sp[(long long)t * plane + (long long)yy * W + xx];
+  }
+  out[pix] = acc + (bias ? bias[0] : 0.f);
 }
 
 // pool2x: 3x3 mean, stride 2, zero pad 1, divisor 9 (update.py:94-95)
@@ -520,6 +558,14 @@ int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float
   dim3 grid((unsigned)as::cdiv(W, 64), (unsigned)H, (unsigned)B);
   hipLaunchKernelGGL(conv3x3_to1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, Cin, H, W);
   return as::check_launch("conv3x3_to1");
+}
+
+int as_tap_shift_sum(const float* S, const float* bias, float* out, int B, int H, int W, void* stream) {
+  AS_REQUIRE(S && out, AS_ERR_BAD_ARG, "tap_shift_sum: null pointer");
+  AS_REQUIRE(B > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "tap_shift_sum: non-positive size");
+  const long long P = (long long)B * H * W;
+  hipLaunchKernelGGL(tap_shift_sum_kernel, dim3((unsigned)as::cdiv64(P, 256)), dim3(256), 0, as::as_stream(stream), S, bias, out, H, W, P);
+  return as::check_launch("tap_shift_sum");
 }
 
 int as_pool2x(const float* x, float* out, int B, int C, int H, int W, void* stream) {

@@ -141,6 +141,11 @@ int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, f
 int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float* out,
                    int B, int Cin, int H, int W, void* stream);
 
+/* second stage of the MFMA form of a 3x3, Cin -> 1 convolution: S [B,9,H,W] holds, per tap t = ky*3+kx,
+ * the channel reduction sum_c w[c,ky,kx]*x[c] (a 1x1 as_conv2d with the 9 taps as output channels);
+ * out[b,0,y,x] = bias + sum_t S[b,t,y+ky-1,x+kx-1] with zero padding — DispHead.conv2 (update.py:19,24). */
+int as_tap_shift_sum(const float* S, const float* bias, float* out, int B, int H, int W, void* stream);
+
 /* a8  pool2x = avg_pool2d(3,stride 2,pad 1) (update.py:94-95); interp = bilinear align_corners=True
  *     resize (update.py:100-102).  x [B,C,H,W] -> out [B,C,Ho,Wo].                                */
 int as_pool2x(const float* x, float* out, int B, int C, int H, int W, void* stream);
