@@ -34,12 +34,14 @@ class ConvDesc(C.Structure):
         ("h", C.c_void_p), ("z", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
         ("out_ctot", C.c_int), ("out_coff", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("KS", C.c_int),
-        ("act", C.c_int), ("epilogue", C.c_int),
+        ("act", C.c_int), ("epilogue", C.c_int), ("precision", C.c_int),
     ]
 
 
 # name -> (restype, argtypes); every symbol include/anystereo_hip.h declares
 SIGNATURES = {
+    "as_set_precision": (_i, [_i]),
+    "as_get_precision": (_i, []),
     "as_last_error_string": (C.c_char_p, []),
     "as_abi_version": (_i, []),
     "as_device_count": (_i, []),
@@ -54,6 +56,8 @@ SIGNATURES = {
     "as_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
     "as_conv_pack_size": (C.c_int64, [_i, _i, _i]),
     "as_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "as_conv_pack_size_split": (C.c_int64, [_i, _i, _i]),
+    "as_conv_pack_weights_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

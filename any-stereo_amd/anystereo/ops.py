@@ -34,6 +34,15 @@ def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def set_precision(mode: str) -> None:
+    """'fp32' = exact fp32 MFMA; 'split' = 3 x fp16 split-precision MFMA (see as_set_precision)."""
+    L.check(L.load().as_set_precision({"fp32": 0, "split": 1}[mode]), "set_precision")
+
+
+def get_precision() -> str:
+    return "fp32" if L.load().as_get_precision() == 0 else "split"
+
+
 # ------------------------------------------------------------------------------------------------
 # correlation volume / pyramids / lookup
 # ------------------------------------------------------------------------------------------------
@@ -199,9 +208,11 @@ class PackedConv:
         self.wpack = None
         self.bias = None
         self.cin = self.cout = self.ks = 0
+        self.split = False
 
     def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], transform=None):
-        key = tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
+        split = L.load().as_get_precision() == 1
+        key = (split,) + tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
             tuple((None if b is None else (b.data_ptr(), b._version)) for b in biases)
         if key != self._key:
             ws = [w.detach() if transform is None else transform(w.detach()) for w in weights]
@@ -211,12 +222,16 @@ class PackedConv:
             cout, cin, ks, ks2 = w.shape
             if ks != ks2:
                 raise RuntimeError("PackedConv: non-square kernel")
-            n = L.load().as_conv_pack_size(cin, cout, ks)
+            n = (L.load().as_conv_pack_size_split if split else L.load().as_conv_pack_size)(cin, cout, ks)
             if n <= 0:
                 raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}")
-            wp = torch.empty(n, device=w.device, dtype=torch.float32)
+            wp = torch.empty(n, device=w.device, dtype=torch.float16 if split else torch.float32)
             with torch.cuda.device(w.device):
-                L.check(L.load().as_conv_pack_weights(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights")
+                if split:
+                    L.check(L.load().as_conv_pack_weights_split(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights_split")
+                else:
+                    L.check(L.load().as_conv_pack_weights(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights")
+            self.split = split
             if all(b is None for b in biases):
                 bias = None
             else:
@@ -231,7 +246,7 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
            h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None):
     """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue."""
     b, _, hh, ww = srcs[0].shape
-    kc = 8 if pack.ks == 3 else 32  # channels per K chunk of the kernel (csrc/conv.hip ConvCfg)
+    kc = 16 if pack.split else (8 if pack.ks == 3 else 32)  # channels per K chunk of the kernel (csrc/conv.hip)
     if any(s.shape[1] % kc for s in srcs[:-1]):
         # a K chunk must not straddle two tensors: materialise the concat for odd splits (never on the model path)
         srcs = [torch.cat(list(srcs), dim=1)]
@@ -286,6 +301,7 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
         d.h, d.z, d.out = h.data_ptr(), z.data_ptr(), out.data_ptr()
     d.B, d.H, d.W, d.Cin, d.Cout, d.KS = b, hh, ww, cin, cout, pack.ks
     d.act, d.epilogue = act, epilogue
+    d.precision = 1 if pack.split else 0
     with torch.cuda.device(dev):
         L.check(L.load().as_conv2d(C.byref(d), _stream()), "conv2d")
     return (out, out2) if epilogue == L.EPI_GRU_ZR else out

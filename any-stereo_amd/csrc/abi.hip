@@ -1,5 +1,6 @@
 // Error reporting + version/device queries of the C ABI (include/anystereo_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -18,13 +19,29 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+static int g_precision = -1;
+int precision_mode() {
+  if (g_precision < 0) {
+    const char* e = getenv("ANYSTEREO_PRECISION");
+    g_precision = (e && (e[0] == 'f') && e[1] == 'p' && e[2] == '3') ? 0 : 1;  // "fp32" -> 0, default split
+  }
+  return g_precision;
+}
+
 }  // namespace as
 
 extern "C" {
 
+int as_set_precision(int mode) {
+  if (mode != 0 && mode != 1) return as::fail(AS_ERR_BAD_ARG, "set_precision: mode %d (0 = fp32 MFMA, 1 = 3 x fp16 split)", mode);
+  as::g_precision = mode;
+  return AS_OK;
+}
+int as_get_precision(void) { return as::precision_mode(); }
+
 const char* as_last_error_string(void) { return as::err_buf(); }
 
-int as_abi_version(void) { return 1; }
+int as_abi_version(void) { return 2; }
 
 int as_device_count(void) {
   int n = 0;

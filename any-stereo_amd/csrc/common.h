@@ -22,6 +22,11 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Matrix-core arithmetic mode of the GEMM-shaped kernels (as_set_precision): 0 = exact fp32 MFMA,
+// 1 = split-precision 3 x fp16 MFMA (~2^-22 relative per product, needs |x| < 65504).
+int precision_mode();
+inline bool use_split_precision() { return precision_mode() == 1; }
+
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

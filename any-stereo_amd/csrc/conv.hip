@@ -429,6 +429,280 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x
   out[idx] = (1.f - ty) * top + ty * bot;
 }
 
+// ================================================================================================
+// Split-precision implicit GEMM: 3 x v_mfma_f32_32x32x16_f16 per 16-channel k-step.
+//   operand x = hi + lo/2048, hi = fp16(x), lo = fp16((x - hi)*2048)   (22 significand bits)
+//   w*x ~= w_hi*x_hi + (w_hi*x_lo + w_lo*x_hi)/2048,  two fp32 accumulators per output tile
+// 16x the fp32-MFMA rate for 3 instructions => ~5x the matrix throughput at ~2^-22 relative error per
+// product (fp32's own rounding is 2^-24).  Weights are split once at pack time; activations are split
+// while they are staged into LDS.  Requires |x| < 65504.
+//
+// Block = 4 waves, tile 128 pixels x BN (128 | 64) output channels; a wave owns 64 co x 64 px (BN=128)
+// or 64 co x 32 px (BN=64) for ALL of K (no split-K needed at this MFMA rate).
+// LDS images are k-contiguous so a lane's MFMA fragment (8 consecutive channels) is ONE ds_read_b128:
+//   weights  [tap][comp][h][co][8]   (global pack has the same order: staging is a linear 16-B copy)
+//   patch    [comp][h][patch pixel][8]
+// Pipeline unit = one kernel row (KS taps) of a 16-channel chunk: weights double-buffered per unit,
+// the halo patch double-buffered per chunk; next unit/chunk is fetched into registers under the MFMAs.
+// ================================================================================================
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+
+constexpr int kSplitKC = 16;
+
+template <int KS, int TW, int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvParams p) {
+  constexpr int BM = 128;
+  constexpr int TH = BM / TW;
+  constexpr int PAD = KS / 2;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int PATCHP = PH * PW;
+  constexpr int TPU = KS;                    // taps per pipeline unit (one kernel row)
+  constexpr int UPC = KS;                    // units per chunk
+  constexpr int WSEG = BN * 16;              // bytes of one (tap, comp, h) weight segment
+  constexpr int WUNIT = TPU * 4 * WSEG;      // bytes per weight unit buffer
+  constexpr int PBUF = 4 * PATCHP * 16;      // bytes per patch buffer
+  constexpr int NW16 = WUNIT / 16 / 256;     // 16-B pieces of a weight unit per thread
+  constexpr int NPI = (8 * PATCHP + 255) / 256;  // (channel pair, patch pixel) items per thread
+  constexpr int PTW = (BN == 128) ? 2 : 1;   // pixel MFMA tiles per wave
+  static_assert(WUNIT % (16 * 256) == 0, "weight unit must split evenly over the block");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2*WUNIT + 2*PBUF bytes (up to ~72 KiB)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  int id = blockIdx.x;
+  const int tx = id % p.tiles_x;
+  id /= p.tiles_x;
+  const int ty = id % p.tiles_y;
+  id /= p.tiles_y;
+  const int b = id % p.B;
+  const int nt = id / p.B;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int n0 = nt * BN;
+  const long long plane = (long long)p.H * p.W;
+
+  // ---- staging descriptors ----
+  unsigned p_voff[NPI];  // byte offset of channel 2*cp of the chunk at this patch pixel, or OOB sentinel
+  int p_lds[NPI];        // byte offset inside one comp image of the patch buffer
+#pragma unroll
+  for (int i = 0; i < NPI; ++i) {
+    int idx = tid + i * 256;
+    const bool slot = idx < 8 * PATCHP;
+    if (!slot) idx = 8 * PATCHP - 1;
+    const int cp = idx / PATCHP, pp = idx - cp * PATCHP;
+    const int py = pp / PW, px = pp - py * PW;
+    const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+    const bool in = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    p_voff[i] = in ? (unsigned)(((long long)(2 * cp) * plane + (long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
+    p_lds[i] = slot ? (cp >> 2) * (PATCHP * 16) + pp * 16 + (cp & 3) * 4 : -1;
+  }
+  int w_off[NW16];  // in 16-B units relative to the unit's first segment at column n0
+#pragma unroll
+  for (int i = 0; i < NW16; ++i) {
+    const int idx = tid + i * 256;
+    w_off[i] = (idx / BN) * p.Cout_pad + (idx % BN);
+  }
+  const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + n0;
+  const long long wunit16 = (long long)TPU * 4 * p.Cout_pad;  // 16-B units per pipeline unit
+
+  f32x4 pre_w[NW16];
+  float pre_p0[NPI], pre_p1[NPI];
+
+#define AS_SPLIT_FETCH_W(U)                                                                           \
+  {                                                                                                   \
+    const f32x4* wu = wsrc + (long long)(U) * wunit16;                                                 \
+    _Pragma("unroll") for (int i = 0; i < NW16; ++i) pre_w[i] = wu[w_off[i]];                          \
+  }
+#define AS_SPLIT_COMMIT_W(BUF)                                                                        \
+  {                                                                                                   \
+    f32x4* wd = reinterpret_cast<f32x4*>(lds + (BUF) * WUNIT);                                         \
+    _Pragma("unroll") for (int i = 0; i < NW16; ++i) wd[tid + i * 256] = pre_w[i];                     \
+  }
+#define AS_SPLIT_FETCH_P(CHUNK)                                                                       \
+  {                                                                                                   \
+    const int cb = (CHUNK) * kSplitKC;                                                                \
+    const float* sp = p.src[0];                                                                       \
+    int sc = p.src_c[0], sb = 0;                                                                      \
+    if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; }      \
+    if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; }      \
+    if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; }      \
+    const float* spb = sp + ((long long)b * sc + (cb - sb)) * plane;                                   \
+    const int recs = (int)((long long)(sc - (cb - sb)) * plane * 4);                                   \
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
+    const unsigned pl4 = (unsigned)(plane * 4);                                                       \
+    _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
+      const unsigned o0 = p_voff[i];                                                                  \
+      const unsigned o1 = o0 == 0x7FFFFFF0u ? o0 : o0 + pl4;                                           \
+      pre_p0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o0, 0, 0));  \
+      pre_p1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o1, 0, 0));  \
+    }                                                                                                 \
+  }
+#define AS_SPLIT_COMMIT_P(BUF)                                                                        \
+  {                                                                                                   \
+    unsigned char* pd = lds + 2 * WUNIT + (BUF) * PBUF;                                                \
+    _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
+      if (p_lds[i] >= 0) {                                                                            \
+        const _Float16 h0 = (_Float16)pre_p0[i], h1 = (_Float16)pre_p1[i];                             \
+        half2v hi, lo;                                                                                \
+        hi[0] = h0; hi[1] = h1;                                                                       \
+        lo[0] = (_Float16)((pre_p0[i] - (float)h0) * 2048.f);                                          \
+        lo[1] = (_Float16)((pre_p1[i] - (float)h1) * 2048.f);                                          \
+        *reinterpret_cast<half2v*>(pd + p_lds[i]) = hi;                                                \
+        *reinterpret_cast<half2v*>(pd + 2 * PATCHP * 16 + p_lds[i]) = lo;                              \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+
+  // ---- wave tile ----
+  const int co_base = (BN == 128) ? (wave >> 1) * 64 : 0;
+  const int px_base = (BN == 128) ? (wave & 1) * 64 : wave * 32;
+  const int wlane = half * WSEG + (co_base + l31) * 16;
+  int plane_off[PTW];
+#pragma unroll
+  for (int q = 0; q < PTW; ++q) {
+    const int m = px_base + q * 32 + l31;
+    plane_off[q] = half * (PATCHP * 16) + ((m / TW) * PW + (m % TW)) * 16;
+  }
+
+  f32x16 acc_h[2][PTW], acc_x[2][PTW];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < PTW; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc_h[c][q][r] = 0.f; acc_x[c][q][r] = 0.f; }
+
+  const int units = p.chunks * UPC;
+  AS_SPLIT_FETCH_W(0)
+  AS_SPLIT_FETCH_P(0)
+  AS_SPLIT_COMMIT_W(0)
+  AS_SPLIT_COMMIT_P(0)
+  __syncthreads();
+
+  int chunk = 0, tg = 0;
+  for (int u = 0; u < units; ++u) {
+    const bool more_w = u + 1 < units;
+    const bool first_of_chunk = tg == 0, last_of_chunk = tg == UPC - 1;
+    const bool more_p = chunk + 1 < p.chunks;
+    if (more_w) AS_SPLIT_FETCH_W(u + 1)
+    if (first_of_chunk && more_p) AS_SPLIT_FETCH_P(chunk + 1)
+    const unsigned char* wb = lds + (u & 1) * WUNIT + wlane;
+    const unsigned char* pb = lds + 2 * WUNIT + (chunk & 1) * PBUF;
+#pragma unroll
+    for (int t = 0; t < TPU; ++t) {
+      half8 a_hi[2], a_lo[2], b_hi[PTW], b_lo[PTW];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        a_hi[c] = *reinterpret_cast<const half8*>(wb + ((t * 2 + 0) * 2) * WSEG + c * 512);
+        a_lo[c] = *reinterpret_cast<const half8*>(wb + ((t * 2 + 1) * 2) * WSEG + c * 512);
+      }
+      const int tapoff = (tg * PW + t) * 16;  // ky = tg, kx = t
+#pragma unroll
+      for (int q = 0; q < PTW; ++q) {
+        b_hi[q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff);
+        b_lo[q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHP * 16 + plane_off[q] + tapoff);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q) {
+          acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[c], b_hi[q], acc_h[c][q], 0, 0, 0);
+          acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[c], b_lo[q], acc_x[c][q], 0, 0, 0);
+          acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[c], b_hi[q], acc_x[c][q], 0, 0, 0);
+        }
+    }
+    if (more_w) AS_SPLIT_COMMIT_W((u + 1) & 1)
+    if (last_of_chunk && more_p) AS_SPLIT_COMMIT_P((chunk + 1) & 1)
+    __syncthreads();
+    if (++tg == UPC) { tg = 0; ++chunk; }
+  }
+#undef AS_SPLIT_FETCH_W
+#undef AS_SPLIT_COMMIT_W
+#undef AS_SPLIT_FETCH_P
+#undef AS_SPLIT_COMMIT_P
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int q = 0; q < PTW; ++q) {
+    const int m = px_base + q * 32 + l31;
+    const int gy = y0 + m / TW, gx = x0 + m % TW;
+    if (gy >= p.H || gx >= p.W) continue;
+    const long long pixoff = (long long)gy * p.W + gx;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = n0 + co_base + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= p.Cout) continue;
+        float v = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
+        if (p.bias) v += p.bias[co];
+        if (p.add) v += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pixoff];
+        if (EPI == AS_EPI_LINEAR) {
+          p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pixoff] = act_apply(v, p.act);
+        } else if (EPI == AS_EPI_GRU_ZR) {
+          const int ch = p.Cout >> 1;
+          const float g = 1.f / (1.f + expf(-v));
+          if (co < ch) {
+            p.out[((long long)b * ch + co) * plane + pixoff] = g;
+          } else {
+            const long long o = ((long long)b * ch + (co - ch)) * plane + pixoff;
+            p.out2[o] = g * p.h[o];
+          }
+        } else {  // AS_EPI_GRU_Q
+          const long long o = ((long long)b * p.Cout + co) * plane + pixoff;
+          const float zz = p.z[o];
+          p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(v);
+        }
+      }
+    }
+  }
+}
+
+// weight [Cout,Cin,KS,KS] fp32 -> split pack [chunk16][tap][comp][h][Cout_pad][8] fp16 (zero padded)
+__global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout,
+                                          int Cout_pad, int KS, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx & 7);
+  long long t = idx >> 3;
+  const int co = (int)(t % Cout_pad);
+  t /= Cout_pad;
+  const int h = (int)(t & 1);
+  t >>= 1;
+  const int comp = (int)(t & 1);
+  t >>= 1;
+  const int tap = (int)(t % (KS * KS));
+  const int chunk = (int)(t / (KS * KS));
+  const int ci = chunk * kSplitKC + 8 * h + j;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) v = w[((long long)co * Cin + ci) * KS * KS + tap];
+  const _Float16 hi = (_Float16)v;
+  wp[idx] = comp == 0 ? hi : (_Float16)((v - (float)hi) * 2048.f);
+}
+
+template <int KS, int TW, int BN, int EPI>
+int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
+  constexpr int TH = 128 / TW, PATCHP = (TH + KS - 1) * (TW + KS - 1);
+  constexpr size_t lds = 2 * (size_t)(KS * 4 * BN * 16) + 2 * (size_t)(4 * PATCHP * 16);
+  static bool configured = false;  // per instantiation; the attribute is idempotent
+  if (!configured && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  const dim3 grid((unsigned)((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles));
+  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI>), grid, dim3(256), lds, s, p);
+  return as::check_launch("conv2d(split)");
+}
+
+template <int KS, int TW, int BN>
+int launch_conv_split(const ConvParams& p, int epi, hipStream_t s) {
+  if (epi == AS_EPI_LINEAR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_LINEAR>(p, s);
+  if (epi == AS_EPI_GRU_ZR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_ZR>(p, s);
+  return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_Q>(p, s);
+}
+
 template <int KS, int TW>
 int launch_conv(const ConvParams& p, int epi, hipStream_t s) {
   const dim3 grid((unsigned)((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles));
@@ -461,6 +735,21 @@ int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, i
   return as::check_launch("conv_pack_weights");
 }
 
+int64_t as_conv_pack_size_split(int Cin, int Cout, int KS) {
+  if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return -1;
+  const int64_t chunks = (Cin + kSplitKC - 1) / kSplitKC;
+  return chunks * KS * KS * 4 * conv_cout_pad(Cout) * 8;  // fp16 elements
+}
+
+int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream) {
+  AS_REQUIRE(weight && wpack, AS_ERR_BAD_ARG, "conv_pack_split: null pointer");
+  const int64_t total = as_conv_pack_size_split(Cin, Cout, KS);
+  AS_REQUIRE(total > 0, AS_ERR_BAD_ARG, "conv_pack_split: unsupported Cin=%d Cout=%d KS=%d", Cin, Cout, KS);
+  hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream),
+                     weight, (_Float16*)wpack, Cin, Cout, conv_cout_pad(Cout), KS, (long long)total);
+  return as::check_launch("conv_pack_weights_split");
+}
+
 int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(d, AS_ERR_BAD_ARG, "conv2d: null descriptor");
   AS_REQUIRE(d->KS == 1 || d->KS == 3, AS_ERR_BAD_ARG, "conv2d: KS=%d (supported: 1, 3)", d->KS);
@@ -478,10 +767,13 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.src_end[i] = csum;
   }
   AS_REQUIRE(csum == d->Cin, AS_ERR_BAD_SHAPE, "conv2d: sources hold %d channels, Cin=%d", csum, d->Cin);
+  AS_REQUIRE(d->precision == 0 || d->precision == 1, AS_ERR_BAD_ARG, "conv2d: precision=%d", d->precision);
+  const bool split = d->precision == 1;
+  const int kc_req = split ? kSplitKC : conv_kc(d->KS);
   for (int i = 0; i + 1 < d->n_src; ++i)
-    AS_REQUIRE(d->src_c[i] % conv_kc(d->KS) == 0, AS_ERR_BAD_SHAPE,
+    AS_REQUIRE(d->src_c[i] % kc_req == 0, AS_ERR_BAD_SHAPE,
                "conv2d: source %d has %d channels; every source but the last must hold a multiple of %d (concatenate first)",
-               i, d->src_c[i], conv_kc(d->KS));
+               i, d->src_c[i], kc_req);
   p.n_src = d->n_src;
   p.wpack = d->wpack; p.bias = d->bias; p.add = d->add;
   p.add_ctot = d->add_ctot; p.add_coff = d->add_coff;
@@ -502,13 +794,37 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   } else {
     return as::fail(AS_ERR_BAD_ARG, "conv2d: epilogue=%d", epi);
   }
-  const int KC = conv_kc(d->KS);
+  const int KC = split ? kSplitKC : conv_kc(d->KS);
   for (int i = 0; i < d->n_src; ++i)  // 32-bit buffer offsets inside one (batch, source) tensor
     AS_REQUIRE((long long)d->src_c[i] * d->H * d->W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE,
                "conv2d: source %d exceeds 2 GiB per batch element", i);
   p.chunks = (d->Cin + KC - 1) / KC;
   p.n_tiles = p.Cout_pad / kBN;
   hipStream_t s = as::as_stream(stream);
+  if (split) {
+    const int bn = (p.Cout_pad % 128 == 0) ? 128 : 64;
+    p.n_tiles = p.Cout_pad / bn;
+    AS_REQUIRE((long long)d->H * d->W < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: plane too large");
+    if (d->KS == 1) {
+      p.H = 1;
+      p.W = d->H * d->W;
+      p.tiles_x = as::cdiv(p.W, 128);
+      p.tiles_y = 1;
+      AS_REQUIRE((long long)p.B * p.tiles_x * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+      return bn == 128 ? launch_conv_split<1, 128, 128>(p, epi, s) : launch_conv_split<1, 128, 64>(p, epi, s);
+    }
+    p.H = d->H;
+    p.W = d->W;
+    // 128-pixel tile as 8x16 or 4x32, whichever pads the image less (ties: 8x16, smaller halo)
+    const long long a16 = (long long)as::cdiv(p.W, 16) * 16 * as::cdiv(p.H, 8) * 8;
+    const long long a32 = (long long)as::cdiv(p.W, 32) * 32 * as::cdiv(p.H, 4) * 4;
+    const int tw = a32 < a16 ? 32 : 16;
+    p.tiles_x = as::cdiv(p.W, tw);
+    p.tiles_y = as::cdiv(p.H, 128 / tw);
+    AS_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+    if (tw == 16) return bn == 128 ? launch_conv_split<3, 16, 128>(p, epi, s) : launch_conv_split<3, 16, 64>(p, epi, s);
+    return bn == 128 ? launch_conv_split<3, 32, 128>(p, epi, s) : launch_conv_split<3, 32, 64>(p, epi, s);
+  }
   if (d->KS == 1) {
     // no halo: run on the flattened H*W plane
     AS_REQUIRE((long long)d->H * d->W < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: plane too large");

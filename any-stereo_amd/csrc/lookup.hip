@@ -109,6 +109,119 @@ __global__ __launch_bounds__(256) void lookup_fwd_kernel(LookupParams p) {
   }
 }
 
+// ---- cooperative, LDS-staged forward (the shipped path for r=4, G in {0, 8}) -----------------------
+// PMC on the lane-per-pixel kernel above shows compulsory traffic (19 MB fetched, 20.6 MB written at
+// 960x540) but 64 distinct cache lines per wave load: it is request-bound, not byte-bound.  Here a block
+// owns 64 consecutive pixels.  Work items are (pixel, tap, channel quad) in MEMORY order, so consecutive
+// lanes read consecutive 16-B pieces of a pixel's contiguous window run (288 B for 9 taps x 8 channels)
+// — a wave load touches ~7 runs instead of 64 — and each item reads taps t and t+1 (the second is an
+// L1 hit of its neighbour's first).  Results are transposed through an LDS tile [channel][pixel] and
+// leave as full 256-B coalesced NCHW rows.  Interpolation arithmetic is identical to the kernel above.
+template <int R, int G>
+__global__ __launch_bounds__(256) void lookup_fwd_coop_kernel(LookupParams p) {
+  constexpr int K = 2 * R + 1;
+  constexpr int NQ = G / 4;
+  constexpr int PX = 64;
+  constexpr int TS = PX + 1;  // tile row stride (floats)
+  extern __shared__ float sm[];
+  float* sdisp = sm;            // [PX]
+  float* tile = sm + PX;        // [CH][TS]
+  const int tid = threadIdx.x;
+  const long long pix0 = (long long)blockIdx.x * PX;
+  if (tid < PX) sdisp[tid] = (pix0 + tid < p.P) ? p.disp[pix0 + tid] : 0.f;
+  __syncthreads();
+  const unsigned kOOB = 0x7FFFFFF0u;
+
+  for (int level = 0; level < p.L; ++level) {
+    const int chbase = level * K * (G + 1);
+    if constexpr (G > 0) {
+      const int Dl = p.D >> level;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.geo[level], 0, p.geo_bytes[level], 0x00020000);
+      constexpr int ITEMS = PX * K * (NQ > 0 ? NQ : 1);
+      constexpr int NIT = (ITEMS + 255) / 256;
+      f32x4 w0[NIT], w1[NIT];
+      float tt[NIT];
+      bool bm[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int px = idx / (K * NQ), rem = idx - px * (K * NQ);
+        const int tap = rem / NQ, q = rem - tap * NQ;
+        const bool live = idx < ITEMS && pix0 + px < p.P;
+        const float ds = ldexpf(sdisp[px < PX ? px : 0], -level);
+        const int i0 = (int)floorf(ds);
+        tap_weights(ds, i0, tap - R, tt[it], bm[it]);
+        const int dd = i0 - R + tap;
+        const unsigned rowoff = (unsigned)((((pix0 + px) * Dl) * G + 4 * q) * 4);
+        const unsigned o0 = (live && dd >= 0 && dd < Dl) ? rowoff + (unsigned)dd * (G * 4) : kOOB;
+        const unsigned o1 = (live && dd + 1 >= 0 && dd + 1 < Dl) ? rowoff + (unsigned)(dd + 1) * (G * 4) : kOOB;
+        w0[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0, 0, 0));
+        w1[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o1, 0, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < ITEMS) {
+          const int px = idx / (K * NQ), rem = idx - px * (K * NQ);
+          const int tap = rem / NQ, q = rem - tap * NQ;
+          const float a = bm[it] ? 0.f : 1.f - tt[it], c = bm[it] ? 1.f : tt[it];
+          const f32x4 v = a * w0[it] + c * w1[it];
+          float* t = tile + (chbase + (4 * q) * K + tap) * TS + px;
+          t[0] = v.x;
+          t[K * TS] = v.y;
+          t[2 * K * TS] = v.z;
+          t[3 * K * TS] = v.w;
+        }
+      }
+    }
+    {
+      const int Wl = p.W2 >> level;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.corr[level], 0, p.corr_bytes[level], 0x00020000);
+      constexpr int ITEMS = PX * K;
+      constexpr int NIT = (ITEMS + 255) / 256;
+      float w0[NIT], w1[NIT], tt[NIT];
+      bool bm[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        const int px = idx / K, tap = idx - px * K;
+        const bool live = idx < ITEMS && pix0 + px < p.P;
+        const long long pix = pix0 + px;
+        const int x = (int)((pix % p.HW) % p.W);
+        const float ds = ldexpf(sdisp[px < PX ? px : 0], -level);
+        const float xb = ldexpf((float)x, -level) - ds;
+        const int i0 = (int)floorf(xb);
+        tap_weights(xb, i0, tap - R, tt[it], bm[it]);
+        const int dd = i0 - R + tap;
+        const unsigned rowoff = (unsigned)(pix * Wl * 4);
+        const unsigned o0 = (live && dd >= 0 && dd < Wl) ? rowoff + (unsigned)dd * 4u : kOOB;
+        const unsigned o1 = (live && dd + 1 >= 0 && dd + 1 < Wl) ? rowoff + (unsigned)(dd + 1) * 4u : kOOB;
+        w0[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o0, 0, 0));
+        w1[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o1, 0, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < ITEMS) {
+          const int px = idx / K, tap = idx - px * K;
+          const float a = bm[it] ? 0.f : 1.f - tt[it], c = bm[it] ? 1.f : tt[it];
+          tile[(chbase + G * K + tap) * TS + px] = a * w0[it] + c * w1[it];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // coalesced NCHW rows: lane = pixel, 4 channel rows per pass
+  const int px = tid & 63;
+  const long long pix = pix0 + px;
+  if (pix < p.P) {
+    const int b = (int)(pix / p.HW);
+    const int rem = (int)(pix - (long long)b * p.HW);
+    float* o = p.out + (long long)b * p.CH * p.HW + rem;
+    for (int ch = tid >> 6; ch < p.CH; ch += 4) o[(long long)ch * p.HW] = tile[ch * TS + px];
+  }
+}
+
 // Backward w.r.t. the volumes: the transpose of the above.  Each (pixel, task) owns a private
 // window of its pixel's row, so the accumulated window is written with plain stores into the
 // caller-zeroed gradient (no atomics; same property as sampler_kernel.cu:63-104).
@@ -299,6 +412,17 @@ int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, co
   }
   p.disp = disp;
   p.out = out;
+  if (radius == 4 && (G == 8 || G == 0)) {
+    const size_t lds = (size_t)(64 + p.CH * 65) * sizeof(float);
+    const dim3 grid((unsigned)as::cdiv64(p.P, 64));
+    if (G == 8) {
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)lookup_fwd_coop_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((lookup_fwd_coop_kernel<4, 8>), grid, dim3(256), lds, as::as_stream(stream), p);
+    } else {
+      hipLaunchKernelGGL((lookup_fwd_coop_kernel<4, 0>), grid, dim3(256), lds, as::as_stream(stream), p);
+    }
+    return as::check_launch("geo_corr_lookup_fwd");
+  }
   LAUNCH_LOOKUP(lookup_fwd_kernel, p, stream);
   return as::check_launch("geo_corr_lookup_fwd");
 }

@@ -121,6 +121,110 @@ __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
   }
 }
 
+// ---- split-precision variant: 3 x fp16 MFMA (32x32x16) per 16 channels ----------------------------
+// An fp32 operand v is split as v = hi + lo/2048 with hi = fp16(v), lo = fp16((v - hi) * 2048): 22
+// significand bits, the lo part rescaled so it never falls into fp16's subnormal range.  Then
+//   a*b ~= hi_a*hi_b + (hi_a*lo_b + lo_a*hi_b)/2048      (dropped lo*lo term and split residual: ~2^-22 relative)
+// accumulated in fp32 in two accumulators.  That is 3 MFMAs at 16x the fp32-MFMA rate: the all-pairs
+// product stops being matrix-core bound (fp32 MFMA needs >= 11 us at 960x540 even at 100 % utilisation)
+// and becomes the HBM-bound stream it should be.  Requires |v| < 65504 (fp16 range): feature maps are
+// O(1).  Operand k-layout of v_mfma_f32_32x32x16_f16: lane (r = l&31, h = l>>5) holds k = 8h..8h+7.
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr int kKS16 = 6;  // 16-channel k-steps per pass (96 channels)
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 h = (_Float16)v[j];
+    hi[j] = h;
+    lo[j] = (_Float16)((v[j] - (float)h) * 2048.f);
+  }
+}
+
+template <bool A_RESIDENT>
+__global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int row = blockIdx.x;  // b*H + y
+  const int b = row / p.H;
+  const int y = row - b * p.H;
+  const int mt = blockIdx.y * 4 + wave;
+  if (mt >= p.MT) return;
+  const long long cs1 = (long long)p.H * p.W1;
+  const long long cs2 = (long long)p.H * p.W2;
+  const __amdgpu_buffer_rsrc_t r1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.f1 + (long long)b * p.C * cs1), 0, (int)(p.C * cs1 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.f2 + (long long)b * p.C * cs2), 0, (int)(p.C * cs2 * 4), 0x00020000);
+  const unsigned kOOB = 0x7FFFFFF0u;
+  const int x1 = mt * 32 + l31;
+  // channel of element j in k-step s: 16 s + 8 half + j
+  const unsigned a_off = x1 < p.W1 ? (unsigned)((8 * half * cs1 + (long long)y * p.W1 + x1) * 4) : kOOB;
+  const unsigned b_row = (unsigned)((8 * half * cs2 + (long long)y * p.W2) * 4);
+  const unsigned cstr1 = (unsigned)(cs1 * 4), cstr2 = (unsigned)(cs2 * 4);
+  const int ksteps = (p.C + 15) >> 4;
+  const int passes = (ksteps + kKS16 - 1) / kKS16;
+  const long long rowbase = (long long)row * p.W1;
+
+  half8 ahi[kKS16], alo[kKS16];
+  auto load_a = [&](int ps) {
+#pragma unroll
+    for (int s = 0; s < kKS16; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        v[j] = bload(r1, a_off == kOOB ? kOOB : a_off + (unsigned)((ps * kKS16 + s) * 16 + j) * cstr1);
+      split8(v, ahi[s], alo[s]);
+    }
+  };
+  if (A_RESIDENT) load_a(0);
+
+  // N tiles are split over blockIdx.z and B is streamed one 16-channel k-step at a time (8 loads ->
+  // split -> 3 MFMAs): ~110 VGPRs, so 4 waves per SIMD hide the load latency by switching waves.
+  const int ntw = (p.NT + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int nt_lo = blockIdx.z * ntw, nt_hi = min(p.NT, nt_lo + ntw);
+  for (int nt = nt_lo; nt < nt_hi; ++nt) {
+    f32x16 acc_hh, acc_x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_hh[r] = 0.f; acc_x[r] = 0.f; }
+    const int x2 = nt * 32 + l31;
+    const unsigned bo = x2 < p.W2 ? b_row + x2 * 4 : kOOB;
+    for (int ps = 0; ps < passes; ++ps) {
+      if (!A_RESIDENT) load_a(ps);
+#pragma unroll
+      for (int s = 0; s < kKS16; ++s) {
+        float bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          bv[j] = bload(r2, bo == kOOB ? kOOB : bo + (unsigned)((ps * kKS16 + s) * 16 + j) * cstr2);
+        half8 bhi, blo;
+        split8(bv, bhi, blo);
+        acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], bhi, acc_hh, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], blo, acc_x, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], bhi, acc_x, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int xr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool okr = xr < p.W1;
+      float v = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
+      if (okr && x2 < p.W2) p.lvl[0][(rowbase + xr) * p.W2 + x2] = v;
+#pragma unroll
+      for (int s = 1; s < AS_MAX_LEVELS; ++s) {
+        if (s < p.L) {
+          v = (v + __shfl_xor(v, 1 << (s - 1))) * 0.5f;
+          const int wl = p.W2 >> s;
+          const int xs = x2 >> s;
+          if (okr && (l31 & ((1 << s) - 1)) == 0 && xs < wl) p.lvl[s][(rowbase + xr) * wl + xs] = v;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // gev [B,G,D,H,W] -> level i [B,H,W,D>>i,G].  32 consecutive pixels of a row per block; the
 // (g,d) x pixel tile is transposed through LDS so that both the read (x-contiguous) and the write
@@ -279,7 +383,14 @@ int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels
   AS_REQUIRE((long long)C * H * W1 * 4 < 0x7FFFFFF0ll && (long long)C * H * W2 * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE,
              "corr_build: a feature map exceeds 2 GiB per batch element");
   dim3 grid((unsigned)(B * H), (unsigned)as::cdiv(p.MT, 4));
-  if ((C + 1) / 2 <= kKS) hipLaunchKernelGGL(corr_build_kernel<true>, grid, dim3(256), 0, as::as_stream(stream), p);
+  if (as::use_split_precision()) {
+    // enough waves to keep ~4 per SIMD: split the N tiles over grid.z while B*H*MT waves are few
+    int nsplit = 1;
+    while (nsplit < p.NT && (long long)B * H * p.MT * nsplit < 4096) nsplit *= 2;
+    const dim3 g3(grid.x, grid.y, (unsigned)nsplit);
+    if ((C + 15) / 16 <= kKS16) hipLaunchKernelGGL(corr_build_f16x3_kernel<true>, g3, dim3(256), 0, as::as_stream(stream), p);
+    else hipLaunchKernelGGL(corr_build_f16x3_kernel<false>, g3, dim3(256), 0, as::as_stream(stream), p);
+  } else if ((C + 1) / 2 <= kKS) hipLaunchKernelGGL(corr_build_kernel<true>, grid, dim3(256), 0, as::as_stream(stream), p);
   else hipLaunchKernelGGL(corr_build_kernel<false>, grid, dim3(256), 0, as::as_stream(stream), p);
   return as::check_launch("corr_build_pyramid");
 }

@@ -50,6 +50,14 @@ extern "C" {
                            co >= Cout/2: rh = sigmoid(acc+bias+add) * h    -> out2 [B,Cout/2,H,W]  */
 #define AS_EPI_GRU_Q 2  /* out = (1-z)*h + z*tanh(acc+bias+add)            (update.py:39-40)      */
 
+/* Matrix-core arithmetic of the GEMM-shaped kernels (as_corr_build_pyramid, as_conv2d):
+ *   0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32),
+ *   1 = split precision, 3 x fp16 MFMA per product (operand = hi + lo/2048, fp32 accumulation; relative
+ *       error ~2^-22 per product, requires |x| < 65504).  Process-wide; initial value from the environment
+ *       variable ANYSTEREO_PRECISION ("fp32" -> 0, otherwise 1). */
+int as_set_precision(int mode);
+int as_get_precision(void);
+
 const char* as_last_error_string(void);
 int as_abi_version(void);        /* bumped on any signature change */
 int as_device_count(void);       /* hipGetDeviceCount; 0 on a CPU-only host */
@@ -128,11 +136,15 @@ typedef struct {
   int out_ctot, out_coff;
   int B, H, W, Cin, Cout, KS;
   int act, epilogue;
+  int precision;      /* which pack `wpack` is: 0 = fp32 (as_conv_pack_weights), 1 = split fp16 (as_conv_pack_weights_split) */
 } as_conv_desc;
 int as_conv2d(const as_conv_desc* d, void* stream);
 /* weight [Cout,Cin,KS,KS] (nn.Conv2d layout) -> wpack; returns the element count needed when wpack==NULL */
 int64_t as_conv_pack_size(int Cin, int Cout, int KS);
 int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, int KS, void* stream);
+/* the split-precision pack (fp16 hi/lo, k-contiguous): element count is in fp16 units */
+int64_t as_conv_pack_size_split(int Cin, int Cout, int KS);
+int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream);
 
 /* direct (VALU) convolutions for the two shapes where an MFMA tile would be mostly padding:
  *   convd1: 7x7, 1 -> Cout, +bias, ReLU   (update.py:81,87);   conv2 of DispHead: 3x3, Cin -> 1, +bias (update.py:19,24) */

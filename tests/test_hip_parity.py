@@ -32,6 +32,16 @@ def close(a, b, rtol=2e-5, atol=1e-6, what=""):
     assert err <= lim, f"{what}: max abs err {err:.3e} > {lim:.3e}"
 
 
+@pytest.fixture(params=["fp32", "split"])
+def precision(request):
+    """Run a test under both matrix-core modes: exact fp32 MFMA and 3 x fp16 split precision."""
+    from anystereo import ops
+    prev = ops.get_precision()
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(prev)
+
+
 def test_native_library_is_loaded():
     from anystereo import _lib
     lib = _lib.load()
@@ -53,6 +63,28 @@ def test_corr_build_pyramid(b, c, h, w1, w2, L):
     ref = O.corr_pyramid(O.all_pairs_corr(f1.double(), f2.double()), L)
     for i in range(L):
         close(lv[i], ref[i], rtol=1e-6, atol=2e-6 * c ** 0.5, what=f"corr level {i}")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "split"])
+def test_corr_build_precision_modes(mode):
+    """Both matrix-core modes (exact fp32 MFMA / 3 x fp16 split) against the fp64 oracle, with operands
+    spanning 6 orders of magnitude (the split keeps 22 significand bits at every scale)."""
+    from anystereo import ops
+    prev = ops.get_precision()
+    try:
+        ops.set_precision(mode)
+        for (b, c, h, w1, w2, L) in [(1, 96, 3, 70, 70, 2), (1, 256, 2, 40, 33, 4), (1, 40, 2, 33, 20, 1)]:
+            f1 = U((b, c, h, w1), 5) * torch.pow(10.0, U((b, c, h, w1), 6, -3, 3))
+            f2 = U((b, c, h, w2), 7) * torch.pow(10.0, U((b, c, h, w2), 8, -3, 3))
+            lv = ops.corr_build_pyramid(f1.to(DEV), f2.to(DEV), L)
+            ref = O.corr_pyramid(O.all_pairs_corr(f1.double(), f2.double()), L)
+            # error bound relative to sum |a||b| (the scale of the rounding errors), not to the cancelled sum
+            scale = O.all_pairs_corr(f1.abs().double(), f2.abs().double()).max().item()
+            for i in range(L):
+                err = (lv[i].double().cpu() - ref[i]).abs().max().item()
+                assert err <= 2e-6 * scale, f"{mode} level {i}: {err:.3e} vs bound {2e-6 * scale:.3e}"
+    finally:
+        ops.set_precision(prev)
 
 
 @pytest.mark.parametrize("b,g,d,h,w,L", [(2, 8, 48, 3, 20, 2), (1, 8, 48, 4, 70, 2), (1, 4, 17, 2, 33, 3)])
@@ -183,7 +215,7 @@ def _ref_conv(x, w, bias, pad):
     (1, [128, 128, 128], 128, 3, 8, 12, 1), (2, [64], 64, 3, 9, 33, 1), (1, [128], 127, 3, 7, 20, 1),
     (1, [128], 256, 3, 5, 40, 1), (1, [162], 64, 1, 6, 21, 1), (1, [36], 64, 1, 3, 50, 0),
     (1, [228], 128, 1, 1, 300, 1), (1, [64], 9, 1, 1, 77, 0), (1, [20, 12], 40, 3, 17, 9, 2), (1, [16], 32, 3, 34, 60, 3)])
-def test_conv2d_linear(b, cins, cout, ks, h, w, act):
+def test_conv2d_linear(b, cins, cout, ks, h, w, act, precision):
     from anystereo import ops, _lib as L
     cin = sum(cins)
     srcs = [U((b, c, h, w), 90 + i) for i, c in enumerate(cins)]
@@ -203,7 +235,7 @@ def test_conv2d_linear(b, cins, cout, ks, h, w, act):
 
 
 @pytest.mark.parametrize("h,w", [(8, 12), (5, 33), (17, 9)])
-def test_conv_gru_fused(h, w):
+def test_conv_gru_fused(h, w, precision):
     from anystereo.nn.update import ConvGRU
     from anystereo.harness.synthetic import fill_module_deterministic
     gru = ConvGRU(128, 256).to(DEV).eval()
@@ -221,7 +253,7 @@ def test_conv_gru_fused(h, w):
     close(out2, ref, 1e-5, 1e-5, "convgru (cat fallback)")
 
 
-def test_direct_convs_and_resamplers():
+def test_direct_convs_and_resamplers(precision):
     from anystereo import ops
     x = U((2, 1, 19, 37), 110, 0, 30)
     w7, b7 = U((64, 1, 7, 7), 111) * 0.2, U((64,), 112) * 0.1
@@ -237,7 +269,7 @@ def test_direct_convs_and_resamplers():
           1e-5, 1e-6, "interp vs torch")
 
 
-def test_update_block_golden(golden):
+def test_update_block_golden(golden, precision):
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.models.base import default_args
     from anystereo.nn.update import BasicMultiUpdateBlock
@@ -264,7 +296,7 @@ def test_update_block_golden(golden):
 # a12-a17 LIIF
 # ---------------------------------------------------------------------------------------------
 
-def test_liif_golden(golden):
+def test_liif_golden(golden, precision):
     from anystereo import ops
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.nn.liif import liif_out_multi_scale_Training, liif_feat_multiscale_train, AffinityFeature
@@ -303,7 +335,7 @@ def test_liif_golden(golden):
 # ---------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("name", ["igev", "raft"])
-def test_whole_model(name, golden):
+def test_whole_model(name, golden, precision):
     from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
     from anystereo.models import __models__, default_args
     g = golden(f"model_{name}")

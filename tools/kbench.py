@@ -1,0 +1,65 @@
+"""Standalone launches of single hot kernels at a BASELINE config's sizes, for rocprofv3 / PMC passes.
+
+    python tools/kbench.py corr_build lookup --reps 20 [--cfg 2]
+Prints HIP-event time per launch (back-to-back launches on one stream).
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "any-stereo_amd"))
+import torch  # noqa: E402
+
+from anystereo import ops  # noqa: E402
+from anystereo.harness.synthetic import det_uniform  # noqa: E402
+
+CFG = {1: (1, 64, 128, 256, 4, 0), 2: (1, 136, 240, 96, 2, 8), 3: (1, 96, 312, 96, 2, 8), 5: (1, 336, 480, 96, 2, 8)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("kernels", nargs="+")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--cfg", type=int, default=2)
+    ap.add_argument("--precision", default=None)
+    a = ap.parse_args()
+    if a.precision:
+        ops.set_precision(a.precision)
+    b, h, w, c, L, g = CFG[a.cfg]
+    dev = "cuda:0"
+    f1 = det_uniform((b, c, h, w), 1).to(dev)
+    f2 = det_uniform((b, c, h, w), 2).to(dev)
+    gev = det_uniform((b, 8, 48, h, w), 3).to(dev) if g else None
+    disp = det_uniform((b, 1, h, w), 4, 0.0, 40.0).to(dev)
+    corr = ops.corr_build_pyramid(f1, f2, L)
+    geo = ops.geo_pyramid(gev, L) if g else None
+    x128 = [det_uniform((b, 128, h, w), 10 + i).to(dev) for i in range(3)]
+    ctx = det_uniform((b, 384, h, w), 20).to(dev)
+    wzr = det_uniform((256, 384, 3, 3), 30, -0.02, 0.02).to(dev)
+    bzr = det_uniform((256,), 31).to(dev)
+    pzr = ops.PackedConv().get([wzr], [bzr])
+    from anystereo import _lib as Lb
+    fns = {
+        "corr_build": lambda: ops.corr_build_pyramid(f1, f2, L),
+        "geo_pyramid": (lambda: ops.geo_pyramid(gev, L)) if g else None,
+        "lookup": lambda: ops.geo_corr_lookup(geo, corr, disp, 4),
+        "gwc": lambda: ops.gwc_volume(f1, f2, 48, 8),
+        "gru_zr": lambda: ops.conv2d(x128, pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=x128[0]),
+    }
+    for k in a.kernels:
+        fn = fns[k]
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(a.reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        print(f"{k}: {s.elapsed_time(e) / a.reps * 1e3:.2f} us/launch (cfg {a.cfg}, precision {ops.get_precision()})")
+
+
+if __name__ == "__main__":
+    main()
