@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("out_ctot", C.c_int), ("out_coff", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("KS", C.c_int),
         ("act", C.c_int), ("epilogue", C.c_int), ("precision", C.c_int),
+        ("ws", C.c_void_p), ("ws_elems", C.c_int64),
     ]
 
 
@@ -54,6 +55,7 @@ SIGNATURES = {
     "as_gwc_volume_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_disparity_regression": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "as_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
+    "as_conv_ws_elems": (C.c_int64, [_i, _i, _i, _i]),
     "as_conv_pack_size": (C.c_int64, [_i, _i, _i]),
     "as_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv_pack_size_split": (C.c_int64, [_i, _i, _i]),

@@ -302,6 +302,12 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     d.B, d.H, d.W, d.Cin, d.Cout, d.KS = b, hh, ww, cin, cout, pack.ks
     d.act, d.epilogue = act, epilogue
     d.precision = 1 if pack.split else 0
+    ws = None
+    if pack.split:
+        n_ws = L.load().as_conv_ws_elems(b, cout, hh, ww)
+        if n_ws > 0:  # small feature map: give the kernel split-K scratch (caching allocator: no sync)
+            ws = torch.empty(n_ws, device=dev, dtype=torch.float32)
+            d.ws, d.ws_elems = ws.data_ptr(), n_ws
     with torch.cuda.device(dev):
         L.check(L.load().as_conv2d(C.byref(d), _stream()), "conv2d")
     return (out, out2) if epilogue == L.EPI_GRU_ZR else out

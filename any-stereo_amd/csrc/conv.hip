@@ -20,6 +20,8 @@
 // (tap, channel) so every ds_read address is lane_base + compile-time immediate.  The channel concat
 // of the reference (torch.cat([h, x...])) is never materialised: a chunk's channels are read from
 // whichever source tensor owns them.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -43,7 +45,13 @@ struct ConvParams {
   int out_ctot, out_coff;
   int B, H, W, Cin, Cout, Cout_pad, act;
   int tiles_x, tiles_y, n_tiles, chunks;
+  int dbg;  // timing-only ablation switches (env AS_CONV_DBG; results are wrong when non-zero)
+  int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
+  float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
 };
+
+constexpr int kNumCU = 256;   // MI355X
+constexpr int kEpiPartial = 3;  // internal: store the raw partial sums of a K slice into p.ws
 
 template <int KS> struct ConvCfg;
 template <> struct ConvCfg<3> { static constexpr int KC = 8; };
@@ -58,6 +66,106 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case AS_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     case AS_ACT_TANH: return tanhf(v);
     default: return v;
+  }
+}
+
+// ---- epilogue of one 32(co) x 32(pixel) accumulator tile -----------------------------------------
+// All global operands of the tile (context term, h, z) are fetched up front through raw buffer
+// descriptors whose range covers exactly the block's valid output channels: lanes outside the image
+// (sentinel offset) and channels >= Cout read 0 and their stores are dropped by the hardware range check,
+// so there is not a single branch around a memory operation and one latency is paid per tile, not per
+// element.  Bias comes from an LDS copy made by the caller.
+__device__ __forceinline__ float as_bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void as_bstore(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+}
+
+struct EpiCtx {
+  __amdgpu_buffer_rsrc_t r_add, r_out, r_h, r_z;
+  bool has_add;
+  unsigned plane4;   // bytes per channel plane
+};
+
+// n0: first output channel of the block, bn: channels per block (descriptor windows start at channel n0)
+template <int EPI>
+__device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n0, int bn) {
+  EpiCtx e;
+  const long long plane = (long long)p.H * p.W;
+  const int cvalid = min(p.Cout - n0, bn);
+  const int recs = cvalid > 0 ? (int)((long long)cvalid * plane * 4) : 0;
+  e.plane4 = (unsigned)(plane * 4);
+  e.has_add = p.add != nullptr;
+  const float* addp = p.add ? p.add + ((long long)b * p.add_ctot + p.add_coff + n0) * plane : p.out;
+  e.r_add = __builtin_amdgcn_make_buffer_rsrc((void*)addp, 0, p.add ? recs : 0, 0x00020000);
+  if (EPI == kEpiPartial) {
+    // slab of this block's K slice; every channel of the padded tile is stored (the finish kernel ignores >= Cout)
+    const int ks = (int)(blockIdx.x / ((unsigned)p.B * p.tiles_x * p.tiles_y * p.n_tiles));
+    float* dst = p.ws + (((long long)ks * p.B + b) * p.Cout_pad + n0) * plane;
+    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)((long long)bn * plane * 4), 0x00020000);
+    e.r_add = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, 0, 0x00020000);
+    e.has_add = false;
+    e.r_h = e.r_out;
+    e.r_z = e.r_out;
+  } else if (EPI == AS_EPI_LINEAR) {
+    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + ((long long)b * p.out_ctot + p.out_coff + n0) * plane), 0, recs, 0x00020000);
+    e.r_h = e.r_out;
+    e.r_z = e.r_out;
+  } else if (EPI == AS_EPI_GRU_ZR) {
+    const int ch = p.Cout >> 1;
+    const bool is_r = n0 >= ch;            // block-uniform: bn divides ch
+    const int c0 = is_r ? n0 - ch : n0;    // channel inside the [B,ch,H,W] outputs
+    float* dst = (is_r ? p.out2 : p.out) + ((long long)b * ch + c0) * plane;
+    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, recs, 0x00020000);
+    e.r_h = __builtin_amdgcn_make_buffer_rsrc((void*)(p.h + ((long long)b * ch + c0) * plane), 0, is_r ? recs : 0, 0x00020000);
+    e.r_z = e.r_out;
+  } else {
+    const long long o = ((long long)b * p.Cout + n0) * plane;
+    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + o), 0, recs, 0x00020000);
+    e.r_h = __builtin_amdgcn_make_buffer_rsrc((void*)(p.h + o), 0, recs, 0x00020000);
+    e.r_z = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z + o), 0, recs, 0x00020000);
+  }
+  return e;
+}
+
+// v: finished sums of the tile; col0: channel of accumulator row 0 relative to n0; poff: byte offset of this
+// lane's pixel inside a channel plane or the OOB sentinel; bias_s: LDS bias of the block (index = channel - n0)
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile(const ConvParams& p, const EpiCtx& e, const f32x16& v, int col0, int half,
+                                              unsigned poff, const float* bias_s, bool is_r) {
+  constexpr unsigned kOOB = 0x7FFFFFF0u;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {  // two groups of 8 accumulator rows: 8 loads per operand in flight, ~32 VGPRs
+    unsigned off[8];
+    float av[8], hv[8], zv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = g * 8 + i;
+      const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      off[i] = poff == kOOB ? kOOB : (unsigned)col * e.plane4 + poff;
+      av[i] = as_bload(e.r_add, off[i]);                         // 0 when there is no add tensor (0 records)
+      if (EPI == AS_EPI_GRU_ZR) hv[i] = as_bload(e.r_h, off[i]);  // 0 records for the z half
+      if (EPI == AS_EPI_GRU_Q) { hv[i] = as_bload(e.r_h, off[i]); zv[i] = as_bload(e.r_z, off[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = g * 8 + i;
+      const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float x = v[r] + bias_s[col] + av[i];
+      float o;
+      if (EPI == kEpiPartial) {
+        o = v[r];
+      } else if (EPI == AS_EPI_LINEAR) {
+        o = act_apply(x, p.act);
+      } else if (EPI == AS_EPI_GRU_ZR) {
+        const float gte = 1.f / (1.f + expf(-x));
+        o = is_r ? gte * hv[i] : gte;
+      } else {
+        o = (1.f - zv[i]) * hv[i] + zv[i] * tanhf(x);
+      }
+      as_bstore(e.r_out, off[i], o);
+    }
   }
 }
 
@@ -252,33 +360,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   }
 
   // ---- epilogue for tile (co tile = wave>>1, pixel tile = wave&1) ----
-  const int m = (wave & 1) * 32 + l31;
-  const int gy = y0 + m / TW, gx = x0 + m % TW;
-  if (gy >= p.H || gx >= p.W) return;
-  const long long pixoff = (long long)gy * p.W + gx;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = n0 + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (co >= p.Cout) continue;
-    float v = sum[r];
-    if (p.bias) v += p.bias[co];
-    if (p.add) v += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pixoff];
-    if (EPI == AS_EPI_LINEAR) {
-      p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pixoff] = act_apply(v, p.act);
-    } else if (EPI == AS_EPI_GRU_ZR) {
-      const int ch = p.Cout >> 1;
-      const float g = 1.f / (1.f + expf(-v));
-      if (co < ch) {
-        p.out[((long long)b * ch + co) * plane + pixoff] = g;
-      } else {
-        const long long o = ((long long)b * ch + (co - ch)) * plane + pixoff;
-        p.out2[o] = g * p.h[o];
-      }
-    } else {  // AS_EPI_GRU_Q
-      const long long o = ((long long)b * p.Cout + co) * plane + pixoff;
-      const float zz = p.z[o];
-      p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(v);
-    }
+  __syncthreads();  // the reduction slots are consumed: reuse LDS for the block's bias
+  if (tid < kBN) lds[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;
+  __syncthreads();
+  {
+    const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, kBN);
+    const int m = (wave & 1) * 32 + l31;
+    const int gy = y0 + m / TW, gx = x0 + m % TW;
+    const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
+    const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
+    epilogue_tile<EPI>(p, e, sum, (wave >> 1) * 32, half, poff, lds, is_r);
   }
 }
 
@@ -450,26 +541,35 @@ using half2v = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int kSplitKC = 16;
 
+typedef __attribute__((address_space(3))) void as_lds_void;
+typedef __attribute__((address_space(1))) const void as_gbl_void;
+
+// Wave specialisation (8 waves, 2 per SIMD): waves 0-3 are CONSUMERS — their instruction stream is only
+// ds_read_b128 + MFMA; waves 4-7 are LOADERS — weight-image DMA, halo-patch fetch, fp32 -> hi/lo split and
+// the LDS commit.  Measured on the single-role version: an LDS-DMA instruction costs the issuing wave
+// ~180 cycles, so 18 of them per chunk in front of 108 MFMAs could not overlap with them (in-order issue);
+// on a sibling wave of the same SIMD they do.
 template <int KS, int TW, int BN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvParams p) {
+__global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   constexpr int BM = 128;
   constexpr int TH = BM / TW;
   constexpr int PAD = KS / 2;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PATCHP = PH * PW;
-  constexpr int TPU = KS;                    // taps per pipeline unit (one kernel row)
-  constexpr int UPC = KS;                    // units per chunk
+  constexpr int NTAP = KS * KS;
   constexpr int WSEG = BN * 16;              // bytes of one (tap, comp, h) weight segment
-  constexpr int WUNIT = TPU * 4 * WSEG;      // bytes per weight unit buffer
-  constexpr int PBUF = 4 * PATCHP * 16;      // bytes per patch buffer
-  constexpr int NW16 = WUNIT / 16 / 256;     // 16-B pieces of a weight unit per thread
-  constexpr int NPI = (8 * PATCHP + 255) / 256;  // (channel pair, patch pixel) items per thread
-  constexpr int PTW = (BN == 128) ? 2 : 1;   // pixel MFMA tiles per wave
-  static_assert(WUNIT % (16 * 256) == 0, "weight unit must split evenly over the block");
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2*WUNIT + 2*PBUF bytes (up to ~72 KiB)
+  constexpr int WCHUNK = NTAP * 4 * WSEG;    // bytes of one chunk's weight image (16 channels, all taps)
+  constexpr int NWD = WCHUNK / 16 / 256;     // 16-B LDS-DMA pieces per loader thread per chunk
+  constexpr int NPI = (8 * PATCHP + 255) / 256;  // (channel pair, patch pixel) items per loader thread
+  constexpr int PTW = (BN == 128) ? 2 : 1;   // pixel MFMA tiles per consumer wave
+  static_assert(WCHUNK % (16 * 256) == 0, "weight chunk must split evenly over the loader threads");
+  // [W image 0][W image 1][patch image]
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
   const int l31 = lane & 31, half = lane >> 5;
 
   int id = blockIdx.x;
@@ -478,49 +578,61 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvParams p) {
   const int ty = id % p.tiles_y;
   id /= p.tiles_y;
   const int b = id % p.B;
-  const int nt = id / p.B;
+  id /= p.B;
+  const int nt = id % p.n_tiles;
+  const int ks = id / p.n_tiles;  // K slice (0 unless split-K)
+  const int chunk_lo = (int)((long long)p.chunks * ks / p.ksplit);
+  const int chunk_hi = (int)((long long)p.chunks * (ks + 1) / p.ksplit);
   const int x0 = tx * TW, y0 = ty * TH;
   const int n0 = nt * BN;
   const long long plane = (long long)p.H * p.W;
 
-  // ---- staging descriptors ----
-  unsigned p_voff[NPI];  // byte offset of channel 2*cp of the chunk at this patch pixel, or OOB sentinel
-  int p_lds[NPI];        // byte offset inside one comp image of the patch buffer
-#pragma unroll
-  for (int i = 0; i < NPI; ++i) {
-    int idx = tid + i * 256;
-    const bool slot = idx < 8 * PATCHP;
-    if (!slot) idx = 8 * PATCHP - 1;
-    const int cp = idx / PATCHP, pp = idx - cp * PATCHP;
-    const int py = pp / PW, px = pp - py * PW;
-    const int gy = y0 - PAD + py, gx = x0 - PAD + px;
-    const bool in = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    p_voff[i] = in ? (unsigned)(((long long)(2 * cp) * plane + (long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
-    p_lds[i] = slot ? (cp >> 2) * (PATCHP * 16) + pp * 16 + (cp & 3) * 4 : -1;
-  }
-  int w_off[NW16];  // in 16-B units relative to the unit's first segment at column n0
-#pragma unroll
-  for (int i = 0; i < NW16; ++i) {
-    const int idx = tid + i * 256;
-    w_off[i] = (idx / BN) * p.Cout_pad + (idx % BN);
-  }
-  const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + n0;
-  const long long wunit16 = (long long)TPU * 4 * p.Cout_pad;  // 16-B units per pipeline unit
+  f32x16 acc_h[2][PTW], acc_x[2][PTW];
+  const int cw = wave & 3;
+  const int co_base = (BN == 128) ? (cw >> 1) * 64 : 0;
+  const int px_base = (BN == 128) ? (cw & 1) * 64 : cw * 32;
 
-  f32x4 pre_w[NW16];
-  float pre_p0[NPI], pre_p1[NPI];
+  if (loader) {
+    // =========================== LOADER WAVES ===========================
+    const int ltid = tid - 256;
+    const int lwave = wave - 4;
+    unsigned p_voff[NPI];  // byte offset of channel 2*cp of the chunk at this patch pixel, or OOB sentinel
+    int p_lds[NPI];        // byte offset inside one comp image of the patch buffer
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      int idx = ltid + i * 256;
+      const bool slot = idx < 8 * PATCHP;
+      if (!slot) idx = 8 * PATCHP - 1;
+      const int cp = idx / PATCHP, pp = idx - cp * PATCHP;
+      const int py = pp / PW, px = pp - py * PW;
+      const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+      const bool in = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      p_voff[i] = in ? (unsigned)(((long long)(2 * cp) * plane + (long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
+      p_lds[i] = slot ? (cp >> 2) * (PATCHP * 16) + pp * 16 + (cp & 3) * 4 : -1;
+    }
+    // piece i of this thread is 16-B unit (ltid + 256 i) of the chunk image = segment (ltid + 256 i) / BN,
+    // column (ltid + 256 i) % BN; the global pack has the same order, so the DMA destination is linear
+    constexpr int SEG_PER_STEP = 256 / BN;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + n0 + (long long)(ltid / BN) * p.Cout_pad + (ltid % BN);
+    const long long wstep16 = (long long)SEG_PER_STEP * p.Cout_pad;
+    const long long wchunk16 = (long long)NTAP * 4 * p.Cout_pad;
+    half2v c_hi[NPI], c_lo[NPI];
 
-#define AS_SPLIT_FETCH_W(U)                                                                           \
+    // weights: plain 16-B global loads into registers, then ds_write_b128 (an LDS-DMA instruction costs the
+    // issuing wave ~150-180 cycles per 1-KB piece on a busy CU — 18 of them per chunk made the loaders
+    // issue-bound; a global_load + ds_write pair costs ~20, and the loader waves have the VGPRs to spare)
+    f32x4 wreg[NWD];
+#define AS_SPLIT_LOAD_W(CHUNK)                                                                        \
   {                                                                                                   \
-    const f32x4* wu = wsrc + (long long)(U) * wunit16;                                                 \
-    _Pragma("unroll") for (int i = 0; i < NW16; ++i) pre_w[i] = wu[w_off[i]];                          \
+    const f32x4* wc = wsrc + (long long)(CHUNK) * wchunk16;                                            \
+    _Pragma("unroll") for (int i = 0; i < NWD; ++i) wreg[i] = wc[i * wstep16];                         \
   }
-#define AS_SPLIT_COMMIT_W(BUF)                                                                        \
+#define AS_SPLIT_STORE_W(BUF)                                                                         \
   {                                                                                                   \
-    f32x4* wd = reinterpret_cast<f32x4*>(lds + (BUF) * WUNIT);                                         \
-    _Pragma("unroll") for (int i = 0; i < NW16; ++i) wd[tid + i * 256] = pre_w[i];                     \
+    f32x4* wd = reinterpret_cast<f32x4*>(lds + (BUF) * WCHUNK) + ltid;                                 \
+    _Pragma("unroll") for (int i = 0; i < NWD; ++i) wd[i * 256] = wreg[i];                             \
   }
-#define AS_SPLIT_FETCH_P(CHUNK)                                                                       \
+#define AS_SPLIT_FETCH_SPLIT_P(CHUNK)                                                                 \
   {                                                                                                   \
     const int cb = (CHUNK) * kSplitKC;                                                                \
     const float* sp = p.src[0];                                                                       \
@@ -532,129 +644,132 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvParams p) {
     const int recs = (int)((long long)(sc - (cb - sb)) * plane * 4);                                   \
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
     const unsigned pl4 = (unsigned)(plane * 4);                                                       \
+    float v0[NPI], v1[NPI];                                                                           \
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
       const unsigned o0 = p_voff[i];                                                                  \
       const unsigned o1 = o0 == 0x7FFFFFF0u ? o0 : o0 + pl4;                                           \
-      pre_p0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o0, 0, 0));  \
-      pre_p1[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o1, 0, 0));  \
+      v0[i] = as_bload(rs, o0);                                                                       \
+      v1[i] = as_bload(rs, o1);                                                                       \
+    }                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
+      const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];                                       \
+      c_hi[i][0] = h0; c_hi[i][1] = h1;                                                               \
+      c_lo[i][0] = (_Float16)((v0[i] - (float)h0) * 2048.f);                                           \
+      c_lo[i][1] = (_Float16)((v1[i] - (float)h1) * 2048.f);                                           \
     }                                                                                                 \
   }
-#define AS_SPLIT_COMMIT_P(BUF)                                                                        \
+#define AS_SPLIT_COMMIT_P()                                                                           \
   {                                                                                                   \
-    unsigned char* pd = lds + 2 * WUNIT + (BUF) * PBUF;                                                \
+    unsigned char* pd = lds + 2 * WCHUNK;                                                              \
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
       if (p_lds[i] >= 0) {                                                                            \
-        const _Float16 h0 = (_Float16)pre_p0[i], h1 = (_Float16)pre_p1[i];                             \
-        half2v hi, lo;                                                                                \
-        hi[0] = h0; hi[1] = h1;                                                                       \
-        lo[0] = (_Float16)((pre_p0[i] - (float)h0) * 2048.f);                                          \
-        lo[1] = (_Float16)((pre_p1[i] - (float)h1) * 2048.f);                                          \
-        *reinterpret_cast<half2v*>(pd + p_lds[i]) = hi;                                                \
-        *reinterpret_cast<half2v*>(pd + 2 * PATCHP * 16 + p_lds[i]) = lo;                              \
+        *reinterpret_cast<half2v*>(pd + p_lds[i]) = c_hi[i];                                           \
+        *reinterpret_cast<half2v*>(pd + 2 * PATCHP * 16 + p_lds[i]) = c_lo[i];                         \
       }                                                                                               \
     }                                                                                                 \
   }
-
-  // ---- wave tile ----
-  const int co_base = (BN == 128) ? (wave >> 1) * 64 : 0;
-  const int px_base = (BN == 128) ? (wave & 1) * 64 : wave * 32;
-  const int wlane = half * WSEG + (co_base + l31) * 16;
-  int plane_off[PTW];
+    AS_SPLIT_LOAD_W(chunk_lo)
+    AS_SPLIT_FETCH_SPLIT_P(chunk_lo)
+    AS_SPLIT_STORE_W(0)
+    AS_SPLIT_COMMIT_P()
+    __syncthreads();
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+      const bool more = chunk + 1 < chunk_hi;
+      if (more) {
+        AS_SPLIT_LOAD_W(chunk + 1)
+        AS_SPLIT_FETCH_SPLIT_P(chunk + 1)
+        AS_SPLIT_STORE_W(((chunk - chunk_lo) & 1) ^ 1)  // the other W image is free while the consumers work on this one
+      }
+      __syncthreads();  // consumers finished chunk: patch and W image `cur` are free
+      if (more) {
+        AS_SPLIT_COMMIT_P()
+        __syncthreads();
+      }
+    }
+#undef AS_SPLIT_LOAD_W
+#undef AS_SPLIT_STORE_W
+#undef AS_SPLIT_FETCH_SPLIT_P
+#undef AS_SPLIT_COMMIT_P
+  } else {
+    // =========================== CONSUMER WAVES ===========================
+    const int wlane = half * WSEG + (co_base + l31) * 16;
+    int plane_off[PTW];
 #pragma unroll
-  for (int q = 0; q < PTW; ++q) {
-    const int m = px_base + q * 32 + l31;
-    plane_off[q] = half * (PATCHP * 16) + ((m / TW) * PW + (m % TW)) * 16;
+    for (int q = 0; q < PTW; ++q) {
+      const int m = px_base + q * 32 + l31;
+      plane_off[q] = half * (PATCHP * 16) + ((m / TW) * PW + (m % TW)) * 16;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < PTW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_h[c][q][r] = 0.f; acc_x[c][q][r] = 0.f; }
+    __syncthreads();
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+      const bool more = chunk + 1 < chunk_hi;
+      const unsigned char* wb = lds + ((chunk - chunk_lo) & 1) * WCHUNK + wlane;
+      const unsigned char* pb = lds + 2 * WCHUNK;
+      // operand software pipeline: the ds_read_b128 of tap t+1 sit between the two halves of tap t's MFMAs
+      half8 a_hi[2][2], a_lo[2][2], b_hi[2][PTW], b_lo[2][PTW];
+#define AS_SPLIT_LDOPS(TAP, S)                                                                          \
+  {                                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                      \
+      a_hi[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 0) * 2) * WSEG + c * 512);          \
+      a_lo[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 1) * 2) * WSEG + c * 512);          \
+    }                                                                                                   \
+    constexpr int tapoff_ = (((TAP) / KS) * PW + ((TAP) % KS)) * 16;                                     \
+    _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                    \
+      b_hi[S][q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff_);                         \
+      b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHP * 16 + plane_off[q] + tapoff_);       \
+    }                                                                                                   \
+  }
+#define AS_SPLIT_MFMA_C(S, c)                                                                           \
+  _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                      \
+    acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);   \
+    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
+    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0);   \
+  }
+#define AS_SPLIT_STEP(TAP)                                                                              \
+  if constexpr ((TAP) < NTAP) {                                                                         \
+    AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if constexpr ((TAP) + 1 < NTAP) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+      if (!(p.dbg & 4)) {
+        AS_SPLIT_LDOPS(0, 0)
+        AS_SPLIT_STEP(0) AS_SPLIT_STEP(1) AS_SPLIT_STEP(2) AS_SPLIT_STEP(3) AS_SPLIT_STEP(4)
+        AS_SPLIT_STEP(5) AS_SPLIT_STEP(6) AS_SPLIT_STEP(7) AS_SPLIT_STEP(8)
+      }
+#undef AS_SPLIT_STEP
+#undef AS_SPLIT_MFMA_C
+#undef AS_SPLIT_LDOPS
+      __syncthreads();
+      if (more) __syncthreads();
+    }
   }
 
-  f32x16 acc_h[2][PTW], acc_x[2][PTW];
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int q = 0; q < PTW; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_h[c][q][r] = 0.f; acc_x[c][q][r] = 0.f; }
-
-  const int units = p.chunks * UPC;
-  AS_SPLIT_FETCH_W(0)
-  AS_SPLIT_FETCH_P(0)
-  AS_SPLIT_COMMIT_W(0)
-  AS_SPLIT_COMMIT_P(0)
+  // ---- epilogue (consumer waves hold the accumulators) ----
+  float* bias_s = reinterpret_cast<float*>(lds);  // the weight images are dead after the last barrier
+  if (tid < BN) bias_s[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;
   __syncthreads();
-
-  int chunk = 0, tg = 0;
-  for (int u = 0; u < units; ++u) {
-    const bool more_w = u + 1 < units;
-    const bool first_of_chunk = tg == 0, last_of_chunk = tg == UPC - 1;
-    const bool more_p = chunk + 1 < p.chunks;
-    if (more_w) AS_SPLIT_FETCH_W(u + 1)
-    if (first_of_chunk && more_p) AS_SPLIT_FETCH_P(chunk + 1)
-    const unsigned char* wb = lds + (u & 1) * WUNIT + wlane;
-    const unsigned char* pb = lds + 2 * WUNIT + (chunk & 1) * PBUF;
+  if (!loader) {
+    const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN);
+    const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
 #pragma unroll
-    for (int t = 0; t < TPU; ++t) {
-      half8 a_hi[2], a_lo[2], b_hi[PTW], b_lo[PTW];
+    for (int q = 0; q < PTW; ++q) {
+      const int m = px_base + q * 32 + l31;
+      const int gy = y0 + m / TW, gx = x0 + m % TW;
+      const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        a_hi[c] = *reinterpret_cast<const half8*>(wb + ((t * 2 + 0) * 2) * WSEG + c * 512);
-        a_lo[c] = *reinterpret_cast<const half8*>(wb + ((t * 2 + 1) * 2) * WSEG + c * 512);
-      }
-      const int tapoff = (tg * PW + t) * 16;  // ky = tg, kx = t
+        f32x16 v;
 #pragma unroll
-      for (int q = 0; q < PTW; ++q) {
-        b_hi[q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff);
-        b_lo[q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHP * 16 + plane_off[q] + tapoff);
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int q = 0; q < PTW; ++q) {
-          acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[c], b_hi[q], acc_h[c][q], 0, 0, 0);
-          acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[c], b_lo[q], acc_x[c][q], 0, 0, 0);
-          acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[c], b_hi[q], acc_x[c][q], 0, 0, 0);
-        }
-    }
-    if (more_w) AS_SPLIT_COMMIT_W((u + 1) & 1)
-    if (last_of_chunk && more_p) AS_SPLIT_COMMIT_P((chunk + 1) & 1)
-    __syncthreads();
-    if (++tg == UPC) { tg = 0; ++chunk; }
-  }
-#undef AS_SPLIT_FETCH_W
-#undef AS_SPLIT_COMMIT_W
-#undef AS_SPLIT_FETCH_P
-#undef AS_SPLIT_COMMIT_P
-
-  // ---- epilogue ----
-#pragma unroll
-  for (int q = 0; q < PTW; ++q) {
-    const int m = px_base + q * 32 + l31;
-    const int gy = y0 + m / TW, gx = x0 + m % TW;
-    if (gy >= p.H || gx >= p.W) continue;
-    const long long pixoff = (long long)gy * p.W + gx;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = n0 + co_base + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= p.Cout) continue;
-        float v = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
-        if (p.bias) v += p.bias[co];
-        if (p.add) v += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pixoff];
-        if (EPI == AS_EPI_LINEAR) {
-          p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pixoff] = act_apply(v, p.act);
-        } else if (EPI == AS_EPI_GRU_ZR) {
-          const int ch = p.Cout >> 1;
-          const float g = 1.f / (1.f + expf(-v));
-          if (co < ch) {
-            p.out[((long long)b * ch + co) * plane + pixoff] = g;
-          } else {
-            const long long o = ((long long)b * ch + (co - ch)) * plane + pixoff;
-            p.out2[o] = g * p.h[o];
-          }
-        } else {  // AS_EPI_GRU_Q
-          const long long o = ((long long)b * p.Cout + co) * plane + pixoff;
-          const float zz = p.z[o];
-          p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(v);
-        }
+        for (int r = 0; r < 16; ++r) v[r] = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
+        epilogue_tile<EPI>(p, e, v, co_base + c * 32, half, poff, bias_s, is_r);
       }
     }
   }
@@ -682,22 +797,64 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16*
   wp[idx] = comp == 0 ? hi : (_Float16)((v - (float)hi) * 2048.f);
 }
 
+// ---- split-K finish: sum the K-slice slabs and apply the fused epilogue (one lane per output element) ----
+template <int EPI>
+__global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
+  const long long plane = (long long)p.H * p.W;
+  const long long total = (long long)p.B * p.Cout * plane;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long long pix = idx % plane;
+  const int co = (int)((idx / plane) % p.Cout);
+  const int b = (int)(idx / (plane * p.Cout));
+  float x = 0.f;
+  for (int ks = 0; ks < p.ksplit; ++ks) x += p.ws[(((long long)ks * p.B + b) * p.Cout_pad + co) * plane + pix];
+  if (p.bias) x += p.bias[co];
+  if (p.add) x += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pix];
+  if (EPI == AS_EPI_LINEAR) {
+    p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pix] = act_apply(x, p.act);
+  } else if (EPI == AS_EPI_GRU_ZR) {
+    const int ch = p.Cout >> 1;
+    const float g = 1.f / (1.f + expf(-x));
+    if (co < ch) p.out[((long long)b * ch + co) * plane + pix] = g;
+    else {
+      const long long o = ((long long)b * ch + (co - ch)) * plane + pix;
+      p.out2[o] = g * p.h[o];
+    }
+  } else {
+    const long long o = ((long long)b * p.Cout + co) * plane + pix;
+    const float zz = p.z[o];
+    p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(x);
+  }
+}
+
 template <int KS, int TW, int BN, int EPI>
 int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   constexpr int TH = 128 / TW, PATCHP = (TH + KS - 1) * (TW + KS - 1);
-  constexpr size_t lds = 2 * (size_t)(KS * 4 * BN * 16) + 2 * (size_t)(4 * PATCHP * 16);
+  constexpr size_t lds = 2 * (size_t)(KS * KS * 4 * BN * 16) + (size_t)(4 * PATCHP * 16);
+  static_assert(lds <= 160 * 1024, "conv_split: LDS budget");
   static bool configured = false;  // per instantiation; the attribute is idempotent
   if (!configured && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  const dim3 grid((unsigned)((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles));
-  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI>), grid, dim3(256), lds, s, p);
+  const dim3 grid((unsigned)((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles * p.ksplit));
+  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI>), grid, dim3(512), lds, s, p);
   return as::check_launch("conv2d(split)");
 }
 
 template <int KS, int TW, int BN>
 int launch_conv_split(const ConvParams& p, int epi, hipStream_t s) {
+  if (p.ksplit > 1) {
+    int rc = launch_conv_split_epi<KS, TW, BN, kEpiPartial>(p, s);
+    if (rc != AS_OK) return rc;
+    const long long total = (long long)p.B * p.Cout * p.H * p.W;
+    const dim3 g((unsigned)as::cdiv64(total, 256));
+    if (epi == AS_EPI_LINEAR) hipLaunchKernelGGL(conv_finish_kernel<AS_EPI_LINEAR>, g, dim3(256), 0, s, p);
+    else if (epi == AS_EPI_GRU_ZR) hipLaunchKernelGGL(conv_finish_kernel<AS_EPI_GRU_ZR>, g, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_finish_kernel<AS_EPI_GRU_Q>, g, dim3(256), 0, s, p);
+    return as::check_launch("conv2d(split-K finish)");
+  }
   if (epi == AS_EPI_LINEAR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_LINEAR>(p, s);
   if (epi == AS_EPI_GRU_ZR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_ZR>(p, s);
   return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_Q>(p, s);
@@ -713,6 +870,21 @@ int launch_conv(const ConvParams& p, int epi, hipStream_t s) {
 }
 
 int conv_kc(int KS) { return KS == 3 ? ConvCfg<3>::KC : ConvCfg<1>::KC; }
+
+// Small feature maps give too few blocks to pull the weight stream (each CU fills its LDS at ~35 GB/s, so
+// a 1/16-res GRU conv on 36 CUs is bound by 36 x that): split K over more blocks when a workspace is given.
+void conv_pick_ksplit(ConvParams& p, const as_conv_desc* d) {
+  p.ksplit = 1;
+  p.ws = nullptr;
+  if (!d->ws || d->ws_elems <= 0) return;
+  const long long blocks = (long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles;
+  const long long slab = (long long)p.B * p.Cout_pad * p.H * p.W;
+  // one block per CU (the tile's LDS footprint): more blocks than CUs would just queue a second round
+  int ks = (int)(kNumCU / blocks);
+  if (ks > 8) ks = 8;
+  while (ks > 1 && (p.chunks / ks < 2 || slab * ks > d->ws_elems)) --ks;
+  if (ks > 1) { p.ksplit = ks; p.ws = d->ws; }
+}
 int conv_cout_pad(int Cout) { return ((Cout + kBN - 1) / kBN) * kBN; }
 
 }  // namespace
@@ -750,6 +922,16 @@ int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Co
   return as::check_launch("conv_pack_weights_split");
 }
 
+int64_t as_conv_ws_elems(int B, int Cout, int H, int W) {
+  if (B <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  const int cpad = conv_cout_pad(Cout);
+  const int bn = (cpad % 128 == 0) ? 128 : 64;
+  const long long tiles = (long long)B * as::cdiv64((long long)H * W, 128) * (cpad / bn);
+  int ks = (int)(kNumCU / tiles);
+  if (ks > 8) ks = 8;
+  return ks > 1 ? (int64_t)ks * B * cpad * H * W : 0;
+}
+
 int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(d, AS_ERR_BAD_ARG, "conv2d: null descriptor");
   AS_REQUIRE(d->KS == 1 || d->KS == 3, AS_ERR_BAD_ARG, "conv2d: KS=%d (supported: 1, 3)", d->KS);
@@ -758,6 +940,11 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(d->wpack && d->out, AS_ERR_BAD_ARG, "conv2d: null wpack/out");
   AS_REQUIRE((reinterpret_cast<uintptr_t>(d->wpack) & 15) == 0, AS_ERR_BAD_ARG, "conv2d: wpack not 16-B aligned");
   ConvParams p{};
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("AS_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
   int csum = 0;
   for (int i = 0; i < d->n_src; ++i) {
     AS_REQUIRE(d->src[i] && d->src_c[i] > 0, AS_ERR_BAD_ARG, "conv2d: source %d null or empty", i);
@@ -801,6 +988,8 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   p.chunks = (d->Cin + KC - 1) / KC;
   p.n_tiles = p.Cout_pad / kBN;
   hipStream_t s = as::as_stream(stream);
+  p.ksplit = 1;
+  p.ws = nullptr;
   if (split) {
     const int bn = (p.Cout_pad % 128 == 0) ? 128 : 64;
     p.n_tiles = p.Cout_pad / bn;
@@ -811,6 +1000,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
       p.tiles_x = as::cdiv(p.W, 128);
       p.tiles_y = 1;
       AS_REQUIRE((long long)p.B * p.tiles_x * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+      conv_pick_ksplit(p, d);
       return bn == 128 ? launch_conv_split<1, 128, 128>(p, epi, s) : launch_conv_split<1, 128, 64>(p, epi, s);
     }
     p.H = d->H;
@@ -822,6 +1012,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.tiles_x = as::cdiv(p.W, tw);
     p.tiles_y = as::cdiv(p.H, 128 / tw);
     AS_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+    conv_pick_ksplit(p, d);
     if (tw == 16) return bn == 128 ? launch_conv_split<3, 16, 128>(p, epi, s) : launch_conv_split<3, 16, 64>(p, epi, s);
     return bn == 128 ? launch_conv_split<3, 32, 128>(p, epi, s) : launch_conv_split<3, 32, 64>(p, epi, s);
   }

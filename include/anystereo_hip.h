@@ -137,8 +137,12 @@ typedef struct {
   int B, H, W, Cin, Cout, KS;
   int act, epilogue;
   int precision;      /* which pack `wpack` is: 0 = fp32 (as_conv_pack_weights), 1 = split fp16 (as_conv_pack_weights_split) */
+  float* ws;          /* optional scratch for split-K on small feature maps (precision 1): partial-sum slabs */
+  int64_t ws_elems;   /* capacity of ws in floats; as_conv_ws_elems() gives the useful maximum; 0/NULL = never split K */
 } as_conv_desc;
 int as_conv2d(const as_conv_desc* d, void* stream);
+/* floats of split-K scratch worth passing in as_conv_desc.ws for this problem (0: the problem is large enough) */
+int64_t as_conv_ws_elems(int B, int Cout, int H, int W);
 /* weight [Cout,Cin,KS,KS] (nn.Conv2d layout) -> wpack; returns the element count needed when wpack==NULL */
 int64_t as_conv_pack_size(int Cin, int Cout, int KS);
 int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, int KS, void* stream);

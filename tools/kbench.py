@@ -40,11 +40,19 @@ def main():
     bzr = det_uniform((256,), 31).to(dev)
     pzr = ops.PackedConv().get([wzr], [bzr])
     from anystereo import _lib as Lb
+
+    def zr_at(div):
+        hh, ww = h // div, w // div
+        xs = [det_uniform((b, 128, hh, ww), 40 + i).to(dev) for i in range(3)]
+        cx = det_uniform((b, 384, hh, ww), 50).to(dev)
+        return lambda: ops.conv2d(xs, pzr, add=cx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=xs[0])
     fns = {
         "corr_build": lambda: ops.corr_build_pyramid(f1, f2, L),
         "geo_pyramid": (lambda: ops.geo_pyramid(gev, L)) if g else None,
         "lookup": lambda: ops.geo_corr_lookup(geo, corr, disp, 4),
         "gwc": lambda: ops.gwc_volume(f1, f2, 48, 8),
+        "gru08_zr": zr_at(2),
+        "gru16_zr": zr_at(4),
         "gru_zr": lambda: ops.conv2d(x128, pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=x128[0]),
     }
     for k in a.kernels:
