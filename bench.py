@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16/bf16 MFMA dense peak (~2.5 PF)
 
 
 def parse():
@@ -84,6 +85,9 @@ def main():
     from anystereo.models import __models__, default_args
 
     _lib.load()
+    from anystereo import ops as _ops
+    precision = _ops.get_precision()
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("ANYSTEREO_MIOPEN_BENCHMARK", "1")))
     args = default_args("continuous_IGEVStereo")
     model = __models__["continuous_IGEVStereo"](args).eval()
     fill_module_deterministic(model, base_seed=1)  # random-init weights of the named architecture (no checkpoints offline)
@@ -173,8 +177,11 @@ def main():
                                    "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
             else:
                 ach = e["flops"] / avg_s / 1e12
-                rooflines[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                # split precision spends 3 fp16 MFMA products per algorithmic product: the attainable peak for
+                # ALGORITHMIC flops is the fp16 dense peak / 3; in fp32 mode it is the fp32-input MFMA peak
+                peak = MFMA_F16_PEAK_TFLOPS / 3.0 if precision == "split" else MFMA_F32_PEAK_TFLOPS
+                rooflines[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "traffic": None,
                                    "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
         dominant = max(rooflines, key=lambda k: rooflines[k]["total_ms"]) if rooflines else None
         cpu = None
@@ -184,7 +191,7 @@ def main():
             "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",
             "value": round(world * a.steps / dt, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if precision == "fp32" else "f32 (3xf16 split-precision MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"coreContinuous_IGEV inference, {a.width}x{a.height} SceneFlow-shape synthetic pair "
                                    f"(padded {wp}x{hp}), {a.iters} GRU iters, scale {a.scale}, Q={Q} queries, 1 pair per GPU, "
                                    f"random-init weights", "pairs_per_gpu": 1, "parallelism": f"replicas x{world}",

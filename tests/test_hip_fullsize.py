@@ -1,0 +1,167 @@
+"""GPU (-m gpu): the BASELINE.json configurations at FULL size, through size-independent properties
+(the CPU oracle cannot finish these sizes in seconds): exact-integer lookups, pooling consistency,
+checksums, linearity, identity kernels, constant-field upsampling, oracle spot checks on row crops,
+determinism and hipGraph-vs-eager equality of the whole model.
+
+cfg 2: IGEV 960x540 -> 1/4 res 136x240;  cfg 3: KITTI 1242x375 x2 -> 96x312;  cfg 5: Middlebury-F -> 336x480;
+cfg 1: RAFT 256x512 -> 64x128 (C=256, 4 levels).
+"""
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CFGS = {"cfg1_raft": (1, 256, 64, 128, 4, 0), "cfg2": (1, 96, 136, 240, 2, 8), "cfg3": (1, 96, 96, 312, 2, 8),
+        "cfg5": (1, 96, 336, 480, 2, 8)}
+
+
+def U(shape, seed, lo=-1.0, hi=1.0):
+    from anystereo.harness.synthetic import det_uniform
+    return det_uniform(shape, seed, lo, hi)
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+def test_build_and_lookup_fullsize(name):
+    from anystereo import ops
+    b, c, h, w, L, g = CFGS[name]
+    f1, f2 = U((b, c, h, w), 1).to(DEV), U((b, c, h, w), 2).to(DEV)
+    lv = ops.corr_build_pyramid(f1, f2, L)
+    # checksum of checksums: sum_x2 corr[b,y,x1,x2] == sum_c f1[c,y,x1] * (sum_x2 f2[c,y,x2])
+    want = torch.einsum("bcyx,bcy->byx", f1.double(), f2.double().sum(-1))
+    got = lv[0].double().sum(-1)
+    assert (got - want).abs().max().item() < 1e-6 * c * w
+    # pyramid: every level is the pair-mean of the level above, bit for bit
+    for i in range(1, L):
+        n = lv[i - 1].shape[-1] // 2
+        ref = (lv[i - 1][..., 0:2 * n:2] + lv[i - 1][..., 1:2 * n:2]) * 0.5
+        assert torch.equal(lv[i], ref), f"level {i} is not pool(level {i - 1})"
+    # linearity in f1
+    lv2 = ops.corr_build_pyramid(f1 * 2.0, f2, L)
+    assert torch.equal(lv2[0], lv[0] * 2.0)
+    # spot check two rows against the fp64 oracle
+    rows = [0, h - 1]
+    ref = O.all_pairs_corr(f1[:, :, rows].double().cpu(), f2[:, :, rows].double().cpu())
+    assert (lv[0][:, rows].double().cpu() - ref).abs().max().item() < 2e-6 * c
+
+    geo = None
+    if g:
+        gev = U((b, g, 48, h, w), 3).to(DEV)
+        geo = ops.geo_pyramid(gev, L)
+        assert torch.equal(geo[0], gev.permute(0, 3, 4, 2, 1).contiguous())
+    # integer disparity: the lookup is an exact gather (t == 0), zero outside the volume
+    d0 = 3.0
+    disp = torch.full((b, 1, h, w), d0, device=DEV)
+    out = ops.geo_corr_lookup(geo, lv, disp, 4)
+    assert out.shape == (b, L * 9 * (g + 1), h, w)
+    xs = torch.arange(w, device=DEV)
+    for k in range(-4, 5):
+        idx = xs - int(d0) + k
+        ok = (idx >= 0) & (idx < w)
+        ref = torch.gather(lv[0], 3, idx.clamp(0, w - 1).view(1, 1, w, 1).expand(b, h, w, 1))[..., 0] * ok
+        ch = g * 9 + (k + 4)
+        assert torch.equal(out[:, ch], ref), f"corr tap {k}"
+        if g:
+            dd = int(d0) + k
+            ref_g = geo[0][:, :, :, dd, :].permute(0, 3, 1, 2) if 0 <= dd < 48 else torch.zeros(b, g, h, w, device=DEV)
+            assert torch.equal(out[:, [c_ * 9 + (k + 4) for c_ in range(g)]], ref_g), f"geo tap {k}"
+    # fractional disparities: oracle on a 2-row crop
+    disp = U((b, 1, h, w), 5, -5.0, 60.0).to(DEV)
+    out = ops.geo_corr_lookup(geo, lv, disp, 4)
+    geo_c = [t[:, rows].permute(0, 1, 2, 4, 3).double().cpu() for t in geo] if g else None
+    ref = O.geo_corr_lookup(geo_c, [t[:, rows].double().cpu() for t in lv], disp[:, :, rows].double().cpu(), 4)
+    err = (out[:, :, rows].double().cpu() - ref).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "split"])
+def test_conv_gru_fullsize_properties(mode):
+    """cfg 2 sizes (136x240, 68x120, 34x60): identity kernel reproduces its input, the conv is linear,
+    the fused GRU matches its own unfused pieces."""
+    from anystereo import _lib as L
+    from anystereo import ops
+    prev = ops.get_precision()
+    ops.set_precision(mode)
+    try:
+        for (h, w) in [(136, 240), (68, 120), (34, 60)]:
+            x = [U((1, 128, h, w), 10 + i, -2, 2).to(DEV) for i in range(3)]
+            wid = torch.zeros(128, 384, 3, 3, device=DEV)
+            for co in range(128):
+                wid[co, 128 + co, 1, 1] = 1.0  # centre tap of source 1
+            pk = ops.PackedConv().get([wid], [None])
+            y = ops.conv2d(x, pk)
+            assert (y - x[1]).abs().max().item() <= 2e-6 * 2, "identity kernel"
+            wr = (U((128, 384, 3, 3), 20) * 0.02).to(DEV)
+            pr = ops.PackedConv().get([wr], [None])
+            ya = ops.conv2d(x, pr)
+            yb = ops.conv2d([x[0] * 2, x[1] * 2, x[2] * 2], pr)
+            assert (yb - 2 * ya).abs().max().item() <= 1e-5, "linearity"
+            # shifting the input shifts the output (interior): translation equivariance
+            xs = [torch.roll(t, shifts=(1, 2), dims=(2, 3)) for t in x]
+            ys = ops.conv2d(xs, pr)
+            assert (ys[:, :, 3:-3, 4:-4] - torch.roll(ya, (1, 2), (2, 3))[:, :, 3:-3, 4:-4]).abs().max().item() <= 1e-5
+            # fused GRU epilogues == composition of LINEAR convs + pointwise math
+            wz = (U((256, 384, 3, 3), 21) * 0.02).to(DEV)
+            bz = (U((256,), 22) * 0.1).to(DEV)
+            ctx = U((1, 384, h, w), 23).to(DEV)
+            pz = ops.PackedConv().get([wz], [bz])
+            z, rh = ops.conv2d(x, pz, add=ctx, add_coff=0, epilogue=L.EPI_GRU_ZR, h=x[0])
+            lin = ops.conv2d(x, pz, add=ctx, add_coff=0)
+            assert (z - torch.sigmoid(lin[:, :128])).abs().max().item() <= 2e-6
+            assert (rh - torch.sigmoid(lin[:, 128:]) * x[0]).abs().max().item() <= 4e-6
+            bq = (U((128,), 24) * 0.1).to(DEV)
+            pq = ops.PackedConv().get([wr], [bq])
+            hn = ops.conv2d([rh, x[1], x[2]], pq, add=ctx, add_coff=256, epilogue=L.EPI_GRU_Q, h=x[0], z=z)
+            linq = ops.conv2d([rh, x[1], x[2]], pq, add=ctx, add_coff=256)
+            assert (hn - ((1 - z) * x[0] + z * torch.tanh(linq))).abs().max().item() <= 4e-6
+    finally:
+        ops.set_precision(prev)
+
+
+def test_liif_fullsize_properties():
+    """cfg 3: 96x312 low-res, scale 2 -> 1 863 000 queries; constant disparity + uniform logits upsample exactly."""
+    from anystereo import ops
+    h, w, s = 96, 312, 2.0
+    q_h, q_w = int(h * 4 * s), int(w * 4 * s)
+    coord = O.make_coord([q_h, q_w]).view(1, -1, 2).to(DEV)
+    q = coord.shape[1]
+    disp = torch.full((1, 1, h, w), 7.25, device=DEV)
+    mask = torch.zeros(1, 9, q, device=DEV)
+    out = ops.convex_upsample(disp, mask, coord, scale=torch.tensor([s], device=DEV), mask_is_logits=True)
+    interior = out.view(q_h, q_w)[int(4 * s):-int(4 * s), int(4 * s):-int(4 * s)]
+    assert (interior - 7.25 * 4 * s).abs().max().item() < 1e-4
+    # nearest gather: every query of a 1/4-res cell reads that cell (value = cell index), rel coords inside the cell
+    feat = torch.arange(h * w, device=DEV, dtype=torch.float32).view(1, 1, h, w)
+    lat = torch.empty(1, 3, q, device=DEV)
+    ops.liif_gather(feat, coord, lat, 0)
+    cell = lat[0, 0].view(q_h, q_w)
+    step = int(4 * s)
+    want = feat[0, 0].repeat_interleave(step, 0).repeat_interleave(step, 1)
+    assert torch.equal(cell, want)
+    assert lat[0, 1:].abs().max().item() <= 1.0 + 1e-4  # |rel| <= 1 (half a cell in normalised units x cell count x 2)
+
+
+def test_whole_model_cfg2_determinism_and_graph():
+    """Full 960x540, 32 iterations: finite, bitwise repeatable, and the hipGraph replay equals the eager run."""
+    from anystereo.harness.query import pad_for_multi_train
+    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
+    from anystereo.models import __models__, default_args
+    model = __models__["continuous_IGEVStereo"](default_args("continuous_IGEVStereo")).eval()
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV)
+    img1, img2 = synthetic_pair(1, 540, 960, shift=8, seed=1234)
+    i1, i2, coord, _ = pad_for_multi_train(img1, img2, 1.0, divis_by=32)
+    i1, i2, coord = i1.to(DEV), i2.to(DEV), coord.unsqueeze(0).to(DEV)
+    sc = torch.tensor([[1.0]], device=DEV)
+    with torch.no_grad():
+        a = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        b = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        model.enable_graph(True)
+        c = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        d = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+    assert a.shape == (1, 1, 540 * 960) and torch.isfinite(a).all()
+    assert torch.equal(a, b), "eager forward is not bitwise repeatable"
+    assert torch.equal(c, d), "graph replay is not bitwise repeatable"
+    assert (a - c).abs().max().item() < 1e-3, "hipGraph replay differs from eager"
