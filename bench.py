@@ -87,7 +87,7 @@ def main():
     _lib.load()
     from anystereo import ops as _ops
     precision = _ops.get_precision()
-    torch.backends.cudnn.benchmark = bool(int(os.environ.get("ANYSTEREO_MIOPEN_BENCHMARK", "1")))
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("ANYSTEREO_MIOPEN_BENCHMARK", "0")))
     args = default_args("continuous_IGEVStereo")
     model = __models__["continuous_IGEVStereo"](args).eval()
     fill_module_deterministic(model, base_seed=1)  # random-init weights of the named architecture (no checkpoints offline)
@@ -164,6 +164,12 @@ def main():
 
     if rank == 0:
         alg = algorithmic(1, hp // 4, wp // 4, Q, a.iters)
+        # the short HBM-bound kernels (10-60 us) are re-timed as 20 back-to-back launches between ONE event pair:
+        # a start/stop pair around a single launch adds ~3 us of its own (rocprofv3 durations confirm)
+        micro = micro_time_small_kernels(dev, hp // 4, wp // 4)
+        for k, v in micro.items():
+            kstats[k] = v
+        traffic = load_pmc_traffic()
         rooflines = {}
         for name, st in kstats.items():
             if name not in alg or st["count"] == 0:
@@ -173,7 +179,7 @@ def main():
             if e["bound"] == "hbm":
                 ach = e["bytes"] / avg_s / 1e9
                 rooflines[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
                                    "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
             else:
                 ach = e["flops"] / avg_s / 1e12
@@ -181,7 +187,7 @@ def main():
                 # ALGORITHMIC flops is the fp16 dense peak / 3; in fp32 mode it is the fp32-input MFMA peak
                 peak = MFMA_F16_PEAK_TFLOPS / 3.0 if precision == "split" else MFMA_F32_PEAK_TFLOPS
                 rooflines[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                                   "frac": round(ach / peak, 4), "traffic": None,
+                                   "frac": round(ach / peak, 4), "traffic": traffic.get(name),
                                    "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
         dominant = max(rooflines, key=lambda k: rooflines[k]["total_ms"]) if rooflines else None
         cpu = None
@@ -210,6 +216,44 @@ def main():
     if dist:
         td.barrier()
         td.destroy_process_group()
+
+
+def micro_time_small_kernels(dev, h, w, reps=20):
+    """corr_build and lookup on operands of the workload's shapes (C=96, L=2, G=8, D=48), `reps` launches
+    back to back between one HIP event pair on the launch stream."""
+    from anystereo import ops
+    from anystereo.harness.synthetic import det_uniform
+    f1 = det_uniform((1, 96, h, w), 1).to(dev)
+    f2 = det_uniform((1, 96, h, w), 2).to(dev)
+    gev = det_uniform((1, 8, 48, h, w), 3).to(dev)
+    disp = det_uniform((1, 1, h, w), 4, 0.0, 40.0).to(dev)
+    corr = ops.corr_build_pyramid(f1, f2, 2)
+    geo = ops.geo_pyramid(gev, 2)
+    out = {}
+    for name, fn in (("corr_build", lambda: ops.corr_build_pyramid(f1, f2, 2)),
+                     ("lookup", lambda: ops.geo_corr_lookup(geo, corr, disp, 4))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        out[name] = {"count": reps, "total_ms": s.elapsed_time(e)}
+    return out
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command (profiles/rNN_pmc_traffic.json, produced by tools/profile_round.sh; gfx950 FETCH_SIZE correction applied)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return {}
+    d = json.load(open(files[-1]))
+    return {k: (None if v.get("hbm_bytes") is None else int(v["hbm_bytes"])) for k, v in d.items()}
 
 
 def cpu_baseline(args, model, img1, img2, a):
