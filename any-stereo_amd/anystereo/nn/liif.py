@@ -135,6 +135,21 @@ class liif_out_multi_scale_Training(nn.Module):
         with scope("structure_feature"):
             sfs = [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
         ctot = sum(s.shape[1] + 2 for s in sfs)
+        # queries are processed in slabs of <= 2^20 so the [B,228,Q] latent stays below 1 GB (Middlebury-F has
+        # 5.7 M queries = 5.2 GB if materialised at once, liif.py:675) and inside the kernels' 32-bit offsets
+        qmax = self.query_chunk
+        if q <= qmax:
+            return self._mask_logits(sfs, coord, ctot)
+        out = torch.empty((b, self.outputdim, q), device=coord.device, dtype=torch.float32)
+        for q0 in range(0, q, qmax):
+            q1 = min(q, q0 + qmax)
+            out[:, :, q0:q1] = self._mask_logits(sfs, coord[:, q0:q1].contiguous(), ctot)
+        return out
+
+    query_chunk = 1 << 20
+
+    def _mask_logits(self, sfs, coord, ctot):
+        b, q = coord.shape[:2]
         latent = torch.empty((b, ctot, q), device=coord.device, dtype=torch.float32)
         off = 0
         with scope("liif_gather"):

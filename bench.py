@@ -191,7 +191,7 @@ def main():
                                    "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
         dominant = max(rooflines, key=lambda k: rooflines[k]["total_ms"]) if rooflines else None
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), bounded sample
             cpu = cpu_baseline(args, model, img1, img2, a)
         line = {
             "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",

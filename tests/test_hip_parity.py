@@ -318,6 +318,11 @@ def test_liif_golden(golden, precision):
         mask = up([g["x4"].to(DEV), g["x2"].to(DEV)], g["coord"].to(DEV), torch.tensor([[1.5]], device=DEV))
     assert mask.shape == g["mask"].shape
     close(mask, g["mask"], 2e-5, 2e-5, "liif mask logits")
+    up.query_chunk = 256  # force the query-slab path used for > 2^20 queries (Middlebury-F: 5.7 M)
+    with torch.no_grad():
+        mask_c = up([g["x4"].to(DEV), g["x2"].to(DEV)], g["coord"].to(DEV), torch.tensor([[1.5]], device=DEV))
+    close(mask_c, mask, 2e-6, 2e-6, "query-slab processing")
+    up.query_chunk = 1 << 20
     coord = g["coord"].clone().to(DEV)
     cu = context_upsample_multiscale_train((g["dlow"] * 4.0 * 1.5).to(DEV), torch.softmax(g["mask"], 1).to(DEV), coord)
     close(cu, g["convex"], 1e-5, 1e-5, "convex upsample (reference contract)")
