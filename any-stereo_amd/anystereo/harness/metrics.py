@@ -1,0 +1,63 @@
+"""§8(f2)/(f3): the training loss and the evaluation metrics that define "parity" for Any-Stereo.
+
+sequence_loss_multiscale  train_continuous_IGEV.py:68-94   (exponentially weighted masked L1 over the GRU predictions)
+fetch_optimizer           train_continuous_IGEV.py:125-134 (AdamW + linear OneCycleLR)
+EPE / D1 / Thres          metrics_utils/metrics.py:66-90 with the per-image wrapper :22-42
+Host-side tensor code (any device); pinned by tests/golden/loss_metrics.npz captured from the reference.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def sequence_loss_multiscale(disp_preds, disp_gt, valid, loss_gamma=0.9, max_disp=700):
+    """disp_preds: list of [B,1,Q]; disp_gt, valid [B,1,Q].  Returns (loss, {'epe','1px','3px'})."""
+    n = len(disp_preds)
+    assert n >= 1
+    valid = (valid >= 0.5) & (disp_gt < max_disp)
+    assert valid.shape == disp_gt.shape, [valid.shape, disp_gt.shape]
+    loss = 0.0
+    for i, pred in enumerate(disp_preds):
+        gamma = loss_gamma ** (15 / (n - 1)) if n > 1 else loss_gamma
+        w = gamma ** (n - i - 1)
+        err = (pred - disp_gt).abs()
+        assert err.shape == valid.shape
+        loss = loss + w * err[valid.bool()].mean()
+    epe = torch.sum((disp_preds[-1] - disp_gt) ** 2, dim=1).sqrt().view(-1)[valid.view(-1)]
+    metrics = {"epe": epe.mean().item(), "1px": (epe > 1).float().mean().item(), "3px": (epe > 3).float().mean().item()}
+    return loss, metrics
+
+
+def fetch_optimizer(lr, wdecay, num_steps, params, lr_fixed=False):
+    opt = torch.optim.AdamW(params, lr=lr, weight_decay=wdecay, eps=1e-8)
+    sched = None if lr_fixed else torch.optim.lr_scheduler.OneCycleLR(
+        opt, lr, num_steps + 100, pct_start=0.01, cycle_momentum=False, anneal_strategy="linear")
+    return opt, sched
+
+
+def _per_image(fn, d_est, d_gt, mask, *args):
+    assert d_est.dim() == 3 and d_est.shape == d_gt.shape == mask.shape
+    return torch.stack([fn(d_est[i], d_gt[i], mask[i], *args) for i in range(d_gt.shape[0])]).mean()
+
+
+@torch.no_grad()
+def epe_metric(d_est, d_gt, mask):
+    """mean over images of the masked mean |D_est - D_gt|  (metrics.py:84-90)."""
+    return _per_image(lambda e, g, m: (e[m] - g[m]).abs().mean(), d_est, d_gt, mask)
+
+
+@torch.no_grad()
+def d1_metric(d_est, d_gt, mask):
+    """fraction with error > 3 px AND > 5 % of |gt|  (metrics.py:66-72)."""
+    def f(e, g, m):
+        e, g = e[m], g[m]
+        err = (g - e).abs()
+        return ((err > 3) & (err / g.abs() > 0.05)).float().mean()
+    return _per_image(f, d_est, d_gt, mask)
+
+
+@torch.no_grad()
+def thres_metric(d_est, d_gt, mask, thres):
+    """fraction with error > thres  (metrics.py:74-81)."""
+    assert isinstance(thres, (int, float))
+    return _per_image(lambda e, g, m: ((g[m] - e[m]).abs() > thres).float().mean(), d_est, d_gt, mask)

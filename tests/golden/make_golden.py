@@ -208,6 +208,29 @@ def main():
         json.dump(cases, f, indent=1)
     print("wrote state_dict_keys.json, query_grid.json")
 
+    # ---- §8(f2)/(f3): loss + metrics --------------------------------------------------------------
+    # train_continuous_IGEV.py cannot be imported (argparse + dataset imports at module scope need cv2 etc.),
+    # so sequence_loss_multiscale is compiled from its AST node like pad_for_multi_train above.
+    tree = ast.parse(open(os.path.join(REF, "train_continuous_IGEV.py")).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "sequence_loss_multiscale"][0]
+    ns2 = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "train_continuous_IGEV.py", "exec"), ns2)
+    sys.modules.setdefault("metrics_utils", types.ModuleType("metrics_utils")).__path__ = [REF + "/metrics_utils"]
+    if "torchvision" not in sys.modules:  # experiment.py:7 imports torchvision.utils for image logging only
+        tv = types.ModuleType("torchvision"); tv.utils = types.ModuleType("torchvision.utils")
+        sys.modules["torchvision"], sys.modules["torchvision.utils"] = tv, tv.utils
+    import metrics_utils.metrics as rmet
+    B, Q = 2, 500
+    gt = det_uniform((B, 1, Q), 201, 0.0, 900.0)
+    valid = (det_uniform((B, 1, Q), 202, 0.0, 1.0) > 0.2).float()
+    preds = [gt + det_uniform((B, 1, Q), 210 + i, -6.0, 6.0) * (1.0 - 0.15 * i) for i in range(5)]
+    loss, met = ns2["sequence_loss_multiscale"](preds, gt, valid, max_disp=700)
+    est, g3 = preds[-1][:, 0].reshape(B, 20, 25), gt[:, 0].reshape(B, 20, 25)
+    m3 = (g3 > 0) & (g3 < 192)
+    save("loss_metrics", gt=gt, valid=valid, **{f"pred{i}": p for i, p in enumerate(preds)}, loss=loss,
+         epe_m=met["epe"], px1=met["1px"], px3=met["3px"],
+         EPE=rmet.EPE_metric(est, g3, m3), D1=rmet.D1_metric(est, g3, m3), Thres2=rmet.Thres_metric(est, g3, m3, 2.0))
+
 
 if __name__ == "__main__":
     argparse.ArgumentParser().parse_args()

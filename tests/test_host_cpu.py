@@ -128,3 +128,40 @@ def test_query_grid_harness(golden):
         got = [coord[0].tolist(), coord[-1].tolist(), float(coord.double().sum())]
         assert abs(got[2] - case["coord_sum"]) < 1e-3 * max(1.0, abs(case["coord_sum"]))
         assert max(abs(a - b) for a, b in zip(got[0] + got[1], case["first"] + case["last"])) < 1e-6
+
+
+def test_loss_and_metrics_match_reference(golden):
+    """§8(f2)/(f3): sequence_loss_multiscale and EPE/D1/Thres against values captured from the reference
+    (tests/golden/make_golden.py, loss_metrics.npz)."""
+    from anystereo.harness import metrics as M
+    g = golden("loss_metrics")
+    gt, valid = g["gt"], g["valid"]
+    preds = [g[f"pred{i}"] for i in range(5)]
+    loss, met = M.sequence_loss_multiscale(preds, gt, valid, max_disp=700)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    for k, gk in (("epe", "epe_m"), ("1px", "px1"), ("3px", "px3")):
+        assert abs(met[k] - float(g[gk])) <= 1e-6
+    est, g3 = preds[-1][:, 0].reshape(2, 20, 25), gt[:, 0].reshape(2, 20, 25)
+    m3 = (g3 > 0) & (g3 < 192)
+    assert abs(M.epe_metric(est, g3, m3).item() - float(g["EPE"])) <= 1e-6
+    assert abs(M.d1_metric(est, g3, m3).item() - float(g["D1"])) <= 1e-7
+    assert abs(M.thres_metric(est, g3, m3, 2.0).item() - float(g["Thres2"])) <= 1e-7
+    # single prediction: the reference would divide by zero (n-1); we keep gamma unadjusted instead of raising
+    l1, _ = M.sequence_loss_multiscale(preds[-1:], gt, valid)
+    assert torch.isfinite(l1)
+
+
+def test_fetch_optimizer_schedule():
+    """AdamW + linear one-cycle: peak lr after 1 % of num_steps+100, linear decay afterwards
+    (train_continuous_IGEV.py:125-134)."""
+    from anystereo.harness.metrics import fetch_optimizer
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    opt, sched = fetch_optimizer(2e-4, 1e-5, 900, p)
+    assert opt.defaults["eps"] == 1e-8 and opt.defaults["weight_decay"] == 1e-5
+    lrs = []
+    for _ in range(1000):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step(); sched.step()
+    assert abs(max(lrs) - 2e-4) < 1e-12 and lrs.index(max(lrs)) == 9
+    assert lrs[0] == pytest.approx(2e-4 / 25) and lrs[-1] < lrs[500] < lrs[100]
+    assert fetch_optimizer(2e-4, 1e-5, 900, p, lr_fixed=True)[1] is None
