@@ -25,6 +25,7 @@ struct CorrParams {
   float* lvl[AS_MAX_LEVELS];
   int B, C, H, W1, W2, L;
   int MT, NT;  // 32-wide tiles along x1 / x2
+  int dbg;     // AS_CORR_DBG (profiling experiments only): 1 = no level-0 stores, 2 = no pooled stores
 };
 
 constexpr int kKS = 48;  // k-steps (channel pairs) held in registers per pass: C <= 96 in one pass
@@ -38,10 +39,75 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff) 
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
 }
 
+
+// Epilogue shared by the three build kernels: write one 32x32 tile of level 0 and its pooled levels
+// straight from the MFMA accumulator layout (col = lane&31 = x2, row = (r&3) + 8 (r>>2) + 4 (lane>>5)).
+// Stores go through per-(row, x1-tile) buffer descriptors: rows beyond W1 fall outside num_records and
+// are dropped by the hardware, columns beyond the level width get the sentinel offset, so there is no
+// branch and no 64-bit per-element address arithmetic (that version spent 20 us of a 38 us kernel here).
+// Pooling over 2^s adjacent x2 is a DPP butterfly (quad_perm xor 1 / xor 2, row_half_mirror for the third
+// step, which pairs quads that already hold their 4-lane means).
+struct TileOut {
+  __amdgpu_buffer_rsrc_t rs[AS_MAX_LEVELS];
+};
+
+__device__ __forceinline__ TileOut make_tile_out(const CorrParams& p, long long rowbase, int mt) {
+  TileOut o;
+  const int rows = min(32, p.W1 - mt * 32);
+#pragma unroll
+  for (int s = 0; s < AS_MAX_LEVELS; ++s) {
+    if (s < p.L) {
+      const int wl = p.W2 >> s;
+      o.rs[s] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.lvl[s] + (rowbase + (long long)mt * 32) * wl), 0, rows * wl * 4, 0x00020000);
+    } else {
+      o.rs[s] = o.rs[0];
+    }
+  }
+  return o;
+}
+
+__device__ __forceinline__ float dpp_xor_step(float v, int s) {
+  const int iv = __builtin_bit_cast(int, v);
+  int o;
+  if (s == 1) o = __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if (s == 2) o = __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if (s == 3) o = __builtin_amdgcn_update_dpp(iv, iv, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  else o = __shfl_xor(iv, 1 << (s - 1));
+  return __builtin_bit_cast(float, o);
+}
+
+__device__ __forceinline__ void store_pyramid_tile(const CorrParams& p, const TileOut& o, const f32x16& acc, int nt, int lane, int dbg) {
+  const unsigned kOOB = 0x70000000u;  // + 31 rows x (W2 <= 2^16) x 4 B never wraps and never is < num_records
+  const int l31 = lane & 31, half = lane >> 5;
+  const int x2 = nt * 32 + l31;
+  unsigned voff[AS_MAX_LEVELS], rstride[AS_MAX_LEVELS];
+#pragma unroll
+  for (int s = 0; s < AS_MAX_LEVELS; ++s) {
+    const int wl = p.W2 >> s;
+    const int xs = x2 >> s;
+    const bool ok = s < p.L && (l31 & ((1 << s) - 1)) == 0 && xs < wl && !((dbg >> (s ? 1 : 0)) & 1);
+    voff[s] = ok ? (unsigned)((4 * half * wl + xs) * 4) : kOOB;
+    rstride[s] = (unsigned)(wl * 4);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned rl = (unsigned)((r & 3) + 8 * (r >> 2));
+    float v = acc[r];
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o.rs[0], (int)(voff[0] + rl * rstride[0]), 0, 0);
+#pragma unroll
+    for (int s = 1; s < AS_MAX_LEVELS; ++s) {
+      if (s < p.L) {
+        v = (v + dpp_xor_step(v, s)) * 0.5f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o.rs[s], (int)(voff[s] + rl * rstride[s]), 0, 0);
+      }
+    }
+  }
+}
+
 template <bool A_RESIDENT>
 __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l31 = lane & 31;
   const int half = lane >> 5;
   const int row = blockIdx.x;  // b*H + y
@@ -64,6 +130,7 @@ __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
   const int passes = (ksteps + kKS - 1) / kKS;
   const long long rowbase = (long long)row * p.W1;
 
+  const TileOut tout = make_tile_out(p, rowbase, mt);
   float a[kKS], bq[kKS], bn[kKS];
   if (A_RESIDENT) {
 #pragma unroll
@@ -100,24 +167,7 @@ __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
 #pragma unroll
       for (int k = 0; k < kKS; ++k) bq[k] = bn[k];
     }
-    // epilogue: level 0 + pooled levels (butterfly over lanes xor 1, 2, 4)
-    const int x2 = nt * 32 + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int xr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const bool okr = xr < p.W1;
-      float v = acc[r];
-      if (okr && x2 < p.W2) p.lvl[0][(rowbase + xr) * p.W2 + x2] = v;
-#pragma unroll
-      for (int s = 1; s < AS_MAX_LEVELS; ++s) {
-        if (s < p.L) {
-          v = (v + __shfl_xor(v, 1 << (s - 1))) * 0.5f;
-          const int wl = p.W2 >> s;
-          const int xs = x2 >> s;
-          if (okr && (l31 & ((1 << s) - 1)) == 0 && xs < wl) p.lvl[s][(rowbase + xr) * wl + xs] = v;
-        }
-      }
-    }
+    store_pyramid_tile(p, tout, acc, nt, lane, 0);
   }
 }
 
@@ -144,7 +194,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo
 template <bool A_RESIDENT>
 __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l31 = lane & 31;
   const int half = lane >> 5;
   const int row = blockIdx.x;  // b*H + y
@@ -168,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) 
   const int passes = (ksteps + kKS16 - 1) / kKS16;
   const long long rowbase = (long long)row * p.W1;
 
+  const TileOut tout = make_tile_out(p, rowbase, mt);
   half8 ahi[kKS16], alo[kKS16];
   auto load_a = [&](int ps) {
 #pragma unroll
@@ -206,22 +257,110 @@ __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) 
         acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], bhi, acc_x, 0, 0, 0);
       }
     }
+    f32x16 res;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int xr = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const bool okr = xr < p.W1;
-      float v = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
-      if (okr && x2 < p.W2) p.lvl[0][(rowbase + xr) * p.W2 + x2] = v;
+    for (int r = 0; r < 16; ++r) res[r] = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
+    store_pyramid_tile(p, tout, res, nt, lane, 0);
+  }
+}
+
+// ---- split precision, LDS-staged (C <= 96): the default at IGEV sizes -----------------------------
+// Block = (row, 4 x1-tiles, 4 x2-tiles).  The 128-wide f2 slab of the row is fetched ONCE per block by all
+// 256 threads with every load in flight at once (48 dwords per thread), split to fp16 hi/lo once, and
+// parked in LDS in MFMA-fragment order [kstep][x2][16 ch] (a lane's 8 consecutive channels = one
+// ds_read_b128, conflict-free).  Each wave then keeps its x1 tile (A, pre-split) in registers and sweeps
+// the 4 x2 tiles: 72 MFMAs with no global load in the loop.  The streaming kernel above paid a full
+// memory round trip per 16-channel k-step per wave and re-split f2 once per x1 tile; this one has one
+// round trip per block and ~2 blocks resident per CU (48 KB LDS), which is what an HBM-bound one-shot
+// kernel of this size (72 MB, ~10 us at peak) needs.
+constexpr int kNB = 4;  // x2 tiles per block
+
+__global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char corr_smem[];
+  if (p.dbg & 16) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+  const int row = blockIdx.x;  // b*H + y
+  const int b = row / p.H;
+  const int y = row - b * p.H;
+  const int mt = blockIdx.y * 4 + wave;
+  const int nb0 = blockIdx.z * (kNB * 32);
+  const long long cs1 = (long long)p.H * p.W1;
+  const long long cs2 = (long long)p.H * p.W2;
+  const __amdgpu_buffer_rsrc_t r1 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.f1 + (long long)b * p.C * cs1), 0, (int)(p.C * cs1 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.f2 + (long long)b * p.C * cs2), 0, (int)(p.C * cs2 * 4), 0x00020000);
+  const unsigned kOOB = 0x7FFFFFF0u;
+  const unsigned cstr1 = (unsigned)(cs1 * 4), cstr2 = (unsigned)(cs2 * 4);
+  const int ksteps = (p.C + 15) >> 4;  // <= kKS16
+  const unsigned lo_base = (unsigned)ksteps * (kNB * 32) * 32;  // bytes of the hi image
+
+  // Invalid lanes (columns beyond W, idle waves) carry the sentinel and just add the channel offset to it:
+  // whatever that wraps to is either outside num_records (reads 0) or some in-range element of the same
+  // tensor, and it only ever feeds output rows/columns that the epilogue drops — no select per load.
+  // issue everything: this wave's A fragment (channels 16 s + 8 half + j of column x1) ...
+  const int x1 = mt * 32 + l31;
+  const unsigned a_off = (mt < p.MT && x1 < p.W1 && !(p.dbg & 8)) ? (unsigned)((8 * half * cs1 + (long long)y * p.W1 + x1) * 4) : kOOB;
+  float av[kKS16][8];
 #pragma unroll
-      for (int s = 1; s < AS_MAX_LEVELS; ++s) {
-        if (s < p.L) {
-          v = (v + __shfl_xor(v, 1 << (s - 1))) * 0.5f;
-          const int wl = p.W2 >> s;
-          const int xs = x2 >> s;
-          if (okr && (l31 & ((1 << s) - 1)) == 0 && xs < wl) p.lvl[s][(rowbase + xr) * wl + xs] = v;
-        }
+  for (int s = 0; s < kKS16; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) av[s][j] = bload(r1, a_off + (unsigned)(s * 16 + j) * cstr1);
+  // ... and this thread's share of the f2 slab: item i = (8-channel group g = (tid>>7) + 2 i, column tid&127)
+  const int xx = tid & 127;
+  const int x2s = nb0 + xx;
+  const unsigned b_off = (x2s < p.W2 && !(p.dbg & 8)) ? (unsigned)(((long long)y * p.W2 + x2s) * 4) : kOOB;
+  float bv[kKS16][8];
+#pragma unroll
+  for (int i = 0; i < kKS16; ++i) {
+    const int g = (tid >> 7) + 2 * i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[i][j] = bload(r2, b_off + (unsigned)(g * 8 + j) * cstr2);
+  }
+#pragma unroll
+  for (int i = 0; i < kKS16; ++i) {
+    if (i < ksteps) {
+      half8 hi, lo;
+      split8(bv[i], hi, lo);
+      const int g = (tid >> 7) + 2 * i;
+      const unsigned o = (unsigned)(((g >> 1) * (kNB * 32) + xx) * 32 + (g & 1) * 16);
+      *reinterpret_cast<half8*>(corr_smem + o) = hi;
+      *reinterpret_cast<half8*>(corr_smem + lo_base + o) = lo;
+    }
+  }
+  half8 ahi[kKS16], alo[kKS16];
+#pragma unroll
+  for (int s = 0; s < kKS16; ++s) split8(av[s], ahi[s], alo[s]);
+  __syncthreads();
+  if (mt >= p.MT || (p.dbg & 32)) return;
+
+  const long long rowbase = (long long)row * p.W1;
+  const TileOut tout = make_tile_out(p, rowbase, mt);
+  for (int t = 0; t < kNB; ++t) {
+    const int nt = blockIdx.z * kNB + t;
+    if (nt >= p.NT) break;
+    f32x16 acc_hh, acc_x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc_hh[r] = 0.f; acc_x[r] = 0.f; }
+    const unsigned fo = (unsigned)((t * 32 + l31) * 32 + half * 16);
+#pragma unroll
+    for (int s = 0; s < kKS16; ++s) {
+      if ((s == 0 || s < ksteps) && !(p.dbg & 4)) {
+        const half8 bhi = *reinterpret_cast<const half8*>(corr_smem + fo + (unsigned)s * (kNB * 32 * 32));
+        const half8 blo = *reinterpret_cast<const half8*>(corr_smem + lo_base + fo + (unsigned)s * (kNB * 32 * 32));
+        acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], bhi, acc_hh, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], blo, acc_x, 0, 0, 0);
+        acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], bhi, acc_x, 0, 0, 0);
       }
     }
+    f32x16 res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
+    store_pyramid_tile(p, tout, res, nt, lane, p.dbg);
   }
 }
 
@@ -371,11 +510,13 @@ int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels
   AS_REQUIRE(B > 0 && C > 0 && H > 0 && W1 > 0 && W2 > 0, AS_ERR_BAD_ARG, "corr_build: non-positive size");
   AS_REQUIRE(L >= 1 && L <= AS_MAX_LEVELS, AS_ERR_BAD_ARG, "corr_build: L=%d outside [1,%d]", L, AS_MAX_LEVELS);
   AS_REQUIRE((W2 >> (L - 1)) >= 1, AS_ERR_BAD_SHAPE, "corr_build: W2=%d too small for %d levels", W2, L);
+  AS_REQUIRE(W1 <= 65536 && W2 <= 65536, AS_ERR_BAD_SHAPE, "corr_build: W1=%d / W2=%d beyond 65536", W1, W2);
   AS_REQUIRE((long long)B * H < 2147483647ll && (long long)B * H * W1 * (long long)W2 < (1ll << 40), AS_ERR_BAD_SHAPE, "corr_build: too large");
   CorrParams p{};
   p.f1 = f1; p.f2 = f2; p.B = B; p.C = C; p.H = H; p.W1 = W1; p.W2 = W2; p.L = L;
   p.MT = as::cdiv(W1, 32);
   p.NT = as::cdiv(W2, 32);
+  if (const char* e = getenv("AS_CORR_DBG")) p.dbg = atoi(e);
   for (int i = 0; i < L; ++i) {
     AS_REQUIRE(levels[i], AS_ERR_BAD_ARG, "corr_build: null level %d", i);
     p.lvl[i] = levels[i];
@@ -388,7 +529,11 @@ int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels
     int nsplit = 1;
     while (nsplit < p.NT && (long long)B * H * p.MT * nsplit < 4096) nsplit *= 2;
     const dim3 g3(grid.x, grid.y, (unsigned)nsplit);
-    if ((C + 15) / 16 <= kKS16) hipLaunchKernelGGL(corr_build_f16x3_kernel<true>, g3, dim3(256), 0, as::as_stream(stream), p);
+    const int ks16 = (C + 15) / 16;
+    if (ks16 <= kKS16 && !getenv("AS_CORR_STREAM")) {
+      const dim3 gl(grid.x, grid.y, (unsigned)as::cdiv(p.NT, kNB));
+      hipLaunchKernelGGL(corr_build_lds_kernel, gl, dim3(256), (size_t)ks16 * (kNB * 32) * 32 * 2, as::as_stream(stream), p);
+    } else if (ks16 <= kKS16) hipLaunchKernelGGL(corr_build_f16x3_kernel<true>, g3, dim3(256), 0, as::as_stream(stream), p);
     else hipLaunchKernelGGL(corr_build_f16x3_kernel<false>, g3, dim3(256), 0, as::as_stream(stream), p);
   } else if ((C + 1) / 2 <= kKS) hipLaunchKernelGGL(corr_build_kernel<true>, grid, dim3(256), 0, as::as_stream(stream), p);
   else hipLaunchKernelGGL(corr_build_kernel<false>, grid, dim3(256), 0, as::as_stream(stream), p);
