@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ...nn import blocks as B
 from ...nn import functional as AF
-from ...nn.encoders import Feature, MultiBasicEncoder
+from ...nn.encoders import Feature, MultiBasicEncoder, _plain_conv
 from ...nn.geometry import Combined_Geo_Encoding_Volume
 from ..base import ContinuousStereoBase
 
@@ -95,7 +95,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
             cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
             net_list = [torch.tanh(x[0]) for x in cnet_list]
             inp_list = [torch.relu(x[1]) for x in cnet_list]
-            ctx_list = [conv(i) for i, conv in zip(inp_list, self.context_zqr_convs)]
+            ctx_list = [_plain_conv(self, conv, i) for i, conv in zip(inp_list, self.context_zqr_convs)]
         net_list = [n.float() for n in net_list]
         # cz, cr, cq stay VIEWS of one [B,3*hidden,h,w] tensor: the GRU kernels index it in place
         inp_list = [list(c.float().split(split_size=c.shape[1] // 3, dim=1)) for c in ctx_list]

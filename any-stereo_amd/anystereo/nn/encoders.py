@@ -1,5 +1,11 @@
-"""Feature / context encoders — PyTorch-ROCm (MIOpen), not hand-written: north_star keeps
-"the feature/context CNN backbones" on the host framework.
+"""Feature / context encoders.
+
+Training / autograd / CPU construction run on plain PyTorch modules (MIOpen on the GPU).  In inference
+(`eval()`, no grad, CUDA) the BatchNorm residual trunk of the context net takes the fused path: BatchNorm is
+folded into the conv weights (`ops.PackedConv.get_folded`), every stride-1 3x3 conv runs on the library's
+implicit-GEMM kernel with ReLU and the residual tail `relu(x + relu(.))` fused into its epilogue
+(`as_conv2d`, AS_EPI_LINEAR with `h`), and the stride-2 convs keep MIOpen but with folded weights, so no
+BatchNorm / ReLU / add pass over the full-resolution 64-channel maps remains.
 
 State-dict keys follow models/coreContinuous_IGEV/extractor.py so reference checkpoints load:
 ResidualBlock :10-62, BasicEncoder :126-198, MultiBasicEncoder :200-304, Feature :327-361.
@@ -12,7 +18,34 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .. import _lib as L
+from .. import ops
 from .blocks import BasicConv_IN, Conv2x_IN
+
+
+def _fused_ok(x: torch.Tensor, mod: nn.Module) -> bool:
+    """Inference fast path: eval mode, CUDA fp32 input, nothing to differentiate."""
+    return (not mod.training) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
+class _FoldCache:
+    """BatchNorm-folded (weight, bias) of a conv that stays on MIOpen (stride 2 / 7x7), rebuilt on parameter change."""
+
+    def __init__(self):
+        self._key, self._wb = None, None
+
+    def get(self, conv, bn):
+        ts = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts)
+        if key != self._key:
+            self._wb, self._key = ops.fold_bn(conv, bn), key
+        return self._wb
+
+
+def _conv_hip_ok(conv: nn.Conv2d) -> bool:
+    k = conv.kernel_size[0]
+    return (conv.kernel_size in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == (k // 2, k // 2)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 16 == 0)
 
 
 def _norm(kind: str, c: int, groups: int | None = None):
@@ -42,12 +75,30 @@ class ResidualBlock(nn.Module):
             self.norm3 = _norm(norm_fn, planes, planes // 8)
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
 
+        self._pk1, self._pk2 = ops.PackedConv(), ops.PackedConv()
+        self._f1, self._fd = _FoldCache(), _FoldCache()
+
     def forward(self, x):
+        if _fused_ok(x, self) and isinstance(self.norm1, nn.BatchNorm2d) and _conv_hip_ok(self.conv2):
+            return self._forward_fused(x)
         y = self.relu(self.norm1(self.conv1(x)))
         y = self.relu(self.norm2(self.conv2(y)))
         if self.downsample is not None:
             x = self.downsample(x)
         return self.relu(x + y)
+
+    def _forward_fused(self, x):
+        x = x.contiguous()
+        if _conv_hip_ok(self.conv1):
+            y = ops.conv2d([x], self._pk1.get_folded(self.conv1, self.norm1), act=L.ACT_RELU)
+        else:  # stride 2: MIOpen with the folded weights
+            w, b = self._f1.get(self.conv1, self.norm1)
+            y = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
+        if self.downsample is not None:
+            w, b = self._fd.get(self.downsample[0], self.downsample[1])
+            x = nn.functional.conv2d(x, w, b, self.downsample[0].stride)
+        # relu(x + relu(bn2(conv2 y))) in the conv epilogue
+        return ops.conv2d([y], self._pk2.get_folded(self.conv2, self.norm2), act=L.ACT_RELU, h=x.contiguous())
 
 
 def _init_encoder(mod: nn.Module):
@@ -83,7 +134,13 @@ class _Trunk(nn.Module):
         return seq
 
     def trunk(self, x):
-        x = self.relu1(self.norm1(self.conv1(x)))
+        if _fused_ok(x, self) and isinstance(self.norm1, nn.BatchNorm2d):
+            if not hasattr(self, "_f_stem"):
+                self._f_stem = _FoldCache()
+            w, b = self._f_stem.get(self.conv1, self.norm1)
+            x = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
+        else:
+            x = self.relu1(self.norm1(self.conv1(x)))
         return self.layer3(self.layer2(self.layer1(x)))
 
 
@@ -129,16 +186,34 @@ class MultiBasicEncoder(_Trunk):
             v = x
             x = x[: x.shape[0] // 2]
         tail = (v,) if dual_inp else ()
-        o04 = [f(x) for f in self.outputs04]
+        o04 = [self._head(f, x) for f in self.outputs04]
         if num_layers == 1:
             return (o04,) + tail
         y = self.layer4(x)
-        o08 = [f(y) for f in self.outputs08]
+        o08 = [self._head(f, y) for f in self.outputs08]
         if num_layers == 2:
             return (o04, o08) + tail
         z = self.layer5(y)
-        o16 = [f(z) for f in self.outputs16]
+        o16 = [self._head(f, z) for f in self.outputs16]
         return (o04, o08, o16) + tail
+
+
+def _plain_conv(mod: nn.Module, conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """conv(x) on the implicit-GEMM kernel when the inference fast path applies, else the module itself."""
+    if _fused_ok(x, mod) and _conv_hip_ok(conv):
+        packs = mod.__dict__.setdefault("_hip_packs", {})
+        pk = packs.setdefault(id(conv), ops.PackedConv())
+        return ops.conv2d([x.contiguous()], pk.get([conv.weight], [conv.bias]))
+    return conv(x)
+
+
+def _multi_head(self, f, x):
+    if isinstance(f, nn.Sequential):
+        return _plain_conv(self, f[1], f[0](x))
+    return _plain_conv(self, f, x)
+
+
+MultiBasicEncoder._head = _multi_head
 
 
 # ---- MobileNetV2-100 trunk with timm's naming ---------------------------------------------

@@ -210,35 +210,61 @@ class PackedConv:
         self.cin = self.cout = self.ks = 0
         self.split = False
 
+    def get_folded(self, conv, bn):
+        """Pack of `bn(conv(x))` for an eval-mode BatchNorm: w' = w * g/sqrt(var+eps), b' = (b - mean) * g/sqrt(var+eps) + beta
+        (the affine map BatchNorm applies with its running statistics).  Rebuilt when any of the six tensors changes."""
+        split = L.load().as_get_precision() == 1
+        ts = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = ("bn", split) + tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts)
+        if key != self._key:
+            w, b = fold_bn(conv, bn)
+            self._build([w], [b], split, key)
+        return self
+
     def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], transform=None):
         split = L.load().as_get_precision() == 1
         key = (split,) + tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
             tuple((None if b is None else (b.data_ptr(), b._version)) for b in biases)
         if key != self._key:
             ws = [w.detach() if transform is None else transform(w.detach()) for w in weights]
-            ws = [w.reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1))) for w in ws]
-            w = torch.cat(ws, dim=0).contiguous().float() if len(ws) > 1 else ws[0].contiguous().float()
-            _req(w, "conv weight")
-            cout, cin, ks, ks2 = w.shape
-            if ks != ks2:
-                raise RuntimeError("PackedConv: non-square kernel")
-            n = (L.load().as_conv_pack_size_split if split else L.load().as_conv_pack_size)(cin, cout, ks)
-            if n <= 0:
-                raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}")
-            wp = torch.empty(n, device=w.device, dtype=torch.float16 if split else torch.float32)
-            with torch.cuda.device(w.device):
-                if split:
-                    L.check(L.load().as_conv_pack_weights_split(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights_split")
-                else:
-                    L.check(L.load().as_conv_pack_weights(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights")
-            self.split = split
-            if all(b is None for b in biases):
-                bias = None
-            else:
-                bias = torch.cat([(torch.zeros(wi.shape[0], device=w.device) if bi is None else bi.detach().float())
-                                  for wi, bi in zip(ws, biases)]).contiguous()
-            self.wpack, self.bias, self.cin, self.cout, self.ks, self._key = wp, bias, cin, cout, ks, key
+            self._build(ws, biases, split, key)
         return self
+
+    def _build(self, ws, biases, split, key):
+        ws = [w.reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1))) for w in ws]
+        w = torch.cat(ws, dim=0).contiguous().float() if len(ws) > 1 else ws[0].contiguous().float()
+        _req(w, "conv weight")
+        cout, cin, ks, ks2 = w.shape
+        if ks != ks2:
+            raise RuntimeError("PackedConv: non-square kernel")
+        n = (L.load().as_conv_pack_size_split if split else L.load().as_conv_pack_size)(cin, cout, ks)
+        if n <= 0:
+            raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}")
+        wp = torch.empty(n, device=w.device, dtype=torch.float16 if split else torch.float32)
+        with torch.cuda.device(w.device):
+            if split:
+                L.check(L.load().as_conv_pack_weights_split(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights_split")
+            else:
+                L.check(L.load().as_conv_pack_weights(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights")
+        self.split = split
+        if all(b is None for b in biases):
+            bias = None
+        else:
+            bias = torch.cat([(torch.zeros(wi.shape[0], device=w.device) if bi is None else bi.detach().float())
+                              for wi, bi in zip(ws, biases)]).contiguous()
+        self.wpack, self.bias, self.cin, self.cout, self.ks, self._key = wp, bias, cin, cout, ks, key
+
+
+@torch.no_grad()
+def fold_bn(conv, bn):
+    """(weight, bias) of the conv that equals eval-mode `bn(conv(x))`; scale computed in fp64, returned fp32."""
+    var, mean = bn.running_var.double(), bn.running_mean.double()
+    g = torch.ones_like(var) if bn.weight is None else bn.weight.double()
+    beta = torch.zeros_like(var) if bn.bias is None else bn.bias.double()
+    s = g / torch.sqrt(var + bn.eps)
+    w = (conv.weight.double() * s.view(-1, *([1] * (conv.weight.dim() - 1)))).float()
+    b0 = torch.zeros_like(var) if conv.bias is None else conv.bias.double()
+    return w, ((b0 - mean) * s + beta).float()
 
 
 def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE, add: Optional[torch.Tensor] = None,
@@ -278,6 +304,11 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
             out = torch.empty((b, cout, hh, ww), device=dev, dtype=torch.float32)
         _req(out, "out")
         d.out, d.out_ctot, d.out_coff = out.data_ptr(), out.shape[1], out_coff
+        if h is not None:  # residual tail: out = relu(h + act(conv))
+            _req(h, "h")
+            if tuple(h.shape) != (b, cout, hh, ww):
+                raise RuntimeError("conv2d(LINEAR): residual h must be [B,Cout,H,W]")
+            d.h = h.data_ptr()
     elif epilogue == L.EPI_GRU_ZR:
         ch = cout // 2
         _req(h, "h")

@@ -110,7 +110,9 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
     e.r_z = e.r_out;
   } else if (EPI == AS_EPI_LINEAR) {
     e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + ((long long)b * p.out_ctot + p.out_coff + n0) * plane), 0, recs, 0x00020000);
-    e.r_h = e.r_out;
+    // optional residual (ResidualBlock tail, extractor.py:56-62): out = relu(h + act(...)); 0 records when absent
+    const float* res = p.h ? p.h + ((long long)b * p.Cout + n0) * plane : p.out;
+    e.r_h = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, p.h ? recs : 0, 0x00020000);
     e.r_z = e.r_out;
   } else if (EPI == AS_EPI_GRU_ZR) {
     const int ch = p.Cout >> 1;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvParams& p, const EpiCtx&
       const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       off[i] = poff == kOOB ? kOOB : (unsigned)col * e.plane4 + poff;
       av[i] = as_bload(e.r_add, off[i]);                         // 0 when there is no add tensor (0 records)
-      if (EPI == AS_EPI_GRU_ZR) hv[i] = as_bload(e.r_h, off[i]);  // 0 records for the z half
+      if (EPI == AS_EPI_GRU_ZR || EPI == AS_EPI_LINEAR) hv[i] = as_bload(e.r_h, off[i]);  // 0 records: z half / no residual
       if (EPI == AS_EPI_GRU_Q) { hv[i] = as_bload(e.r_h, off[i]); zv[i] = as_bload(e.r_z, off[i]); }
     }
 #pragma unroll
@@ -158,6 +160,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvParams& p, const EpiCtx&
         o = v[r];
       } else if (EPI == AS_EPI_LINEAR) {
         o = act_apply(x, p.act);
+        if (p.h) o = fmaxf(o + hv[i], 0.f);
       } else if (EPI == AS_EPI_GRU_ZR) {
         const float gte = 1.f / (1.f + expf(-x));
         o = is_r ? gte * hv[i] : gte;
@@ -812,7 +815,9 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   if (p.bias) x += p.bias[co];
   if (p.add) x += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pix];
   if (EPI == AS_EPI_LINEAR) {
-    p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pix] = act_apply(x, p.act);
+    float o = act_apply(x, p.act);
+    if (p.h) o = fmaxf(o + p.h[((long long)b * p.Cout + co) * plane + pix], 0.f);
+    p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pix] = o;
   } else if (EPI == AS_EPI_GRU_ZR) {
     const int ch = p.Cout >> 1;
     const float g = 1.f / (1.f + expf(-x));

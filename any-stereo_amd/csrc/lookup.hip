@@ -131,81 +131,98 @@ __global__ __launch_bounds__(256) void lookup_fwd_coop_kernel(LookupParams p) {
   if (tid < PX) sdisp[tid] = (pix0 + tid < p.P) ? p.disp[pix0 + tid] : 0.f;
   __syncthreads();
   const unsigned kOOB = 0x7FFFFFF0u;
+  constexpr int LV = 2;  // levels gathered per pass: every window load of both levels (and both volumes) is in
+                         // flight before the first one is consumed — one memory round trip per pass, not four
+  constexpr int GITEMS = PX * K * (NQ > 0 ? NQ : 1);
+  constexpr int GNIT = NQ > 0 ? (GITEMS + 255) / 256 : 1;
+  constexpr int CITEMS = PX * K;
+  constexpr int CNIT = (CITEMS + 255) / 256;
 
-  for (int level = 0; level < p.L; ++level) {
-    const int chbase = level * K * (G + 1);
-    if constexpr (G > 0) {
-      const int Dl = p.D >> level;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.geo[level], 0, p.geo_bytes[level], 0x00020000);
-      constexpr int ITEMS = PX * K * (NQ > 0 ? NQ : 1);
-      constexpr int NIT = (ITEMS + 255) / 256;
-      f32x4 w0[NIT], w1[NIT];
-      float tt[NIT];
-      bool bm[NIT];
+  for (int level0 = 0; level0 < p.L; level0 += LV) {
+    f32x4 g0[LV][GNIT], g1[LV][GNIT];
+    float c0[LV][CNIT], c1[LV][CNIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        const int px = idx / (K * NQ), rem = idx - px * (K * NQ);
-        const int tap = rem / NQ, q = rem - tap * NQ;
-        const bool live = idx < ITEMS && pix0 + px < p.P;
-        const float ds = ldexpf(sdisp[px < PX ? px : 0], -level);
-        const int i0 = (int)floorf(ds);
-        tap_weights(ds, i0, tap - R, tt[it], bm[it]);
-        const int dd = i0 - R + tap;
-        const unsigned rowoff = (unsigned)((((pix0 + px) * Dl) * G + 4 * q) * 4);
-        const unsigned o0 = (live && dd >= 0 && dd < Dl) ? rowoff + (unsigned)dd * (G * 4) : kOOB;
-        const unsigned o1 = (live && dd + 1 >= 0 && dd + 1 < Dl) ? rowoff + (unsigned)(dd + 1) * (G * 4) : kOOB;
-        w0[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0, 0, 0));
-        w1[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o1, 0, 0));
-      }
+    for (int lv = 0; lv < LV; ++lv) {
+      const int level = level0 + lv;
+      if (level < p.L) {
+        if constexpr (G > 0) {
+          const int Dl = p.D >> level;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.geo[level], 0, p.geo_bytes[level], 0x00020000);
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < ITEMS) {
-          const int px = idx / (K * NQ), rem = idx - px * (K * NQ);
-          const int tap = rem / NQ, q = rem - tap * NQ;
-          const float a = bm[it] ? 0.f : 1.f - tt[it], c = bm[it] ? 1.f : tt[it];
-          const f32x4 v = a * w0[it] + c * w1[it];
-          float* t = tile + (chbase + (4 * q) * K + tap) * TS + px;
-          t[0] = v.x;
-          t[K * TS] = v.y;
-          t[2 * K * TS] = v.z;
-          t[3 * K * TS] = v.w;
+          for (int it = 0; it < GNIT; ++it) {
+            const int idx = tid + it * 256;
+            const int px = idx / (K * NQ), rem = idx - px * (K * NQ);
+            const int tap = rem / NQ, q = rem - tap * NQ;
+            const bool live = idx < GITEMS && pix0 + px < p.P;
+            const float ds = ldexpf(sdisp[px < PX ? px : 0], -level);
+            const int dd = (int)floorf(ds) - R + tap;
+            const unsigned rowoff = (unsigned)((((pix0 + px) * Dl) * G + 4 * q) * 4);
+            const unsigned o0 = (live && dd >= 0 && dd < Dl) ? rowoff + (unsigned)dd * (G * 4) : kOOB;
+            const unsigned o1 = (live && dd + 1 >= 0 && dd + 1 < Dl) ? rowoff + (unsigned)(dd + 1) * (G * 4) : kOOB;
+            g0[lv][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o0, 0, 0));
+            g1[lv][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o1, 0, 0));
+          }
+        }
+        const int Wl = p.W2 >> level;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.corr[level], 0, p.corr_bytes[level], 0x00020000);
+#pragma unroll
+        for (int it = 0; it < CNIT; ++it) {
+          const int idx = tid + it * 256;
+          const int px = idx / K, tap = idx - px * K;
+          const bool live = idx < CITEMS && pix0 + px < p.P;
+          const long long pix = pix0 + px;
+          const int x = (int)((pix % p.HW) % p.W);
+          const float ds = ldexpf(sdisp[px < PX ? px : 0], -level);
+          const float xb = ldexpf((float)x, -level) - ds;
+          const int dd = (int)floorf(xb) - R + tap;
+          const unsigned rowoff = (unsigned)(pix * Wl * 4);
+          const unsigned o0 = (live && dd >= 0 && dd < Wl) ? rowoff + (unsigned)dd * 4u : kOOB;
+          const unsigned o1 = (live && dd + 1 >= 0 && dd + 1 < Wl) ? rowoff + (unsigned)(dd + 1) * 4u : kOOB;
+          c0[lv][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)o0, 0, 0));
+          c1[lv][it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)o1, 0, 0));
         }
       }
     }
-    {
-      const int Wl = p.W2 >> level;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.corr[level], 0, p.corr_bytes[level], 0x00020000);
-      constexpr int ITEMS = PX * K;
-      constexpr int NIT = (ITEMS + 255) / 256;
-      float w0[NIT], w1[NIT], tt[NIT];
-      bool bm[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        const int px = idx / K, tap = idx - px * K;
-        const bool live = idx < ITEMS && pix0 + px < p.P;
-        const long long pix = pix0 + px;
-        const int x = (int)((pix % p.HW) % p.W);
-        const float ds = ldexpf(sdisp[px < PX ? px : 0], -level);
-        const float xb = ldexpf((float)x, -level) - ds;
-        const int i0 = (int)floorf(xb);
-        tap_weights(xb, i0, tap - R, tt[it], bm[it]);
-        const int dd = i0 - R + tap;
-        const unsigned rowoff = (unsigned)(pix * Wl * 4);
-        const unsigned o0 = (live && dd >= 0 && dd < Wl) ? rowoff + (unsigned)dd * 4u : kOOB;
-        const unsigned o1 = (live && dd + 1 >= 0 && dd + 1 < Wl) ? rowoff + (unsigned)(dd + 1) * 4u : kOOB;
-        w0[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o0, 0, 0));
-        w1[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o1, 0, 0));
-      }
+    for (int lv = 0; lv < LV; ++lv) {
+      const int level = level0 + lv;
+      if (level < p.L) {
+        const int chbase = level * K * (G + 1);
+        if constexpr (G > 0) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < ITEMS) {
-          const int px = idx / K, tap = idx - px * K;
-          const float a = bm[it] ? 0.f : 1.f - tt[it], c = bm[it] ? 1.f : tt[it];
-          tile[(chbase + G * K + tap) * TS + px] = a * w0[it] + c * w1[it];
+          for (int it = 0; it < GNIT; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < GITEMS) {
+              const int px = idx / (K * NQ), rem = idx - px * (K * NQ);
+              const int tap = rem / NQ, q = rem - tap * NQ;
+              const float ds = ldexpf(sdisp[px], -level);
+              float tt;
+              bool bm;
+              tap_weights(ds, (int)floorf(ds), tap - R, tt, bm);
+              const float a = bm ? 0.f : 1.f - tt, c = bm ? 1.f : tt;
+              const f32x4 v = a * g0[lv][it] + c * g1[lv][it];
+              float* t = tile + (chbase + (4 * q) * K + tap) * TS + px;
+              t[0] = v.x;
+              t[K * TS] = v.y;
+              t[2 * K * TS] = v.z;
+              t[3 * K * TS] = v.w;
+            }
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < CNIT; ++it) {
+          const int idx = tid + it * 256;
+          if (idx < CITEMS) {
+            const int px = idx / K, tap = idx - px * K;
+            const int x = (int)(((pix0 + px) % p.HW) % p.W);
+            const float ds = ldexpf(sdisp[px], -level);
+            const float xb = ldexpf((float)x, -level) - ds;
+            float tt;
+            bool bm;
+            tap_weights(xb, (int)floorf(xb), tap - R, tt, bm);
+            const float a = bm ? 0.f : 1.f - tt, c = bm ? 1.f : tt;
+            tile[(chbase + G * K + tap) * TS + px] = a * c0[lv][it] + c * c1[lv][it];
+          }
         }
       }
     }
@@ -217,8 +234,11 @@ __global__ __launch_bounds__(256) void lookup_fwd_coop_kernel(LookupParams p) {
   if (pix < p.P) {
     const int b = (int)(pix / p.HW);
     const int rem = (int)(pix - (long long)b * p.HW);
-    float* o = p.out + (long long)b * p.CH * p.HW + rem;
-    for (int ch = tid >> 6; ch < p.CH; ch += 4) o[(long long)ch * p.HW] = tile[ch * TS + px];
+    const int ch0 = tid >> 6;
+    float* o = p.out + ((long long)b * p.CH + ch0) * p.HW + rem;
+    const float* t = tile + ch0 * TS + px;
+    const long long step = 4ll * p.HW;
+    for (int ch = ch0; ch < p.CH; ch += 4, o += step, t += 4 * TS) *o = *t;
   }
 }
 

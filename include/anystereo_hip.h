@@ -45,7 +45,7 @@ extern "C" {
 #define AS_ACT_RELU 1
 #define AS_ACT_SIGMOID 2
 #define AS_ACT_TANH 3
-#define AS_EPI_LINEAR 0 /* out = act(acc + bias + add)                                            */
+#define AS_EPI_LINEAR 0 /* out = act(acc + bias + add); with h != NULL: out = relu(h + act(...))    (extractor.py:56-62) */
 #define AS_EPI_GRU_ZR 1 /* co <  Cout/2: z  = sigmoid(acc+bias+add)        -> out  [B,Cout/2,H,W]
                            co >= Cout/2: rh = sigmoid(acc+bias+add) * h    -> out2 [B,Cout/2,H,W]  */
 #define AS_EPI_GRU_Q 2  /* out = (1-z)*h + z*tanh(acc+bias+add)            (update.py:39-40)      */
@@ -129,7 +129,7 @@ typedef struct {
   const float* bias;
   const float* add;   /* [B, add_ctot, H, W], channels [add_coff, add_coff+Cout) are used */
   int add_ctot, add_coff;
-  const float* h;     /* AS_EPI_GRU_ZR / AS_EPI_GRU_Q: hidden state [B,Cout(/2),H,W] */
+  const float* h;     /* AS_EPI_GRU_ZR / AS_EPI_GRU_Q: hidden state [B,Cout(/2),H,W]; AS_EPI_LINEAR: optional residual [B,Cout,H,W] */
   const float* z;     /* AS_EPI_GRU_Q */
   float* out;
   float* out2;        /* AS_EPI_GRU_ZR */

@@ -253,6 +253,29 @@ def test_conv_gru_fused(h, w, precision):
     close(out2, ref, 1e-5, 1e-5, "convgru (cat fallback)")
 
 
+@pytest.mark.parametrize("cin,cout,stride,h,w", [(64, 64, 1, 18, 37), (64, 96, 2, 18, 36), (128, 128, 1, 7, 129)])
+def test_residual_block_fused_inference(cin, cout, stride, h, w, precision):
+    """§8 f4: the inference fast path of the BatchNorm ResidualBlock (folded BN, ReLU + residual tail in the conv
+    epilogue) against the fp64 evaluation of the plain module (extractor.py:10-62)."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn.encoders import ResidualBlock
+    blk = ResidualBlock(cin, cout, "batch", stride).eval()
+    fill_module_deterministic(blk, 5)
+    with torch.no_grad():
+        for i, m in enumerate(mm for mm in blk.modules() if isinstance(mm, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(U((m.num_features,), 120 + i) * 0.3)
+            m.running_var.copy_(U((m.num_features,), 130 + i, 0.5, 2.0))
+            m.weight.copy_(U((m.num_features,), 140 + i, 0.5, 1.5))
+            m.bias.copy_(U((m.num_features,), 150 + i) * 0.2)
+    x = U((2, cin, h, w), 160, -2, 2)
+    with torch.enable_grad():  # grad mode keeps the plain PyTorch path
+        ref = blk.double()(x.double()).detach()
+    blk = blk.float().to(DEV)
+    with torch.no_grad():
+        out = blk(x.to(DEV))
+    close(out, ref, 2e-5, 2e-5, "residual block (fused)")
+
+
 def test_direct_convs_and_resamplers(precision):
     from anystereo import ops
     x = U((2, 1, 19, 37), 110, 0, 30)
