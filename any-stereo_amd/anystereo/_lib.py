@@ -16,7 +16,7 @@ import torch  # noqa: F401
 AS_MAX_LEVELS = 4
 AS_MAX_SRCS = 4
 AS_F32, AS_F16, AS_F64 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 3, 4, 5
 EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanystereo_hip.so")
@@ -64,6 +64,8 @@ SIGNATURES = {
     "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "as_pool2x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_dwconv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_conv3d_k3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_interp_bilinear_ac": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_structure_feature": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

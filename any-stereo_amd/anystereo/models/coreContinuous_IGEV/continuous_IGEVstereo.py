@@ -90,7 +90,11 @@ class continuous_IGEVStereo(ContinuousStereoBase):
             gwc_volume = self.corr_stem(gwc_volume)
             gwc_volume = self.corr_feature_att(gwc_volume, features_left[0])
             geo_encoding_volume = self.cost_agg(gwc_volume, features_left)
-            init_disp = self._hot_init_disp(self.classifier(geo_encoding_volume).squeeze(1))
+            if B.fused_ok(geo_encoding_volume, self) and B.conv3d_k3_ok(self.classifier):
+                cost = B.conv3d_fused(self, self.classifier, None, geo_encoding_volume, 0)
+            else:
+                cost = self.classifier(geo_encoding_volume)
+            init_disp = self._hot_init_disp(cost.squeeze(1))
             del gwc_volume
             cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
             net_list = [torch.tanh(x[0]) for x in cnet_list]

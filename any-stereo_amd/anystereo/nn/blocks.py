@@ -1,13 +1,33 @@
-"""Backbone building blocks that stay on PyTorch-ROCm / MIOpen (SURVEY.md §2 rows 9-10:
-out of the hot-path scope by north_star's own wording).  They exist so that the two
-models run end to end and so that `state_dict` keys equal the reference's
-(models/coreContinuous_IGEV/submodule.py:6-252, extractor.py:10-361).
+"""Backbone building blocks with the reference's `state_dict` keys
+(models/coreContinuous_IGEV/submodule.py:6-252, extractor.py:10-361).  Plain PyTorch modules (MIOpen on the GPU)
+for training / autograd; in inference the BatchNorm 3-D convolutions (cost-volume stem and hourglass) run on the
+library's direct kernel with BatchNorm folded and LeakyReLU fused (`as_conv3d_k3`).
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import _lib as L
+from .. import ops
+
+
+def fused_ok(x: torch.Tensor, mod: nn.Module) -> bool:
+    """Inference fast path: eval mode, CUDA fp32 input, nothing to differentiate."""
+    return (not mod.training) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
+def conv3d_k3_ok(conv: nn.Module) -> bool:
+    return (isinstance(conv, nn.Conv3d) and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
+            and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1)
+
+
+def conv3d_fused(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
+    cache = mod.__dict__.setdefault("_c3d_cache", {})
+    fc = cache.setdefault(id(conv), ops.FoldedConv("c3d"))
+    w, b = fc.get(conv, bn)
+    return ops.conv3d_k3(x.contiguous(), w, b, conv.stride[0], act)
 
 
 def _conv_nd(is_3d: bool, deconv: bool):
@@ -33,9 +53,12 @@ class _ConvNormAct(nn.Module):
         raise NotImplementedError
 
     def forward(self, x):
+        norm = getattr(self, self.norm_attr) if self.use_norm else None
+        if fused_ok(x, self) and conv3d_k3_ok(self.conv) and (norm is None or isinstance(norm, nn.BatchNorm3d)):
+            return conv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
         x = self.conv(x)
         if self.use_norm:
-            x = getattr(self, self.norm_attr)(x)
+            x = norm(x)
         return F.leaky_relu(x, 0.01) if self.relu else x
 
 

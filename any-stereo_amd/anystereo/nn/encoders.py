@@ -228,7 +228,14 @@ class _DSConv(nn.Module):
         self.bn2 = nn.BatchNorm2d(cout)
         self.res = stride == 1 and cin == cout
 
+        self._fdw, self._pk = ops.FoldedConv(), ops.PackedConv()
+
     def forward(self, x):
+        if _fused_ok(x, self):
+            x = x.contiguous()
+            w, b = self._fdw.get(self.conv_dw, self.bn1)
+            y = ops.dwconv3x3(x, w, b, self.conv_dw.stride[0], L.ACT_RELU6)
+            return ops.conv2d([y], self._pk.get_folded(self.conv_pw, self.bn2), add=x if self.res else None)
         y = nn.functional.relu6(self.bn1(self.conv_dw(x)))
         y = self.bn2(self.conv_pw(y))
         return x + y if self.res else y
@@ -246,7 +253,16 @@ class _InvRes(nn.Module):
         self.bn3 = nn.BatchNorm2d(cout)
         self.res = stride == 1 and cin == cout
 
+        self._fdw, self._pk1, self._pk3 = ops.FoldedConv(), ops.PackedConv(), ops.PackedConv()
+
     def forward(self, x):
+        if _fused_ok(x, self):
+            # pw (+bn1, ReLU6) and pwl (+bn3, + skip) on the implicit-GEMM kernel, dw (+bn2, ReLU6) on the direct one
+            x = x.contiguous()
+            y = ops.conv2d([x], self._pk1.get_folded(self.conv_pw, self.bn1), act=L.ACT_RELU6)
+            w, b = self._fdw.get(self.conv_dw, self.bn2)
+            y = ops.dwconv3x3(y, w, b, self.conv_dw.stride[0], L.ACT_RELU6)
+            return ops.conv2d([y], self._pk3.get_folded(self.conv_pwl, self.bn3), add=x if self.res else None)
         y = nn.functional.relu6(self.bn1(self.conv_pw(x)))
         y = nn.functional.relu6(self.bn2(self.conv_dw(y)))
         y = self.bn3(self.conv_pwl(y))
@@ -302,7 +318,13 @@ class Feature(nn.Module):
         self.conv4 = BasicConv_IN(chans[1] * 2, chans[1] * 2, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x):
-        x = self.act1(self.bn1(self.conv_stem(x)))
+        if _fused_ok(x, self) and isinstance(self.bn1, nn.BatchNorm2d):
+            if not hasattr(self, "_f_stem"):
+                self._f_stem = _FoldCache()
+            w, b = self._f_stem.get(self.conv_stem, self.bn1)
+            x = nn.functional.conv2d(x, w, b, self.conv_stem.stride, self.conv_stem.padding).clamp_(0.0, 6.0)
+        else:
+            x = self.act1(self.bn1(self.conv_stem(x)))
         x2 = self.block0(x)
         x4 = self.block1(x2)
         x8 = self.block2(x4)

@@ -394,6 +394,64 @@ def pool2x(x):
     return out
 
 
+def dwconv3x3(x, weight, bias=None, stride: int = 1, act: int = L.ACT_NONE, residual=None):
+    """act(depthwise conv3x3(x, padding 1, stride) + bias) (+ residual) — conv_dw of a MobileNetV2 block."""
+    _req(x, "x"), _req(weight, "weight")
+    b, c, h, w = x.shape
+    if tuple(weight.shape) != (c, 1, 3, 3):
+        raise RuntimeError("dwconv3x3: weight must be [C,1,3,3]")
+    out = torch.empty((b, c, (h - 1) // stride + 1, (w - 1) // stride + 1), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _req(residual, "residual")
+        if residual.shape != out.shape:
+            raise RuntimeError("dwconv3x3: residual shape mismatch")
+    if bias is not None:
+        _req(bias, "bias")
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_dwconv3x3(_p(x), _p(weight), _p(bias), _p(residual), _p(out), b, c, h, w, stride, act, _stream()),
+                "dwconv3x3")
+    return out
+
+
+def conv3d_k3(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
+    """act(Conv3d 3x3x3(x, padding 1, stride) + bias); wpack = weight.permute(1,2,3,4,0) as [Cin,27,Cout]."""
+    _req(x, "x"), _req(wpack, "wpack")
+    b, cin, d, h, w = x.shape
+    if wpack.dim() != 3 or wpack.shape[0] != cin or wpack.shape[1] != 27:
+        raise RuntimeError("conv3d_k3: wpack must be [Cin,27,Cout]")
+    cout = wpack.shape[2]
+    if bias is not None:
+        _req(bias, "bias")
+    out = torch.empty((b, cout, (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1), device=x.device,
+                      dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_conv3d_k3(_p(x), _p(wpack), _p(bias), _p(out), b, cin, cout, d, h, w, stride, act, _stream()),
+                "conv3d_k3")
+    return out
+
+
+class FoldedConv:
+    """Cache of the (BatchNorm-folded) weight / bias of a conv that runs on a direct kernel or stays on MIOpen;
+    `layout` = None keeps the module's layout, 'c3d' gives the [Cin,27,Cout] pack of as_conv3d_k3."""
+
+    def __init__(self, layout=None):
+        self._key, self._wb, self.layout = None, None, layout
+
+    @torch.no_grad()
+    def get(self, conv, bn=None):
+        ts = [conv.weight, conv.bias] + ([] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var])
+        key = tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts)
+        if key != self._key:
+            if bn is None:
+                w, b = conv.weight.detach().float(), None if conv.bias is None else conv.bias.detach().float().contiguous()
+            else:
+                w, b = fold_bn(conv, bn)
+            if self.layout == "c3d":
+                w = w.permute(1, 2, 3, 4, 0).reshape(w.shape[1], 27, w.shape[0])
+            self._wb, self._key = (w.contiguous(), b), key
+        return self._wb
+
+
 def interp(x, ho: int, wo: int):
     """F.interpolate(x, (ho, wo), mode='bilinear', align_corners=True) (update.py:100-102)."""
     _req(x, "x")

@@ -1,0 +1,175 @@
+// §8 f4 — backbone-side one-shot operators that MIOpen serves badly at these shapes (measured at 960x540:
+// depthwise 3x3 on [1,32,272,480]: 225 us for 33 MB of traffic; Conv3d 8->8 on [1,8,48,136,240]: 885 us for
+// 100 MB / 5.4 GFLOP).  Both are direct convolutions: a lane owns one output position (x fastest, so loads
+// and stores are coalesced 256-B rows), weights are wave-uniform and arrive through the scalar cache
+// (s_load) as SGPR operands of the FMAs, the zero padding comes from the buffer range check (sentinel
+// offset) so there is no branch around a load.  BatchNorm (eval) is folded into weights/bias by the caller;
+// the activation is fused.
+#include "common.h"
+
+namespace {
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case AS_ACT_RELU: return fmaxf(v, 0.f);
+    case AS_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case AS_ACT_TANH: return tanhf(v);
+    case AS_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+    case AS_ACT_LEAKY: return v >= 0.f ? v : 0.01f * v;
+    default: return v;
+  }
+}
+
+constexpr unsigned kOOB = 0x70000000u;  // lane sentinel: stays out of range after adding any in-tensor scalar offset
+
+// ------------------------------------------------------------------------------------------------
+// depthwise 3x3, padding 1, stride S: block = 64 x 4 outputs of one (b, c) plane.
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ res,
+                                                        float* __restrict__ out, int C, int H, int W, int Ho, int Wo, int act) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bc = blockIdx.z;
+  const int c = bc % C;
+  const int oy = blockIdx.y * 4 + wave;
+  const int ox = blockIdx.x * 64 + lane;
+  if (oy >= Ho) return;
+  const long long plane = (long long)H * W;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)bc * plane), 0, (int)(plane * 4), 0x00020000);
+  float wk[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wk[t] = w[c * 9 + t];  // uniform -> scalar loads
+  unsigned xo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ix = ox * S + k - 1;
+    xo[k] = (ox < Wo && ix >= 0 && ix < W) ? (unsigned)(ix * 4) : kOOB;
+  }
+  float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * S + ky - 1;
+    if (iy < 0 || iy >= H) continue;  // wave-uniform
+    const unsigned so = (unsigned)(iy * W * 4);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) acc = fmaf(bload(rs, xo[kx], so), wk[ky * 3 + kx], acc);
+  }
+  if (ox < Wo) {
+    const long long o = ((long long)bc * Ho + oy) * Wo + ox;
+    float v = act_apply(acc, act);
+    if (res) v += res[o];
+    out[o] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv3d 3x3x3, padding 1, stride S (all three dims), Cin arbitrary, CT output channels per thread
+// (Cout = groups x CT, group = blockIdx.z % groups).  wpack [Cin][27][Cout].
+// Block = 64 x-positions x 4 y-rows of one (b, z, group).
+// ------------------------------------------------------------------------------------------------
+template <int S, int CT>
+__global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int Cin, int Cout, int D, int H, int W, int Do, int Ho, int Wo, int act) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int groups = Cout / CT;
+  int id = blockIdx.z;
+  const int g = id % groups;
+  id /= groups;
+  const int oz = id % Do;
+  const int b = id / Do;
+  const int oy = blockIdx.y * 4 + wave;
+  const int ox = blockIdx.x * 64 + lane;
+  if (oy >= Ho) return;
+  const long long plane = (long long)H * W;
+  const long long vol = (long long)D * plane;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * Cin * vol), 0, (int)((long long)Cin * vol * 4), 0x00020000);
+  unsigned xo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ix = ox * S + k - 1;
+    xo[k] = (ox < Wo && ix >= 0 && ix < W) ? (unsigned)(ix * 4) : kOOB;
+  }
+  float acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc[j] = bias ? bias[g * CT + j] : 0.f;
+  const float* wg = wp + g * CT;
+  for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const int iz = oz * S + kz - 1;
+      if (iz < 0 || iz >= D) continue;  // block-uniform
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * S + ky - 1;
+        if (iy < 0 || iy >= H) continue;  // wave-uniform
+        const unsigned so = (unsigned)((((long long)ci * D + iz) * H + iy) * W * 4);
+        float v[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v[kx] = bload(rs, xo[kx], so);
+        const float* wt = wg + (long long)(ci * 27 + kz * 9 + ky * 3) * Cout;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int j = 0; j < CT; ++j) acc[j] = fmaf(v[kx], wt[kx * Cout + j], acc[j]);
+      }
+    }
+  }
+  if (ox < Wo) {
+    const long long ovol = (long long)Do * Ho * Wo;
+    float* o = out + ((long long)b * Cout + g * CT) * ovol + ((long long)oz * Ho + oy) * Wo + ox;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) o[j * ovol] = act_apply(acc[j], act);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int as_dwconv3x3(const float* x, const float* weight, const float* bias, const float* residual, float* out,
+                 int B, int C, int H, int W, int stride, int act, void* stream) {
+  AS_REQUIRE(x && weight && out, AS_ERR_BAD_ARG, "dwconv3x3: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "dwconv3x3: non-positive size");
+  AS_REQUIRE(stride == 1 || stride == 2, AS_ERR_BAD_ARG, "dwconv3x3: stride=%d (supported: 1, 2)", stride);
+  AS_REQUIRE(act >= AS_ACT_NONE && act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "dwconv3x3: act=%d", act);
+  AS_REQUIRE((long long)H * W * 4 < (long long)kOOB, AS_ERR_BAD_SHAPE, "dwconv3x3: plane too large");
+  AS_REQUIRE((long long)B * C <= 65535, AS_ERR_BAD_SHAPE, "dwconv3x3: B*C=%lld exceeds the grid limit", (long long)B * C);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const dim3 grid((unsigned)as::cdiv(Wo, 64), (unsigned)as::cdiv(Ho, 4), (unsigned)(B * C));
+  if (stride == 1) hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, residual, out, C, H, W, Ho, Wo, act);
+  else hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, residual, out, C, H, W, Ho, Wo, act);
+  return as::check_launch("dwconv3x3");
+}
+
+int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* out,
+                 int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream) {
+  AS_REQUIRE(x && wpack && out, AS_ERR_BAD_ARG, "conv3d_k3: null pointer");
+  AS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "conv3d_k3: non-positive size");
+  AS_REQUIRE(stride == 1 || stride == 2, AS_ERR_BAD_ARG, "conv3d_k3: stride=%d (supported: 1, 2)", stride);
+  AS_REQUIRE(act >= AS_ACT_NONE && act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "conv3d_k3: act=%d", act);
+  AS_REQUIRE((long long)Cin * D * H * W * 4 < (long long)kOOB, AS_ERR_BAD_SHAPE, "conv3d_k3: input exceeds 1.75 GiB per batch element");
+  const int Do = (D - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const int ct = (Cout % 8 == 0) ? 8 : 1;
+  const long long gz = (long long)B * Do * (Cout / ct);
+  AS_REQUIRE(gz <= 65535, AS_ERR_BAD_SHAPE, "conv3d_k3: B*Do*groups=%lld exceeds the grid limit", gz);
+  const dim3 grid((unsigned)as::cdiv(Wo, 64), (unsigned)as::cdiv(Ho, 4), (unsigned)gz);
+  hipStream_t s = as::as_stream(stream);
+#define AS_C3D(S_, CT_) hipLaunchKernelGGL((conv3d_k3_kernel<S_, CT_>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, Do, Ho, Wo, act)
+  if (stride == 1) { if (ct == 8) AS_C3D(1, 8); else AS_C3D(1, 1); }
+  else { if (ct == 8) AS_C3D(2, 8); else AS_C3D(2, 1); }
+#undef AS_C3D
+  return as::check_launch("conv3d_k3");
+}
+
+}  // extern "C"

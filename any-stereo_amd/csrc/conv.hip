@@ -65,6 +65,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case AS_ACT_RELU: return fmaxf(v, 0.f);
     case AS_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     case AS_ACT_TANH: return tanhf(v);
+    case AS_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+    case AS_ACT_LEAKY: return v >= 0.f ? v : 0.01f * v;
     default: return v;
   }
 }
@@ -978,7 +980,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
     p.out_coff = d->out_coff;
     AS_REQUIRE(p.out_coff >= 0 && p.out_coff + d->Cout <= p.out_ctot, AS_ERR_BAD_SHAPE, "conv2d: out channel window outside out_ctot");
-    AS_REQUIRE(d->act >= AS_ACT_NONE && d->act <= AS_ACT_TANH, AS_ERR_BAD_ARG, "conv2d: act=%d", d->act);
+    AS_REQUIRE(d->act >= AS_ACT_NONE && d->act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "conv2d: act=%d", d->act);
   } else if (epi == AS_EPI_GRU_ZR) {
     AS_REQUIRE(d->h && d->out2 && (d->Cout % (2 * kBN)) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and Cout %% 128 == 0");
   } else if (epi == AS_EPI_GRU_Q) {

@@ -45,6 +45,8 @@ extern "C" {
 #define AS_ACT_RELU 1
 #define AS_ACT_SIGMOID 2
 #define AS_ACT_TANH 3
+#define AS_ACT_RELU6 4 /* min(max(x,0),6): MobileNetV2 blocks of the feature net (extractor.py:331-342) */
+#define AS_ACT_LEAKY 5 /* LeakyReLU(0.01): BasicConv / BasicConv_IN (submodule.py:6-33)                 */
 #define AS_EPI_LINEAR 0 /* out = act(acc + bias + add); with h != NULL: out = relu(h + act(...))    (extractor.py:56-62) */
 #define AS_EPI_GRU_ZR 1 /* co <  Cout/2: z  = sigmoid(acc+bias+add)        -> out  [B,Cout/2,H,W]
                            co >= Cout/2: rh = sigmoid(acc+bias+add) * h    -> out2 [B,Cout/2,H,W]  */
@@ -166,6 +168,21 @@ int as_tap_shift_sum(const float* S, const float* bias, float* out, int B, int H
  *     resize (update.py:100-102).  x [B,C,H,W] -> out [B,C,Ho,Wo].                                */
 int as_pool2x(const float* x, float* out, int B, int C, int H, int W, void* stream);
 int as_interp_bilinear_ac(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f4  backbone-side one-shot operators, direct convolutions with fused bias + activation;
+ *     eval-mode BatchNorm is folded into weight/bias by the caller.
+ *   as_dwconv3x3: depthwise 3x3, padding 1, stride 1|2 — conv_dw (+bn, +ReLU6) of the MobileNetV2 blocks of
+ *     Feature (extractor.py:327-342).  x [B,C,H,W], weight [C,1,3,3], bias [C]|NULL, residual [B,C,Ho,Wo]|NULL
+ *     (added after the activation) -> out [B,C,Ho,Wo], Ho = (H-1)/stride+1.
+ *   as_conv3d_k3: Conv3d 3x3x3, padding 1, stride 1|2 (all dims), no groups — corr_stem / classifier / hourglass
+ *     convs (continuous_IGEVstereo.py:22-89,:139,:158).  x [B,Cin,D,H,W]; wpack [Cin,27,Cout] (= weight
+ *     [Cout,Cin,3,3,3] permuted so one tap's Cout weights are contiguous); bias [Cout]|NULL -> out [B,Cout,Do,Ho,Wo].
+ * ------------------------------------------------------------------------------------------- */
+int as_dwconv3x3(const float* x, const float* weight, const float* bias, const float* residual, float* out,
+                 int B, int C, int H, int W, int stride, int act, void* stream);
+int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* out,
+                 int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a12/a13  cosine affinity to the 8 neighbours, written straight into channels [C, C+8) of the

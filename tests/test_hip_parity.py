@@ -276,6 +276,66 @@ def test_residual_block_fused_inference(cin, cout, stride, h, w, precision):
     close(out, ref, 2e-5, 2e-5, "residual block (fused)")
 
 
+@pytest.mark.parametrize("b,c,h,w,stride,act", [(2, 32, 17, 70, 1, 4), (1, 96, 18, 67, 2, 4), (1, 5, 3, 3, 2, 0), (1, 8, 65, 130, 1, 5)])
+def test_dwconv3x3(b, c, h, w, stride, act):
+    from anystereo import ops
+    x, wt, bias = U((b, c, h, w), 170, -3, 3), U((c, 1, 3, 3), 171), U((c,), 172)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), stride=stride, padding=1, groups=c)
+    ref = {0: ref, 4: ref.clamp(0, 6), 5: torch.nn.functional.leaky_relu(ref, 0.01)}[act]
+    res = U(tuple(ref.shape), 173)
+    out = ops.dwconv3x3(x.to(DEV), wt.to(DEV), bias.to(DEV), stride, act, residual=res.to(DEV))
+    close(out, ref + res.double(), 1e-6, 1e-6, "dwconv3x3")
+    close(ops.dwconv3x3(x.to(DEV), wt.to(DEV), None, stride, act), {0: lambda t: t, 4: lambda t: t.clamp(0, 6), 5: lambda t: torch.nn.functional.leaky_relu(t, 0.01)}[act](
+        torch.nn.functional.conv2d(x.double(), wt.double(), None, stride=stride, padding=1, groups=c)), 1e-6, 1e-6, "dwconv3x3 (no bias)")
+
+
+@pytest.mark.parametrize("b,cin,cout,d,h,w,stride,act", [(1, 8, 8, 6, 9, 70, 1, 5), (2, 8, 1, 5, 6, 33, 1, 0), (1, 8, 16, 7, 9, 66, 2, 5),
+                                                         (1, 16, 16, 4, 5, 20, 1, 5), (1, 3, 5, 3, 4, 7, 2, 1)])
+def test_conv3d_k3(b, cin, cout, d, h, w, stride, act):
+    from anystereo import ops
+    x = U((b, cin, d, h, w), 180, -2, 2)
+    wt = U((cout, cin, 3, 3, 3), 181) * (3.0 / (cin * 27)) ** 0.5
+    bias = U((cout,), 182) * 0.1
+    ref = torch.nn.functional.conv3d(x.double(), wt.double(), bias.double(), stride=stride, padding=1)
+    ref = {0: ref, 1: ref.relu(), 5: torch.nn.functional.leaky_relu(ref, 0.01)}[act]
+    wp = wt.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous()
+    out = ops.conv3d_k3(x.to(DEV), wp.to(DEV), bias.to(DEV), stride, act)
+    close(out, ref, 2e-6, 2e-6, "conv3d_k3")
+
+
+def _randomize_bn(mod, seed):
+    with torch.no_grad():
+        for i, m in enumerate(mm for mm in mod.modules() if isinstance(mm, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))):
+            m.running_mean.copy_(U((m.num_features,), seed + 4 * i) * 0.3)
+            m.running_var.copy_(U((m.num_features,), seed + 4 * i + 1, 0.5, 2.0))
+            m.weight.copy_(U((m.num_features,), seed + 4 * i + 2, 0.5, 1.5))
+            m.bias.copy_(U((m.num_features,), seed + 4 * i + 3) * 0.2)
+
+
+def _fused_vs_plain(mod, x, rtol, what):
+    with torch.enable_grad():  # grad mode keeps the plain PyTorch path
+        ref = mod.double()(x.double()).detach()
+    mod = mod.float().to(DEV)
+    with torch.no_grad():
+        out = mod(x.to(DEV))
+    close(out, ref, rtol, rtol, what)
+
+
+def test_backbone_blocks_fused_inference(precision):
+    """§8 f4: MobileNetV2 blocks (pw/dw/pwl with folded BN, ReLU6, skip) and the BatchNorm Conv3d block."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn.blocks import BasicConv
+    from anystereo.nn.encoders import _DSConv, _InvRes
+    for k, (mod, shape) in enumerate([(_InvRes(24, 24, 1), (2, 24, 17, 37)), (_InvRes(16, 24, 2), (1, 16, 18, 40)),
+                                      (_DSConv(32, 16, 1), (1, 32, 9, 70)), (_InvRes(64, 64, 1), (1, 64, 5, 9)),
+                                      (BasicConv(8, 16, is_3d=True, kernel_size=3, padding=1, stride=2), (1, 8, 6, 9, 33)),
+                                      (BasicConv(16, 16, is_3d=True, kernel_size=3, padding=1, stride=1), (1, 16, 4, 6, 21))]):
+        mod = mod.eval()
+        fill_module_deterministic(mod, 7 + k)
+        _randomize_bn(mod, 200 + 40 * k)
+        _fused_vs_plain(mod, U(shape, 190 + k, -2, 2), 3e-5, f"fused block {k}")
+
+
 def test_direct_convs_and_resamplers(precision):
     from anystereo import ops
     x = U((2, 1, 19, 37), 110, 0, 30)
