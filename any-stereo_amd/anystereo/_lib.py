@@ -19,7 +19,8 @@ AS_F32, AS_F16, AS_F64 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 3, 4, 5
 EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanystereo_hip.so")
+# ANYSTEREO_LIB selects another build of the same library (A/B timing of kernel variants); default = the in-tree build
+LIB_PATH = os.environ.get("ANYSTEREO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanystereo_hip.so")
 
 _vp, _i, _fp = C.c_void_p, C.c_int, C.c_void_p
 _pp = C.POINTER(C.c_void_p)

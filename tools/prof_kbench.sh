@@ -7,5 +7,11 @@ rm -rf $out; mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python $ROOT/tools/kbench.py "$@" > $out.log 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)
-if [ -n "$f" ]; then grep -v "at::native\|elementwise" $f | cut -d, -f1-4 | cut -c1-160 | head -${TOPN:-8}; else tail -5 $out.log; fi
+if [ -n "$f" ]; then python - "$f" "${TOPN:-8}" <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "at::native" not in r["Name"] and "elementwise" not in r["Name"]]
+for r in rows[:int(sys.argv[2])]:
+    print(f"{float(r['AverageNs']) / 1e3:10.2f} us x{r['Calls']:>4}  {r['Name'][:90]}")
+PY
+else tail -5 $out.log; fi
 rm -rf $out $out.log
