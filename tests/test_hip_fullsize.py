@@ -120,6 +120,20 @@ def test_conv_gru_fullsize_properties(mode):
         ops.set_precision(prev)
 
 
+def test_conv_bitwise_repeatable():
+    """Race detector: the GRU-shaped convs give bit-identical results run after run (cfg 2 sizes, both pipelines)."""
+    from anystereo import _lib as L
+    from anystereo import ops
+    for (h, w, cins) in [(136, 240, [128, 128, 128]), (68, 120, [128, 128, 128]), (34, 60, [128, 128])]:
+        srcs = [U((1, c, h, w), 30 + i).to(DEV) for i, c in enumerate(cins)]
+        wt = (U((256, sum(cins), 3, 3), 40) * 0.05).to(DEV)
+        pk = ops.PackedConv().get([wt], [U((256,), 41).to(DEV)])
+        ref = [t.clone() for t in ops.conv2d(srcs, pk, epilogue=L.EPI_GRU_ZR, h=srcs[0])]
+        for _ in range(10):
+            out = ops.conv2d(srcs, pk, epilogue=L.EPI_GRU_ZR, h=srcs[0])
+            assert all(torch.equal(a, b) for a, b in zip(out, ref))
+
+
 def test_liif_fullsize_properties():
     """cfg 3: 96x312 low-res, scale 2 -> 1 863 000 queries; constant disparity + uniform logits upsample exactly."""
     from anystereo import ops
@@ -156,6 +170,8 @@ def test_whole_model_cfg2_determinism_and_graph():
     i1, i2, coord = i1.to(DEV), i2.to(DEV), coord.unsqueeze(0).to(DEV)
     sc = torch.tensor([[1.0]], device=DEV)
     with torch.no_grad():
+        # first call: MIOpen picks its solvers for the remaining backbone convs (may differ from the steady state)
+        model(i1, i2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=sc)
         a = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
         b = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
         model.enable_graph(True)
