@@ -76,16 +76,30 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda):
-            features_left = self.feature(image1)
-            features_right = self.feature(image2)
-            stem_2x = self.stem_2(image1)
-            stem_2y = self.stem_2(image2)
-            stem_4x = self.stem_4(stem_2x)
-            stem_4y = self.stem_4(stem_2y)
-            features_left[0] = torch.cat((features_left[0], stem_4x), 1)
-            features_right[0] = torch.cat((features_right[0], stem_4y), 1)
-            match_left = self.desc(self.conv(features_left[0]))
-            match_right = self.desc(self.conv(features_right[0]))
+            if B.fused_ok(image1, self):
+                # inference: left and right image as ONE batch through the (per-sample) feature net, stems and
+                # descriptor head — same arithmetic per sample, half the launches, twice the blocks per launch
+                n = image1.shape[0]
+                both = torch.cat((image1, image2), 0)
+                feats = self.feature(both)
+                stem_2b = self.stem_2(both)
+                stem_4b = self.stem_4(stem_2b)
+                feats[0] = torch.cat((feats[0], stem_4b), 1)
+                match = self.desc(self.conv(feats[0]))
+                features_left = [f[:n] for f in feats]
+                stem_2x, stem_4x = stem_2b[:n], stem_4b[:n]
+                match_left, match_right = match[:n], match[n:]
+            else:
+                features_left = self.feature(image1)
+                features_right = self.feature(image2)
+                stem_2x = self.stem_2(image1)
+                stem_2y = self.stem_2(image2)
+                stem_4x = self.stem_4(stem_2x)
+                stem_4y = self.stem_4(stem_2y)
+                features_left[0] = torch.cat((features_left[0], stem_4x), 1)
+                features_right[0] = torch.cat((features_right[0], stem_4y), 1)
+                match_left = self.desc(self.conv(features_left[0]))
+                match_right = self.desc(self.conv(features_right[0]))
             gwc_volume = self._hot_gwc(match_left, match_right)
             gwc_volume = self.corr_stem(gwc_volume)
             gwc_volume = self.corr_feature_att(gwc_volume, features_left[0])
