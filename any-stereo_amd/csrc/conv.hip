@@ -554,10 +554,13 @@ typedef __attribute__((address_space(1))) const void as_gbl_void;
 // the LDS commit.  Measured on the single-role version: an LDS-DMA instruction costs the issuing wave
 // ~180 cycles, so 18 of them per chunk in front of 108 MFMAs could not overlap with them (in-order issue);
 // on a sibling wave of the same SIMD they do.
-template <int KS, int TW, int BN, int EPI>
+template <int KS, int TW, int BN, int EPI, int NSUB = 1>
 __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
-  constexpr int BM = 128;
-  constexpr int TH = BM / TW;
+  // Block = NSUB sub-tiles of 128 pixels (TH x TW each, consecutive tile ids of the image) x BN output channels.
+  // NSUB = 2 with BN = 64 halves the weight bytes a CU pulls per MFMA (the per-CU L1 fill rate, ~45 GB/s, is what
+  // the loader waves run into) while 255 tiles of a 136x240 map still pair up into exactly 2 rounds of 256 blocks.
+  constexpr int BM = 128 * NSUB;
+  constexpr int TH = 128 / TW;
   constexpr int PAD = KS / 2;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PATCHP = PH * PW;
@@ -565,8 +568,11 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   constexpr int WSEG = BN * 16;              // bytes of one (tap, comp, h) weight segment
   constexpr int WCHUNK = NTAP * 4 * WSEG;    // bytes of one chunk's weight image (16 channels, all taps)
   constexpr int NWD = WCHUNK / 16 / 256;     // 16-B LDS-DMA pieces per loader thread per chunk
-  constexpr int NPI = (8 * PATCHP + 255) / 256;  // (channel pair, patch pixel) items per loader thread
-  constexpr int PTW = (BN == 128) ? 2 : 1;   // pixel MFMA tiles per consumer wave
+  constexpr int PATCHT = NSUB * PATCHP;      // patch pixels of the block (sub-tile patches back to back)
+  constexpr int NPI = (8 * PATCHT + 255) / 256;  // (channel pair, patch pixel) items per loader thread
+  constexpr int WPX = 256 / BN;              // consumer waves along the pixel dimension (4 consumers = (BN/64) x WPX)
+  constexpr int PTW = BM / (WPX * 32);       // pixel MFMA tiles per consumer wave
+  static_assert(PTW == 1 || PTW == 2, "consumer tile is 64 co x 32|64 px");
   static_assert(WCHUNK % (16 * 256) == 0, "weight chunk must split evenly over the loader threads");
   // [W image 0][W image 1][patch image]
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -578,24 +584,30 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   const int l31 = lane & 31, half = lane >> 5;
 
   int id = blockIdx.x;
-  const int tx = id % p.tiles_x;
-  id /= p.tiles_x;
-  const int ty = id % p.tiles_y;
-  id /= p.tiles_y;
+  const int ntile = p.tiles_x * p.tiles_y;
+  const int ngroup = (ntile + NSUB - 1) / NSUB;
+  const int group = id % ngroup;
+  id /= ngroup;
   const int b = id % p.B;
   id /= p.B;
   const int nt = id % p.n_tiles;
   const int ks = id / p.n_tiles;  // K slice (0 unless split-K)
   const int chunk_lo = (int)((long long)p.chunks * ks / p.ksplit);
   const int chunk_hi = (int)((long long)p.chunks * (ks + 1) / p.ksplit);
-  const int x0 = tx * TW, y0 = ty * TH;
+  int sx0[NSUB], sy0[NSUB];  // origin of each sub-tile; a missing one (odd tile count) sits below the image
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) {
+    const int t = group * NSUB + u;
+    sx0[u] = (t % p.tiles_x) * TW;
+    sy0[u] = t < ntile ? (t / p.tiles_x) * TH : p.H + PAD + 1;
+  }
   const int n0 = nt * BN;
   const long long plane = (long long)p.H * p.W;
 
   f32x16 acc_h[2][PTW], acc_x[2][PTW];
   const int cw = wave & 3;
   const int co_base = (BN == 128) ? (cw >> 1) * 64 : 0;
-  const int px_base = (BN == 128) ? (cw & 1) * 64 : cw * 32;
+  const int px_base = (BN == 128) ? (cw & 1) * (PTW * 32) : cw * (PTW * 32);
 
   if (loader) {
     // =========================== LOADER WAVES ===========================
@@ -606,14 +618,15 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
       int idx = ltid + i * 256;
-      const bool slot = idx < 8 * PATCHP;
-      if (!slot) idx = 8 * PATCHP - 1;
-      const int cp = idx / PATCHP, pp = idx - cp * PATCHP;
+      const bool slot = idx < 8 * PATCHT;
+      if (!slot) idx = 8 * PATCHT - 1;
+      const int cp = idx / PATCHT, ppt = idx - cp * PATCHT;
+      const int su = ppt / PATCHP, pp = ppt - su * PATCHP;
       const int py = pp / PW, px = pp - py * PW;
-      const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+      const int gy = (NSUB > 1 && su ? sy0[NSUB - 1] : sy0[0]) - PAD + py, gx = (NSUB > 1 && su ? sx0[NSUB - 1] : sx0[0]) - PAD + px;
       const bool in = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       p_voff[i] = in ? (unsigned)(((long long)(2 * cp) * plane + (long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
-      p_lds[i] = slot ? (cp >> 2) * (PATCHP * 16) + pp * 16 + (cp & 3) * 4 : -1;
+      p_lds[i] = slot ? (cp >> 2) * (PATCHT * 16) + ppt * 16 + (cp & 3) * 4 : -1;
     }
     // piece i of this thread is 16-B unit (ltid + 256 i) of the chunk image = segment (ltid + 256 i) / BN,
     // column (ltid + 256 i) % BN; the global pack has the same order, so the DMA destination is linear
@@ -669,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
       if (p_lds[i] >= 0) {                                                                            \
         *reinterpret_cast<half2v*>(pd + p_lds[i]) = c_hi[i];                                           \
-        *reinterpret_cast<half2v*>(pd + 2 * PATCHP * 16 + p_lds[i]) = c_lo[i];                         \
+        *reinterpret_cast<half2v*>(pd + 2 * PATCHT * 16 + p_lds[i]) = c_lo[i];                         \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -701,8 +714,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     int plane_off[PTW];
 #pragma unroll
     for (int q = 0; q < PTW; ++q) {
-      const int m = px_base + q * 32 + l31;
-      plane_off[q] = half * (PATCHP * 16) + ((m / TW) * PW + (m % TW)) * 16;
+      const int mt = px_base + q * 32 + l31;  // pixel of the block; sub-tile mt / 128, pixel m inside it
+      const int m = mt & 127;
+      plane_off[q] = half * (PATCHT * 16) + ((mt >> 7) * PATCHP + (m / TW) * PW + (m % TW)) * 16;
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     constexpr int tapoff_ = (((TAP) / KS) * PW + ((TAP) % KS)) * 16;                                     \
     _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                    \
       b_hi[S][q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff_);                         \
-      b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHP * 16 + plane_off[q] + tapoff_);       \
+      b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHT * 16 + plane_off[q] + tapoff_);       \
     }                                                                                                   \
   }
 #define AS_SPLIT_MFMA_C(S, c)                                                                           \
@@ -766,8 +780,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
 #pragma unroll
     for (int q = 0; q < PTW; ++q) {
-      const int m = px_base + q * 32 + l31;
-      const int gy = y0 + m / TW, gx = x0 + m % TW;
+      const int mt = px_base + q * 32 + l31, m = mt & 127;
+      const int su = (NSUB > 1) ? __builtin_amdgcn_readfirstlane(mt >> 7) : 0;  // a wave's 64 pixels lie in one sub-tile
+      const int gy = (su ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = (su ? sx0[NSUB - 1] : sx0[0]) + m % TW;
       const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -835,22 +850,23 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   }
 }
 
-template <int KS, int TW, int BN, int EPI>
+template <int KS, int TW, int BN, int EPI, int NSUB = 1>
 int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   constexpr int TH = 128 / TW, PATCHP = (TH + KS - 1) * (TW + KS - 1);
-  constexpr size_t lds = 2 * (size_t)(KS * KS * 4 * BN * 16) + (size_t)(4 * PATCHP * 16);
+  constexpr size_t lds = 2 * (size_t)(KS * KS * 4 * BN * 16) + (size_t)(4 * NSUB * PATCHP * 16);
   static_assert(lds <= 160 * 1024, "conv_split: LDS budget");
   static bool configured = false;  // per instantiation; the attribute is idempotent
   if (!configured && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  const dim3 grid((unsigned)((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles * p.ksplit));
-  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI>), grid, dim3(512), lds, s, p);
+  const long long groups = as::cdiv64((long long)p.tiles_x * p.tiles_y, NSUB);
+  const dim3 grid((unsigned)((long long)p.B * groups * p.n_tiles * p.ksplit));
+  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB>), grid, dim3(512), lds, s, p);
   return as::check_launch("conv2d(split)");
 }
 
-template <int KS, int TW, int BN>
+template <int KS, int TW, int BN, int NSUB = 1>
 int launch_conv_split(const ConvParams& p, int epi, hipStream_t s) {
   if (p.ksplit > 1) {
     int rc = launch_conv_split_epi<KS, TW, BN, kEpiPartial>(p, s);
@@ -862,9 +878,9 @@ int launch_conv_split(const ConvParams& p, int epi, hipStream_t s) {
     else hipLaunchKernelGGL(conv_finish_kernel<AS_EPI_GRU_Q>, g, dim3(256), 0, s, p);
     return as::check_launch("conv2d(split-K finish)");
   }
-  if (epi == AS_EPI_LINEAR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_LINEAR>(p, s);
-  if (epi == AS_EPI_GRU_ZR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_ZR>(p, s);
-  return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_Q>(p, s);
+  if (epi == AS_EPI_LINEAR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_LINEAR, NSUB>(p, s);
+  if (epi == AS_EPI_GRU_ZR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_ZR, NSUB>(p, s);
+  return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_Q, NSUB>(p, s);
 }
 
 template <int KS, int TW>
@@ -1020,6 +1036,16 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.tiles_y = as::cdiv(p.H, 128 / tw);
     AS_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
     conv_pick_ksplit(p, d);
+    // big maps: 256-pixel x 64-channel blocks (two sub-tiles) pull 30 % fewer bytes per MFMA through the CU's L1
+    static const int wide_mode = getenv("AS_CONV_WIDE") ? atoi(getenv("AS_CONV_WIDE")) : 1;
+    const long long wide_blocks = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, 2) * (p.Cout_pad / 64);
+    const long long now_blocks = (long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles;
+    const bool wide_ok = bn == 128 ? (wide_blocks >= kNumCU && as::cdiv64(wide_blocks, kNumCU) <= as::cdiv64(now_blocks, kNumCU))
+                                   : wide_blocks >= 2 * kNumCU;  // bn == 64: a wide block is twice the work of a current one
+    if (wide_mode && p.ksplit == 1 && wide_ok) {
+      p.n_tiles = p.Cout_pad / 64;
+      return tw == 16 ? launch_conv_split<3, 16, 64, 2>(p, epi, s) : launch_conv_split<3, 32, 64, 2>(p, epi, s);
+    }
     if (tw == 16) return bn == 128 ? launch_conv_split<3, 16, 128>(p, epi, s) : launch_conv_split<3, 16, 64>(p, epi, s);
     return bn == 128 ? launch_conv_split<3, 32, 128>(p, epi, s) : launch_conv_split<3, 32, 64>(p, epi, s);
   }
