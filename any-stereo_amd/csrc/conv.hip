@@ -1040,7 +1040,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     static const int wide_mode = getenv("AS_CONV_WIDE") ? atoi(getenv("AS_CONV_WIDE")) : 1;
     const long long wide_blocks = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, 2) * (p.Cout_pad / 64);
     const long long now_blocks = (long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles;
-    const bool wide_ok = bn == 128 ? (wide_blocks >= kNumCU && as::cdiv64(wide_blocks, kNumCU) <= as::cdiv64(now_blocks, kNumCU))
+    const bool wide_ok = bn == 128 ? as::cdiv64(wide_blocks, kNumCU) <= as::cdiv64(now_blocks, kNumCU)
                                    : wide_blocks >= 2 * kNumCU;  // bn == 64: a wide block is twice the work of a current one
     if (wide_mode && p.ksplit == 1 && wide_ok) {
       p.n_tiles = p.Cout_pad / 64;
