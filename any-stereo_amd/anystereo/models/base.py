@@ -10,6 +10,7 @@ the product never imports the oracle.
 from __future__ import annotations
 
 import argparse
+import os
 
 import torch
 import torch.nn as nn
@@ -141,11 +142,54 @@ class ContinuousStereoBase(nn.Module):
         hr = hr_coord if (hr_coord.dtype == torch.float32 and hr_coord.is_contiguous()) else hr_coord.float().contiguous()
         return self._hot_upsample(disp, x.contiguous(), None if stem_2x is None else stem_2x.float().contiguous(), hr, scale_vec)
 
+    # Inference schedule of the GRU loop (same operators, same operands, same results as the loop below).
+    # In the reference order, iteration i+1 starts with lookup(disp_i) -> motion encoder, but only gru04 consumes the
+    # motion features: gru16 and gru08 of iteration i+1 depend on the hidden states alone.  So the chain
+    #     disp_head(i) -> disp += delta -> lookup(i+1) -> motion encoder(i+1)          (side stream)
+    # runs concurrently with
+    #     gru16(i+1) -> gru08(i+1)                                                    (main stream)
+    # — both chains are made of kernels that leave most of the 256 CUs idle at 1/8 and 1/16 resolution — and the
+    # two streams meet only at gru04.  Fork/join is by events, so the whole thing is capturable as one hipGraph.
+    pipelined_loop = os.environ.get("ANYSTEREO_PIPELINED_LOOP", "1") != "0"
+
+    def _iterate_pipelined(self, lookup_fn, net, inp, disp, coords, iters):
+        from ..nn.update import interp, pool2x
+        ub = self.update_block
+        dev = disp.device
+        main = torch.cuda.current_stream(dev)
+        side = ub._side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            mf = ub.encoder(disp, lookup_fn(disp, coords))
+        for itr in range(iters):
+            net[2] = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
+            net[1] = ub.gru08(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+            up = interp(net[1], net[0])
+            main.wait_stream(side)  # motion features (and the disparity they were computed from) are ready
+            mf.record_stream(main)
+            net[0] = ub.gru04(net[0], *(inp[0]), mf, up)
+            net[0].record_stream(side)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                disp = disp + ub.disp_head(net[0])
+                if itr + 1 < iters:
+                    mf = ub.encoder(disp, lookup_fn(disp, coords))
+        main.wait_stream(side)
+        disp.record_stream(main)
+        return disp
+
     def _iterate(self, lookup_fn, net_list, inp_list, disp, coords, iters, test_mode, stem_4x, stem_2x, hr_coord, scale):
         """The GRU loop shared by both models (continuous_IGEVstereo.py:284-301, prune_raft_stereo.py:276-291)."""
         a = self.args
         disp_preds = []
         disp_up = None
+        ub = self.update_block
+        if (test_mode and iters > 0 and a.n_gru_layers == 3 and not a.slow_fast_gru and disp.is_cuda
+                and not torch.is_grad_enabled() and getattr(ub, "parallel_encoder", False)
+                and type(self)._hot_update is ContinuousStereoBase._hot_update and self.pipelined_loop):
+            disp = self._iterate_pipelined(lookup_fn, net_list, inp_list, disp, coords, iters)
+            disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, None, hr_coord=hr_coord, scale=scale)
+            return disp, disp_up, [disp_up]
         for itr in range(iters):
             disp = disp.detach()
             geo_feat = lookup_fn(disp, coords)
