@@ -133,44 +133,86 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
   return e;
 }
 
-// v: finished sums of the tile; col0: channel of accumulator row 0 relative to n0; poff: byte offset of this
-// lane's pixel inside a channel plane or the OOB sentinel; bias_s: LDS bias of the block (index = channel - n0)
+// The epilogue of a block is a sequence of ROUNDS (one per 8 accumulator rows of a 32x32 tile).  Each round
+// needs up to three global operands (context term, h, z); the rounds are software pipelined: epi_load(i+1) is
+// issued before epi_finish(i) computes and stores, so only the first memory latency is exposed per block.
+// col0: channel of accumulator row 0 relative to n0; poff: byte offset of this lane's pixel inside a channel
+// plane or the OOB sentinel; bias_s: LDS bias of the block (index = channel - n0).
+struct EpiRegs {
+  unsigned off[8];
+  float av[8], hv[8], zv[8];
+};
+
+template <int EPI>
+__device__ __forceinline__ void epi_load(const EpiCtx& e, int col0, int half, unsigned poff, int g, EpiRegs& R) {
+  constexpr unsigned kOOB = 0x7FFFFFF0u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = g * 8 + i;
+    const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    R.off[i] = poff == kOOB ? kOOB : (unsigned)col * e.plane4 + poff;
+    R.av[i] = as_bload(e.r_add, R.off[i]);                         // 0 when there is no add tensor (0 records)
+    if (EPI == AS_EPI_GRU_ZR || EPI == AS_EPI_LINEAR) R.hv[i] = as_bload(e.r_h, R.off[i]);  // 0 records: z half / no residual
+    if (EPI == AS_EPI_GRU_Q) { R.hv[i] = as_bload(e.r_h, R.off[i]); R.zv[i] = as_bload(e.r_z, R.off[i]); }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_finish(const ConvParams& p, const EpiCtx& e, const f32x16& v, int col0, int half, int g,
+                                           const float* bias_s, bool is_r, const EpiRegs& R) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = g * 8 + i;
+    const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const float x = v[r] + bias_s[col] + R.av[i];
+    float o;
+    if (EPI == kEpiPartial) {
+      o = v[r];
+    } else if (EPI == AS_EPI_LINEAR) {
+      o = act_apply(x, p.act);
+      if (p.h) o = fmaxf(o + R.hv[i], 0.f);
+    } else if (EPI == AS_EPI_GRU_ZR) {
+      const float gte = 1.f / (1.f + expf(-x));
+      o = is_r ? gte * R.hv[i] : gte;
+    } else {
+      o = (1.f - R.zv[i]) * R.hv[i] + R.zv[i] * tanhf(x);
+    }
+    as_bstore(e.r_out, R.off[i], o);
+  }
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_tile(const ConvParams& p, const EpiCtx& e, const f32x16& v, int col0, int half,
                                               unsigned poff, const float* bias_s, bool is_r) {
-  constexpr unsigned kOOB = 0x7FFFFFF0u;
+  EpiRegs R0, R1;
+  epi_load<EPI>(e, col0, half, poff, 0, R0);
+  epi_load<EPI>(e, col0, half, poff, 1, R1);
+  epi_finish<EPI>(p, e, v, col0, half, 0, bias_s, is_r, R0);
+  epi_finish<EPI>(p, e, v, col0, half, 1, bias_s, is_r, R1);
+}
+
+// Block epilogue of the split-precision kernel: rounds (q, c, g) over the wave's PTW x 2 accumulator tiles,
+// loads of round i+1 in flight while round i is finished.  poff[q]: pixel offset of the lane in pixel tile q.
+template <int EPI, int PTW>
+__device__ __forceinline__ void epilogue_block(const ConvParams& p, const EpiCtx& e, const f32x16 (&acc_h)[2][PTW],
+                                               const f32x16 (&acc_x)[2][PTW], int co_base, const unsigned (&poff)[PTW],
+                                               int half, const float* bias_s, bool is_r) {
+  constexpr int NR = PTW * 4;
+  EpiRegs R[2];
+  epi_load<EPI>(e, co_base, half, poff[0], 0, R[0]);
+  f32x16 v;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {  // two groups of 8 accumulator rows: 8 loads per operand in flight, ~32 VGPRs
-    unsigned off[8];
-    float av[8], hv[8], zv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = g * 8 + i;
-      const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      off[i] = poff == kOOB ? kOOB : (unsigned)col * e.plane4 + poff;
-      av[i] = as_bload(e.r_add, off[i]);                         // 0 when there is no add tensor (0 records)
-      if (EPI == AS_EPI_GRU_ZR || EPI == AS_EPI_LINEAR) hv[i] = as_bload(e.r_h, off[i]);  // 0 records: z half / no residual
-      if (EPI == AS_EPI_GRU_Q) { hv[i] = as_bload(e.r_h, off[i]); zv[i] = as_bload(e.r_z, off[i]); }
+  for (int i = 0; i < NR; ++i) {
+    const int q = i >> 2, c = (i >> 1) & 1, g = i & 1;
+    if (i + 1 < NR) {
+      const int i1 = i + 1;
+      epi_load<EPI>(e, co_base + ((i1 >> 1) & 1) * 32, half, poff[i1 >> 2], i1 & 1, R[i1 & 1]);
     }
+    if (g == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = g * 8 + i;
-      const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float x = v[r] + bias_s[col] + av[i];
-      float o;
-      if (EPI == kEpiPartial) {
-        o = v[r];
-      } else if (EPI == AS_EPI_LINEAR) {
-        o = act_apply(x, p.act);
-        if (p.h) o = fmaxf(o + hv[i], 0.f);
-      } else if (EPI == AS_EPI_GRU_ZR) {
-        const float gte = 1.f / (1.f + expf(-x));
-        o = is_r ? gte * hv[i] : gte;
-      } else {
-        o = (1.f - zv[i]) * hv[i] + zv[i] * tanhf(x);
-      }
-      as_bstore(e.r_out, off[i], o);
+      for (int r = 0; r < 16; ++r) v[r] = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
     }
+    epi_finish<EPI>(p, e, v, co_base + c * 32, half, g, bias_s, is_r, R[i & 1]);
   }
 }
 
@@ -778,20 +820,15 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   if (!loader) {
     const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN);
     const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
+    unsigned poff[PTW];
 #pragma unroll
     for (int q = 0; q < PTW; ++q) {
       const int mt = px_base + q * 32 + l31, m = mt & 127;
       const int su = (NSUB > 1) ? __builtin_amdgcn_readfirstlane(mt >> 7) : 0;  // a wave's 64 pixels lie in one sub-tile
       const int gy = (su ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = (su ? sx0[NSUB - 1] : sx0[0]) + m % TW;
-      const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        f32x16 v;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
-        epilogue_tile<EPI>(p, e, v, co_base + c * 32, half, poff, bias_s, is_r);
-      }
+      poff[q] = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
     }
+    epilogue_block<EPI, PTW>(p, e, acc_h, acc_x, co_base, poff, half, bias_s, is_r);
   }
 }
 
