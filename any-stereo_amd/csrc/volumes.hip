@@ -375,45 +375,71 @@ struct GeoParams {
   int B, G, D, H, W, L;
 };
 
-__device__ __forceinline__ float geo_pooled(const float* tile, int g, int d, int level, int D, int px) {
-  // mean over the 2^level raw disparities [d<<level, (d+1)<<level) of channel g, as repeated pair means
-  // ((a+b)/2 of (a+b)/2 ...) — bitwise what repeated avg_pool2d computes.
-  float v[8];
-  const int n = 1 << level;
-  for (int i = 0; i < n; ++i) v[i] = tile[(g * D + (d << level) + i) * 33 + px];
-  for (int s = n; s > 1; s >>= 1)
-    for (int i = 0; i < (s >> 1); ++i) v[i] = (v[2 * i] + v[2 * i + 1]) * 0.5f;
+// mean over the 2^LV raw disparities [d<<LV, (d+1)<<LV) of channel g at pixel px, as repeated pair means
+// ((a+b)/2 of (a+b)/2 ...) — bitwise what repeated avg_pool2d computes.  tile rows are (disparity, channel):
+// row r = dd*G + g at pitch 33 floats, so 64 consecutive output elements (g fastest, then d) read 64 distinct banks.
+template <int LV>
+__device__ __forceinline__ float geo_pooled(const float* tile, int g, int d, int G, int px) {
+  constexpr int N = 1 << LV;
+  float v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = tile[(((d << LV) + i) * G + g) * 33 + px];
+#pragma unroll
+  for (int s2 = N; s2 > 1; s2 >>= 1)
+#pragma unroll
+    for (int i = 0; i < (s2 >> 1); ++i) v[i] = (v[2 * i] + v[2 * i + 1]) * 0.5f;
   return v[0];
 }
 
+// TG / TD: compile-time G / D (8 / 48 for IGEV: index arithmetic by constants) or 0 = runtime values.
+template <int TG, int TD>
 __global__ __launch_bounds__(256) void geo_pyramid_kernel(GeoParams p) {
   extern __shared__ float tile[];  // [G*D][33]
+  const int G = TG ? TG : p.G, D = TD ? TD : p.D;
   const int xt = blockIdx.x;
   const int row = blockIdx.y;  // b*H + y
   const int b = row / p.H;
   const int y = row - b * p.H;
   const int x0 = xt * 32;
-  const int GD = p.G * p.D;
+  const int GD = G * D;
   const long long plane = (long long)p.H * p.W;
-  const float* src = p.gev + (long long)b * GD * plane + (long long)y * p.W + x0;
-  for (int idx = threadIdx.x; idx < GD * 32; idx += 256) {
-    const int gd = idx >> 5, px = idx & 31;
-    tile[gd * 33 + px] = (x0 + px < p.W) ? src[(long long)gd * plane + px] : 0.f;
+  // staging: unconditional buffer loads, 16 in flight per thread (the `cond ? load : 0` form costs a branch and a
+  // full memory round trip per element); columns beyond W read 0 through the sentinel
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.gev + (long long)b * GD * plane), 0, (int)((long long)GD * plane * 4), 0x00020000);
+  const unsigned plane_u = (unsigned)plane;
+  const int px_l = threadIdx.x & 31, gd_l = threadIdx.x >> 5;  // 8 (g,d) rows x 32 pixels per pass
+  const unsigned base = (x0 + px_l < p.W) ? ((unsigned)(y * p.W + x0 + px_l)) * 4u : 0x70000000u;
+  constexpr int NB = 16;
+#pragma unroll 1
+  for (int r0 = 0; r0 < GD; r0 += 8 * NB) {
+    float v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v[i] = bload(rs, base + (unsigned)(r0 + i * 8 + gd_l) * plane_u * 4u);  // rows >= GD: out of range -> 0
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int gd = r0 + i * 8 + gd_l;  // source row g*D + d -> tile row d*G + g
+      const int g = gd / D, d = gd - g * D;
+      if (gd < GD) tile[(d * G + g) * 33 + px_l] = v[i];
+    }
   }
   __syncthreads();
   const int npx = min(32, p.W - x0);
   const long long pix0 = (long long)row * p.W + x0;
-  for (int lv = 0; lv < p.L; ++lv) {
-    const int Dl = p.D >> lv;
-    const int per = Dl * p.G;
-    float* dst = p.lvl[lv] + pix0 * per;
-    for (int idx = threadIdx.x; idx < npx * per; idx += 256) {
-      const int px = idx / per;
-      const int rem = idx - px * per;
-      const int d = rem / p.G, g = rem - d * p.G;
-      dst[idx] = geo_pooled(tile, g, d, lv, p.D, px);
-    }
+#define AS_GEO_LEVEL(LV)                                                          \
+  if ((LV) < p.L) {                                                               \
+    const int per = (D >> (LV)) * G;                                              \
+    float* dst = p.lvl[LV] + pix0 * per;                                          \
+    for (int idx = threadIdx.x; idx < npx * per; idx += 256) {                    \
+      const int px = idx / per;                                                   \
+      const int rem = idx - px * per;                                             \
+      const int d = rem / G, g = rem - d * G;                                     \
+      dst[idx] = geo_pooled<LV>(tile, g, d, G, px);                               \
+    }                                                                             \
   }
+  AS_GEO_LEVEL(0) AS_GEO_LEVEL(1) AS_GEO_LEVEL(2) AS_GEO_LEVEL(3)
+#undef AS_GEO_LEVEL
+  static_assert(AS_MAX_LEVELS == 4, "geo_pyramid: one AS_GEO_LEVEL per level");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -421,56 +447,97 @@ __global__ __launch_bounds__(256) void geo_pyramid_kernel(GeoParams p) {
 // Block = 64 consecutive x of one row; fl tile and fr tile(+D-1 halo) staged in LDS once, each
 // of the 4 waves owns a quarter of the disparities and keeps its accumulators in registers.
 // ------------------------------------------------------------------------------------------------
-constexpr int kGwcMaxDpt = 16;
+// Rewritten for round 1b: the first version staged its tiles with `cond ? load : 0` (a branch and a full
+// memory round trip per element, 66 per thread) and ran at 7 % of the HBM roofline.  Now: every fr element of
+// the block's (row, 64-column) slab (+D-1 halo, all C channels) is fetched with ONE batch of unconditional
+// buffer loads (zero padding from the range check) and parked in LDS; fl comes straight from global into
+// registers (a lane's own column, 256-B coalesced rows); each wave owns G/4 groups and keeps all D
+// accumulators of a lane in registers; the sliding window fr[c][x-d] is read four disparities at a time
+// with ds_read_b128 (neighbouring lanes hit the same addresses: LDS broadcast, no bank conflict).
+// ------------------------------------------------------------------------------------------------
+constexpr int kGwcNit = 48;  // staging rounds: C * (64 + DMAX) <= 48 * 256 elements per block
 
-template <int DPT>
-__global__ __launch_bounds__(256) void gwc_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
+// CG: channels per group; kGwcD = DMAX: disparities per lane held in registers (48 | 64, D <= DMAX)
+template <int CG, int kGwcD>
+__global__ __launch_bounds__(256, 3) void gwc_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
                                                   float* __restrict__ out, int B, int C, int H, int W, int D, int G) {
-  extern __shared__ float sm[];
-  const int FW = 64 + D - 1;
-  float* fl_s = sm;             // [C][64]
-  float* fr_s = sm + C * 64;    // [C][FW], local index = (x - x0) - d + (D-1)
+  extern __shared__ __attribute__((aligned(16))) float gwc_sm[];  // [C][FWP]: local index j <-> column x0 - (kGwcD - 1) - 1 + j ... see below
+  constexpr int FW = 64 + kGwcD;          // 112 columns: x0 - 48 .. x0 + 63 (one spare on the left keeps reads 16-B aligned)
+  constexpr int FWP = FW + 4;             // row pitch (floats): 116 -> rows start 16-B aligned, banks skewed by 20
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row = blockIdx.y;
   const int b = row / H;
   const int y = row - b * H;
   const int x0 = blockIdx.x * 64;
   const long long plane = (long long)H * W;
-  const float* flp = fl + (long long)b * C * plane + (long long)y * W;
-  const float* frp = fr + (long long)b * C * plane + (long long)y * W;
-  for (int idx = threadIdx.x; idx < C * 64; idx += 256) {
-    const int c = idx >> 6, lx = idx & 63;
-    fl_s[idx] = (x0 + lx < W) ? flp[(long long)c * plane + x0 + lx] : 0.f;
-  }
-  for (int idx = threadIdx.x; idx < C * FW; idx += 256) {
-    const int c = idx / FW, j = idx - c * FW;
-    const int xs = x0 + j - (D - 1);
-    fr_s[idx] = (xs >= 0 && xs < W) ? frp[(long long)c * plane + xs] : 0.f;
+  const unsigned kOOB = 0x7FFFFFF0u;
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(fr + (long long)b * C * plane), 0, (int)((long long)C * plane * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(fl + (long long)b * C * plane), 0, (int)((long long)C * plane * 4), 0x00020000);
+  // ---- stage fr: item = (channel c, column j), j = 0..FW-1 <-> x = x0 - kGwcD + j; batches of 16 loads in flight ----
+  const int items = C * FW;
+  const unsigned plane_u = (unsigned)plane, row_u = (unsigned)(y * W);
+  constexpr int NB = 16;
+#pragma unroll 1
+  for (int i0 = 0; i0 < kGwcNit; i0 += NB) {
+    if (i0 * 256 >= items) break;
+    float v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = tid + (i0 + i) * 256;
+      const int c = idx / FW, j = idx - c * FW;
+      const int xs = x0 - kGwcD + j;
+      const unsigned o = ((unsigned)c * plane_u + row_u + (unsigned)xs) * 4u;  // < 2^31 (host check); garbage when invalid
+      v[i] = bload(rr, (idx < items && xs >= 0 && xs < W) ? o : kOOB);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = tid + (i0 + i) * 256;
+      if (idx < items) {
+        const int c = idx / FW, j = idx - c * FW;
+        gwc_sm[c * FWP + j] = v[i];
+      }
+    }
   }
   __syncthreads();
-  const int lx = threadIdx.x & 63;
-  const int dg = threadIdx.x >> 6;
-  const int dpt = (D + 3) >> 2;
-  const int d0 = dg * dpt;
-  const int cg = C / G;
-  const float inv = 1.0f / (float)cg;
-  const int x = x0 + lx;
-  for (int g = 0; g < G; ++g) {
-    float acc[DPT];
+  // ---- this lane's column: wave w owns groups [w G/4, (w+1) G/4); the D accumulators in two halves of DH ----
+  const int gpw = G >> 2;
+  const int x = x0 + lane;
+  const unsigned lo = x < W ? (row_u + (unsigned)x) * 4u : 0x70000000u;
+  const unsigned pl4 = plane_u * 4u;
+  const float inv = 1.0f / (float)CG;
+  constexpr int DH = kGwcD / 2;
+#pragma unroll 1
+  for (int gi = 0; gi < gpw; ++gi) {
+    const int g = wave * gpw + gi;
+    float a[CG];
 #pragma unroll
-    for (int i = 0; i < DPT; ++i) acc[i] = 0.f;
-    for (int c = 0; c < cg; ++c) {
-      const float a = fl_s[(g * cg + c) * 64 + lx];
-      const float* r = fr_s + (g * cg + c) * FW + lx + (D - 1) - d0;
+    for (int c = 0; c < CG; ++c) a[c] = bload(rl, lo + (unsigned)(g * CG + c) * pl4);  // x >= W: sentinel + offset, any in-range garbage is never stored
+#pragma unroll 1
+    for (int hd = 0; hd < 2; ++hd) {
+      float acc[DH];
 #pragma unroll
-      for (int i = 0; i < DPT; ++i)
-        if (i < dpt && d0 + i < D) acc[i] += a * r[-i];
-    }
-    if (x < W) {
+      for (int d = 0; d < DH; ++d) acc[d] = 0.f;
+      // fr[c][x - d] lives at local column kGwcD + lane - d
+      const float* r0 = gwc_sm + (g * CG) * FWP + lane + kGwcD - hd * DH;
 #pragma unroll
-      for (int i = 0; i < DPT; ++i) {
-        const int d = d0 + i;
-        if (i < dpt && d < D) out[(((long long)b * G + g) * D + d) * plane + (long long)y * W + x] = acc[i] * inv;
+      for (int c = 0; c < CG; ++c) {
+        const float* r = r0 + c * FWP;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) acc[d] = fmaf(a[c], r[-d], acc[d]);
+        __builtin_amdgcn_sched_barrier(0);  // one channel's window at a time
       }
+      // stores through a descriptor over this batch element's [G,D,H,W] volume: columns beyond W carry the sentinel,
+      // disparities beyond D fall outside num_records of the group window
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(out + (((long long)b * G + g) * D) * plane), 0, (int)((long long)D * plane * 4), 0x00020000);
+      const unsigned so = x < W ? lo + (unsigned)(hd * DH) * pl4 : 0x70000000u;
+#pragma unroll
+      for (int d = 0; d < DH; ++d)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc[d] * inv), ro, (int)(so + (unsigned)d * pl4), 0, 0);
     }
   }
 }
@@ -553,10 +620,15 @@ int as_geo_pyramid(const float* gev, float* const* levels, int B, int G, int D, 
     AS_REQUIRE(levels[i], AS_ERR_BAD_ARG, "geo_pyramid: null level %d", i);
     p.lvl[i] = levels[i];
   }
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)geo_pyramid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  AS_REQUIRE((long long)G * D * H * W * 4 < 0x70000000ll, AS_ERR_BAD_SHAPE, "geo_pyramid: volume exceeds 1.75 GiB per batch element");
   dim3 grid((unsigned)as::cdiv(W, 32), (unsigned)(B * H));
-  hipLaunchKernelGGL(geo_pyramid_kernel, grid, dim3(256), lds, as::as_stream(stream), p);
+  if (G == 8 && D == 48) {
+    hipLaunchKernelGGL((geo_pyramid_kernel<8, 48>), grid, dim3(256), lds, as::as_stream(stream), p);
+  } else {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)geo_pyramid_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((geo_pyramid_kernel<0, 0>), grid, dim3(256), lds, as::as_stream(stream), p);
+  }
   return as::check_launch("geo_pyramid");
 }
 
@@ -564,19 +636,26 @@ int as_gwc_volume_fwd(const float* fl, const float* fr, float* out, int B, int C
   AS_REQUIRE(fl && fr && out, AS_ERR_BAD_ARG, "gwc: null pointer");
   AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0 && G > 0, AS_ERR_BAD_ARG, "gwc: non-positive size");
   AS_REQUIRE(C % G == 0, AS_ERR_BAD_SHAPE, "gwc: C=%d not divisible by G=%d", C, G);
-  AS_REQUIRE(D <= 4 * kGwcMaxDpt, AS_ERR_BAD_SHAPE, "gwc: D=%d above the supported %d", D, 4 * kGwcMaxDpt);
   AS_REQUIRE((long long)B * H <= 65535, AS_ERR_BAD_SHAPE, "gwc: B*H=%lld exceeds grid.y", (long long)B * H);
-  const size_t lds = (size_t)C * (64 + 64 + D - 1) * sizeof(float);
-  AS_REQUIRE(lds <= 160 * 1024, AS_ERR_BAD_SHAPE, "gwc: C=%d D=%d needs %zu B of LDS (> 160 KiB)", C, D, lds);
+  AS_REQUIRE(D >= 1 && D <= 64, AS_ERR_BAD_SHAPE, "gwc: D=%d (supported: 1..64)", D);
+  AS_REQUIRE(G % 4 == 0 && C % G == 0 && (C / G == 12 || C / G == 8 || C / G == 4), AS_ERR_BAD_SHAPE,
+             "gwc: C=%d G=%d (supported: G %% 4 == 0, C/G in {4, 8, 12})", C, G);
+  const int dmax = D <= 48 ? 48 : 64;
+  AS_REQUIRE((long long)C * (64 + dmax) <= kGwcNit * 256, AS_ERR_BAD_SHAPE, "gwc: C=%d too large for one LDS slab", C);
+  AS_REQUIRE((long long)C * H * W * 4 < 0x70000000ll && (long long)64 * H * W * 4 < 0x0FFFFFFFll, AS_ERR_BAD_SHAPE,
+             "gwc: a feature map / disparity slab too large for 32-bit buffer offsets");
+  const size_t lds = (size_t)C * (64 + dmax + 4) * sizeof(float);
   dim3 grid((unsigned)as::cdiv(W, 64), (unsigned)(B * H));
-  const int dpt = (D + 3) / 4;
-  if (dpt <= 12) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gwc_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gwc_kernel<12>, grid, dim3(256), lds, as::as_stream(stream), fl, fr, out, B, C, H, W, D, G);
-  } else {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gwc_kernel<kGwcMaxDpt>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gwc_kernel<kGwcMaxDpt>, grid, dim3(256), lds, as::as_stream(stream), fl, fr, out, B, C, H, W, D, G);
+  const int cg = C / G;
+  hipStream_t s = as::as_stream(stream);
+#define AS_GWC(CG_, DM_)                                                                                         \
+  {                                                                                                              \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gwc_kernel<CG_, DM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((gwc_kernel<CG_, DM_>), grid, dim3(256), lds, s, fl, fr, out, B, C, H, W, D, G);           \
   }
+  if (dmax == 48) { if (cg == 12) AS_GWC(12, 48) else if (cg == 8) AS_GWC(8, 48) else AS_GWC(4, 48) }
+  else { if (cg == 12) AS_GWC(12, 64) else if (cg == 8) AS_GWC(8, 64) else AS_GWC(4, 64) }
+#undef AS_GWC
   return as::check_launch("gwc_volume_fwd");
 }
 
