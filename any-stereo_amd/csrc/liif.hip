@@ -16,7 +16,18 @@ __global__ __launch_bounds__(256) void sf_norm_copy_kernel(const float* __restri
   const float* xp = x + b * C * plane + rem;
   float* op = out + b * (C + 8) * plane + rem;
   float ss = 0.f;
-  for (int c = 0; c < C; ++c) {
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {  // 8 independent loads in flight per lane
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = xp[(long long)(c + i) * plane];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      op[(long long)(c + i) * plane] = v[i];
+      ss += v[i] * v[i];
+    }
+  }
+  for (; c < C; ++c) {
     const float v = xp[(long long)c * plane];
     op[(long long)c * plane] = v;
     ss += v * v;
@@ -56,15 +67,21 @@ __global__ __launch_bounds__(256) void sf_affinity_kernel(const float* __restric
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  // sum_c (x_c(p)/n0) (x_c(q)/nq) = (sum_c x_c(p) x_c(q)) / (n0 nq): the 9 divisions per channel of the literal form
+  // (liif.py:439-441) leave the loop; the difference is one rounding of the final quotient
+#pragma unroll 2
   for (int c = 0; c < C; ++c) {
     const float* xc = xp + (long long)c * plane;
-    const float fc = xc[rem] / n0;
+    const float fc = xc[rem];
+    float nb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += fc * (xc[noff[j]] / nn[j]);
+    for (int j = 0; j < 8; ++j) nb[j] = xc[noff[j]];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(fc, nb[j], acc[j]);
   }
   float* op = out + (b * (C + 8) + C) * plane + rem;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) op[(long long)j * plane] = ok[j] ? fmaxf(acc[j], 0.f) : 0.f;
+  for (int j = 0; j < 8; ++j) op[(long long)j * plane] = ok[j] ? fmaxf(acc[j] / (n0 * nn[j]), 0.f) : 0.f;
 }
 
 // grid_sample(mode='nearest', align_corners=False) source index, evaluated with the same fp32
