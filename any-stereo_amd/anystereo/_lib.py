@@ -67,6 +67,7 @@ SIGNATURES = {
     "as_pool2x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "as_dwconv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_conv3d_k3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_deconv3d_k4s2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_interp_bilinear_ac": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_structure_feature": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

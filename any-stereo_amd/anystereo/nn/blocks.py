@@ -23,6 +23,19 @@ def conv3d_k3_ok(conv: nn.Module) -> bool:
             and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1)
 
 
+def deconv3d_k4s2_ok(conv: nn.Module) -> bool:
+    return (isinstance(conv, nn.ConvTranspose3d) and conv.kernel_size == (4, 4, 4) and conv.padding == (1, 1, 1)
+            and conv.stride == (2, 2, 2) and conv.dilation == (1, 1, 1) and conv.groups == 1
+            and conv.output_padding == (0, 0, 0))
+
+
+def deconv3d_fused(mod: nn.Module, conv: nn.ConvTranspose3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
+    cache = mod.__dict__.setdefault("_c3d_cache", {})
+    fc = cache.setdefault(id(conv), ops.FoldedConv("d3d"))
+    w, b = fc.get(conv, bn)
+    return ops.deconv3d_k4s2(x.contiguous(), w, b, act)
+
+
 def conv3d_fused(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
     cache = mod.__dict__.setdefault("_c3d_cache", {})
     fc = cache.setdefault(id(conv), ops.FoldedConv("c3d"))
@@ -54,8 +67,11 @@ class _ConvNormAct(nn.Module):
 
     def forward(self, x):
         norm = getattr(self, self.norm_attr) if self.use_norm else None
-        if fused_ok(x, self) and conv3d_k3_ok(self.conv) and (norm is None or isinstance(norm, nn.BatchNorm3d)):
-            return conv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
+        if fused_ok(x, self) and (norm is None or isinstance(norm, nn.BatchNorm3d)):
+            if conv3d_k3_ok(self.conv):
+                return conv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
+            if deconv3d_k4s2_ok(self.conv):
+                return deconv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
         x = self.conv(x)
         if self.use_norm:
             x = norm(x)

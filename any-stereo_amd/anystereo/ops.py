@@ -256,13 +256,16 @@ class PackedConv:
 
 
 @torch.no_grad()
-def fold_bn(conv, bn):
-    """(weight, bias) of the conv that equals eval-mode `bn(conv(x))`; scale computed in fp64, returned fp32."""
+def fold_bn(conv, bn, out_dim: int = 0):
+    """(weight, bias) of the conv that equals eval-mode `bn(conv(x))`; scale computed in fp64, returned fp32.
+    out_dim: the weight's output-channel dimension (0 for Conv*, 1 for ConvTranspose*)."""
     var, mean = bn.running_var.double(), bn.running_mean.double()
     g = torch.ones_like(var) if bn.weight is None else bn.weight.double()
     beta = torch.zeros_like(var) if bn.bias is None else bn.bias.double()
     s = g / torch.sqrt(var + bn.eps)
-    w = (conv.weight.double() * s.view(-1, *([1] * (conv.weight.dim() - 1)))).float()
+    shape = [1] * conv.weight.dim()
+    shape[out_dim] = -1
+    w = (conv.weight.double() * s.view(*shape)).float()
     b0 = torch.zeros_like(var) if conv.bias is None else conv.bias.double()
     return w, ((b0 - mean) * s + beta).float()
 
@@ -430,6 +433,22 @@ def conv3d_k3(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
     return out
 
 
+def deconv3d_k4s2(x, wpack, bias=None, act: int = L.ACT_NONE):
+    """act(ConvTranspose3d(k=4, s=2, p=1)(x) + bias); wpack = weight.permute(0,2,3,4,1) as [Cin,4,4,4,Cout]."""
+    _req(x, "x"), _req(wpack, "wpack")
+    b, cin, d, h, w = x.shape
+    if wpack.dim() != 5 or wpack.shape[0] != cin or tuple(wpack.shape[1:4]) != (4, 4, 4):
+        raise RuntimeError("deconv3d_k4s2: wpack must be [Cin,4,4,4,Cout]")
+    cout = wpack.shape[4]
+    if bias is not None:
+        _req(bias, "bias")
+    out = torch.empty((b, cout, 2 * d, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_deconv3d_k4s2(_p(x), _p(wpack), _p(bias), _p(out), b, cin, cout, d, h, w, act, _stream()),
+                "deconv3d_k4s2")
+    return out
+
+
 class FoldedConv:
     """Cache of the (BatchNorm-folded) weight / bias of a conv that runs on a direct kernel or stays on MIOpen;
     `layout` = None keeps the module's layout, 'c3d' gives the [Cin,27,Cout] pack of as_conv3d_k3."""
@@ -445,9 +464,11 @@ class FoldedConv:
             if bn is None:
                 w, b = conv.weight.detach().float(), None if conv.bias is None else conv.bias.detach().float().contiguous()
             else:
-                w, b = fold_bn(conv, bn)
+                w, b = fold_bn(conv, bn, out_dim=1 if self.layout == "d3d" else 0)
             if self.layout == "c3d":
                 w = w.permute(1, 2, 3, 4, 0).reshape(w.shape[1], 27, w.shape[0])
+            elif self.layout == "d3d":  # ConvTranspose3d weight [Cin,Cout,4,4,4] -> [Cin,4,4,4,Cout]
+                w = w.permute(0, 2, 3, 4, 1)
             self._wb, self._key = (w.contiguous(), b), key
         return self._wb
 

@@ -133,6 +133,82 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose3d kernel 4, stride 2, padding 1 (all dims): out[o] = sum_{i,k : o = 2 i - 1 + k} in[i] w[k].
+// Per dimension an output position takes exactly two taps: k = (o+1)%2 + {0, 2} from i = (o + 1 - k) / 2.
+// A lane owns the output PAIR x = 2 px, 2 px + 1 (they share the inputs px-1, px, px+1), the block a fixed
+// (z, y), so the tap set is wave-uniform and the weights are SGPR operands: 3 loads feed 4*CT FMAs.
+// wpack [Cin][4][4][4][Cout] (= weight [Cin,Cout,4,4,4] with Cout moved last).
+// ------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void deconv3d_k4s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int Cin, int Cout, int D, int H, int W, int act) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const int groups = Cout / CT;
+  int id = blockIdx.z;
+  const int g = id % groups;
+  id /= groups;
+  const int oz = id % Do;
+  const int b = id / Do;
+  const int oy = blockIdx.y * 4 + wave;
+  const int px = blockIdx.x * 64 + lane;  // input column; outputs 2 px and 2 px + 1
+  if (oy >= Ho) return;
+  const long long plane = (long long)H * W;
+  const long long vol = (long long)D * plane;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * Cin * vol), 0, (int)((long long)Cin * vol * 4), 0x00020000);
+  unsigned xo[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ix = px + k - 1;
+    xo[k] = (px < W && ix >= 0 && ix < W) ? (unsigned)(ix * 4) : kOOB;
+  }
+  float a0[CT], a1[CT];  // outputs 2 px (even) and 2 px + 1 (odd)
+#pragma unroll
+  for (int j = 0; j < CT; ++j) { a0[j] = bias ? bias[g * CT + j] : 0.f; a1[j] = a0[j]; }
+  const int kz0 = (oz + 1) & 1, ky0 = (oy + 1) & 1;
+  const float* wg = wp + g * CT;
+  for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+    for (int tz = 0; tz < 2; ++tz) {
+      const int kz = kz0 + 2 * tz;
+      const int iz = (oz + 1 - kz) >> 1;  // exact: same parity
+      if (iz < 0 || iz >= D) continue;
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        const int ky = ky0 + 2 * ty;
+        const int iy = (oy + 1 - ky) >> 1;
+        if (iy < 0 || iy >= H) continue;
+        const unsigned so = (unsigned)((((long long)ci * D + iz) * H + iy) * W * 4);
+        const float vm = bload(rs, xo[0], so), v0 = bload(rs, xo[1], so), vp = bload(rs, xo[2], so);
+        const float* wt = wg + (long long)(((ci * 4 + kz) * 4 + ky) * 4) * Cout;  // [kx][co]
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          // even output 2 px: (ix = px, kx = 1), (ix = px - 1, kx = 3);  odd 2 px + 1: (ix = px + 1, kx = 0), (ix = px, kx = 2)
+          a0[j] = fmaf(v0, wt[1 * Cout + j], a0[j]);
+          a0[j] = fmaf(vm, wt[3 * Cout + j], a0[j]);
+          a1[j] = fmaf(vp, wt[0 * Cout + j], a1[j]);
+          a1[j] = fmaf(v0, wt[2 * Cout + j], a1[j]);
+        }
+      }
+    }
+  }
+  if (px < W) {
+    const long long ovol = (long long)Do * Ho * Wo;
+    float* o = out + ((long long)b * Cout + g * CT) * ovol + ((long long)oz * Ho + oy) * Wo + 2 * px;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      f32x2 v;
+      v.x = act_apply(a0[j], act);
+      v.y = act_apply(a1[j], act);
+      *reinterpret_cast<f32x2*>(o + j * ovol) = v;  // Wo even: 8-B aligned
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -170,6 +246,23 @@ int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* o
   else { if (ct == 8) AS_C3D(2, 8); else AS_C3D(2, 1); }
 #undef AS_C3D
   return as::check_launch("conv3d_k3");
+}
+
+int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, float* out,
+                     int B, int Cin, int Cout, int D, int H, int W, int act, void* stream) {
+  AS_REQUIRE(x && wpack && out, AS_ERR_BAD_ARG, "deconv3d_k4s2: null pointer");
+  AS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "deconv3d_k4s2: non-positive size");
+  AS_REQUIRE(act >= AS_ACT_NONE && act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "deconv3d_k4s2: act=%d", act);
+  AS_REQUIRE((long long)Cin * D * H * W * 4 < (long long)kOOB, AS_ERR_BAD_SHAPE, "deconv3d_k4s2: input exceeds 1.75 GiB per batch element");
+  AS_REQUIRE((reinterpret_cast<uintptr_t>(out) & 7) == 0, AS_ERR_BAD_ARG, "deconv3d_k4s2: out not 8-B aligned");
+  const int ct = (Cout % 8 == 0) ? 8 : 1;
+  const long long gz = (long long)B * 2 * D * (Cout / ct);
+  AS_REQUIRE(gz <= 65535, AS_ERR_BAD_SHAPE, "deconv3d_k4s2: B*Do*groups=%lld exceeds the grid limit", gz);
+  const dim3 grid((unsigned)as::cdiv(W, 64), (unsigned)as::cdiv(2 * H, 4), (unsigned)gz);
+  hipStream_t s = as::as_stream(stream);
+  if (ct == 8) hipLaunchKernelGGL((deconv3d_k4s2_kernel<8>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, act);
+  else hipLaunchKernelGGL((deconv3d_k4s2_kernel<1>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, act);
+  return as::check_launch("deconv3d_k4s2");
 }
 
 }  // extern "C"

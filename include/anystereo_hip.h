@@ -183,6 +183,11 @@ int as_dwconv3x3(const float* x, const float* weight, const float* bias, const f
                  int B, int C, int H, int W, int stride, int act, void* stream);
 int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* out,
                  int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
+/*   as_deconv3d_k4s2: ConvTranspose3d kernel 4, stride 2, padding 1 (all dims) — the hourglass up-convolutions
+ *     (continuous_IGEVstereo.py:43-51).  x [B,Cin,D,H,W]; wpack [Cin,4,4,4,Cout] (= weight [Cin,Cout,4,4,4] with
+ *     Cout moved last); bias [Cout]|NULL -> out [B,Cout,2D,2H,2W]. */
+int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, float* out,
+                     int B, int Cin, int Cout, int D, int H, int W, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a12/a13  cosine affinity to the 8 neighbours, written straight into channels [C, C+8) of the

@@ -303,6 +303,18 @@ def test_conv3d_k3(b, cin, cout, d, h, w, stride, act):
     close(out, ref, 2e-6, 2e-6, "conv3d_k3")
 
 
+@pytest.mark.parametrize("b,cin,cout,d,h,w,act", [(1, 16, 8, 4, 6, 70, 0), (2, 8, 16, 3, 5, 33, 5), (1, 5, 3, 2, 3, 9, 1)])
+def test_deconv3d_k4s2(b, cin, cout, d, h, w, act):
+    from anystereo import ops
+    x = U((b, cin, d, h, w), 185, -2, 2)
+    wt = U((cin, cout, 4, 4, 4), 186) * (3.0 / (cin * 8)) ** 0.5
+    bias = U((cout,), 187) * 0.1
+    ref = torch.nn.functional.conv_transpose3d(x.double(), wt.double(), bias.double(), stride=2, padding=1)
+    ref = {0: ref, 1: ref.relu(), 5: torch.nn.functional.leaky_relu(ref, 0.01)}[act]
+    out = ops.deconv3d_k4s2(x.to(DEV), wt.permute(0, 2, 3, 4, 1).contiguous().to(DEV), bias.to(DEV), act)
+    close(out, ref, 2e-6, 2e-6, "deconv3d_k4s2")
+
+
 def _randomize_bn(mod, seed):
     with torch.no_grad():
         for i, m in enumerate(mm for mm in mod.modules() if isinstance(mm, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))):
@@ -329,7 +341,9 @@ def test_backbone_blocks_fused_inference(precision):
     for k, (mod, shape) in enumerate([(_InvRes(24, 24, 1), (2, 24, 17, 37)), (_InvRes(16, 24, 2), (1, 16, 18, 40)),
                                       (_DSConv(32, 16, 1), (1, 32, 9, 70)), (_InvRes(64, 64, 1), (1, 64, 5, 9)),
                                       (BasicConv(8, 16, is_3d=True, kernel_size=3, padding=1, stride=2), (1, 8, 6, 9, 33)),
-                                      (BasicConv(16, 16, is_3d=True, kernel_size=3, padding=1, stride=1), (1, 16, 4, 6, 21))]):
+                                      (BasicConv(16, 16, is_3d=True, kernel_size=3, padding=1, stride=1), (1, 16, 4, 6, 21)),
+                                      (BasicConv(16, 8, deconv=True, is_3d=True, kernel_size=(4, 4, 4), padding=(1, 1, 1),
+                                                 stride=(2, 2, 2)), (1, 16, 3, 5, 21))]):
         mod = mod.eval()
         fill_module_deterministic(mod, 7 + k)
         _randomize_bn(mod, 200 + 40 * k)
