@@ -71,6 +71,7 @@ SIGNATURES = {
     "as_interp_bilinear_ac": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_structure_feature": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_gather_mlp1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_convex_upsample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 

@@ -46,12 +46,14 @@ class MLP(nn.Module):
         self.layers = nn.Sequential(*layers)
         self._packs = [ops.PackedConv() for m in self.layers if isinstance(m, nn.Linear)]
 
-    def forward_cm(self, x_cm: torch.Tensor) -> torch.Tensor:
-        """x_cm [B, in_dim, Q] channel-major -> [B, out_dim, Q]."""
+    def forward_cm(self, x_cm: torch.Tensor, start: int = 0) -> torch.Tensor:
+        """x_cm [B, C, Q] channel-major = input of Linear layer `start` -> [B, out_dim, Q]."""
         b, c, q = x_cm.shape
         x = x_cm.view(b, c, 1, q)
         lin = [m for m in self.layers if isinstance(m, nn.Linear)]
         for i, (m, pk) in enumerate(zip(lin, self._packs)):
+            if i < start:
+                continue
             act = L.ACT_RELU if i + 1 < len(lin) else L.ACT_NONE
             x = ops.conv2d([x], pk.get([m.weight], [m.bias]), act=act)
         return x.view(b, -1, q)
@@ -135,21 +137,46 @@ class liif_out_multi_scale_Training(nn.Module):
         with scope("structure_feature"):
             sfs = [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
         ctot = sum(s.shape[1] + 2 for s in sfs)
+        lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
+        pre = self._first_layer_lowres(sfs, lin[0]) if (self.fused_first_layer and len(sfs) <= 2 and len(lin) > 1) else None
         # queries are processed in slabs of <= 2^20 so the [B,228,Q] latent stays below 1 GB (Middlebury-F has
         # 5.7 M queries = 5.2 GB if materialised at once, liif.py:675) and inside the kernels' 32-bit offsets
         qmax = self.query_chunk
         if q <= qmax:
-            return self._mask_logits(sfs, coord, ctot)
+            return self._mask_logits(sfs, coord, ctot, pre)
         out = torch.empty((b, self.outputdim, q), device=coord.device, dtype=torch.float32)
         for q0 in range(0, q, qmax):
             q1 = min(q, q0 + qmax)
-            out[:, :, q0:q1] = self._mask_logits(sfs, coord[:, q0:q1].contiguous(), ctot)
+            out[:, :, q0:q1] = self._mask_logits(sfs, coord[:, q0:q1].contiguous(), ctot, pre)
         return out
 
     query_chunk = 1 << 20
+    # The first Linear layer commutes with the nearest gather: its feature blocks are applied once per LOW-resolution
+    # pixel (two 1x1 convs) and the per-query kernel only gathers + adds (csrc/liif.hip, as_liif_gather_mlp1).
+    fused_first_layer = True
 
-    def _mask_logits(self, sfs, coord, ctot):
+    def _first_layer_lowres(self, sfs, lin0):
+        if not hasattr(self, "_pk_u"):
+            self._pk_u = [ops.PackedConv() for _ in range(2)]
+        us, rel_cols, off = [], [], 0
+        with scope("liif_mlp"):
+            for s, pk in zip(sfs, self._pk_u):
+                c = s.shape[1]
+                us.append(ops.conv2d([s], pk.get([lin0.weight], [None], transform=lambda w, o=off, c=c: w[:, o:o + c])))
+                rel_cols.append(off + c)
+                off += c + 2
+            # slices + cat only: index tensors would need a host->device copy, which a graph capture forbids
+            wrel = torch.cat([lin0.weight.detach()[:, o:o + 2] for o in rel_cols], dim=1).float().contiguous()
+        return us, wrel, None if lin0.bias is None else lin0.bias.detach().float().contiguous()
+
+    def _mask_logits(self, sfs, coord, ctot, pre=None):
         b, q = coord.shape[:2]
+        if pre is not None:
+            us, wrel, b1 = pre
+            with scope("liif_gather"):
+                h1 = ops.liif_gather_mlp1(us[0], us[1] if len(us) > 1 else None, coord, wrel, b1)
+            with scope("liif_mlp"):
+                return self.imnet.forward_cm(h1, start=1)
         latent = torch.empty((b, ctot, q), device=coord.device, dtype=torch.float32)
         off = 0
         with scope("liif_gather"):

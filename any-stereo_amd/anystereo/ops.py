@@ -512,6 +512,28 @@ def liif_gather(feat: torch.Tensor, coord: torch.Tensor, latent: torch.Tensor, l
                 "liif_gather")
 
 
+def liif_gather_mlp1(u0, u1, coord, wrel, bias):
+    """relu(u0[nearest0(q)] + u1[nearest1(q)] + wrel·rel(q) + bias) -> [B,C,Q]: gather + first MLP layer (see the header)."""
+    _req(u0, "u0"), _req(coord, "coord"), _req(wrel, "wrel")
+    b, c, h0, w0 = u0.shape
+    q = coord.shape[1]
+    h1 = w1 = 0
+    if u1 is not None:
+        _req(u1, "u1")
+        if u1.shape[0] != b or u1.shape[1] != c:
+            raise RuntimeError("liif_gather_mlp1: u1 must be [B,C,H1,W1]")
+        h1, w1 = u1.shape[2], u1.shape[3]
+    if tuple(coord.shape) != (b, q, 2) or tuple(wrel.shape) != (c, 2 * (1 if u1 is None else 2)):
+        raise RuntimeError("liif_gather_mlp1: coord must be [B,Q,2] and wrel [C,2*n_src]")
+    if bias is not None:
+        _req(bias, "bias")
+    out = torch.empty((b, c, q), device=u0.device, dtype=torch.float32)
+    with torch.cuda.device(u0.device):
+        L.check(L.load().as_liif_gather_mlp1(_p(u0), _p(u1), _p(coord), _p(wrel), _p(bias), _p(out), b, c, h0, w0, h1, w1, q,
+                                             _stream()), "liif_gather_mlp1")
+    return out
+
+
 def convex_upsample(disp, mask, coord, scale=None, mask_is_logits=False):
     """(softmax(mask) ·) disp[3x3 nbr of the nearest low-res pixel] -> [B,1,Q]; with `scale` [B] the
     disparity is multiplied by 4*scale_b on the fly

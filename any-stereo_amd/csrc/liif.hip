@@ -120,6 +120,77 @@ __global__ __launch_bounds__(256) void liif_gather_kernel(GatherParams p) {
   lp[(long long)(p.C + 1) * p.Q] = __fmul_rn(__fsub_rn(cc, qx), (float)p.W);
 }
 
+// ---- a14 + first layer of a15 fused -----------------------------------------------------------
+// The first MLP layer is linear in the latent [q_feat0 | rel0 | q_feat1 | rel1] and q_feat_i is a nearest GATHER
+// of a low-resolution map, so  W1·latent(q) = (W1a·sf0)[n0(q)] + (W1b·sf1)[n1(q)] + Wrel·rel(q):  the two big
+// products are evaluated once per LOW-resolution pixel (u0 = W1a·sf0, u1 = W1b·sf1, plain 1x1 convs: 2.8 GFLOP
+// instead of 30 GFLOP at 960x540) and this kernel only gathers, adds the 4-term relative-coordinate product and the
+// bias, applies ReLU and writes the hidden layer [B,C,Q] — the 228-channel latent is never materialised.
+// Same function as liif.py:108-137 + the first Linear/ReLU of liif.py:9-25; the summation order differs.
+struct Mlp1Params {
+  const float* u[2];
+  const float* coord;
+  const float* wrel;  // [C][2*n_src]: columns (rel_row, rel_col) per source
+  const float* bias;  // [C] or null
+  float* out;         // [B,C,Q]
+  int B, C, Q, n_src;
+  int H[2], W[2];
+  float lo, hi;
+  float c0y[2], sy[2], c0x[2], sx[2];
+};
+
+__global__ __launch_bounds__(256) void liif_mlp1_gather_kernel(Mlp1Params p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)p.B * p.Q) return;
+  const int b = (int)(t / p.Q);
+  const int q = (int)(t - (long long)b * p.Q);
+  const float cr = p.coord[t * 2 + 0], cc = p.coord[t * 2 + 1];
+  const float crc = fminf(fmaxf(cr, p.lo), p.hi), ccc = fminf(fmaxf(cc, p.lo), p.hi);
+  const float* up[2];
+  long long plane[2];
+  float rel[4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (s < p.n_src) {
+      const int iy = nearest_idx(crc, p.H[s]), ix = nearest_idx(ccc, p.W[s]);
+      plane[s] = (long long)p.H[s] * p.W[s];
+      up[s] = p.u[s] + (long long)b * p.C * plane[s] + (long long)iy * p.W[s] + ix;
+      const float qy = __fadd_rn(p.c0y[s], __fmul_rn(p.sy[s], (float)iy));
+      const float qx = __fadd_rn(p.c0x[s], __fmul_rn(p.sx[s], (float)ix));
+      rel[2 * s] = __fmul_rn(__fsub_rn(cr, qy), (float)p.H[s]);
+      rel[2 * s + 1] = __fmul_rn(__fsub_rn(cc, qx), (float)p.W[s]);
+    } else {
+      up[s] = p.u[0];
+      plane[s] = 0;
+      rel[2 * s] = rel[2 * s + 1] = 0.f;
+    }
+  }
+  float* op = p.out + (long long)b * p.C * p.Q + q;
+  const int nw = 2 * p.n_src;
+  for (int c0 = 0; c0 < p.C; c0 += 8) {  // 16 gathers in flight per lane; wrel / bias are wave-uniform (scalar loads)
+    float a0[8], a1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;
+      a0[i] = c < p.C ? up[0][(long long)c * plane[0]] : 0.f;
+      a1[i] = (c < p.C && p.n_src > 1) ? up[1][(long long)c * plane[1]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i;
+      if (c < p.C) {
+        float v = a0[i] + a1[i];
+        const float* w = p.wrel + c * nw;
+        v = fmaf(w[0], rel[0], v);
+        v = fmaf(w[1], rel[1], v);
+        if (p.n_src > 1) { v = fmaf(w[2], rel[2], v); v = fmaf(w[3], rel[3], v); }
+        if (p.bias) v += p.bias[c];
+        op[(long long)c * p.Q] = fmaxf(v, 0.f);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_convex_kernel(const float* __restrict__ disp, const float* __restrict__ scale,
                                                              const float* __restrict__ mask, const float* __restrict__ coord,
                                                              float* __restrict__ out, int B, int H, int W, int Q, int logits,
@@ -188,6 +259,24 @@ int as_liif_gather(const float* feat, const float* coord, float* latent, int B, 
   p.c0x = (float)(-1.0 + 1.0 / W); p.sx = (float)(2.0 * (1.0 / W));
   hipLaunchKernelGGL(liif_gather_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream), p);
   return as::check_launch("liif_gather");
+}
+
+int as_liif_gather_mlp1(const float* u0, const float* u1, const float* coord, const float* wrel, const float* bias, float* out,
+                        int B, int C, int H0, int W0, int H1, int W1, int Q, void* stream) {
+  AS_REQUIRE(u0 && coord && wrel && out, AS_ERR_BAD_ARG, "liif_gather_mlp1: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H0 > 0 && W0 > 0 && Q > 0, AS_ERR_BAD_ARG, "liif_gather_mlp1: non-positive size");
+  AS_REQUIRE(!u1 || (H1 > 0 && W1 > 0), AS_ERR_BAD_ARG, "liif_gather_mlp1: second source without a size");
+  Mlp1Params p{};
+  p.u[0] = u0; p.u[1] = u1; p.coord = coord; p.wrel = wrel; p.bias = bias; p.out = out;
+  p.B = B; p.C = C; p.Q = Q; p.n_src = u1 ? 2 : 1;
+  p.H[0] = H0; p.W[0] = W0; p.H[1] = u1 ? H1 : 1; p.W[1] = u1 ? W1 : 1;
+  p.lo = (float)(-1.0 + 1e-6); p.hi = (float)(1.0 - 1e-6);
+  for (int s = 0; s < 2; ++s) {
+    p.c0y[s] = (float)(-1.0 + 1.0 / p.H[s]); p.sy[s] = (float)(2.0 * (1.0 / p.H[s]));
+    p.c0x[s] = (float)(-1.0 + 1.0 / p.W[s]); p.sx[s] = (float)(2.0 * (1.0 / p.W[s]));
+  }
+  hipLaunchKernelGGL(liif_mlp1_gather_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("liif_gather_mlp1");
 }
 
 int as_convex_upsample(const float* disp, const float* scale, const float* mask, const float* coord, float* out,

@@ -209,6 +209,13 @@ int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, floa
 int as_structure_feature(const float* x, float* out, float* ws /* [B,H,W] scratch */, int B, int C, int H, int W, void* stream);
 int as_liif_gather(const float* feat, const float* coord, float* latent,
                    int B, int C, int H, int W, int Q, int lat_ctot, int lat_coff, void* stream);
+/* a14 + first layer of a15 fused: out[b,c,q] = relu(u0[b,c,n0(q)] + u1[b,c,n1(q)] + wrel[c,:]·rel(q) + bias[c]) where
+ *   u_i = W1_i·feat_i are the first Linear layer's blocks applied at LOW resolution (1x1 as_conv2d), n_i the nearest
+ *   source pixel and rel(q) = (rel_row0, rel_col0, rel_row1, rel_col1) as in as_liif_gather (liif.py:108-137 followed
+ *   by the first Linear + ReLU of the MLP, liif.py:9-25).  u0 [B,C,H0,W0]; u1 [B,C,H1,W1] or NULL; wrel [C,2*n_src];
+ *   bias [C]|NULL; coord [B,Q,2] -> out [B,C,Q]. */
+int as_liif_gather_mlp1(const float* u0, const float* u1, const float* coord, const float* wrel, const float* bias, float* out,
+                        int B, int C, int H0, int W0, int H1, int W1, int Q, void* stream);
 int as_convex_upsample(const float* disp, const float* scale, const float* mask, const float* coord,
                        float* out, int B, int H, int W, int Q, int mask_is_logits, void* stream);
 

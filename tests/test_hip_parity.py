@@ -420,6 +420,22 @@ def test_liif_golden(golden, precision):
         mask_c = up([g["x4"].to(DEV), g["x2"].to(DEV)], g["coord"].to(DEV), torch.tensor([[1.5]], device=DEV))
     close(mask_c, mask, 2e-6, 2e-6, "query-slab processing")
     up.query_chunk = 1 << 20
+    up.fused_first_layer = False  # literal order: gather the 228-channel latent, then all four Linear layers per query
+    with torch.no_grad():
+        mask_l = up([g["x4"].to(DEV), g["x2"].to(DEV)], g["coord"].to(DEV), torch.tensor([[1.5]], device=DEV))
+    close(mask_l, g["mask"], 2e-5, 2e-5, "liif mask logits (unfused first layer)")
+    close(mask_l, mask, 1e-5, 1e-5, "first layer at low resolution == per-query")
+    up.fused_first_layer = True
+    with torch.no_grad():  # single-source form (stem_2x absent)
+        u1 = liif_out_multi_scale_Training(encoder_dim=176, mlphidden_list=[128, 64, 64], pos_dim=0, unfold="with_v2ISU",
+                                           affinity_settings={"win_w": 3, "win_h": 3, "dilation": [1, 2, 4, 8]},
+                                           number_input=1, chanels=[176]).eval()
+        fill_module_deterministic(u1, base_seed=9, gain=2.0)
+        u1 = u1.to(DEV)
+        ma = u1([g["x4"].to(DEV)], g["coord"].to(DEV), torch.tensor([[1.5]], device=DEV))
+        u1.fused_first_layer = False
+        mb = u1([g["x4"].to(DEV)], g["coord"].to(DEV), torch.tensor([[1.5]], device=DEV))
+    close(ma, mb, 1e-5, 1e-5, "single-source fused first layer")
     coord = g["coord"].clone().to(DEV)
     cu = context_upsample_multiscale_train((g["dlow"] * 4.0 * 1.5).to(DEV), torch.softmax(g["mask"], 1).to(DEV), coord)
     close(cu, g["convex"], 1e-5, 1e-5, "convex upsample (reference contract)")
