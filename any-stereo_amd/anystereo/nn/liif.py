@@ -159,7 +159,7 @@ class liif_out_multi_scale_Training(nn.Module):
         if not hasattr(self, "_pk_u"):
             self._pk_u = [ops.PackedConv() for _ in range(2)]
         us, rel_cols, off = [], [], 0
-        with scope("liif_mlp"):
+        with scope("liif_mlp_lowres"):
             for s, pk in zip(sfs, self._pk_u):
                 c = s.shape[1]
                 us.append(ops.conv2d([s], pk.get([lin0.weight], [None], transform=lambda w, o=off, c=c: w[:, o:o + c])))

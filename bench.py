@@ -61,7 +61,8 @@ def algorithmic(B, h, w, Q, iters, C=96, L=2, G=8, D=48, r=4):
         "gru04_zr_conv": {"bound": "mfma", "flops": 2 * P * 384 * 9 * 256},
         "gru04_q_conv": {"bound": "mfma", "flops": 2 * P * 384 * 9 * 128},
         "disp_head_conv1": {"bound": "mfma", "flops": 2 * P * 128 * 9 * 256},
-        "liif_mlp": {"bound": "mfma", "flops": 2 * Q * B * (228 * 128 + 128 * 64 + 64 * 64 + 64 * 9)},
+        # layers 2..4 at query resolution (the first Linear layer runs at low resolution: liif_mlp_lowres)
+        "liif_mlp": {"bound": "mfma", "flops": 2 * Q * B * (128 * 64 + 64 * 64 + 64 * 9)},
     }
 
 
