@@ -45,7 +45,6 @@ struct ConvParams {
   int out_ctot, out_coff;
   int B, H, W, Cin, Cout, Cout_pad, act;
   int tiles_x, tiles_y, n_tiles, chunks;
-  int dbg;  // timing-only ablation switches (env AS_CONV_DBG; results are wrong when non-zero)
   int xcd_map;  // conv_split_kernel: XCD-aware block order (channel tiles of one pixel tile on the same XCD)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
@@ -818,11 +817,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
   }
-      if (!(p.dbg & 4)) {
-        AS_SPLIT_LDOPS(0, 0)
-        AS_SPLIT_STEP(0) AS_SPLIT_STEP(1) AS_SPLIT_STEP(2) AS_SPLIT_STEP(3) AS_SPLIT_STEP(4)
-        AS_SPLIT_STEP(5) AS_SPLIT_STEP(6) AS_SPLIT_STEP(7) AS_SPLIT_STEP(8)
-      }
+      AS_SPLIT_LDOPS(0, 0)
+      AS_SPLIT_STEP(0) AS_SPLIT_STEP(1) AS_SPLIT_STEP(2) AS_SPLIT_STEP(3) AS_SPLIT_STEP(4)
+      AS_SPLIT_STEP(5) AS_SPLIT_STEP(6) AS_SPLIT_STEP(7) AS_SPLIT_STEP(8)
 #undef AS_SPLIT_STEP
 #undef AS_SPLIT_MFMA_C
 #undef AS_SPLIT_LDOPS
@@ -1021,11 +1018,6 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(d->wpack && d->out, AS_ERR_BAD_ARG, "conv2d: null wpack/out");
   AS_REQUIRE((reinterpret_cast<uintptr_t>(d->wpack) & 15) == 0, AS_ERR_BAD_ARG, "conv2d: wpack not 16-B aligned");
   ConvParams p{};
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("AS_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
-  }
   int csum = 0;
   for (int i = 0; i < d->n_src; ++i) {
     AS_REQUIRE(d->src[i] && d->src_c[i] > 0, AS_ERR_BAD_ARG, "conv2d: source %d null or empty", i);

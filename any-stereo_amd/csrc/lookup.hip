@@ -242,6 +242,113 @@ __global__ __launch_bounds__(256) void lookup_fwd_coop_kernel(LookupParams p) {
   }
 }
 
+// ---- quad-per-pixel forward (the shipped path for r = 4 with (G, L) = (8, 2) or (0, 4)) -------------------
+// Ablation of the cooperative kernel above at 960x540 (14.9 us): launch + disparity 3.5 us, gather phase 6.2 us of
+// which 5.2 us remain with every load disabled — the (pixel, tap, quad) work items cost ~150 VALU instructions each
+// in index arithmetic (64-bit row offsets, three divisions, tap weights evaluated twice) — and 5.2 us in a store
+// loop that exposed one LDS latency per channel.  Here four lanes share a pixel: lane (px, sub) owns ONE window —
+// (level, channel quad) of the geometry volume, i.e. 10 consecutive taps x 4 channels = ten 16-B loads 32 B apart
+// (the sibling quad's lane reads the interleaved other half of the same 320-B run), plus, for quad 0, the 10-tap
+// correlation window of that level — so floor/frac and the row offset are computed once per lane, all loads are in
+// flight together, and the 36 (+9) results go to the LDS tile [channel][pixel]; the tile leaves as 256-B NCHW rows,
+// eight LDS reads in flight per lane.  Interpolation arithmetic is identical to the kernels above.
+template <int G>
+__global__ __launch_bounds__(256) void lookup_fwd_quad_kernel(LookupParams p) {
+  constexpr int R = 4, K = 9, NW = 10;
+  constexpr int PX = 64, TS = PX + 1;
+  extern __shared__ float tile[];  // [CH][TS]
+  const int tid = threadIdx.x;
+  const int px = tid >> 2, sub = tid & 3;
+  const long long pix0 = (long long)blockIdx.x * PX;
+  const long long pix = pix0 + px;
+  const bool live = pix < p.P;
+  const int level = G ? (sub >> 1) : sub;
+  const int q = G ? (sub & 1) : 0;
+  const unsigned kOOB = 0x7FFFFFF0u;
+  const float d0 = pix < p.P ? p.disp[pix] : 0.f;
+  const float ds = ldexpf(d0, -level);  // disp / 2**level (exact)
+  f32x4 gw[NW];
+  float cw[NW];
+  float xb = 0.f;
+  int ci0 = 0;
+  if (G) {
+    const int Dl = p.D >> level;
+    const int i0 = (int)floorf(ds);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.geo[level], 0, p.geo_bytes[level], 0x00020000);
+    const unsigned rowoff = ((unsigned)pix * (unsigned)Dl * G + 4u * q) * 4u;  // < 2^31 (host check)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int dd = i0 - R + j;
+      const unsigned off = (live && dd >= 0 && dd < Dl) ? rowoff + (unsigned)dd * (G * 4) : kOOB;
+      gw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    }
+  }
+  const bool do_corr = (q == 0);
+  {
+    const int Wl = p.W2 >> level;
+    const int x = (int)((pix % p.HW) % p.W);
+    xb = ldexpf((float)x, -level) - ds;  // coords/2**i - disp/2**i
+    ci0 = (int)floorf(xb);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.corr[level], 0, p.corr_bytes[level], 0x00020000);
+    const unsigned rowoff = (unsigned)pix * (unsigned)Wl * 4u;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int dd = ci0 - R + j;
+      const unsigned off = (live && do_corr && dd >= 0 && dd < Wl) ? rowoff + (unsigned)dd * 4u : kOOB;
+      cw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)off, 0, 0));
+    }
+  }
+  const int chbase = level * K * (G + 1);
+  if (G) {
+    const int i0 = (int)floorf(ds);
+    float* t = tile + (chbase + (4 * q) * K) * TS + px;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float tt;
+      bool bump;
+      tap_weights(ds, i0, k - R, tt, bump);
+      const float a = bump ? 0.f : 1.f - tt, c = bump ? 1.f : tt;
+      const f32x4 v = a * gw[k] + c * gw[k + 1];
+      t[(0 * K + k) * TS] = v.x;
+      t[(1 * K + k) * TS] = v.y;
+      t[(2 * K + k) * TS] = v.z;
+      t[(3 * K + k) * TS] = v.w;
+    }
+  }
+  if (do_corr) {
+    float* t = tile + (chbase + G * K) * TS + px;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float tt;
+      bool bump;
+      tap_weights(xb, ci0, k - R, tt, bump);
+      const float a = bump ? 0.f : 1.f - tt, c = bump ? 1.f : tt;
+      t[k * TS] = a * cw[k] + c * cw[k + 1];
+    }
+  }
+  __syncthreads();
+  // coalesced NCHW rows: lane = pixel, wave w takes channels w, w+4, ...; 8 LDS reads in flight per lane
+  const int lx = tid & 63;
+  const long long opix = pix0 + lx;
+  if (opix < p.P) {
+    const int b = (int)(opix / p.HW);
+    const int rem = (int)(opix - (long long)b * p.HW);
+    const int ch0 = tid >> 6;
+    float* o = p.out + ((long long)b * p.CH + ch0) * p.HW + rem;
+    const float* t = tile + ch0 * TS + lx;
+    const long long step = 4ll * p.HW;
+    int ch = ch0;
+    for (; ch + 28 < p.CH; ch += 32, o += 8 * step, t += 32 * TS) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = t[i * 4 * TS];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i * step] = v[i];
+    }
+    for (; ch < p.CH; ch += 4, o += step, t += 4 * TS) *o = *t;
+  }
+}
+
 // Backward w.r.t. the volumes: the transpose of the above.  Each (pixel, task) owns a private
 // window of its pixel's row, so the accumulated window is written with plain stores into the
 // caller-zeroed gradient (no atomics; same property as sampler_kernel.cu:63-104).
@@ -432,6 +539,16 @@ int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, co
   }
   p.disp = disp;
   p.out = out;
+  // quarter-resolution maps up to ~64k pixels are latency-bound (one round of blocks): the quad kernel's short
+  // instruction stream wins (12.0 vs 14.3 us at 960x540); beyond that the cooperative kernel's fully coalesced
+  // window reads win (54 vs 67 us at Middlebury-F)
+  if (radius == 4 && p.P <= 65536 && ((G == 8 && L == 2) || (G == 0 && L == 4))) {
+    const size_t lds = (size_t)(p.CH * 65) * sizeof(float);
+    const dim3 grid((unsigned)as::cdiv64(p.P, 64));
+    if (G == 8) hipLaunchKernelGGL((lookup_fwd_quad_kernel<8>), grid, dim3(256), lds, as::as_stream(stream), p);
+    else hipLaunchKernelGGL((lookup_fwd_quad_kernel<0>), grid, dim3(256), lds, as::as_stream(stream), p);
+    return as::check_launch("geo_corr_lookup_fwd");
+  }
   if (radius == 4 && (G == 8 || G == 0)) {
     const size_t lds = (size_t)(64 + p.CH * 65) * sizeof(float);
     const dim3 grid((unsigned)as::cdiv64(p.P, 64));

@@ -25,7 +25,6 @@ struct CorrParams {
   float* lvl[AS_MAX_LEVELS];
   int B, C, H, W1, W2, L;
   int MT, NT;  // 32-wide tiles along x1 / x2
-  int dbg;     // AS_CORR_DBG (profiling experiments only): 1 = no level-0 stores, 2 = no pooled stores
 };
 
 constexpr int kKS = 48;  // k-steps (channel pairs) held in registers per pass: C <= 96 in one pass
@@ -76,7 +75,7 @@ __device__ __forceinline__ float dpp_xor_step(float v, int s) {
   return __builtin_bit_cast(float, o);
 }
 
-__device__ __forceinline__ void store_pyramid_tile(const CorrParams& p, const TileOut& o, const f32x16& acc, int nt, int lane, int dbg) {
+__device__ __forceinline__ void store_pyramid_tile(const CorrParams& p, const TileOut& o, const f32x16& acc, int nt, int lane) {
   const unsigned kOOB = 0x70000000u;  // + 31 rows x (W2 <= 2^16) x 4 B never wraps and never is < num_records
   const int l31 = lane & 31, half = lane >> 5;
   const int x2 = nt * 32 + l31;
@@ -85,7 +84,7 @@ __device__ __forceinline__ void store_pyramid_tile(const CorrParams& p, const Ti
   for (int s = 0; s < AS_MAX_LEVELS; ++s) {
     const int wl = p.W2 >> s;
     const int xs = x2 >> s;
-    const bool ok = s < p.L && (l31 & ((1 << s) - 1)) == 0 && xs < wl && !((dbg >> (s ? 1 : 0)) & 1);
+    const bool ok = s < p.L && (l31 & ((1 << s) - 1)) == 0 && xs < wl;
     voff[s] = ok ? (unsigned)((4 * half * wl + xs) * 4) : kOOB;
     rstride[s] = (unsigned)(wl * 4);
   }
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
 #pragma unroll
       for (int k = 0; k < kKS; ++k) bq[k] = bn[k];
     }
-    store_pyramid_tile(p, tout, acc, nt, lane, 0);
+    store_pyramid_tile(p, tout, acc, nt, lane);
   }
 }
 
@@ -260,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) 
     f32x16 res;
 #pragma unroll
     for (int r = 0; r < 16; ++r) res[r] = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
-    store_pyramid_tile(p, tout, res, nt, lane, 0);
+    store_pyramid_tile(p, tout, res, nt, lane);
   }
 }
 
@@ -277,7 +276,6 @@ constexpr int kNB = 4;  // x2 tiles per block
 
 __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char corr_smem[];
-  if (p.dbg & 16) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
   // tensor, and it only ever feeds output rows/columns that the epilogue drops — no select per load.
   // issue everything: this wave's A fragment (channels 16 s + 8 half + j of column x1) ...
   const int x1 = mt * 32 + l31;
-  const unsigned a_off = (mt < p.MT && x1 < p.W1 && !(p.dbg & 8)) ? (unsigned)((8 * half * cs1 + (long long)y * p.W1 + x1) * 4) : kOOB;
+  const unsigned a_off = (mt < p.MT && x1 < p.W1) ? (unsigned)((8 * half * cs1 + (long long)y * p.W1 + x1) * 4) : kOOB;
   float av[kKS16][8];
 #pragma unroll
   for (int s = 0; s < kKS16; ++s)
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
   // ... and this thread's share of the f2 slab: item i = (8-channel group g = (tid>>7) + 2 i, column tid&127)
   const int xx = tid & 127;
   const int x2s = nb0 + xx;
-  const unsigned b_off = (x2s < p.W2 && !(p.dbg & 8)) ? (unsigned)(((long long)y * p.W2 + x2s) * 4) : kOOB;
+  const unsigned b_off = x2s < p.W2 ? (unsigned)(((long long)y * p.W2 + x2s) * 4) : kOOB;
   float bv[kKS16][8];
 #pragma unroll
   for (int i = 0; i < kKS16; ++i) {
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
 #pragma unroll
   for (int s = 0; s < kKS16; ++s) split8(av[s], ahi[s], alo[s]);
   __syncthreads();
-  if (mt >= p.MT || (p.dbg & 32)) return;
+  if (mt >= p.MT) return;
 
   const long long rowbase = (long long)row * p.W1;
   const TileOut tout = make_tile_out(p, rowbase, mt);
@@ -349,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
     const unsigned fo = (unsigned)((t * 32 + l31) * 32 + half * 16);
 #pragma unroll
     for (int s = 0; s < kKS16; ++s) {
-      if ((s == 0 || s < ksteps) && !(p.dbg & 4)) {
+      if (s == 0 || s < ksteps) {
         const half8 bhi = *reinterpret_cast<const half8*>(corr_smem + fo + (unsigned)s * (kNB * 32 * 32));
         const half8 blo = *reinterpret_cast<const half8*>(corr_smem + lo_base + fo + (unsigned)s * (kNB * 32 * 32));
         acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], bhi, acc_hh, 0, 0, 0);
@@ -360,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
     f32x16 res;
 #pragma unroll
     for (int r = 0; r < 16; ++r) res[r] = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
-    store_pyramid_tile(p, tout, res, nt, lane, p.dbg);
+    store_pyramid_tile(p, tout, res, nt, lane);
   }
 }
 
@@ -583,7 +581,6 @@ int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels
   p.f1 = f1; p.f2 = f2; p.B = B; p.C = C; p.H = H; p.W1 = W1; p.W2 = W2; p.L = L;
   p.MT = as::cdiv(W1, 32);
   p.NT = as::cdiv(W2, 32);
-  if (const char* e = getenv("AS_CORR_DBG")) p.dbg = atoi(e);
   for (int i = 0; i < L; ++i) {
     AS_REQUIRE(levels[i], AS_ERR_BAD_ARG, "corr_build: null level %d", i);
     p.lvl[i] = levels[i];
@@ -597,7 +594,7 @@ int as_corr_build_pyramid(const float* f1, const float* f2, float* const* levels
     while (nsplit < p.NT && (long long)B * H * p.MT * nsplit < 4096) nsplit *= 2;
     const dim3 g3(grid.x, grid.y, (unsigned)nsplit);
     const int ks16 = (C + 15) / 16;
-    if (ks16 <= kKS16 && !getenv("AS_CORR_STREAM")) {
+    if (ks16 <= kKS16) {
       const dim3 gl(grid.x, grid.y, (unsigned)as::cdiv(p.NT, kNB));
       hipLaunchKernelGGL(corr_build_lds_kernel, gl, dim3(256), (size_t)ks16 * (kNB * 32) * 32 * 2, as::as_stream(stream), p);
     } else if (ks16 <= kKS16) hipLaunchKernelGGL(corr_build_f16x3_kernel<true>, g3, dim3(256), 0, as::as_stream(stream), p);
