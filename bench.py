@@ -165,8 +165,8 @@ def main():
 
     if rank == 0:
         alg = algorithmic(1, hp // 4, wp // 4, Q, a.iters)
-        # the short HBM-bound kernels (10-60 us) are re-timed as 20 back-to-back launches between ONE event pair:
-        # a start/stop pair around a single launch adds ~3 us of its own (rocprofv3 durations confirm)
+        # the short HBM-bound kernels (10-60 us) are re-timed as 20 back-to-back launches (one hipGraph) between ONE
+        # event pair: a start/stop pair around a single launch adds ~3 us of its own (rocprofv3 durations confirm)
         micro = micro_time_small_kernels(dev, hp // 4, wp // 4)
         for k, v in micro.items():
             kstats[k] = v
@@ -220,8 +220,9 @@ def main():
 
 
 def micro_time_small_kernels(dev, h, w, reps=20):
-    """corr_build and lookup on operands of the workload's shapes (C=96, L=2, G=8, D=48), `reps` launches
-    back to back between one HIP event pair on the launch stream."""
+    """corr_build and lookup on operands of the workload's shapes (C=96, L=2, G=8, D=48): `reps` launches captured
+    into one hipGraph (the host launch path, ~20 us per call through Python + ctypes, is longer than these kernels)
+    and replayed between one HIP event pair on the launch stream."""
     from anystereo import ops
     from anystereo.harness.synthetic import det_uniform
     f1 = det_uniform((1, 96, h, w), 1).to(dev)
@@ -232,17 +233,29 @@ def micro_time_small_kernels(dev, h, w, reps=20):
     geo = ops.geo_pyramid(gev, 2)
     out = {}
     for name, fn in (("corr_build", lambda: ops.corr_build_pyramid(f1, f2, 2)),
-                     ("lookup", lambda: ops.geo_corr_lookup(geo, corr, disp, 4))):
-        for _ in range(3):
-            fn()
+                     ("lookup", lambda: ops.geo_corr_lookup(geo, corr, disp, 4)),
+                     ("gwc_volume", lambda: ops.gwc_volume(f1, f2, 48, 8)),
+                     ("geo_pyramid", lambda: ops.geo_pyramid(gev, 2))):
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(reps):
-            fn()
+        g.replay()
         e.record()
         torch.cuda.synchronize()
         out[name] = {"count": reps, "total_ms": s.elapsed_time(e)}
+        del g
     return out
 
 
