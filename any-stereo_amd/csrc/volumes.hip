@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256, 3) void gwc_kernel(const float* __restrict__ f
   // ---- stage fr: item = (channel c, column j), j = 0..FW-1 <-> x = x0 - kGwcD + j; batches of 16 loads in flight ----
   const int items = C * FW;
   const unsigned plane_u = (unsigned)plane, row_u = (unsigned)(y * W);
-  constexpr int NB = 16;
+  constexpr int NB = 24;  // two batches cover C = 96
 #pragma unroll 1
   for (int i0 = 0; i0 < kGwcNit; i0 += NB) {
     if (i0 * 256 >= items) break;
