@@ -40,6 +40,7 @@ def main():
     bzr = det_uniform((256,), 31).to(dev)
     pzr = ops.PackedConv().get([wzr], [bzr])
     from anystereo import _lib as Lb
+    w3d = det_uniform((8, 27, 8), 60, -0.1, 0.1).to(dev)
 
     def zr_at(div):
         hh, ww = h // div, w // div
@@ -51,6 +52,7 @@ def main():
         "geo_pyramid": (lambda: ops.geo_pyramid(gev, L)) if g else None,
         "lookup": lambda: ops.geo_corr_lookup(geo, corr, disp, 4),
         "gwc": lambda: ops.gwc_volume(f1, f2, 48, 8),
+        "conv3d_stem": (lambda: ops.conv3d_k3(gev, w3d, None, 1, 5)) if g else None,
         "gru08_zr": zr_at(2),
         "gru16_zr": zr_at(4),
         "gru_zr": lambda: ops.conv2d(x128, pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=x128[0]),
