@@ -16,7 +16,7 @@ import torch  # noqa: F401
 AS_MAX_LEVELS = 4
 AS_MAX_SRCS = 4
 AS_F32, AS_F16, AS_F64 = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_RELU6, ACT_LEAKY = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_RELU6, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3, 4, 5, 6
 EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
 
 # ANYSTEREO_LIB selects another build of the same library (A/B timing of kernel variants); default = the in-tree build
@@ -68,6 +68,9 @@ SIGNATURES = {
     "as_dwconv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_conv3d_k3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_deconv3d_k4s2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_instance_norm_ws_bytes": (C.c_int64, [_i]),
+    "as_instance_norm_act": (_i, [_vp, _vp, _vp, _i, C.c_int64, C.c_float, _i, _vp]),
+    "as_layernorm2d_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_float, _i, _vp]),
     "as_interp_bilinear_ac": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_structure_feature": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

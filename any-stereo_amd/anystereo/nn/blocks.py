@@ -18,6 +18,28 @@ def fused_ok(x: torch.Tensor, mod: nn.Module) -> bool:
     return (not mod.training) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
 
+def conv2d_hip_ok(conv: nn.Module) -> bool:
+    """Conv2d shapes the implicit-GEMM kernel serves: 1x1 / 3x3, stride 1, 'same' padding, no dilation / groups."""
+    if not isinstance(conv, nn.Conv2d):
+        return False
+    k = conv.kernel_size[0]
+    return (conv.kernel_size in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == (k // 2, k // 2)
+            and conv.dilation == (1, 1) and conv.groups == 1)
+
+
+def conv2d_plain(mod: nn.Module, conv: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """conv(x) (no norm, no activation) on the library kernel when it applies, else the module itself (MIOpen)."""
+    if conv2d_hip_ok(conv):
+        packs = mod.__dict__.setdefault("_hip_packs", {})
+        pk = packs.setdefault(id(conv), ops.PackedConv())
+        return ops.conv2d([x.contiguous()], pk.get([conv.weight], [conv.bias]))
+    return conv(x)
+
+
+def _plain_instance_norm(norm) -> bool:
+    return isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats
+
+
 def conv3d_k3_ok(conv: nn.Module) -> bool:
     return (isinstance(conv, nn.Conv3d) and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
             and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.dilation == (1, 1, 1) and conv.groups == 1)
@@ -72,6 +94,9 @@ class _ConvNormAct(nn.Module):
                 return conv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
             if deconv3d_k4s2_ok(self.conv):
                 return deconv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
+        if fused_ok(x, self) and x.dim() == 4 and _plain_instance_norm(norm):
+            # conv (library kernel where it applies, else MIOpen) -> fused InstanceNorm + LeakyReLU
+            return ops.instance_norm_act(conv2d_plain(self, self.conv, x), norm.eps, L.ACT_LEAKY if self.relu else L.ACT_NONE)
         x = self.conv(x)
         if self.use_norm:
             x = norm(x)
@@ -177,6 +202,13 @@ class _HighResAgg(nn.Module):
     def forward(self, x):
         x = self.embeding(x)
         x = x * self.sca(x)
+        conv, norm, act = self.head[0], self.head[1], self.head[2]
+        code = L.ACT_RELU if isinstance(act, nn.ReLU) else (L.ACT_GELU if isinstance(act, nn.GELU) and act.approximate == "none" else None)
+        if fused_ok(x, self) and code is not None:
+            if isinstance(norm, LayerNorm2d) and norm.weight.numel() <= 64:
+                return ops.layernorm2d_act(conv2d_plain(self, conv, x), norm.weight.detach(), norm.bias.detach(), norm.eps, code)
+            if _plain_instance_norm(norm):
+                return ops.instance_norm_act(conv2d_plain(self, conv, x), norm.eps, code)
         return self.head(x)
 
 

@@ -449,6 +449,28 @@ def deconv3d_k4s2(x, wpack, bias=None, act: int = L.ACT_NONE):
     return out
 
 
+def instance_norm_act(x, eps: float = 1e-5, act: int = L.ACT_NONE):
+    """act(InstanceNorm(x)) over the trailing spatial dims of x [B,C,*], affine = False (BasicConv_IN tail)."""
+    _req(x, "x")
+    b, c = x.shape[:2]
+    hw = x[0, 0].numel()
+    out = torch.empty_like(x)
+    ws = torch.empty(L.load().as_instance_norm_ws_bytes(b * c) // 8, device=x.device, dtype=torch.float64)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_instance_norm_act(_p(x), _p(out), _p(ws), b * c, hw, eps, act, _stream()), "instance_norm_act")
+    return out
+
+
+def layernorm2d_act(x, weight, bias, eps: float = 1e-6, act: int = L.ACT_NONE):
+    """act(LayerNorm2d(x)): per-pixel normalisation over channels of NCHW x with affine weight / bias."""
+    _req(x, "x"), _req(weight, "weight"), _req(bias, "bias")
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_layernorm2d_act(_p(x), _p(weight), _p(bias), _p(out), b, c, h, w, eps, act, _stream()), "layernorm2d_act")
+    return out
+
+
 class FoldedConv:
     """Cache of the (BatchNorm-folded) weight / bias of a conv that runs on a direct kernel or stays on MIOpen;
     `layout` = None keeps the module's layout, 'c3d' gives the [Cin,27,Cout] pack of as_conv3d_k3."""

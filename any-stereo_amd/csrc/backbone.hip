@@ -22,6 +22,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case AS_ACT_TANH: return tanhf(v);
     case AS_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
     case AS_ACT_LEAKY: return v >= 0.f ? v : 0.01f * v;
+    case AS_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     default: return v;
   }
 }
@@ -209,6 +210,85 @@ __global__ __launch_bounds__(256) void deconv3d_k4s2_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm2d (affine = False, biased variance over H*W, submodule.py BasicConv_IN) + activation.
+// pass 1: each (plane, segment) block reduces sum and sum of squares in fp64 (no cancellation issue) into
+// ws[plane][seg][2]; pass 2 re-derives mean / rstd from the kInSeg partials of its plane and applies them.
+// ------------------------------------------------------------------------------------------------
+constexpr int kInSeg = 8;
+
+__global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__ x, double* __restrict__ ws, long long HW) {
+  const long long plane = blockIdx.y;
+  const int seg = blockIdx.x;
+  const long long per = (HW + kInSeg - 1) / kInSeg;
+  const long long lo = seg * per, hi = min(HW, lo + per);
+  const float* xp = x + plane * HW;
+  double s = 0.0, ss = 0.0;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256 * 4) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i + k * 256 < hi) ? xp[i + k * 256] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s += (double)v[k]; ss += (double)v[k] * (double)v[k]; }
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ws[(plane * kInSeg + seg) * 2 + 0] = red[0][0];
+    ws[(plane * kInSeg + seg) * 2 + 1] = red[1][0];
+  }
+}
+
+__global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const double* __restrict__ ws,
+                                                       float* __restrict__ out, long long HW, float eps, int act) {
+  const long long plane = blockIdx.y;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0, ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < kInSeg; ++k) { s += ws[(plane * kInSeg + k) * 2]; ss += ws[(plane * kInSeg + k) * 2 + 1]; }
+  const double mean = s / (double)HW;
+  const double var = fmax(ss / (double)HW - mean * mean, 0.0);
+  const float m = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (i < HW) out[plane * HW + i] = act_apply((x[plane * HW + i] - m) * rstd, act);
+}
+
+// LayerNorm2d: per-pixel normalisation over the C channels of an NCHW tensor, affine, + activation
+// (submodule.py:148-187: mu = mean_c x, var = mean_c (x-mu)^2, y = w (x-mu)/sqrt(var+eps) + b).  Lane = pixel.
+template <int CMAX>
+__global__ __launch_bounds__(256) void layernorm2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ out,
+                                                          int C, long long HW, long long P, float eps, int act) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= P) return;
+  const long long bi = pix / HW, rem = pix - bi * HW;
+  const float* xp = x + bi * C * HW + rem;
+  float v[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) v[c] = c < C ? xp[(long long)c * HW] : 0.f;
+  float mu = 0.f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) mu += v[c];
+  mu /= (float)C;
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) { const float d = c < C ? v[c] - mu : 0.f; var += d * d; }
+  var /= (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+  float* op = out + bi * C * HW + rem;
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c)
+    if (c < C) op[(long long)c * HW] = act_apply(w[c] * ((v[c] - mu) * rstd) + b[c], act);
+}
+
 }  // namespace
 
 extern "C" {
@@ -263,6 +343,33 @@ int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, floa
   if (ct == 8) hipLaunchKernelGGL((deconv3d_k4s2_kernel<8>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, act);
   else hipLaunchKernelGGL((deconv3d_k4s2_kernel<1>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, act);
   return as::check_launch("deconv3d_k4s2");
+}
+
+int64_t as_instance_norm_ws_bytes(int planes) { return planes > 0 ? (int64_t)planes * kInSeg * 2 * (int64_t)sizeof(double) : 0; }
+
+int as_instance_norm_act(const float* x, float* out, void* ws, int planes, int64_t HW, float eps, int act, void* stream) {
+  AS_REQUIRE(x && out && ws, AS_ERR_BAD_ARG, "instance_norm: null pointer");
+  AS_REQUIRE(planes > 0 && planes <= 65535 && HW > 0, AS_ERR_BAD_ARG, "instance_norm: planes=%d HW=%lld", planes, (long long)HW);
+  AS_REQUIRE(act >= AS_ACT_NONE && act <= AS_ACT_GELU, AS_ERR_BAD_ARG, "instance_norm: act=%d", act);
+  AS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7) == 0, AS_ERR_BAD_ARG, "instance_norm: ws not 8-B aligned");
+  hipStream_t s = as::as_stream(stream);
+  hipLaunchKernelGGL(in_stats_kernel, dim3(kInSeg, (unsigned)planes), dim3(256), 0, s, x, (double*)ws, (long long)HW);
+  hipLaunchKernelGGL(in_apply_kernel, dim3((unsigned)as::cdiv64(HW, 256), (unsigned)planes), dim3(256), 0, s, x, (const double*)ws, out,
+                     (long long)HW, eps, act);
+  return as::check_launch("instance_norm_act");
+}
+
+int as_layernorm2d_act(const float* x, const float* weight, const float* bias, float* out, int B, int C, int H, int W, float eps,
+                       int act, void* stream) {
+  AS_REQUIRE(x && weight && bias && out, AS_ERR_BAD_ARG, "layernorm2d: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && C <= 64 && H > 0 && W > 0, AS_ERR_BAD_ARG, "layernorm2d: B=%d C=%d (C <= 64) H=%d W=%d", B, C, H, W);
+  AS_REQUIRE(act >= AS_ACT_NONE && act <= AS_ACT_GELU, AS_ERR_BAD_ARG, "layernorm2d: act=%d", act);
+  const long long HW = (long long)H * W, P = HW * B;
+  const dim3 grid((unsigned)as::cdiv64(P, 256));
+  hipStream_t s = as::as_stream(stream);
+  if (C <= 32) hipLaunchKernelGGL(layernorm2d_kernel<32>, grid, dim3(256), 0, s, x, weight, bias, out, C, HW, P, eps, act);
+  else hipLaunchKernelGGL(layernorm2d_kernel<64>, grid, dim3(256), 0, s, x, weight, bias, out, C, HW, P, eps, act);
+  return as::check_launch("layernorm2d_act");
 }
 
 }  // extern "C"

@@ -47,6 +47,7 @@ extern "C" {
 #define AS_ACT_TANH 3
 #define AS_ACT_RELU6 4 /* min(max(x,0),6): MobileNetV2 blocks of the feature net (extractor.py:331-342) */
 #define AS_ACT_LEAKY 5 /* LeakyReLU(0.01): BasicConv / BasicConv_IN (submodule.py:6-33)                 */
+#define AS_ACT_GELU 6  /* exact (erf) GELU: HighRes_Aggregation_LN_GeLU head (submodule.py:233-252); norm kernels only */
 #define AS_EPI_LINEAR 0 /* out = act(acc + bias + add); with h != NULL: out = relu(h + act(...))    (extractor.py:56-62) */
 #define AS_EPI_GRU_ZR 1 /* co <  Cout/2: z  = sigmoid(acc+bias+add)        -> out  [B,Cout/2,H,W]
                            co >= Cout/2: rh = sigmoid(acc+bias+add) * h    -> out2 [B,Cout/2,H,W]  */
@@ -188,6 +189,15 @@ int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* o
  *     Cout moved last); bias [Cout]|NULL -> out [B,Cout,2D,2H,2W]. */
 int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, float* out,
                      int B, int Cin, int Cout, int D, int H, int W, int act, void* stream);
+/*   as_instance_norm_act: act(InstanceNorm2d/3d(x)) with affine = False and biased variance — the IN + LeakyReLU / ReLU tail
+ *     of BasicConv_IN and the stems (submodule.py:76-103, continuous_IGEVstereo.py:105-118).  x, out [planes = B*C][HW];
+ *     ws: caller scratch of as_instance_norm_ws_bytes(planes) bytes (fp64 partial sums), 8-B aligned.
+ *   as_layernorm2d_act: act(w * (x - mean_c) / sqrt(var_c + eps) + b) per pixel over the C <= 64 channels of NCHW x —
+ *     LayerNorm2d (submodule.py:148-187) + the ReLU / GELU that follows it in the HighRes_Aggregation heads. */
+int64_t as_instance_norm_ws_bytes(int planes);
+int as_instance_norm_act(const float* x, float* out, void* ws, int planes, int64_t HW, float eps, int act, void* stream);
+int as_layernorm2d_act(const float* x, const float* weight, const float* bias, float* out, int B, int C, int H, int W, float eps,
+                       int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a12/a13  cosine affinity to the 8 neighbours, written straight into channels [C, C+8) of the

@@ -336,18 +336,41 @@ def _fused_vs_plain(mod, x, rtol, what):
 def test_backbone_blocks_fused_inference(precision):
     """§8 f4: MobileNetV2 blocks (pw/dw/pwl with folded BN, ReLU6, skip) and the BatchNorm Conv3d block."""
     from anystereo.harness.synthetic import fill_module_deterministic
-    from anystereo.nn.blocks import BasicConv
+    from anystereo.nn.blocks import BasicConv, BasicConv_IN, HighRes_Aggregation, HighRes_Aggregation_LN_GeLU
     from anystereo.nn.encoders import _DSConv, _InvRes
     for k, (mod, shape) in enumerate([(_InvRes(24, 24, 1), (2, 24, 17, 37)), (_InvRes(16, 24, 2), (1, 16, 18, 40)),
                                       (_DSConv(32, 16, 1), (1, 32, 9, 70)), (_InvRes(64, 64, 1), (1, 64, 5, 9)),
                                       (BasicConv(8, 16, is_3d=True, kernel_size=3, padding=1, stride=2), (1, 8, 6, 9, 33)),
                                       (BasicConv(16, 16, is_3d=True, kernel_size=3, padding=1, stride=1), (1, 16, 4, 6, 21)),
                                       (BasicConv(16, 8, deconv=True, is_3d=True, kernel_size=(4, 4, 4), padding=(1, 1, 1),
-                                                 stride=(2, 2, 2)), (1, 16, 3, 5, 21))]):
+                                                 stride=(2, 2, 2)), (1, 16, 3, 5, 21)),
+                                      (BasicConv_IN(12, 32, kernel_size=3, stride=1, padding=1), (2, 12, 11, 37)),
+                                      (BasicConv_IN(16, 8, deconv=True, kernel_size=4, stride=2, padding=1), (1, 16, 7, 9)),
+                                      (HighRes_Aggregation_LN_GeLU(3, 32), (1, 3, 16, 36)),
+                                      (HighRes_Aggregation(3, 48), (2, 3, 12, 20))]):
         mod = mod.eval()
         fill_module_deterministic(mod, 7 + k)
         _randomize_bn(mod, 200 + 40 * k)
         _fused_vs_plain(mod, U(shape, 190 + k, -2, 2), 3e-5, f"fused block {k}")
+
+
+def test_norm_kernels():
+    from anystereo import _lib as L
+    from anystereo import ops
+    x = U((2, 5, 37, 50), 300, -3, 5)
+    ref = torch.nn.functional.instance_norm(x.double(), eps=1e-5)
+    close(ops.instance_norm_act(x.to(DEV), 1e-5, L.ACT_NONE), ref, 2e-6, 2e-6, "instance norm")
+    close(ops.instance_norm_act(x.to(DEV), 1e-5, L.ACT_LEAKY), torch.nn.functional.leaky_relu(ref, 0.01), 2e-6, 2e-6, "IN + leaky")
+    x3 = U((1, 3, 4, 9, 11), 301) + 100.0  # large mean: the fp64 partial sums must not cancel
+    close(ops.instance_norm_act(x3.to(DEV), 1e-5, L.ACT_RELU), torch.nn.functional.instance_norm(x3.double(), eps=1e-5).relu(), 2e-4, 2e-4, "IN 3-D, offset data")
+    for c in (32, 48):
+        y = U((2, c, 9, 21), 302 + c, -2, 4)
+        w, b = U((c,), 303, 0.5, 1.5), U((c,), 304) * 0.3
+        mu = y.double().mean(1, keepdim=True)
+        var = (y.double() - mu).pow(2).mean(1, keepdim=True)
+        ln = w.double().view(1, -1, 1, 1) * ((y.double() - mu) / (var + 1e-6).sqrt()) + b.double().view(1, -1, 1, 1)
+        close(ops.layernorm2d_act(y.to(DEV), w.to(DEV), b.to(DEV), 1e-6, L.ACT_GELU), torch.nn.functional.gelu(ln), 3e-6, 3e-6, "LN + GELU")
+        close(ops.layernorm2d_act(y.to(DEV), w.to(DEV), b.to(DEV), 1e-6, L.ACT_RELU), ln.relu(), 3e-6, 3e-6, "LN + ReLU")
 
 
 def test_direct_convs_and_resamplers(precision):
