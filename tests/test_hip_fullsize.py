@@ -181,3 +181,29 @@ def test_whole_model_cfg2_determinism_and_graph():
     assert torch.equal(a, b), "eager forward is not bitwise repeatable"
     assert torch.equal(c, d), "graph replay is not bitwise repeatable"
     assert (a - c).abs().max().item() < 1e-3, "hipGraph replay differs from eager"
+
+
+def test_batch_consistency_and_raft_runs():
+    """Two different pairs in one forward give what the two single-pair forwards give (every kernel indexes the batch
+    correctly: left/right batching, XCD block order, sub-tile pairing), for IGEV and for the RAFT variant."""
+    from anystereo.harness.query import pad_for_multi_train
+    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
+    from anystereo.models import __models__, default_args
+    for name, divis in (("continuous_IGEVStereo", 32), ("continuous_RAFTStereo", 16)):
+        model = __models__[name](default_args(name)).eval()
+        fill_module_deterministic(model, base_seed=3)
+        model = model.to(DEV)
+        ins = []
+        for seed in (11, 12):
+            img1, img2 = synthetic_pair(1, 180, 300, shift=6, seed=seed)
+            i1, i2, coord, _ = pad_for_multi_train(img1, img2, 1.5, divis_by=divis)
+            ins.append((i1.to(DEV), i2.to(DEV), coord.unsqueeze(0).to(DEV)))
+        sc = torch.tensor([[1.5]], device=DEV)
+        with torch.no_grad():
+            singles = [model(a, b, iters=4, test_mode=True, hr_coord=c.clone(), scale=sc) for a, b, c in ins]
+            both = model(torch.cat([t[0] for t in ins]), torch.cat([t[1] for t in ins]), iters=4, test_mode=True,
+                         hr_coord=torch.cat([t[2] for t in ins]), scale=sc.repeat(2, 1))
+        assert torch.isfinite(both).all()
+        for k in range(2):
+            err = (both[k] - singles[k][0]).abs().max().item()
+            assert err < 2e-3, f"{name}: pair {k} differs between batched and single forward by {err}"
