@@ -150,6 +150,8 @@ class ContinuousStereoBase(nn.Module):
     #     gru16(i+1) -> gru08(i+1)                                                    (main stream)
     # — both chains are made of kernels that leave most of the 256 CUs idle at 1/8 and 1/16 resolution — and the
     # two streams meet only at gru04.  Fork/join is by events, so the whole thing is capturable as one hipGraph.
+    # (Measured and not kept: a third stream for the encoder's disparity branch — 0.70 vs 0.60 ms per iteration under
+    # graph replay; and a stream that waits on a stream which waited on it crashes capture on this stack.)
     pipelined_loop = os.environ.get("ANYSTEREO_PIPELINED_LOOP", "1") != "0"
 
     def _iterate_pipelined(self, lookup_fn, net, inp, disp, coords, iters):

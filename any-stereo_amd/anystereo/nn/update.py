@@ -115,23 +115,39 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 64, 128 - 1, 3, padding=1)
         self._pc1, self._pc2, self._pd2, self._pc = (ops.PackedConv() for _ in range(4))
 
+
     def forward(self, disp, corr):
         _no_grad_only(disp, corr, self.convc1.weight)
         disp, corr = _f(disp), _f(corr)
+        cd = self.new_buffer(disp)
+        self.corr_branch(corr, cd)
+        self.disp_branch(disp, cd)
+        return self.merge(cd, disp)
+
+    # The three pieces of forward(), exposed so the inference schedule (models/base.py::_iterate_pipelined) can run
+    # the two independent branches on different streams.  cd [B,128,h,w]: channels [0,64) = correlation branch,
+    # [64,128) = disparity branch (the reference's torch.cat, update.py:90, never materialised separately).
+    def new_buffer(self, disp):
         b, _, h, w = disp.shape
+        return torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
+
+    def corr_branch(self, corr, cd):
         with scope("enc_convc1"):
-            cor = ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
-        cd = torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
+            cor = ops.conv2d([_f(corr)], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
         with scope("enc_convc2"):
             ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out=cd, out_coff=0)
+
+    def disp_branch(self, disp, cd):
         with scope("enc_convd1"):
-            d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()))
+            d1 = ops.conv7x7_c1_relu(_f(disp), _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()))
         with scope("enc_convd2"):
             ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out=cd, out_coff=64)
-        out = torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
+
+    def merge(self, cd, disp):
+        out = torch.empty_like(cd)
         with scope("enc_conv"):
             ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out=out, out_coff=0)
-        out[:, 127:128].copy_(disp)
+        out[:, 127:128].copy_(_f(disp))
         return out
 
 
@@ -162,11 +178,11 @@ class BasicMultiUpdateBlock(nn.Module):
     # parallel branches under hipGraph).  Same arithmetic, same results; set `parallel_encoder=False` to serialise.
     parallel_encoder = True
 
-    def _side_stream(self, device):
+    def _side_stream(self, device, index: int = 0):
         streams = self.__dict__.setdefault("_streams", {})
-        if device not in streams:
-            streams[device] = torch.cuda.Stream(device=device)
-        return streams[device]
+        if (device, index) not in streams:
+            streams[(device, index)] = torch.cuda.Stream(device=device)
+        return streams[(device, index)]
 
     def forward(self, net, inp, corr=None, disp=None, iter04=True, iter08=True, iter16=True, update=True):
         motion_features = None
