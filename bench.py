@@ -300,7 +300,7 @@ def load_pmc_traffic():
     if not files:
         return {}
     d = json.load(open(files[-1]))
-    return {k: (None if v.get("hbm_bytes") is None else int(v["hbm_bytes"])) for k, v in d.items()}
+    return {k: (None if v.get("hbm_bytes") is None else int(v["hbm_bytes"])) for k, v in d.items() if not k.startswith("_")}
 
 
 def cpu_baseline(args, model, img1, img2, a):

@@ -5,6 +5,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/_tr -- python $ROOT/bench.py --no-cpu-baseline --no-graph --steps 2 --warmup 2 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/_tr -- python $ROOT/bench.py --no-cpu-baseline --no-batched --no-graph --steps 2 --warmup 2 > /dev/null 2>&1
 python $ROOT/tools/pass_breakdown.py $OUT/_tr $OUT/${TAG}_pass_breakdown.json
 rm -rf $OUT/_tr
