@@ -41,6 +41,10 @@ def main():
     pzr = ops.PackedConv().get([wzr], [bzr])
     from anystereo import _lib as Lb
     w3d = det_uniform((8, 27, 8), 60, -0.1, 0.1).to(dev)
+    xl1 = det_uniform((1, 64, 4 * h, 4 * w), 61).to(dev)
+    pl1 = ops.PackedConv().get([det_uniform((64, 64, 3, 3), 62, -0.05, 0.05).to(dev)], [det_uniform((64,), 63).to(dev)])
+    xq = det_uniform((1, 128, 1, 16 * h * w), 64).to(dev)
+    pq2 = ops.PackedConv().get([det_uniform((64, 128, 1, 1), 65, -0.05, 0.05).to(dev)], [det_uniform((64,), 66).to(dev)])
 
     def zr_at(div):
         hh, ww = h // div, w // div
@@ -52,6 +56,8 @@ def main():
         "geo_pyramid": (lambda: ops.geo_pyramid(gev, L)) if g else None,
         "lookup": lambda: ops.geo_corr_lookup(geo, corr, disp, 4),
         "gwc": lambda: ops.gwc_volume(f1, f2, 48, 8),
+        "cnet_l1": (lambda: ops.conv2d([xl1], pl1, act=Lb.ACT_RELU)),
+        "liif_l2": (lambda: ops.conv2d([xq], pq2, act=Lb.ACT_RELU)),
         "conv3d_stem": (lambda: ops.conv3d_k3(gev, w3d, None, 1, 5)) if g else None,
         "gru08_zr": zr_at(2),
         "gru16_zr": zr_at(4),
