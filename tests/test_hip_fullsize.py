@@ -207,3 +207,35 @@ def test_batch_consistency_and_raft_runs():
         for k in range(2):
             err = (both[k] - singles[k][0]).abs().max().item()
             assert err < 2e-3, f"{name}: pair {k} differs between batched and single forward by {err}"
+
+
+@pytest.mark.parametrize("mode", ["fp32", "split"])
+def test_conv1x1_many_pixels(mode):
+    """1x1 convs at query resolution (the weights-resident direct kernel in split mode): against the fp64 product on a
+    pixel subset, incl. two sources, a ragged pixel count, an add window, a residual and an output channel window."""
+    from anystereo import _lib as L
+    from anystereo import ops
+    prev = ops.get_precision()
+    ops.set_precision(mode)
+    try:
+        for (cins, cout, npx, act) in [([128], 64, 518400, L.ACT_RELU), ([184, 44], 128, 300001, L.ACT_NONE), ([64], 9, 131072, L.ACT_NONE)]:
+            srcs = [U((1, c, 1, npx), 70 + i).to(DEV) for i, c in enumerate(cins)]
+            cin = sum(cins)
+            wt = (U((cout, cin, 1, 1), 75) * (3.0 / cin) ** 0.5).to(DEV)
+            bias = (U((cout,), 76) * 0.1).to(DEV)
+            add = U((1, cout + 3, 1, npx), 77).to(DEV)
+            res = U((1, cout, 1, npx), 78).to(DEV)
+            pk = ops.PackedConv().get([wt], [bias])
+            big = torch.full((1, cout + 5, 1, npx), 7.0, device=DEV)
+            ops.conv2d(srcs, pk, act=act, add=add, add_coff=2, out=big, out_coff=1, h=res)
+            idx = torch.cat([torch.arange(0, 700), torch.arange(npx // 2, npx // 2 + 300), torch.arange(npx - 500, npx)]).to(DEV)
+            x = torch.cat(srcs, 1)[0, :, 0][:, idx].double()
+            ref = wt[:, :, 0, 0].double() @ x + bias.double()[:, None] + add[0, 2:2 + cout, 0][:, idx].double()
+            if act == L.ACT_RELU:
+                ref = ref.relu()
+            ref = (ref + res[0, :, 0][:, idx].double()).relu()
+            got = big[0, 1:1 + cout, 0][:, idx].double()
+            assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (cins, cout)
+            assert (big[:, :1] == 7.0).all() and (big[:, 1 + cout:] == 7.0).all()
+    finally:
+        ops.set_precision(prev)
