@@ -20,32 +20,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
-from .blocks import BasicConv_IN, Conv2x_IN
-
-
-def _fused_ok(x: torch.Tensor, mod: nn.Module) -> bool:
-    """Inference fast path: eval mode, CUDA fp32 input, nothing to differentiate."""
-    return (not mod.training) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-
-
-class _FoldCache:
-    """BatchNorm-folded (weight, bias) of a conv that stays on MIOpen (stride 2 / 7x7), rebuilt on parameter change."""
-
-    def __init__(self):
-        self._key, self._wb = None, None
-
-    def get(self, conv, bn):
-        ts = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts)
-        if key != self._key:
-            self._wb, self._key = ops.fold_bn(conv, bn), key
-        return self._wb
-
-
-def _conv_hip_ok(conv: nn.Conv2d) -> bool:
-    k = conv.kernel_size[0]
-    return (conv.kernel_size in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == (k // 2, k // 2)
-            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 16 == 0)
+from .blocks import BasicConv_IN, Conv2x_IN, conv2d_hip_ok as _conv_hip_ok, conv2d_plain, fused_ok as _fused_ok
 
 
 def _norm(kind: str, c: int, groups: int | None = None):
@@ -76,7 +51,7 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
 
         self._pk1, self._pk2 = ops.PackedConv(), ops.PackedConv()
-        self._f1, self._fd = _FoldCache(), _FoldCache()
+        self._f1, self._fd = ops.FoldedConv(), ops.FoldedConv()
 
     def forward(self, x):
         if _fused_ok(x, self) and isinstance(self.norm1, nn.BatchNorm2d) and _conv_hip_ok(self.conv2):
@@ -136,7 +111,7 @@ class _Trunk(nn.Module):
     def trunk(self, x):
         if _fused_ok(x, self) and isinstance(self.norm1, nn.BatchNorm2d):
             if not hasattr(self, "_f_stem"):
-                self._f_stem = _FoldCache()
+                self._f_stem = ops.FoldedConv()
             w, b = self._f_stem.get(self.conv1, self.norm1)
             x = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
         else:
@@ -200,11 +175,7 @@ class MultiBasicEncoder(_Trunk):
 
 def _plain_conv(mod: nn.Module, conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """conv(x) on the implicit-GEMM kernel when the inference fast path applies, else the module itself."""
-    if _fused_ok(x, mod) and _conv_hip_ok(conv):
-        packs = mod.__dict__.setdefault("_hip_packs", {})
-        pk = packs.setdefault(id(conv), ops.PackedConv())
-        return ops.conv2d([x.contiguous()], pk.get([conv.weight], [conv.bias]))
-    return conv(x)
+    return conv2d_plain(mod, conv, x) if _fused_ok(x, mod) else conv(x)
 
 
 def _multi_head(self, f, x):
@@ -320,7 +291,7 @@ class Feature(nn.Module):
     def forward(self, x):
         if _fused_ok(x, self) and isinstance(self.bn1, nn.BatchNorm2d):
             if not hasattr(self, "_f_stem"):
-                self._f_stem = _FoldCache()
+                self._f_stem = ops.FoldedConv()
             w, b = self._f_stem.get(self.conv_stem, self.bn1)
             x = nn.functional.conv2d(x, w, b, self.conv_stem.stride, self.conv_stem.padding).clamp_(0.0, 6.0)
         else:
