@@ -61,3 +61,32 @@ def thres_metric(d_est, d_gt, mask, thres):
     """fraction with error > thres  (metrics.py:74-81)."""
     assert isinstance(thres, (int, float))
     return _per_image(lambda e, g, m: ((g[m] - e[m]).abs() > thres).float().mean(), d_est, d_gt, mask)
+
+
+def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0):
+    """One optimisation step with the reference's ordering (train_continuous_IGEV.py:214-239, multi_training branch):
+    zero_grad -> forward(train mode) -> sequence_loss_multiscale with valid = (gt < 512) & (gt > 0) -> scaled backward ->
+    unscale -> clip_grad_norm_(1.0) -> optimizer step -> scheduler step (unless fixed lr) -> scaler update.
+    `batch` = (image1, image2, hr_coord, hr_disp_gt, scale); `scaler` may be None (no mixed precision).
+    Model-agnostic host logic: it needs a model whose forward is differentiable (the HIP hot modules are
+    inference-only in round 1)."""
+    image1, image2, hr_coord, hr_disp_gt, scale = batch
+    optimizer.zero_grad()
+    assert model.training
+    _, disp_preds = model(image1, image2, iters=train_iters, hr_coord=hr_coord, scale=scale)
+    loss, metrics = sequence_loss_multiscale(disp_preds, hr_disp_gt, (hr_disp_gt < 512) & (hr_disp_gt > 0.0), max_disp=max_disp)
+    if scaler is not None:
+        scaler.scale(loss).backward()
+        scaler.unscale_(optimizer)
+    else:
+        loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+    if scaler is not None:
+        scaler.step(optimizer)
+    else:
+        optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    if scaler is not None:
+        scaler.update()
+    return loss.detach(), metrics

@@ -165,3 +165,30 @@ def test_fetch_optimizer_schedule():
     assert abs(max(lrs) - 2e-4) < 1e-12 and lrs.index(max(lrs)) == 9
     assert lrs[0] == pytest.approx(2e-4 / 25) and lrs[-1] < lrs[500] < lrs[100]
     assert fetch_optimizer(2e-4, 1e-5, 900, p, lr_fixed=True)[1] is None
+
+
+def test_train_step_semantics():
+    """Step ordering of train_continuous_IGEV.py:214-239 on a differentiable stand-in model: the gradient is clipped to
+    norm 1 before AdamW sees it, and the schedule advances once per step."""
+    from anystereo.harness.metrics import fetch_optimizer, train_step
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([3.0, -2.0]))
+
+        def forward(self, image1, image2, iters=2, hr_coord=None, scale=None):
+            base = (image1.mean() * self.w[0] + image2.mean() * self.w[1]) * 100.0
+            preds = [base + hr_coord[..., :1].transpose(1, 2) * (i + 1) for i in range(iters)]
+            return None, preds
+
+    torch.manual_seed(0)
+    m = Toy().train()
+    opt, sched = fetch_optimizer(1e-2, 0.0, 50, m.parameters())
+    b, q = 2, 40
+    batch = (torch.rand(b, 3, 8, 8), torch.rand(b, 3, 8, 8), torch.rand(b, q, 2), torch.rand(b, 1, q) * 100 + 1, torch.ones(b, 1))
+    w0, lr0 = m.w.detach().clone(), opt.param_groups[0]["lr"]
+    loss, met = train_step(m, opt, sched, None, batch, train_iters=3, max_disp=192)
+    assert torch.isfinite(loss) and set(met) == {"epe", "1px", "3px"}
+    assert m.w.grad.norm().item() <= 1.0 + 1e-5, "gradient must be clipped to norm 1 before the step"
+    assert not torch.equal(m.w.detach(), w0) and opt.param_groups[0]["lr"] != lr0
