@@ -347,6 +347,9 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     return (out, out2) if epilogue == L.EPI_GRU_ZR else out
 
 
+_TAPMAJOR = {}  # (data_ptr, version, device) of a [Cout,1,7,7] weight -> its [49,Cout] transpose
+
+
 def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0):
     """relu(conv7x7(x [B,1,H,W]) + bias) into channels [out_coff, out_coff+Cout) of `out` (update.py:81,87)."""
     _req(x, "x"), _req(weight, "weight")
@@ -357,8 +360,16 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0):
     if out is None:
         out = torch.empty((b, cout, h, w), device=x.device, dtype=torch.float32)
     _req(out, "out")
+    key = (weight.data_ptr(), weight._version, weight.device)
+    wt = _TAPMAJOR.get(key)
+    if wt is None:  # tap-major copy, rebuilt when the weight changes (one entry per live weight tensor)
+        if len(_TAPMAJOR) > 64:
+            _TAPMAJOR.clear()
+        wt = torch.zeros((49, (cout + 63) // 64 * 64), device=weight.device, dtype=torch.float32)
+        wt[:, :cout] = weight.detach().reshape(cout, 49).t()
+        _TAPMAJOR[key] = wt
     with torch.cuda.device(x.device):
-        L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(weight), _p(bias), _p(out), b, h, w, cout, out.shape[1], out_coff, _stream()),
+        L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(wt), _p(bias), _p(out), b, h, w, cout, out.shape[1], out_coff, 1, _stream()),
                 "conv7x7_c1_relu")
     return out
 

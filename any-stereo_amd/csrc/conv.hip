@@ -471,6 +471,51 @@ __global__ __launch_bounds__(256) void conv7x7_c1_kernel(const float* __restrict
   }
 }
 
+// Tap-major variant (the shipped path): weights as wt[49][Cout_pad].  The kernel above walks the output channels in its
+// outer loop and pulls 49 scalar weights per channel (3136 dependent s_load dwords per wave) on 135 blocks — 30 us at
+// 136x240, on the critical stream of the GRU loop.  Here a block owns a 16x16 pixel tile and CO = 8 output channels
+// (8x the blocks), the kernel rows are the outer loop and one row's 7 x 8 weights arrive as seven s_load_dwordx8.
+template <int CO>
+__global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int H, int W, int Cout, int CP, int out_ctot, int out_coff) {
+  __shared__ float patch[22 * 22];
+  const int groups = CP / CO;
+  const int b = blockIdx.z / groups;
+  const int c0 = (blockIdx.z - b * groups) * CO;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
+  const long long plane = (long long)H * W;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * plane), 0, (int)(plane * 4), 0x00020000);
+  for (int idx = threadIdx.x; idx < 22 * 22; idx += 256) {
+    const int py = idx / 22, px = idx - py * 22;
+    const int gy = y0 - 3 + py, gx = x0 - 3 + px;
+    patch[idx] = as_bload(rs, (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)((gy * W + gx) * 4) : 0x7FFFFFF0u);
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  float acc[CO];
+#pragma unroll
+  for (int j = 0; j < CO; ++j) acc[j] = 0.f;
+#pragma unroll 1  // one kernel row (7 x CO weights = 56 SGPRs) live at a time
+  for (int ky = 0; ky < 7; ++ky) {
+    const float* pr = patch + (ly + ky) * 22 + lx;
+    const float* wr = wt + (ky * 7) * CP + c0;  // wave-uniform, unconditional (wt is zero padded to CP columns)
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      const float v = pr[kx];
+#pragma unroll
+      for (int j = 0; j < CO; ++j) acc[j] = fmaf(v, wr[kx * CP + j], acc[j]);
+    }
+  }
+  const int gy = y0 + ly, gx = x0 + lx;
+  if (gy < H && gx < W) {
+    float* o = out + ((long long)b * out_ctot + out_coff + c0) * plane + (long long)gy * W + gx;
+#pragma unroll
+    for (int j = 0; j < CO; ++j)
+      if (c0 + j < Cout) o[(long long)j * plane] = fmaxf(acc[j] + (bias ? bias[c0 + j] : 0.f), 0.f);
+  }
+}
+
 // 3x3, Cin -> 1, + bias (DispHead.conv2, update.py:19,24).  64 pixels of a row x 4 channel slices.
 __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out,
@@ -1131,13 +1176,21 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
 }
 
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out, int B, int H, int W,
-                       int Cout, int out_ctot, int out_coff, void* stream) {
+                       int Cout, int out_ctot, int out_coff, int tap_major, void* stream) {
   AS_REQUIRE(x && weight && out, AS_ERR_BAD_ARG, "conv7x7_c1: null pointer");
+  AS_REQUIRE((long long)H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "conv7x7_c1: plane too large");
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, AS_ERR_BAD_ARG, "conv7x7_c1: non-positive size");
   AS_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctot, AS_ERR_BAD_SHAPE, "conv7x7_c1: out channel window outside out_ctot");
   AS_REQUIRE(B <= 65535 && as::cdiv(H, 16) <= 65535, AS_ERR_BAD_SHAPE, "conv7x7_c1: grid too large");
   dim3 grid((unsigned)as::cdiv(W, 16), (unsigned)as::cdiv(H, 16), (unsigned)B);
-  hipLaunchKernelGGL(conv7x7_c1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, out_ctot, out_coff);
+  if (tap_major) {
+    const int CP = (Cout + 63) / 64 * 64;
+    AS_REQUIRE((long long)B * (CP / 8) <= 65535, AS_ERR_BAD_SHAPE, "conv7x7_c1: grid too large");
+    const dim3 g3(grid.x, grid.y, (unsigned)(B * (CP / 8)));
+    hipLaunchKernelGGL(conv7x7_c1_tm_kernel<8>, g3, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, CP, out_ctot, out_coff);
+  } else {
+    hipLaunchKernelGGL(conv7x7_c1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, out_ctot, out_coff);
+  }
   return as::check_launch("conv7x7_c1_relu");
 }
 

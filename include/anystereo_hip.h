@@ -154,9 +154,11 @@ int64_t as_conv_pack_size_split(int Cin, int Cout, int KS);
 int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream);
 
 /* direct (VALU) convolutions for the two shapes where an MFMA tile would be mostly padding:
- *   convd1: 7x7, 1 -> Cout, +bias, ReLU   (update.py:81,87);   conv2 of DispHead: 3x3, Cin -> 1, +bias (update.py:19,24) */
+ *   convd1: 7x7, 1 -> Cout, +bias, ReLU   (update.py:81,87);   conv2 of DispHead: 3x3, Cin -> 1, +bias (update.py:19,24)
+ *   tap_major = 0: weight is the module's [Cout,1,7,7]; tap_major = 1: weight is its transpose [49][Cout_pad], Cout_pad =
+ *   Cout rounded up to 64, zero padded (one tap's weights contiguous -> vector scalar loads; the fast path). */
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out,
-                       int B, int H, int W, int Cout, int out_ctot, int out_coff, void* stream);
+                       int B, int H, int W, int Cout, int out_ctot, int out_coff, int tap_major, void* stream);
 int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float* out,
                    int B, int Cin, int H, int W, void* stream);
 
