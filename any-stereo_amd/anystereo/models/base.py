@@ -173,7 +173,7 @@ class ContinuousStereoBase(nn.Module):
             net[0].record_stream(side)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                disp = disp + ub.disp_head(net[0])
+                disp = ub.disp_head(net[0], addend=disp)
                 if itr + 1 < iters:
                     mf = ub.encoder(disp, lookup_fn(disp, coords))
         main.wait_stream(side)

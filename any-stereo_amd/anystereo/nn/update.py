@@ -41,7 +41,9 @@ class DispHead(nn.Module):
         self._p1 = ops.PackedConv()
         self._p2 = ops.PackedConv()
 
-    def forward(self, x):
+    def forward(self, x, addend=None):
+        """delta = conv2(relu(conv1(x))) (update.py:23-24); with `addend` the result is addend + delta (the loop's
+        `disp = disp + delta_disp`, fused into the last kernel)."""
         _no_grad_only(x, self.conv1.weight)
         with scope("disp_head_conv1"):
             t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
@@ -50,8 +52,9 @@ class DispHead(nn.Module):
             with scope("disp_head_conv2"):
                 taps = ops.conv2d([t], self._p2.get([self.conv2.weight], [None],
                                                     transform=lambda w: w[0].permute(1, 2, 0).reshape(9, -1, 1, 1).contiguous()))
-                return ops.tap_shift_sum(taps, _f(self.conv2.bias.detach()))
-        return ops.conv2d([t], self._p2.get([self.conv2.weight], [self.conv2.bias]))
+                return ops.tap_shift_sum(taps, _f(self.conv2.bias.detach()), None if addend is None else _f(addend))
+        out = ops.conv2d([t], self._p2.get([self.conv2.weight], [self.conv2.bias]))
+        return out if addend is None else addend + out
 
 
 class FlowHead(DispHead):
@@ -119,15 +122,19 @@ class BasicMotionEncoder(nn.Module):
     def forward(self, disp, corr):
         _no_grad_only(disp, corr, self.convc1.weight)
         disp, corr = _f(disp), _f(corr)
-        cd = self.new_buffer(disp)
+        cd, out = self.new_buffer(disp), self.new_output(disp)
         self.corr_branch(corr, cd)
-        self.disp_branch(disp, cd)
-        return self.merge(cd, disp)
+        self.disp_branch(disp, cd, out)
+        return self.merge(cd, disp, out)
 
     # The three pieces of forward(), exposed so the inference schedule (models/base.py::_iterate_pipelined) can run
     # the two independent branches on different streams.  cd [B,128,h,w]: channels [0,64) = correlation branch,
     # [64,128) = disparity branch (the reference's torch.cat, update.py:90, never materialised separately).
     def new_buffer(self, disp):
+        b, _, h, w = disp.shape
+        return torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
+
+    def new_output(self, disp):
         b, _, h, w = disp.shape
         return torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
 
@@ -137,17 +144,23 @@ class BasicMotionEncoder(nn.Module):
         with scope("enc_convc2"):
             ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out=cd, out_coff=0)
 
-    def disp_branch(self, disp, cd):
+    def disp_branch(self, disp, cd, out=None):
+        """convd1 -> convd2 into cd[:, 64:]; with `out` the disparity itself is also placed in out[:, 127] (update.py:91)."""
         with scope("enc_convd1"):
-            d1 = ops.conv7x7_c1_relu(_f(disp), _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()))
+            d1 = ops.conv7x7_c1_relu(_f(disp), _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()),
+                                     copy_out=out, copy_coff=127)
         with scope("enc_convd2"):
             ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out=cd, out_coff=64)
 
-    def merge(self, cd, disp):
-        out = torch.empty_like(cd)
+    def merge(self, cd, disp, out=None):
+        """relu(conv(cd)) into channels [0,127) and disp in channel 127; `out` given = disp_branch already placed disp."""
+        have_disp = out is not None
+        if out is None:
+            out = torch.empty_like(cd)
         with scope("enc_conv"):
             ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out=out, out_coff=0)
-        out[:, 127:128].copy_(_f(disp))
+        if not have_disp:
+            out[:, 127:128].copy_(_f(disp))
         return out
 
 

@@ -350,8 +350,9 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
 _TAPMAJOR = {}  # (data_ptr, version, device) of a [Cout,1,7,7] weight -> its [49,Cout] transpose
 
 
-def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0):
-    """relu(conv7x7(x [B,1,H,W]) + bias) into channels [out_coff, out_coff+Cout) of `out` (update.py:81,87)."""
+def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_coff=0):
+    """relu(conv7x7(x [B,1,H,W]) + bias) into channels [out_coff, out_coff+Cout) of `out` (update.py:81,87);
+    with `copy_out` [B,C,H,W], x is also written to its channel `copy_coff`."""
     _req(x, "x"), _req(weight, "weight")
     b, one, h, w = x.shape
     cout = weight.shape[0]
@@ -369,7 +370,12 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0):
         wt[:, :cout] = weight.detach().reshape(cout, 49).t()
         _TAPMAJOR[key] = wt
     with torch.cuda.device(x.device):
-        L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(wt), _p(bias), _p(out), b, h, w, cout, out.shape[1], out_coff, 1, _stream()),
+        if copy_out is not None:
+            _req(copy_out, "copy_out")
+            if copy_out.shape[0] != b or tuple(copy_out.shape[2:]) != (h, w):
+                raise RuntimeError("conv7x7_c1_relu: copy_out shape mismatch")
+        L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(wt), _p(bias), _p(out), b, h, w, cout, out.shape[1], out_coff, 1,
+                                            _p(copy_out), 0 if copy_out is None else copy_out.shape[1], copy_coff, _stream()),
                 "conv7x7_c1_relu")
     return out
 
@@ -386,15 +392,19 @@ def conv3x3_to1(x, weight, bias):
     return out
 
 
-def tap_shift_sum(s, bias):
-    """out[b,0,y,x] = bias + sum_t s[b,t,y+ky-1,x+kx-1] (zero padded) — see as_tap_shift_sum."""
+def tap_shift_sum(s, bias, addend=None):
+    """out[b,0,y,x] = (addend +) bias + sum_t s[b,t,y+ky-1,x+kx-1] (zero padded) — see as_tap_shift_sum."""
     _req(s, "s")
+    if addend is not None:
+        _req(addend, "addend")
+        if tuple(addend.shape) != (s.shape[0], 1, s.shape[2], s.shape[3]):
+            raise RuntimeError("tap_shift_sum: addend must be [B,1,H,W]")
     b, nine, h, w = s.shape
     if nine != 9:
         raise RuntimeError("tap_shift_sum: expects [B,9,H,W]")
     out = torch.empty((b, 1, h, w), device=s.device, dtype=torch.float32)
     with torch.cuda.device(s.device):
-        L.check(L.load().as_tap_shift_sum(_p(s), _p(bias), _p(out), b, h, w, _stream()), "tap_shift_sum")
+        L.check(L.load().as_tap_shift_sum(_p(s), _p(bias), _p(addend), _p(out), b, h, w, _stream()), "tap_shift_sum")
     return out
 
 

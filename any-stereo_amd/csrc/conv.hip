@@ -478,7 +478,8 @@ __global__ __launch_bounds__(256) void conv7x7_c1_kernel(const float* __restrict
 template <int CO>
 __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            int H, int W, int Cout, int CP, int out_ctot, int out_coff) {
+                                                            int H, int W, int Cout, int CP, int out_ctot, int out_coff,
+                                                            float* __restrict__ copy_out, int copy_ctot, int copy_coff) {
   __shared__ float patch[22 * 22];
   const int groups = CP / CO;
   const int b = blockIdx.z / groups;
@@ -513,6 +514,8 @@ __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < CO; ++j)
       if (c0 + j < Cout) o[(long long)j * plane] = fmaxf(acc[j] + (bias ? bias[c0 + j] : 0.f), 0.f);
+    // optional pass-through of the input plane (the `cat([out, disp])` of the motion encoder, update.py:91)
+    if (copy_out && c0 == 0) copy_out[((long long)b * copy_ctot + copy_coff) * plane + (long long)gy * W + gx] = patch[(ly + 3) * 22 + lx + 3];
   }
 }
 
@@ -552,7 +555,8 @@ __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float* __restric
 // out[b,0,y,x] = bias + sum_t S[b,t,y+ky-1,x+kx-1]  (t = ky*3+kx, zero outside): second half of a 3x3,
 // Cin -> 1 convolution whose per-tap channel reductions S were produced by a 1x1 MFMA conv (Cin -> 9).
 __global__ __launch_bounds__(256) void tap_shift_sum_kernel(const float* __restrict__ S, const float* __restrict__ bias,
-                                                            float* __restrict__ out, int H, int W, long long P) {
+                                                            const float* __restrict__ addend, float* __restrict__ out, int H,
+                                                            int W, long long P) {
   const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
   if (pix >= P) return;
   const long long plane = (long long)H * W;
@@ -566,7 +570,8 @@ __global__ __launch_bounds__(256) void tap_shift_sum_kernel(const float* __restr
     const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
     if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += sp[(long long)t * plane + (long long)yy * W + xx];
   }
-  out[pix] = acc + (bias ? bias[0] : 0.f);
+  const float delta = acc + (bias ? bias[0] : 0.f);
+  out[pix] = addend ? addend[pix] + delta : delta;  // disp + delta_disp of the GRU loop fused (continuous_IGEVstereo.py:296)
 }
 
 // pool2x: 3x3 mean, stride 2, zero pad 1, divisor 9 (update.py:94-95)
@@ -1176,7 +1181,8 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
 }
 
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out, int B, int H, int W,
-                       int Cout, int out_ctot, int out_coff, int tap_major, void* stream) {
+                       int Cout, int out_ctot, int out_coff, int tap_major, float* copy_out, int copy_ctot, int copy_coff,
+                       void* stream) {
   AS_REQUIRE(x && weight && out, AS_ERR_BAD_ARG, "conv7x7_c1: null pointer");
   AS_REQUIRE((long long)H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "conv7x7_c1: plane too large");
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, AS_ERR_BAD_ARG, "conv7x7_c1: non-positive size");
@@ -1187,8 +1193,11 @@ int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, f
     const int CP = (Cout + 63) / 64 * 64;
     AS_REQUIRE((long long)B * (CP / 8) <= 65535, AS_ERR_BAD_SHAPE, "conv7x7_c1: grid too large");
     const dim3 g3(grid.x, grid.y, (unsigned)(B * (CP / 8)));
-    hipLaunchKernelGGL(conv7x7_c1_tm_kernel<8>, g3, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, CP, out_ctot, out_coff);
+    AS_REQUIRE(!copy_out || (copy_coff >= 0 && copy_coff < copy_ctot), AS_ERR_BAD_SHAPE, "conv7x7_c1: copy channel outside copy_ctot");
+    hipLaunchKernelGGL(conv7x7_c1_tm_kernel<8>, g3, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, CP, out_ctot, out_coff,
+                       copy_out, copy_ctot, copy_coff);
   } else {
+    AS_REQUIRE(!copy_out, AS_ERR_BAD_ARG, "conv7x7_c1: the input pass-through needs tap_major weights");
     hipLaunchKernelGGL(conv7x7_c1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, out_ctot, out_coff);
   }
   return as::check_launch("conv7x7_c1_relu");
@@ -1203,11 +1212,11 @@ int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float
   return as::check_launch("conv3x3_to1");
 }
 
-int as_tap_shift_sum(const float* S, const float* bias, float* out, int B, int H, int W, void* stream) {
+int as_tap_shift_sum(const float* S, const float* bias, const float* addend, float* out, int B, int H, int W, void* stream) {
   AS_REQUIRE(S && out, AS_ERR_BAD_ARG, "tap_shift_sum: null pointer");
   AS_REQUIRE(B > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "tap_shift_sum: non-positive size");
   const long long P = (long long)B * H * W;
-  hipLaunchKernelGGL(tap_shift_sum_kernel, dim3((unsigned)as::cdiv64(P, 256)), dim3(256), 0, as::as_stream(stream), S, bias, out, H, W, P);
+  hipLaunchKernelGGL(tap_shift_sum_kernel, dim3((unsigned)as::cdiv64(P, 256)), dim3(256), 0, as::as_stream(stream), S, bias, addend, out, H, W, P);
   return as::check_launch("tap_shift_sum");
 }
 

@@ -156,16 +156,20 @@ int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Co
 /* direct (VALU) convolutions for the two shapes where an MFMA tile would be mostly padding:
  *   convd1: 7x7, 1 -> Cout, +bias, ReLU   (update.py:81,87);   conv2 of DispHead: 3x3, Cin -> 1, +bias (update.py:19,24)
  *   tap_major = 0: weight is the module's [Cout,1,7,7]; tap_major = 1: weight is its transpose [49][Cout_pad], Cout_pad =
- *   Cout rounded up to 64, zero padded (one tap's weights contiguous -> vector scalar loads; the fast path). */
+ *   Cout rounded up to 64, zero padded (one tap's weights contiguous -> vector scalar loads; the fast path).
+ *   copy_out != NULL (tap_major only): x is also copied into channel copy_coff of copy_out [B,copy_ctot,H,W] — the
+ *   `torch.cat([out, disp])` tail of BasicMotionEncoder (update.py:91) without a copy kernel. */
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out,
-                       int B, int H, int W, int Cout, int out_ctot, int out_coff, int tap_major, void* stream);
+                       int B, int H, int W, int Cout, int out_ctot, int out_coff, int tap_major,
+                       float* copy_out, int copy_ctot, int copy_coff, void* stream);
 int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float* out,
                    int B, int Cin, int H, int W, void* stream);
 
 /* second stage of the MFMA form of a 3x3, Cin -> 1 convolution: S [B,9,H,W] holds, per tap t = ky*3+kx,
  * the channel reduction sum_c w[c,ky,kx]*x[c] (a 1x1 as_conv2d with the 9 taps as output channels);
  * out[b,0,y,x] = bias + sum_t S[b,t,y+ky-1,x+kx-1] with zero padding — DispHead.conv2 (update.py:19,24). */
-int as_tap_shift_sum(const float* S, const float* bias, float* out, int B, int H, int W, void* stream);
+int as_tap_shift_sum(const float* S, const float* bias, const float* addend /* [B,1,H,W] or NULL: out = addend + (...) */,
+                     float* out, int B, int H, int W, void* stream);
 
 /* a8  pool2x = avg_pool2d(3,stride 2,pad 1) (update.py:94-95); interp = bilinear align_corners=True
  *     resize (update.py:100-102).  x [B,C,H,W] -> out [B,C,Ho,Wo].                                */

@@ -169,14 +169,22 @@ def test_whole_model_cfg2_determinism_and_graph():
     i1, i2, coord, _ = pad_for_multi_train(img1, img2, 1.0, divis_by=32)
     i1, i2, coord = i1.to(DEV), i2.to(DEV), coord.unsqueeze(0).to(DEV)
     sc = torch.tensor([[1.0]], device=DEV)
-    with torch.no_grad():
-        # first call: MIOpen picks its solvers for the remaining backbone convs (may differ from the steady state)
-        model(i1, i2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=sc)
-        a = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
-        b = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
-        model.enable_graph(True)
-        c = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
-        d = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+    # The library's kernels are deterministic (fixed summation order, no atomics); the few backbone layers left on MIOpen
+    # (stride-2 / transposed convs) are only so with its atomics-based solvers excluded — found with tools/find_nondet.py:
+    # the first run-to-run difference (1 ulp) appears in the stride-2 ResidualBlock cnet.layer5.0.
+    prev_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        with torch.no_grad():
+            # first call: MIOpen picks its solvers for the remaining backbone convs (may differ from the steady state)
+            model(i1, i2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            a = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            b = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            model.enable_graph(True)
+            c = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            d = model(i1, i2, iters=32, test_mode=True, hr_coord=coord.clone(), scale=sc)
+    finally:
+        torch.backends.cudnn.deterministic = prev_det
     assert a.shape == (1, 1, 540 * 960) and torch.isfinite(a).all()
     assert torch.equal(a, b), "eager forward is not bitwise repeatable"
     assert torch.equal(c, d), "graph replay is not bitwise repeatable"
