@@ -657,11 +657,18 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PATCHP = PH * PW;
   constexpr int NTAP = KS * KS;
+  // Pipeline unit = NSC 16-channel chunks.  3x3: one chunk (9 taps = 108 MFMAs per consumer wave between barriers).
+  // 1x1: FOUR chunks (64 channels) — with a single chunk the 12 MFMAs of a unit cannot cover the latency of the next
+  // unit's loads (128 -> 64 at 518 400 pixels: 136 us, latency bound); the four chunks are laid out and consumed
+  // exactly like four taps of one chunk (weight image [sub-chunk][comp][h][co][8], one patch sub-image per sub-chunk).
+  constexpr int NSC = (KS == 1) ? 4 : 1;
+  constexpr int NTAPE = NTAP * NSC;          // "taps" of a unit's weight image
   constexpr int WSEG = BN * 16;              // bytes of one (tap, comp, h) weight segment
-  constexpr int WCHUNK = NTAP * 4 * WSEG;    // bytes of one chunk's weight image (16 channels, all taps)
+  constexpr int WCHUNK = NTAPE * 4 * WSEG;   // bytes of one unit's weight image
   constexpr int NWD = WCHUNK / 16 / 256;     // 16-B LDS-DMA pieces per loader thread per chunk
   constexpr int PATCHT = NSUB * PATCHP;      // patch pixels of the block (sub-tile patches back to back)
-  constexpr int NPI = (8 * PATCHT + 255) / 256;  // (channel pair, patch pixel) items per loader thread
+  constexpr int NPI = (8 * PATCHT + 255) / 256;  // (channel pair, patch pixel) items per loader thread and sub-chunk
+  constexpr int PIMG = 4 * PATCHT * 16;      // bytes of one sub-chunk's patch image [comp][h][pixel][8]
   constexpr int WPX = 256 / BN;              // consumer waves along the pixel dimension (4 consumers = (BN/64) x WPX)
   constexpr int PTW = BM / (WPX * 32);       // pixel MFMA tiles per consumer wave
   static_assert(PTW == 1 || PTW == 2, "consumer tile is 64 co x 32|64 px");
@@ -742,8 +749,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     constexpr int SEG_PER_STEP = 256 / BN;
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + n0 + (long long)(ltid / BN) * p.Cout_pad + (ltid % BN);
     const long long wstep16 = (long long)SEG_PER_STEP * p.Cout_pad;
-    const long long wchunk16 = (long long)NTAP * 4 * p.Cout_pad;
-    half2v c_hi[NPI], c_lo[NPI];
+    const long long wchunk16 = (long long)NTAPE * 4 * p.Cout_pad;  // 16-B units of one pipeline unit in the pack
+    half2v c_hi[NSC][NPI], c_lo[NSC][NPI];
 
     // weights: plain 16-B global loads into registers, then ds_write_b128 (an LDS-DMA instruction costs the
     // issuing wave ~150-180 cycles per 1-KB piece on a busy CU — 18 of them per chunk made the loaders
@@ -760,15 +767,16 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     _Pragma("unroll") for (int i = 0; i < NWD; ++i) wd[i * 256] = wreg[i];                             \
   }
 #define AS_SPLIT_FETCH_SPLIT_P(CHUNK)                                                                 \
-  {                                                                                                   \
-    const int cb = (CHUNK) * kSplitKC;                                                                \
+  _Pragma("unroll") for (int sc_ = 0; sc_ < NSC; ++sc_) {                                              \
+    const int cb = ((CHUNK) * NSC + sc_) * kSplitKC;                                                  \
     const float* sp = p.src[0];                                                                       \
     int sc = p.src_c[0], sb = 0;                                                                      \
     if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; }      \
     if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; }      \
     if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; }      \
-    const float* spb = sp + ((long long)b * sc + (cb - sb)) * plane;                                   \
-    const int recs = (int)((long long)(sc - (cb - sb)) * plane * 4);                                   \
+    const int left = sc - (cb - sb);  /* channels of the source from this chunk on; <= 0 in the zero padding of the last unit */ \
+    const float* spb = sp + ((long long)b * sc + (left > 0 ? cb - sb : 0)) * plane;                    \
+    const int recs = left > 0 ? (int)((long long)left * plane * 4) : 0;                                \
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
     const unsigned pl4 = (unsigned)(plane * 4);                                                       \
     float v0[NPI], v1[NPI];                                                                           \
@@ -780,18 +788,18 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     }                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
       const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];                                       \
-      c_hi[i][0] = h0; c_hi[i][1] = h1;                                                               \
-      c_lo[i][0] = (_Float16)((v0[i] - (float)h0) * 2048.f);                                           \
-      c_lo[i][1] = (_Float16)((v1[i] - (float)h1) * 2048.f);                                           \
+      c_hi[sc_][i][0] = h0; c_hi[sc_][i][1] = h1;                                                     \
+      c_lo[sc_][i][0] = (_Float16)((v0[i] - (float)h0) * 2048.f);                                      \
+      c_lo[sc_][i][1] = (_Float16)((v1[i] - (float)h1) * 2048.f);                                      \
     }                                                                                                 \
   }
 #define AS_SPLIT_COMMIT_P()                                                                           \
-  {                                                                                                   \
-    unsigned char* pd = lds + 2 * WCHUNK;                                                              \
+  _Pragma("unroll") for (int sc_ = 0; sc_ < NSC; ++sc_) {                                              \
+    unsigned char* pd = lds + 2 * WCHUNK + sc_ * PIMG;                                                 \
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
       if (p_lds[i] >= 0) {                                                                            \
-        *reinterpret_cast<half2v*>(pd + p_lds[i]) = c_hi[i];                                           \
-        *reinterpret_cast<half2v*>(pd + 2 * PATCHT * 16 + p_lds[i]) = c_lo[i];                         \
+        *reinterpret_cast<half2v*>(pd + p_lds[i]) = c_hi[sc_][i];                                      \
+        *reinterpret_cast<half2v*>(pd + 2 * PATCHT * 16 + p_lds[i]) = c_lo[sc_][i];                    \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -846,7 +854,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       a_hi[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 0) * 2) * WSEG + c * 512);          \
       a_lo[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 1) * 2) * WSEG + c * 512);          \
     }                                                                                                   \
-    constexpr int tapoff_ = (((TAP) / KS) * PW + ((TAP) % KS)) * 16;                                     \
+    constexpr int tapoff_ = (KS == 1) ? (TAP) * PIMG : (((TAP) / KS) * PW + ((TAP) % KS)) * 16;          \
     _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                    \
       b_hi[S][q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff_);                         \
       b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHT * 16 + plane_off[q] + tapoff_);       \
@@ -859,10 +867,10 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0);   \
   }
 #define AS_SPLIT_STEP(TAP)                                                                              \
-  if constexpr ((TAP) < NTAP) {                                                                         \
+  if constexpr ((TAP) < NTAPE) {                                                                        \
     AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if constexpr ((TAP) + 1 < NTAP) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                           \
+    if constexpr ((TAP) + 1 < NTAPE) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                          \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
@@ -955,7 +963,8 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
 template <int KS, int TW, int BN, int EPI, int NSUB = 1>
 int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   constexpr int TH = 128 / TW, PATCHP = (TH + KS - 1) * (TW + KS - 1);
-  constexpr size_t lds = 2 * (size_t)(KS * KS * 4 * BN * 16) + (size_t)(4 * NSUB * PATCHP * 16);
+  constexpr int NSC = (KS == 1) ? 4 : 1;
+  constexpr size_t lds = 2 * (size_t)(KS * KS * NSC * 4 * BN * 16) + (size_t)NSC * (4 * NSUB * PATCHP * 16);
   static_assert(lds <= 160 * 1024, "conv_split: LDS budget");
   static bool configured = false;  // per instantiation; the attribute is idempotent
   if (!configured && lds > 64 * 1024) {
@@ -1037,7 +1046,8 @@ int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, i
 
 int64_t as_conv_pack_size_split(int Cin, int Cout, int KS) {
   if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return -1;
-  const int64_t chunks = (Cin + kSplitKC - 1) / kSplitKC;
+  int64_t chunks = (Cin + kSplitKC - 1) / kSplitKC;
+  if (KS == 1) chunks = (chunks + 3) / 4 * 4;  // 1x1: the kernel's pipeline unit is four chunks (zero padded)
   return chunks * KS * KS * 4 * conv_cout_pad(Cout) * 8;  // fp16 elements
 }
 
@@ -1118,6 +1128,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.n_tiles = p.Cout_pad / bn;
     AS_REQUIRE((long long)d->H * d->W < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: plane too large");
     if (d->KS == 1) {
+      p.chunks = (p.chunks + 3) / 4;  // pipeline units of four 16-channel chunks
       p.H = 1;
       p.W = d->H * d->W;
       p.tiles_x = as::cdiv(p.W, 128);
