@@ -40,6 +40,8 @@ def main():
     bzr = det_uniform((256,), 31).to(dev)
     pzr = ops.PackedConv().get([wzr], [bzr])
     from anystereo import _lib as Lb
+    scoord = det_uniform((b, 2, h, w), 67, 0.0, float(w)).to(dev)
+    sgrad = det_uniform((b, 9, h, w), 68).to(dev)
     w3d = det_uniform((8, 27, 8), 60, -0.1, 0.1).to(dev)
     xl1 = det_uniform((1, 64, 4 * h, 4 * w), 61).to(dev)
     pl1 = ops.PackedConv().get([det_uniform((64, 64, 3, 3), 62, -0.05, 0.05).to(dev)], [det_uniform((64,), 63).to(dev)])
@@ -56,6 +58,8 @@ def main():
         "geo_pyramid": (lambda: ops.geo_pyramid(gev, L)) if g else None,
         "lookup": lambda: ops.geo_corr_lookup(geo, corr, disp, 4),
         "gwc": lambda: ops.gwc_volume(f1, f2, 48, 8),
+        "sampler_fwd": lambda: ops.corr_sampler_forward(corr[0], scoord, 4),
+        "sampler_bwd": lambda: ops.corr_sampler_backward(corr[0], scoord, sgrad, 4),
         "cnet_l1": (lambda: ops.conv2d([xl1], pl1, act=Lb.ACT_RELU)),
         "liif_l2": (lambda: ops.conv2d([xq], pq2, act=Lb.ACT_RELU)),
         "conv3d_stem": (lambda: ops.conv3d_k3(gev, w3d, None, 1, 5)) if g else None,
