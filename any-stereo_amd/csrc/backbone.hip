@@ -105,25 +105,29 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
 #pragma unroll
   for (int j = 0; j < CT; ++j) acc[j] = bias ? bias[g * CT + j] : 0.f;
   const float* wg = wp + g * CT;
+  // rows outside the volume: wave-uniform sentinel scalar offset is not possible (soffset is not range checked on every
+  // generation), so invalid rows get the lane sentinel through `rowok`
   for (int ci = 0; ci < Cin; ++ci) {
-#pragma unroll
+#pragma unroll 1  // one (ci, kz) slab at a time: 9 loads in flight, then 9 x CT FMAs against 9 x CT scalar weights
     for (int kz = 0; kz < 3; ++kz) {
       const int iz = oz * S + kz - 1;
       if (iz < 0 || iz >= D) continue;  // block-uniform
+      float v[3][3];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy * S + ky - 1;
-        if (iy < 0 || iy >= H) continue;  // wave-uniform
-        const unsigned so = (unsigned)((((long long)ci * D + iz) * H + iy) * W * 4);
-        float v[3];
+        const bool rowok = iy >= 0 && iy < H;  // wave-uniform
+        const unsigned so = rowok ? (unsigned)((((long long)ci * D + iz) * H + iy) * W * 4) : 0u;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) v[kx] = bload(rs, xo[kx], so);
-        const float* wt = wg + (long long)(ci * 27 + kz * 9 + ky * 3) * Cout;
+        for (int kx = 0; kx < 3; ++kx) v[ky][kx] = bload(rs, rowok ? xo[kx] : kOOB, so);
+      }
+      const float* wt = wg + (long long)(ci * 27 + kz * 9) * Cout;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int j = 0; j < CT; ++j) acc[j] = fmaf(v[kx], wt[kx * Cout + j], acc[j]);
-      }
+          for (int j = 0; j < CT; ++j) acc[j] = fmaf(v[ky][kx], wt[(ky * 3 + kx) * Cout + j], acc[j]);
     }
   }
   if (ox < Wo) {
