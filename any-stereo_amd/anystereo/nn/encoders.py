@@ -23,6 +23,10 @@ from .. import ops
 from .blocks import BasicConv_IN, Conv2x_IN, conv2d_hip_ok as _conv_hip_ok, conv2d_plain, fused_ok as _fused_ok
 
 
+def _plain_in(norm) -> bool:
+    return isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats
+
+
 def _norm(kind: str, c: int, groups: int | None = None):
     if kind == "group":
         return nn.GroupNorm(num_groups=groups if groups is not None else c // 8, num_channels=c)
@@ -56,11 +60,25 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         if _fused_ok(x, self) and isinstance(self.norm1, nn.BatchNorm2d) and _conv_hip_ok(self.conv2):
             return self._forward_fused(x)
+        if _fused_ok(x, self) and _plain_in(self.norm1) and _plain_in(self.norm2):
+            return self._forward_fused_in(x)
         y = self.relu(self.norm1(self.conv1(x)))
         y = self.relu(self.norm2(self.conv2(y)))
         if self.downsample is not None:
             x = self.downsample(x)
         return self.relu(x + y)
+
+    def _forward_fused_in(self, x):
+        """InstanceNorm variant (RAFT feature net): convs on the library kernel where they apply, InstanceNorm + ReLU in
+        one fused pass each (`as_instance_norm_act`)."""
+        x = x.contiguous()
+        y = ops.instance_norm_act(conv2d_plain(self, self.conv1, x), self.norm1.eps, L.ACT_RELU)
+        y = ops.instance_norm_act(conv2d_plain(self, self.conv2, y), self.norm2.eps, L.ACT_RELU)
+        if self.downsample is not None:
+            ds_norm = self.downsample[1]
+            x = conv2d_plain(self, self.downsample[0], x)
+            x = ops.instance_norm_act(x, ds_norm.eps, L.ACT_NONE) if _plain_in(ds_norm) else ds_norm(x)
+        return torch.relu_(x + y)
 
     def _forward_fused(self, x):
         x = x.contiguous()
@@ -114,6 +132,8 @@ class _Trunk(nn.Module):
                 self._f_stem = ops.FoldedConv()
             w, b = self._f_stem.get(self.conv1, self.norm1)
             x = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
+        elif _fused_ok(x, self) and _plain_in(self.norm1):
+            x = ops.instance_norm_act(self.conv1(x), self.norm1.eps, L.ACT_RELU)
         else:
             x = self.relu1(self.norm1(self.conv1(x)))
         return self.layer3(self.layer2(self.layer1(x)))

@@ -337,7 +337,7 @@ def test_backbone_blocks_fused_inference(precision):
     """§8 f4: MobileNetV2 blocks (pw/dw/pwl with folded BN, ReLU6, skip) and the BatchNorm Conv3d block."""
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.nn.blocks import BasicConv, BasicConv_IN, HighRes_Aggregation, HighRes_Aggregation_LN_GeLU
-    from anystereo.nn.encoders import _DSConv, _InvRes
+    from anystereo.nn.encoders import ResidualBlock, _DSConv, _InvRes
     for k, (mod, shape) in enumerate([(_InvRes(24, 24, 1), (2, 24, 17, 37)), (_InvRes(16, 24, 2), (1, 16, 18, 40)),
                                       (_DSConv(32, 16, 1), (1, 32, 9, 70)), (_InvRes(64, 64, 1), (1, 64, 5, 9)),
                                       (BasicConv(8, 16, is_3d=True, kernel_size=3, padding=1, stride=2), (1, 8, 6, 9, 33)),
@@ -347,7 +347,9 @@ def test_backbone_blocks_fused_inference(precision):
                                       (BasicConv_IN(12, 32, kernel_size=3, stride=1, padding=1), (2, 12, 11, 37)),
                                       (BasicConv_IN(16, 8, deconv=True, kernel_size=4, stride=2, padding=1), (1, 16, 7, 9)),
                                       (HighRes_Aggregation_LN_GeLU(3, 32), (1, 3, 16, 36)),
-                                      (HighRes_Aggregation(3, 48), (2, 3, 12, 20))]):
+                                      (HighRes_Aggregation(3, 48), (2, 3, 12, 20)),
+                                      (ResidualBlock(64, 64, "instance", 1), (2, 64, 13, 37)),
+                                      (ResidualBlock(64, 96, "instance", 2), (1, 64, 14, 36))]):
         mod = mod.eval()
         fill_module_deterministic(mod, 7 + k)
         _randomize_bn(mod, 200 + 40 * k)
