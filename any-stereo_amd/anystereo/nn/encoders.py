@@ -73,12 +73,12 @@ class ResidualBlock(nn.Module):
         one fused pass each (`as_instance_norm_act`)."""
         x = x.contiguous()
         y = ops.instance_norm_act(conv2d_plain(self, self.conv1, x), self.norm1.eps, L.ACT_RELU)
-        y = ops.instance_norm_act(conv2d_plain(self, self.conv2, y), self.norm2.eps, L.ACT_RELU)
         if self.downsample is not None:
             ds_norm = self.downsample[1]
             x = conv2d_plain(self, self.downsample[0], x)
             x = ops.instance_norm_act(x, ds_norm.eps, L.ACT_NONE) if _plain_in(ds_norm) else ds_norm(x)
-        return torch.relu_(x + y)
+        # relu(x + relu(IN(conv2 y))) in the normalisation pass
+        return ops.instance_norm_act(conv2d_plain(self, self.conv2, y), self.norm2.eps, L.ACT_RELU, residual=x.contiguous())
 
     def _forward_fused(self, x):
         x = x.contiguous()

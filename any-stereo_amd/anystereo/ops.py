@@ -470,15 +470,20 @@ def deconv3d_k4s2(x, wpack, bias=None, act: int = L.ACT_NONE):
     return out
 
 
-def instance_norm_act(x, eps: float = 1e-5, act: int = L.ACT_NONE):
-    """act(InstanceNorm(x)) over the trailing spatial dims of x [B,C,*], affine = False (BasicConv_IN tail)."""
+def instance_norm_act(x, eps: float = 1e-5, act: int = L.ACT_NONE, residual=None):
+    """act(InstanceNorm(x)) over the trailing spatial dims of x [B,C,*], affine = False (BasicConv_IN tail); with
+    `residual` (same shape): relu(residual + act(InstanceNorm(x))), the tail of an InstanceNorm ResidualBlock."""
     _req(x, "x")
+    if residual is not None:
+        _req(residual, "residual")
+        if residual.shape != x.shape:
+            raise RuntimeError("instance_norm_act: residual shape mismatch")
     b, c = x.shape[:2]
     hw = x[0, 0].numel()
     out = torch.empty_like(x)
     ws = torch.empty(L.load().as_instance_norm_ws_bytes(b * c) // 8, device=x.device, dtype=torch.float64)
     with torch.cuda.device(x.device):
-        L.check(L.load().as_instance_norm_act(_p(x), _p(out), _p(ws), b * c, hw, eps, act, _stream()), "instance_norm_act")
+        L.check(L.load().as_instance_norm_act(_p(x), _p(residual), _p(out), _p(ws), b * c, hw, eps, act, _stream()), "instance_norm_act")
     return out
 
 

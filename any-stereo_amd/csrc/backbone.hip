@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__ x, const double* __restrict__ ws,
-                                                       float* __restrict__ out, long long HW, float eps, int act) {
+                                                       const float* __restrict__ res, float* __restrict__ out, long long HW,
+                                                       float eps, int act) {
   const long long plane = blockIdx.y;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   double s = 0.0, ss = 0.0;
@@ -262,7 +263,11 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float* __restrict__
   const double mean = s / (double)HW;
   const double var = fmax(ss / (double)HW - mean * mean, 0.0);
   const float m = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
-  if (i < HW) out[plane * HW + i] = act_apply((x[plane * HW + i] - m) * rstd, act);
+  if (i < HW) {
+    float v = act_apply((x[plane * HW + i] - m) * rstd, act);
+    if (res) v = fmaxf(v + res[plane * HW + i], 0.f);  // residual tail relu(res + act(IN(x))) (extractor.py:56-62)
+    out[plane * HW + i] = v;
+  }
 }
 
 // LayerNorm2d: per-pixel normalisation over the C channels of an NCHW tensor, affine, + activation
@@ -351,14 +356,15 @@ int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, floa
 
 int64_t as_instance_norm_ws_bytes(int planes) { return planes > 0 ? (int64_t)planes * kInSeg * 2 * (int64_t)sizeof(double) : 0; }
 
-int as_instance_norm_act(const float* x, float* out, void* ws, int planes, int64_t HW, float eps, int act, void* stream) {
+int as_instance_norm_act(const float* x, const float* residual, float* out, void* ws, int planes, int64_t HW, float eps, int act,
+                         void* stream) {
   AS_REQUIRE(x && out && ws, AS_ERR_BAD_ARG, "instance_norm: null pointer");
   AS_REQUIRE(planes > 0 && planes <= 65535 && HW > 0, AS_ERR_BAD_ARG, "instance_norm: planes=%d HW=%lld", planes, (long long)HW);
   AS_REQUIRE(act >= AS_ACT_NONE && act <= AS_ACT_GELU, AS_ERR_BAD_ARG, "instance_norm: act=%d", act);
   AS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 7) == 0, AS_ERR_BAD_ARG, "instance_norm: ws not 8-B aligned");
   hipStream_t s = as::as_stream(stream);
   hipLaunchKernelGGL(in_stats_kernel, dim3(kInSeg, (unsigned)planes), dim3(256), 0, s, x, (double*)ws, (long long)HW);
-  hipLaunchKernelGGL(in_apply_kernel, dim3((unsigned)as::cdiv64(HW, 256), (unsigned)planes), dim3(256), 0, s, x, (const double*)ws, out,
+  hipLaunchKernelGGL(in_apply_kernel, dim3((unsigned)as::cdiv64(HW, 256), (unsigned)planes), dim3(256), 0, s, x, (const double*)ws, residual, out,
                      (long long)HW, eps, act);
   return as::check_launch("instance_norm_act");
 }

@@ -201,7 +201,8 @@ int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, floa
  *   as_layernorm2d_act: act(w * (x - mean_c) / sqrt(var_c + eps) + b) per pixel over the C <= 64 channels of NCHW x —
  *     LayerNorm2d (submodule.py:148-187) + the ReLU / GELU that follows it in the HighRes_Aggregation heads. */
 int64_t as_instance_norm_ws_bytes(int planes);
-int as_instance_norm_act(const float* x, float* out, void* ws, int planes, int64_t HW, float eps, int act, void* stream);
+int as_instance_norm_act(const float* x, const float* residual /* same shape as x, or NULL: out = relu(residual + act(IN(x))) */,
+                         float* out, void* ws, int planes, int64_t HW, float eps, int act, void* stream);
 int as_layernorm2d_act(const float* x, const float* weight, const float* bias, float* out, int B, int C, int H, int W, float eps,
                        int act, void* stream);
 
