@@ -36,7 +36,7 @@ class ConvDesc(C.Structure):
         ("out_ctot", C.c_int), ("out_coff", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("KS", C.c_int),
         ("act", C.c_int), ("epilogue", C.c_int), ("precision", C.c_int),
-        ("ws", C.c_void_p), ("ws_elems", C.c_int64),
+        ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("stride", C.c_int),
     ]
 
 

@@ -19,12 +19,15 @@ def fused_ok(x: torch.Tensor, mod: nn.Module) -> bool:
 
 
 def conv2d_hip_ok(conv: nn.Module) -> bool:
-    """Conv2d shapes the implicit-GEMM kernel serves: 1x1 / 3x3, stride 1, 'same' padding, no dilation / groups."""
+    """Conv2d shapes the implicit-GEMM kernel serves: 1x1 / 3x3 with 'same' padding, no dilation / groups, stride 1 —
+    or stride 2 for 3x3 in split precision."""
     if not isinstance(conv, nn.Conv2d):
         return False
     k = conv.kernel_size[0]
-    return (conv.kernel_size in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.padding == (k // 2, k // 2)
-            and conv.dilation == (1, 1) and conv.groups == 1)
+    if not (conv.kernel_size in ((1, 1), (3, 3)) and conv.padding == (k // 2, k // 2) and conv.dilation == (1, 1)
+            and conv.groups == 1):
+        return False
+    return conv.stride == (1, 1) or (conv.stride == (2, 2) and k == 3 and ops.get_precision() == "split")
 
 
 def conv2d_plain(mod: nn.Module, conv: nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -32,7 +35,7 @@ def conv2d_plain(mod: nn.Module, conv: nn.Module, x: torch.Tensor) -> torch.Tens
     if conv2d_hip_ok(conv):
         packs = mod.__dict__.setdefault("_hip_packs", {})
         pk = packs.setdefault(id(conv), ops.PackedConv())
-        return ops.conv2d([x.contiguous()], pk.get([conv.weight], [conv.bias]))
+        return ops.conv2d([x.contiguous()], pk.get([conv.weight], [conv.bias]), stride=conv.stride[0])
     return conv(x)
 
 

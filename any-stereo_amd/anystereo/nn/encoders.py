@@ -83,7 +83,7 @@ class ResidualBlock(nn.Module):
     def _forward_fused(self, x):
         x = x.contiguous()
         if _conv_hip_ok(self.conv1):
-            y = ops.conv2d([x], self._pk1.get_folded(self.conv1, self.norm1), act=L.ACT_RELU)
+            y = ops.conv2d([x], self._pk1.get_folded(self.conv1, self.norm1), act=L.ACT_RELU, stride=self.conv1.stride[0])
         else:  # stride 2: MIOpen with the folded weights
             w, b = self._f1.get(self.conv1, self.norm1)
             y = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()

@@ -272,9 +272,14 @@ def fold_bn(conv, bn, out_dim: int = 0):
 
 def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE, add: Optional[torch.Tensor] = None,
            add_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0, epilogue: int = L.EPI_LINEAR,
-           h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None):
-    """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue."""
-    b, _, hh, ww = srcs[0].shape
+           h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+           stride: int = 1):
+    """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue.
+    stride 2: 3x3 / padding 1 / LINEAR epilogue in split precision only; outputs are [(H-1)//2+1, (W-1)//2+1]."""
+    b, _, hin, win = srcs[0].shape
+    if stride not in (1, 2):
+        raise RuntimeError("conv2d: stride must be 1 or 2")
+    hh, ww = (hin, win) if stride == 1 else ((hin - 1) // 2 + 1, (win - 1) // 2 + 1)
     kc = 16 if pack.split else (8 if pack.ks == 3 else 32)  # channels per K chunk of the kernel (csrc/conv.hip)
     if any(s.shape[1] % kc for s in srcs[:-1]):
         # a K chunk must not straddle two tensors: materialise the concat for odd splits (never on the model path)
@@ -285,8 +290,8 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
         raise RuntimeError(f"conv2d: at most {L.AS_MAX_SRCS} sources")
     for i, s in enumerate(srcs):
         _req(s, f"src[{i}]")
-        if s.shape[0] != b or tuple(s.shape[2:]) != (hh, ww):
-            raise RuntimeError(f"conv2d: src[{i}] shape {tuple(s.shape)} does not match {(b, '*', hh, ww)}")
+        if s.shape[0] != b or tuple(s.shape[2:]) != (hin, win):
+            raise RuntimeError(f"conv2d: src[{i}] shape {tuple(s.shape)} does not match {(b, '*', hin, win)}")
         d.src[i] = s.data_ptr()
         d.src_c[i] = s.shape[1]
         cin += s.shape[1]
@@ -333,11 +338,12 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
             if tuple(t.shape) != (b, cout, hh, ww):
                 raise RuntimeError("conv2d(GRU_Q): h/z/out must be [B,Cout,H,W]")
         d.h, d.z, d.out = h.data_ptr(), z.data_ptr(), out.data_ptr()
-    d.B, d.H, d.W, d.Cin, d.Cout, d.KS = b, hh, ww, cin, cout, pack.ks
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KS = b, hin, win, cin, cout, pack.ks
+    d.stride = stride
     d.act, d.epilogue = act, epilogue
     d.precision = 1 if pack.split else 0
     ws = None
-    if pack.split:
+    if pack.split and stride == 1:
         n_ws = L.load().as_conv_ws_elems(b, cout, hh, ww)
         if n_ws > 0:  # small feature map: give the kernel split-K scratch (caching allocator: no sync)
             ws = torch.empty(n_ws, device=dev, dtype=torch.float32)

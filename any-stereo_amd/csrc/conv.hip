@@ -43,7 +43,8 @@ struct ConvParams {
   float* out;
   float* out2;
   int out_ctot, out_coff;
-  int B, H, W, Cin, Cout, Cout_pad, act;
+  int B, H, W, Cin, Cout, Cout_pad, act;  // H, W: OUTPUT plane (= input plane for stride 1)
+  int Hi, Wi;                             // input plane (conv_split_kernel with stride 2)
   int tiles_x, tiles_y, n_tiles, chunks;
   int xcd_map;  // conv_split_kernel: XCD-aware block order (channel tiles of one pixel tile on the same XCD)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
@@ -646,7 +647,7 @@ typedef __attribute__((address_space(1))) const void as_gbl_void;
 // the LDS commit.  Measured on the single-role version: an LDS-DMA instruction costs the issuing wave
 // ~180 cycles, so 18 of them per chunk in front of 108 MFMAs could not overlap with them (in-order issue);
 // on a sibling wave of the same SIMD they do.
-template <int KS, int TW, int BN, int EPI, int NSUB = 1>
+template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1>
 __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   // Block = NSUB sub-tiles of 128 pixels (TH x TW each, consecutive tile ids of the image) x BN output channels.
   // NSUB = 2 with BN = 64 halves the weight bytes a CU pulls per MFMA (the per-CU L1 fill rate, ~45 GB/s, is what
@@ -654,7 +655,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   constexpr int BM = 128 * NSUB;
   constexpr int TH = 128 / TW;
   constexpr int PAD = KS / 2;
-  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  // S: stride (1 | 2).  Tiles live in OUTPUT coordinates; the halo patch of a TH x TW output tile spans
+  // (TH-1) S + KS input rows, and a consumer lane's pixel sits at S times its output offset inside it.
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
   constexpr int PATCHP = PH * PW;
   constexpr int NTAP = KS * KS;
   // Pipeline unit = NSC 16-channel chunks.  3x3: one chunk (9 taps = 108 MFMAs per consumer wave between barriers).
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     sy0[u] = t < ntile ? (t / p.tiles_x) * TH : p.H + PAD + 1;
   }
   const int n0 = nt * BN;
-  const long long plane = (long long)p.H * p.W;
+  const long long plane = (long long)p.Hi * p.Wi;  // INPUT plane: source addressing of the loader waves
 
   f32x16 acc_h[2][PTW], acc_x[2][PTW];
   const int cw = wave & 3;
@@ -739,9 +742,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       const int cp = idx / PATCHT, ppt = idx - cp * PATCHT;
       const int su = ppt / PATCHP, pp = ppt - su * PATCHP;
       const int py = pp / PW, px = pp - py * PW;
-      const int gy = (NSUB > 1 && su ? sy0[NSUB - 1] : sy0[0]) - PAD + py, gx = (NSUB > 1 && su ? sx0[NSUB - 1] : sx0[0]) - PAD + px;
-      const bool in = slot && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      p_voff[i] = in ? (unsigned)(((long long)(2 * cp) * plane + (long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
+      const int gy = (NSUB > 1 && su ? sy0[NSUB - 1] : sy0[0]) * S - PAD + py, gx = (NSUB > 1 && su ? sx0[NSUB - 1] : sx0[0]) * S - PAD + px;
+      const bool in = slot && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+      p_voff[i] = in ? (unsigned)(((long long)(2 * cp) * plane + (long long)gy * p.Wi + gx) * 4) : 0x7FFFFFF0u;
       p_lds[i] = slot ? (cp >> 2) * (PATCHT * 16) + ppt * 16 + (cp & 3) * 4 : -1;
     }
     // piece i of this thread is 16-B unit (ltid + 256 i) of the chunk image = segment (ltid + 256 i) / BN,
@@ -833,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     for (int q = 0; q < PTW; ++q) {
       const int mt = px_base + q * 32 + l31;  // pixel of the block; sub-tile mt / 128, pixel m inside it
       const int m = mt & 127;
-      plane_off[q] = half * (PATCHT * 16) + ((mt >> 7) * PATCHP + (m / TW) * PW + (m % TW)) * 16;
+      plane_off[q] = half * (PATCHT * 16) + ((mt >> 7) * PATCHP + (m / TW) * S * PW + (m % TW) * S) * 16;
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -960,15 +963,15 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   }
 }
 
-template <int KS, int TW, int BN, int EPI, int NSUB = 1>
+template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1>
 int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
-  constexpr int TH = 128 / TW, PATCHP = (TH + KS - 1) * (TW + KS - 1);
+  constexpr int TH = 128 / TW, PATCHP = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
   constexpr int NSC = (KS == 1) ? 4 : 1;
   constexpr size_t lds = 2 * (size_t)(KS * KS * NSC * 4 * BN * 16) + (size_t)NSC * (4 * NSUB * PATCHP * 16);
   static_assert(lds <= 160 * 1024, "conv_split: LDS budget");
   static bool configured = false;  // per instantiation; the attribute is idempotent
   if (!configured && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI, NSUB, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
   const long long groups = as::cdiv64((long long)p.tiles_x * p.tiles_y, NSUB);
@@ -976,7 +979,7 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   static const int xcd_mode = getenv("AS_CONV_XCD") ? atoi(getenv("AS_CONV_XCD")) : 1;
   ConvParams q = p;
   q.xcd_map = (xcd_mode && p.n_tiles > 1) ? 1 : 0;
-  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB>), grid, dim3(512), lds, s, q);
+  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB, S>), grid, dim3(512), lds, s, q);
   return as::check_launch("conv2d(split)");
 }
 
@@ -1123,12 +1126,29 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   hipStream_t s = as::as_stream(stream);
   p.ksplit = 1;
   p.ws = nullptr;
+  const int stride = d->stride ? d->stride : 1;  // 0 (zero-initialised descriptor) = 1
+  AS_REQUIRE(stride == 1 || (stride == 2 && split && d->KS == 3 && epi == AS_EPI_LINEAR), AS_ERR_BAD_ARG,
+             "conv2d: stride=%d (stride 2: 3x3, split precision, LINEAR epilogue only)", stride);
   if (split) {
     const int bn = (p.Cout_pad % 128 == 0) ? 128 : 64;
     p.n_tiles = p.Cout_pad / bn;
     AS_REQUIRE((long long)d->H * d->W < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: plane too large");
+    p.Hi = d->H;
+    p.Wi = d->W;
+    if (stride == 2) {
+      // output plane (H-1)/2+1: 8x16 output tiles x 64 channels (the 17x33 halo patch leaves LDS room for one 64-wide weight image pair)
+      p.H = (d->H - 1) / 2 + 1;
+      p.W = (d->W - 1) / 2 + 1;
+      p.n_tiles = p.Cout_pad / 64;
+      p.tiles_x = as::cdiv(p.W, 16);
+      p.tiles_y = as::cdiv(p.H, 8);
+      AS_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
+      return launch_conv_split_epi<3, 16, 64, AS_EPI_LINEAR, 1, 2>(p, s);
+    }
     if (d->KS == 1) {
       p.chunks = (p.chunks + 3) / 4;  // pipeline units of four 16-channel chunks
+      p.Hi = 1;
+      p.Wi = d->H * d->W;
       p.H = 1;
       p.W = d->H * d->W;
       p.tiles_x = as::cdiv(p.W, 128);

@@ -142,6 +142,8 @@ typedef struct {
   int precision;      /* which pack `wpack` is: 0 = fp32 (as_conv_pack_weights), 1 = split fp16 (as_conv_pack_weights_split) */
   float* ws;          /* optional scratch for split-K on small feature maps (precision 1): partial-sum slabs */
   int64_t ws_elems;   /* capacity of ws in floats; as_conv_ws_elems() gives the useful maximum; 0/NULL = never split K */
+  int stride;         /* 0 or 1: 'same' conv, output H x W.  2 (KS 3, precision 1, AS_EPI_LINEAR): padding 1, H and W are the INPUT
+                         plane, out / add / h are [.., (H-1)/2+1, (W-1)/2+1] — the stride-2 convs of the encoders (extractor.py:14,83) */
 } as_conv_desc;
 int as_conv2d(const as_conv_desc* d, void* stream);
 /* floats of split-K scratch worth passing in as_conv_desc.ws for this problem (0: the problem is large enough) */

@@ -234,6 +234,27 @@ def test_conv2d_linear(b, cins, cout, ks, h, w, act, precision):
     assert (big[:, :4] == 7.0).all() and (big[:, 4 + cout:] == 7.0).all()
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w", [(1, 64, 96, 18, 36), (2, 96, 128, 17, 35), (1, 16, 32, 5, 7), (1, 64, 64, 64, 130)])
+def test_conv2d_stride2(b, cin, cout, h, w):
+    """3x3 / stride 2 / padding 1 (split precision): odd and even sizes, bias + ReLU + residual, vs the fp64 conv."""
+    from anystereo import ops, _lib as L
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        x = U((b, cin, h, w), 400, -2, 2)
+        wt = U((cout, cin, 3, 3), 401) * (3.0 / (cin * 9)) ** 0.5
+        bias = U((cout,), 402) * 0.1
+        ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), stride=2, padding=1).relu()
+        res = U(tuple(ref.shape), 403)
+        pk = ops.PackedConv().get([wt.to(DEV)], [bias.to(DEV)])
+        out = ops.conv2d([x.to(DEV)], pk, act=L.ACT_RELU, stride=2)
+        close(out, ref, 1e-5, 1e-5, "conv2d stride 2")
+        out = ops.conv2d([x.to(DEV)], pk, act=L.ACT_RELU, stride=2, h=res.to(DEV))
+        close(out, (ref + res.double()).relu(), 1e-5, 1e-5, "conv2d stride 2 + residual")
+    finally:
+        ops.set_precision(prev)
+
+
 @pytest.mark.parametrize("h,w", [(8, 12), (5, 33), (17, 9)])
 def test_conv_gru_fused(h, w, precision):
     from anystereo.nn.update import ConvGRU
