@@ -76,6 +76,12 @@ SIGNATURES = {
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_liif_gather_mlp1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_convex_upsample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_corr_pyramid_bwd": (_i, [_pp, _vp, C.c_longlong, _i, _i, _vp]),
+    "as_geo_pyramid_bwd": (_i, [_pp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_gwc_volume_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_disparity_regression_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_gather_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_convex_upsample_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

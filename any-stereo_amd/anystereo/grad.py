@@ -1,0 +1,190 @@
+"""Differentiable forms of the HBM-bound hot-path operators (training, SURVEY.md §8 cfg 4).
+
+Each `torch.autograd.Function` below pairs the HIP forward of `anystereo.ops` with a HIP backward
+(csrc/backward.hip, csrc/lookup.hip) — the transposes autograd derives for the reference's einsum /
+avg_pool2d / grid_sample / unfold / softmax call sites.  The only library arithmetic is the pair of plain
+batched GEMMs of the all-pairs correlation's backward (rocBLAS through torch.matmul).  The nn modules switch
+to these when gradients are required; under `torch.no_grad()` they call `ops` directly.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import _p, _req, _stream
+
+
+def needs_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+def _c(t):
+    return t.float().contiguous()
+
+
+# ---- a1/a2: all-pairs correlation + pooled pyramid (geometry.py:63-72, :27-29) ---------------------------------
+class CorrBuildPyramid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, num_levels):
+        ctx.save_for_backward(f1, f2)
+        ctx.num_levels = num_levels
+        return tuple(ops.corr_build_pyramid(f1, f2, num_levels))
+
+    @staticmethod
+    def backward(ctx, *d_levels):
+        f1, f2 = ctx.saved_tensors
+        b, c, h, w1 = f1.shape
+        w2 = f2.shape[3]
+        lv = [torch.zeros((b, h, w1, w2 >> i), device=f1.device, dtype=torch.float32) if g is None else _c(g)
+              for i, g in enumerate(d_levels)]
+        d0 = torch.empty((b, h, w1, w2), device=f1.device, dtype=torch.float32)
+        pp, keep = L.ptr_array([t.data_ptr() for t in lv])
+        with torch.cuda.device(f1.device):
+            L.check(L.load().as_corr_pyramid_bwd(pp, _p(d0), b * h * w1, w2, len(lv), _stream()), "corr_pyramid_bwd")
+        # corr[b,y,i,j] = sum_c f1[b,c,y,i] f2[b,c,y,j]:  d f1[b,:,y,:] = f2[b,:,y,:] @ d0[b,y]^T,  d f2[b,:,y,:] = f1[b,:,y,:] @ d0[b,y]
+        f1r, f2r = f1.permute(0, 2, 1, 3), f2.permute(0, 2, 1, 3)  # [B,H,C,W]
+        df1 = torch.matmul(f2r, d0.transpose(2, 3)).permute(0, 2, 1, 3).contiguous() if ctx.needs_input_grad[0] else None
+        df2 = torch.matmul(f1r, d0).permute(0, 2, 1, 3).contiguous() if ctx.needs_input_grad[1] else None
+        return df1, df2, None
+
+
+# ---- a2: geometry-encoding pyramid (geometry.py:17-25) ---------------------------------------------------------
+class GeoPyramid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gev, num_levels):
+        ctx.shape = tuple(gev.shape)
+        return tuple(ops.geo_pyramid(gev, num_levels))
+
+    @staticmethod
+    def backward(ctx, *d_levels):
+        b, g, d, h, w = ctx.shape
+        dev = next(t for t in d_levels if t is not None).device
+        lv = [torch.zeros((b, h, w, d >> i, g), device=dev, dtype=torch.float32) if t is None else _c(t)
+              for i, t in enumerate(d_levels)]
+        out = torch.empty(ctx.shape, device=dev, dtype=torch.float32)
+        pp, keep = L.ptr_array([t.data_ptr() for t in lv])
+        with torch.cuda.device(dev):
+            L.check(L.load().as_geo_pyramid_bwd(pp, _p(out), b, g, d, h, w, len(lv), _stream()), "geo_pyramid_bwd")
+        return out, None
+
+
+# ---- a3: lookup (gradients to the volumes only; disp arrives detached, continuous_IGEVstereo.py:285) -----------
+class Lookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, radius, n_geo, *levels):
+        geo, corr = list(levels[:n_geo]), list(levels[n_geo:])
+        ctx.radius, ctx.n_geo = radius, n_geo
+        ctx.geo_shapes = [tuple(t.shape) for t in geo]
+        ctx.corr_shapes = [tuple(t.shape) for t in corr]
+        ctx.save_for_backward(disp)
+        return ops.geo_corr_lookup(geo, corr, disp, radius)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (disp,) = ctx.saved_tensors
+        d_geo, d_corr = ops.geo_corr_lookup_backward(disp, _c(d_out), ctx.geo_shapes, ctx.corr_shapes, ctx.radius)
+        return (None, None, None, *d_geo, *d_corr)
+
+
+# ---- a4: group-wise correlation volume (submodule.py:253-271) ---------------------------------------------------
+class GwcVolume(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fl, fr, maxdisp, groups):
+        ctx.save_for_backward(fl, fr)
+        ctx.maxdisp, ctx.groups = maxdisp, groups
+        return ops.gwc_volume(fl, fr, maxdisp, groups)
+
+    @staticmethod
+    def backward(ctx, d_vol):
+        fl, fr = ctx.saved_tensors
+        b, c, h, w = fl.shape
+        d_vol = _c(d_vol)
+        dfl, dfr = torch.empty_like(fl), torch.empty_like(fr)
+        with torch.cuda.device(fl.device):
+            L.check(L.load().as_gwc_volume_bwd(_p(fl), _p(fr), _p(d_vol), _p(dfl), _p(dfr), b, c, h, w, ctx.maxdisp, ctx.groups,
+                                               _stream()), "gwc_volume_bwd")
+        return dfl, dfr, None, None
+
+
+# ---- a5: (softmax +) disparity regression (continuous_IGEVstereo.py:267-268, submodule.py:321-325) --------------
+class DisparityRegression(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, apply_softmax):
+        ctx.save_for_backward(cost)
+        ctx.apply_softmax = bool(apply_softmax)
+        return ops.disparity_regression(cost, ctx.apply_softmax)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (cost,) = ctx.saved_tensors
+        b, d, h, w = cost.shape
+        d_out = _c(d_out)
+        d_cost = torch.empty_like(cost)
+        with torch.cuda.device(cost.device):
+            L.check(L.load().as_disparity_regression_bwd(_p(cost), _p(d_out), _p(d_cost), b, d, h, w, 1 if ctx.apply_softmax else 0,
+                                                         _stream()), "disparity_regression_bwd")
+        return d_cost, None
+
+
+# ---- a12/a13: cat(x, affinity(x.detach())) (liif.py:496-499) ----------------------------------------------------
+class StructureFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.c = x.shape[1]
+        return ops.structure_feature(x)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        return d_out[:, :ctx.c].contiguous()  # the affinity is computed on x.detach()
+
+
+# ---- a14: nearest gather + relative coordinates (liif.py:108-137) -----------------------------------------------
+class LiifGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, coord):
+        b, c, h, w = feat.shape
+        q = coord.shape[1]
+        lat = torch.empty((b, c + 2, q), device=feat.device, dtype=torch.float32)
+        ops.liif_gather(feat, coord, lat, 0)
+        # not save_for_backward: the caller clamps hr_coord IN PLACE afterwards, every iteration (submodule.py:366), which
+        # would trip autograd's version check; the backward clamps again itself and clamping is idempotent
+        ctx.coord = coord
+        ctx.shape = (b, c, h, w)
+        return lat
+
+    @staticmethod
+    def backward(ctx, d_lat):
+        coord = ctx.coord
+        b, c, h, w = ctx.shape
+        d_lat = _c(d_lat)
+        d_feat = torch.empty(ctx.shape, device=d_lat.device, dtype=torch.float32)
+        with torch.cuda.device(d_lat.device):
+            L.check(L.load().as_liif_gather_bwd(_p(d_lat), _p(coord), _p(d_feat), b, c, h, w, coord.shape[1], c + 2, 0, _stream()),
+                    "liif_gather_bwd")
+        return d_feat, None
+
+
+# ---- a16/a17: (softmax +) convex 3x3 upsampling at the queries (submodule.py:357-372) ---------------------------
+class ConvexUpsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, mask, coord, scale, mask_is_logits):
+        ctx.save_for_backward(disp, mask, scale)
+        ctx.coord = coord  # see LiifGather
+        ctx.logits = bool(mask_is_logits)
+        return ops.convex_upsample(disp, mask, coord, scale=scale, mask_is_logits=ctx.logits)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        disp, mask, scale = ctx.saved_tensors
+        coord = ctx.coord
+        b, _, h, w = disp.shape
+        q = coord.shape[1]
+        d_out = _c(d_out)
+        d_mask = torch.empty_like(mask)
+        d_disp = torch.empty_like(disp) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(disp.device):
+            L.check(L.load().as_convex_upsample_bwd(_p(disp), _p(scale), _p(mask), _p(coord), _p(d_out), _p(d_mask), _p(d_disp),
+                                                    b, h, w, q, 1 if ctx.logits else 0, _stream()), "convex_upsample_bwd")
+        return d_disp, d_mask, None, None, None
+

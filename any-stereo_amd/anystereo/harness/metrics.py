@@ -68,12 +68,12 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
     zero_grad -> forward(train mode) -> sequence_loss_multiscale with valid = (gt < 512) & (gt > 0) -> scaled backward ->
     unscale -> clip_grad_norm_(1.0) -> optimizer step -> scheduler step (unless fixed lr) -> scaler update.
     `batch` = (image1, image2, hr_coord, hr_disp_gt, scale); `scaler` may be None (no mixed precision).
-    Model-agnostic host logic: it needs a model whose forward is differentiable (the HIP hot modules are
-    inference-only in round 1)."""
+    Model-agnostic host logic (any module with the reference's forward signature)."""
     image1, image2, hr_coord, hr_disp_gt, scale = batch
     optimizer.zero_grad()
     assert model.training
-    _, disp_preds = model(image1, image2, iters=train_iters, hr_coord=hr_coord, scale=scale)
+    res = model(image1, image2, iters=train_iters, hr_coord=hr_coord, scale=scale)
+    disp_preds = res[1] if isinstance(res, tuple) else res  # IGEV: (init_disp, preds); RAFT: preds (prune_raft_stereo.py:297)
     loss, metrics = sequence_loss_multiscale(disp_preds, hr_disp_gt, (hr_disp_gt < 512) & (hr_disp_gt > 0.0), max_disp=max_disp)
     if scaler is not None:
         scaler.scale(loss).backward()

@@ -75,3 +75,18 @@ def synthetic_pair(batch: int, height: int, width: int, shift: int = 8, seed: in
     noise = det_uniform((batch, 3, height, width), seed + 1, -2.0, 2.0)
     img2 = (torch.roll(img1, shifts=-shift, dims=3) + noise).clamp(0.0, 254.999)
     return img1.contiguous(), img2.contiguous()
+
+
+def tiny_train_case(name: str):
+    """Inputs of the G8 training-step fixture (tests/golden/train_{igev,raft}.npz): a batch of 2 tiny pairs, 300 random
+    queries per sample from the s = 1.5 grid, ground truth U(0.5, 40) — the shape of a cfg-4 step
+    (train_continuous_IGEV.py:214-239, stereo_datasets.py:190-193) at a size the CPU oracle runs in seconds."""
+    from ..nn.liif import make_coord
+    h, w = (64, 128) if name == "igev" else (64, 96)
+    img1, img2 = synthetic_pair(2, h, w, shift=6, seed=77)
+    s, nq = 1.5, 300
+    grid = make_coord([round(h * s), round(w * s)])
+    idx = [(det_uniform((nq,), 300 + b, 0.0, 1.0) * grid.shape[0]).long().clamp(max=grid.shape[0] - 1) for b in range(2)]
+    coord = torch.stack([grid[i] for i in idx]).contiguous()
+    gt = det_uniform((2, 1, nq), 310, 0.5, 40.0)
+    return h, w, img1, img2, coord, gt, torch.tensor([[s], [s]])

@@ -15,6 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import grad as G
 from .. import ops
 from ..harness.timing import scope
 from ..nn import functional as AF
@@ -77,8 +78,11 @@ class ContinuousStereoBase(nn.Module):
         feats = [x, stem_2x] if stem_2x is not None else [x]
         logits = self.liif_up(feats, hr_coord, scale_vec)  # [B,9,Q]
         hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)  # side effect of context_upsample_multiscale_train (submodule.py:366)
+        disp = disp.float().contiguous()
         with scope("convex_upsample"):
-            return ops.convex_upsample(disp.float().contiguous(), logits, hr_coord, scale=scale_vec, mask_is_logits=True)
+            if G.needs_grad(disp, logits):
+                return G.ConvexUpsample.apply(disp, logits.contiguous(), hr_coord, scale_vec, True)
+            return ops.convex_upsample(disp, logits, hr_coord, scale=scale_vec, mask_is_logits=True)
 
     # ---- whole-forward hipGraph ---------------------------------------------------------------
     # A 32-iteration forward is ~2000 short launches; replaying it as ONE captured graph removes the host

@@ -5,28 +5,36 @@ from __future__ import annotations
 
 import torch
 
+from .. import grad as G
 from .. import ops
 from ..harness.timing import scope
 
 
 def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
     """[B,C,H,W] x2 -> [B,num_groups,maxdisp,H,W] group-wise correlation volume."""
-    if torch.is_grad_enabled() and (refimg_fea.requires_grad or targetimg_fea.requires_grad):
-        raise NotImplementedError("anystereo: build_gwc_volume backward is not built yet (inference path)")
+    fl, fr = refimg_fea.float().contiguous(), targetimg_fea.float().contiguous()
     with scope("gwc_volume"):
-        return ops.gwc_volume(refimg_fea.float().contiguous(), targetimg_fea.float().contiguous(), maxdisp, num_groups)
+        if G.needs_grad(fl, fr):
+            return G.GwcVolume.apply(fl, fr, maxdisp, num_groups)
+        return ops.gwc_volume(fl, fr, maxdisp, num_groups)
 
 
 def disparity_regression(x, maxdisp):
     """sum_d d * x[:, d] for a probability volume x [B,D,H,W] -> [B,1,H,W]."""
     assert x.dim() == 4 and x.shape[1] == maxdisp
-    return ops.disparity_regression(x.float().contiguous(), apply_softmax=False)
+    x = x.float().contiguous()
+    if G.needs_grad(x):
+        return G.DisparityRegression.apply(x, False)
+    return ops.disparity_regression(x, apply_softmax=False)
 
 
 def softmax_disparity_regression(cost):
     """Fused F.softmax(cost, 1) + disparity_regression (continuous_IGEVstereo.py:267-268)."""
+    cost = cost.float().contiguous()
     with scope("disparity_regression"):
-        return ops.disparity_regression(cost.float().contiguous(), apply_softmax=True)
+        if G.needs_grad(cost):
+            return G.DisparityRegression.apply(cost, True)
+        return ops.disparity_regression(cost, apply_softmax=True)
 
 
 def context_upsample_multiscale_train(disp_low, up_weights, hr_coord):
@@ -34,6 +42,7 @@ def context_upsample_multiscale_train(disp_low, up_weights, hr_coord):
     disp_low [B,1,h,w] (already scaled), up_weights [B,9,Q] (already softmaxed), hr_coord [B,Q,2].
     Like the reference (submodule.py:366) this clamps `hr_coord` IN PLACE."""
     hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)
-    out = ops.convex_upsample(disp_low.float().contiguous(), up_weights.float().contiguous(),
-                              hr_coord.float().contiguous(), scale=None, mask_is_logits=False)
-    return out[:, 0]
+    d, m, c = disp_low.float().contiguous(), up_weights.float().contiguous(), hr_coord.float().contiguous()
+    if G.needs_grad(d, m):
+        return G.ConvexUpsample.apply(d, m, c, None, False)[:, 0]
+    return ops.convex_upsample(d, m, c, scale=None, mask_is_logits=False)[:, 0]

@@ -13,32 +13,12 @@ from __future__ import annotations
 
 import torch
 
+from .. import grad as G
 from .. import ops
 from ..harness.timing import scope
 
 
-def _needs_grad(*ts) -> bool:
-    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
-
-
-class _LookupFn(torch.autograd.Function):
-    """Lookup with gradients flowing to the pyramid levels only (disp arrives detached,
-    continuous_IGEVstereo.py:285)."""
-
-    @staticmethod
-    def forward(ctx, disp, radius, n_geo, *levels):
-        geo, corr = list(levels[:n_geo]), list(levels[n_geo:])
-        ctx.radius, ctx.n_geo = radius, n_geo
-        ctx.geo_shapes = [tuple(t.shape) for t in geo]
-        ctx.corr_shapes = [tuple(t.shape) for t in corr]
-        ctx.save_for_backward(disp)
-        return ops.geo_corr_lookup(geo, corr, disp, radius)
-
-    @staticmethod
-    def backward(ctx, d_out):
-        (disp,) = ctx.saved_tensors
-        d_geo, d_corr = ops.geo_corr_lookup_backward(disp, d_out.contiguous(), ctx.geo_shapes, ctx.corr_shapes, ctx.radius)
-        return (None, None, None, *d_geo, *d_corr)
+_needs_grad = G.needs_grad
 
 
 class Combined_Geo_Encoding_Volume:
@@ -47,14 +27,19 @@ class Combined_Geo_Encoding_Volume:
         self.radius = radius
         f1 = init_fmap1.float().contiguous()
         f2 = init_fmap2.float().contiguous()
-        if _needs_grad(f1, f2, geo_volume):
-            raise NotImplementedError("anystereo: backward of the volume build is not implemented yet (inference path)")
         with scope("corr_build"):
-            self.init_corr_pyramid = ops.corr_build_pyramid(f1, f2, num_levels)
+            if _needs_grad(f1, f2):
+                self.init_corr_pyramid = list(G.CorrBuildPyramid.apply(f1, f2, num_levels))
+            else:
+                self.init_corr_pyramid = ops.corr_build_pyramid(f1, f2, num_levels)
         self.geo_volume_pyramid = []
         if geo_volume is not None:
+            gev = geo_volume.float().contiguous()
             with scope("geo_pyramid"):
-                self.geo_volume_pyramid = ops.geo_pyramid(geo_volume.float().contiguous(), num_levels)
+                if _needs_grad(gev):
+                    self.geo_volume_pyramid = list(G.GeoPyramid.apply(gev, num_levels))
+                else:
+                    self.geo_volume_pyramid = ops.geo_pyramid(gev, num_levels)
 
     def __call__(self, disp, coords=None):
         disp = disp.float().contiguous()
@@ -64,7 +49,7 @@ class Combined_Geo_Encoding_Volume:
                 raise RuntimeError(f"lookup: coords must be [B,h,w,1] = {(b, h, w, 1)}, got {tuple(coords.shape)}")
         levels = list(self.geo_volume_pyramid) + list(self.init_corr_pyramid)
         if _needs_grad(*levels):
-            return _LookupFn.apply(disp, self.radius, len(self.geo_volume_pyramid), *levels)
+            return G.Lookup.apply(disp, self.radius, len(self.geo_volume_pyramid), *levels)
         with scope("lookup"):
             return ops.geo_corr_lookup(self.geo_volume_pyramid, self.init_corr_pyramid, disp, self.radius)
 

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import grad as G
 from .. import ops
 from ..harness.timing import scope
 
@@ -92,7 +93,8 @@ class StructureFeature(nn.Module):
         self.Affi1 = AffinityFeature(self.win_h, self.win_w, self.dilation[0], 0)
 
     def forward(self, x):
-        return ops.structure_feature(x.float().contiguous())
+        x = x.float().contiguous()
+        return G.StructureFeature.apply(x) if G.needs_grad(x) else ops.structure_feature(x)
 
 
 def liif_feat_multiscale_train(feat, coords, scale=None, local=False, cell=False):
@@ -103,8 +105,11 @@ def liif_feat_multiscale_train(feat, coords, scale=None, local=False, cell=False
     coords = coords.float().contiguous()
     b, c = feat.shape[:2]
     q = coords.shape[1]
-    lat = torch.empty((b, c + 2, q), device=feat.device, dtype=torch.float32)
-    ops.liif_gather(feat, coords, lat, 0)
+    if G.needs_grad(feat):
+        lat = G.LiifGather.apply(feat, coords)
+    else:
+        lat = torch.empty((b, c + 2, q), device=feat.device, dtype=torch.float32)
+        ops.liif_gather(feat, coords, lat, 0)
     lat = lat.permute(0, 2, 1)
     return lat[..., c:], lat[..., :c], None
 
@@ -136,6 +141,8 @@ class liif_out_multi_scale_Training(nn.Module):
         b, q = coord.shape[:2]
         with scope("structure_feature"):
             sfs = [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
+        if G.needs_grad(*sfs, *self.imnet.parameters()):
+            return self._mask_logits_train(sfs, coord)
         ctot = sum(s.shape[1] + 2 for s in sfs)
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
         pre = self._first_layer_lowres(sfs, lin[0]) if (self.fused_first_layer and len(sfs) <= 2 and len(lin) > 1) else None
@@ -168,6 +175,19 @@ class liif_out_multi_scale_Training(nn.Module):
             # slices + cat only: index tensors would need a host->device copy, which a graph capture forbids
             wrel = torch.cat([lin0.weight.detach()[:, o:o + 2] for o in rel_cols], dim=1).float().contiguous()
         return us, wrel, None if lin0.bias is None else lin0.bias.detach().float().contiguous()
+
+    def _mask_logits_train(self, sfs, coord):
+        """Differentiable form: HIP gather (+ scatter-add backward) per source, the MLP as plain library GEMMs over the
+        channel-major latent [B,228,Q] (liif.py:652-678)."""
+        x = torch.cat([G.LiifGather.apply(s, coord) for s in sfs], dim=1)
+        lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
+        for i, m in enumerate(lin):
+            x = torch.matmul(m.weight, x)
+            if m.bias is not None:
+                x = x + m.bias[None, :, None]
+            if i + 1 < len(lin):
+                x = torch.relu(x)
+        return x
 
     def _mask_logits(self, sfs, coord, ctot, pre=None):
         b, q = coord.shape[:2]

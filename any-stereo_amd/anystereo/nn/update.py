@@ -15,8 +15,10 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import _lib as L
+from .. import grad as G
 from .. import ops
 from ..harness.timing import scope
 
@@ -25,11 +27,10 @@ def _f(t):
     return t.float().contiguous()
 
 
-def _no_grad_only(*ts):
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts):
-        raise NotImplementedError(
-            "anystereo: the HIP update block implements the inference path; backward kernels are not built yet "
-            "(run under torch.no_grad())")
+# Training (gradients required): the dense convolutions of this file run as the nn.Conv2d children themselves (library
+# forward + dgrad/wgrad under autograd) in exactly the reference's formulation; the fused HIP epilogues are the
+# inference path.  Hand-written dgrad/wgrad for the GRU is the next step.
+_train = G.needs_grad
 
 
 class DispHead(nn.Module):
@@ -44,7 +45,9 @@ class DispHead(nn.Module):
     def forward(self, x, addend=None):
         """delta = conv2(relu(conv1(x))) (update.py:23-24); with `addend` the result is addend + delta (the loop's
         `disp = disp + delta_disp`, fused into the last kernel)."""
-        _no_grad_only(x, self.conv1.weight)
+        if _train(x, self.conv1.weight):
+            out = self.conv2(self.relu(self.conv1(x)))  # update.py:23-24
+            return out if addend is None else addend + out
         with scope("disp_head_conv1"):
             t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
         if self.conv2.out_channels == 1:
@@ -92,7 +95,13 @@ class ConvGRU(nn.Module):
         self.tag = "gru"  # timing label; BasicMultiUpdateBlock renames it gru04 / gru08 / gru16
 
     def forward(self, h, cz, cr, cq, *x_list):
-        _no_grad_only(h, cz, self.convz.weight, *x_list)
+        if _train(h, cz, cr, cq, self.convz.weight, *x_list):  # update.py:33-41
+            x = torch.cat(x_list, dim=1)
+            hx = torch.cat([h, x], dim=1)
+            z = torch.sigmoid(self.convz(hx) + cz)
+            r = torch.sigmoid(self.convr(hx) + cr)
+            q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)) + cq)
+            return (1 - z) * h + z * q
         h = _f(h)
         xs = [_f(x) for x in x_list]
         ctx, coff = _context_window(cz, cr, cq)
@@ -120,7 +129,11 @@ class BasicMotionEncoder(nn.Module):
 
 
     def forward(self, disp, corr):
-        _no_grad_only(disp, corr, self.convc1.weight)
+        if _train(disp, corr, self.convc1.weight):  # update.py:84-92
+            cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
+            dsp = F.relu(self.convd2(F.relu(self.convd1(disp))))
+            out = F.relu(self.conv(torch.cat([cor, dsp], dim=1)))
+            return torch.cat([out, disp], dim=1)
         disp, corr = _f(disp), _f(corr)
         cd, out = self.new_buffer(disp), self.new_output(disp)
         self.corr_branch(corr, cd)
@@ -165,11 +178,15 @@ class BasicMotionEncoder(nn.Module):
 
 
 def pool2x(x):
+    if _train(x):
+        return F.avg_pool2d(x, 3, stride=2, padding=1)  # update.py:94-95
     with scope("pool2x"):
         return ops.pool2x(_f(x))
 
 
 def interp(x, dest):
+    if _train(x):
+        return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)  # update.py:100-102
     with scope("interp"):
         return ops.interp(_f(x), dest.shape[2], dest.shape[3])
 

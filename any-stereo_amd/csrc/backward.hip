@@ -1,0 +1,264 @@
+// Backward (training, cfg 4) kernels of the HBM-bound hot-path operators — the transposes of volumes.hip / liif.hip.
+// They are what torch.autograd derives for the reference's Python (einsum / avg_pool2d / grid_sample / unfold /
+// softmax call sites cited per entry point in include/anystereo_hip.h); the dense convolutions' dgrad/wgrad are not
+// here (library kernels).  First, correctness-first versions: one thread per output element, coalesced
+// on the side that is written, every output element written exactly once (no zero-fill contract) except the two
+// scatter kernels, which clear their destination on the same stream and accumulate with float atomics exactly like
+// the reference's grid_sample backward does.
+#include "common.h"
+
+namespace {
+
+// ---- a2ᵀ: pooled pyramid levels -> level 0 ----------------------------------------------------------------------
+// level i+1 = mean of adjacent pairs of level i, trailing odd element dropped (geometry.py:24,28), so
+// d level0[r, x] = Σ_i 2^-i · d level_i[r, x >> i]  for the levels whose width still covers x >> i.
+struct PyrBwdParams {
+  const float* lv[4];
+  float* out;
+  long long rows;
+  int W2, L;
+};
+
+__global__ __launch_bounds__(256) void corr_pyramid_bwd_kernel(PyrBwdParams p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.rows * p.W2) return;
+  const long long r = t / p.W2;
+  const int x = (int)(t - r * p.W2);
+  float acc = p.lv[0][t];
+  float sc = 0.5f;
+  for (int i = 1; i < p.L; ++i, sc *= 0.5f) {
+    const int wi = p.W2 >> i, xi = x >> i;
+    if (xi < wi) acc += sc * p.lv[i][r * wi + xi];
+  }
+  p.out[t] = acc;
+}
+
+// geo levels are stored [B,H,W,D>>i,G]; the volume is [B,G,D,H,W] (geometry.py:17-25).
+struct GeoBwdParams {
+  const float* lv[4];
+  float* out;
+  int B, G, D, H, W, L;
+};
+
+__global__ __launch_bounds__(256) void geo_pyramid_bwd_kernel(GeoBwdParams p) {
+  const long long plane = (long long)p.H * p.W;
+  const long long total = (long long)p.B * p.G * p.D * plane;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long long pix = t % plane;
+  long long rest = t / plane;
+  const int d = (int)(rest % p.D);
+  rest /= p.D;
+  const int g = (int)(rest % p.G);
+  const long long b = rest / p.G;
+  const long long P = b * plane + pix;
+  float acc = 0.f, sc = 1.f;
+  for (int i = 0; i < p.L; ++i, sc *= 0.5f) {
+    const int di = p.D >> i, dd = d >> i;
+    if (dd < di) acc += sc * p.lv[i][(P * di + dd) * p.G + g];
+  }
+  p.out[t] = acc;
+}
+
+// ---- a4ᵀ: group-wise correlation (submodule.py:253-271) --------------------------------------------------------
+// vol[b,g,d,y,x] = 1/cpg Σ_c fl[b,g·cpg+c,y,x]·fr[b,g·cpg+c,y,x-d] (x >= d)
+// d_fl[b,ch,y,x] = 1/cpg Σ_{d<=x} dv[b,g,d,y,x]·fr[b,ch,y,x-d];   d_fr[b,ch,y,x] = 1/cpg Σ_{d: x+d<W} dv[b,g,d,y,x+d]·fl[b,ch,y,x+d]
+__global__ __launch_bounds__(256) void gwc_bwd_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
+                                                     const float* __restrict__ dv, float* __restrict__ dfl,
+                                                     float* __restrict__ dfr, int B, int C, int H, int W, int D, int G) {
+  const long long plane = (long long)H * W;
+  const long long total = (long long)B * C * plane;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int x = (int)(t % W);
+  const long long row = t - x;  // offset of (b,ch,y,0)
+  const long long pix = t % plane;
+  const int ch = (int)((t / plane) % C);
+  const long long b = t / plane / C;
+  const int cpg = C / G, g = ch / cpg;
+  const float* dvp = dv + ((b * G + g) * D) * plane + (pix - x);  // (b,g,0,y,0)
+  float al = 0.f, ar = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float* dr = dvp + (long long)d * plane;
+    if (d <= x) al += dr[x] * fr[row + x - d];
+    if (x + d < W) ar += dr[x + d] * fl[row + x + d];
+  }
+  const float inv = 1.f / (float)cpg;
+  dfl[t] = al * inv;
+  dfr[t] = ar * inv;
+}
+
+// ---- a5ᵀ: (softmax +) disparity regression (continuous_IGEVstereo.py:267-268, submodule.py:321-325) ------------
+__global__ __launch_bounds__(256) void dispreg_bwd_kernel(const float* __restrict__ cost, const float* __restrict__ dout,
+                                                         float* __restrict__ dcost, int B, int D, int H, int W, int softmax) {
+  const long long plane = (long long)H * W;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)B * plane) return;
+  const long long b = t / plane, pix = t - b * plane;
+  const float* cp = cost + b * D * plane + pix;
+  float* gp = dcost + b * D * plane + pix;
+  const float g = dout[t];
+  if (!softmax) {
+    for (int d = 0; d < D; ++d) gp[(long long)d * plane] = g * (float)d;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int d = 0; d < D; ++d) mx = fmaxf(mx, cp[(long long)d * plane]);
+  float s = 0.f, m1 = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float e = expf(cp[(long long)d * plane] - mx);
+    s += e;
+    m1 += e * (float)d;
+  }
+  const float mean = m1 / s;
+  for (int d = 0; d < D; ++d) {
+    const float pd = expf(cp[(long long)d * plane] - mx) / s;
+    gp[(long long)d * plane] = g * pd * ((float)d - mean);
+  }
+}
+
+// ---- a14ᵀ: nearest gather (liif.py:108-137) ---------------------------------------------------------------------
+__device__ __forceinline__ int nearest_idx_b(float c, int n) {
+  const float u = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(c, 1.f), (float)n), 1.f), 2.f);
+  return (int)rintf(u);
+}
+
+__global__ __launch_bounds__(256) void liif_gather_bwd_kernel(const float* __restrict__ dlat, const float* __restrict__ coord,
+                                                             float* __restrict__ dfeat, int B, int C, int H, int W, int Q,
+                                                             int lat_ctot, int lat_coff, float lo, float hi) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)B * Q) return;
+  const long long b = t / Q, q = t - b * Q;
+  const int iy = nearest_idx_b(fminf(fmaxf(coord[t * 2 + 0], lo), hi), H);
+  const int ix = nearest_idx_b(fminf(fmaxf(coord[t * 2 + 1], lo), hi), W);
+  if (iy < 0 || iy >= H || ix < 0 || ix >= W) return;
+  const long long plane = (long long)H * W;
+  float* fp = dfeat + b * C * plane + (long long)iy * W + ix;
+  const float* lp = dlat + (b * lat_ctot + lat_coff) * Q + q;
+  for (int c = 0; c < C; ++c) atomicAdd(fp + (long long)c * plane, lp[(long long)c * Q]);
+}
+
+// ---- a16/a17ᵀ: (softmax +) convex 3x3 combination at the nearest low-res pixel (submodule.py:357-372) -----------
+__global__ __launch_bounds__(256) void convex_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ scale,
+                                                        const float* __restrict__ mask, const float* __restrict__ coord,
+                                                        const float* __restrict__ dout, float* __restrict__ dmask,
+                                                        float* __restrict__ ddisp, int B, int H, int W, int Q, int logits,
+                                                        float lo, float hi) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)B * Q) return;
+  const long long b = t / Q, q = t - b * Q;
+  const float* mp = mask + b * 9 * Q + q;
+  float l[9], dk[9];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    l[k] = mp[(long long)k * Q];
+    mx = fmaxf(mx, l[k]);
+  }
+  if (logits) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      l[k] = expf(l[k] - mx);
+      s += l[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) l[k] /= s;
+  }
+  const int iy = nearest_idx_b(fminf(fmaxf(coord[t * 2 + 0], lo), hi), H);
+  const int ix = nearest_idx_b(fminf(fmaxf(coord[t * 2 + 1], lo), hi), W);
+  const float* dp = disp + b * H * W;
+  const float mul = scale ? __fmul_rn(4.f, scale[b]) : 1.f;
+  const float g = dout[t];
+  float out = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = iy + k / 3 - 1, xx = ix + k % 3 - 1;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    dk[k] = in ? dp[(long long)yy * W + xx] * mul : 0.f;
+    out += dk[k] * l[k];
+    if (in && ddisp) atomicAdd(ddisp + b * H * W + (long long)yy * W + xx, g * l[k] * mul);
+  }
+  float* gm = dmask + b * 9 * Q + q;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gm[(long long)k * Q] = logits ? g * l[k] * (dk[k] - out) : g * dk[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int as_corr_pyramid_bwd(const float* const* d_levels, float* d_corr0, long long rows, int W2, int L, void* stream) {
+  AS_REQUIRE(d_levels && d_corr0, AS_ERR_BAD_ARG, "corr_pyramid_bwd: null pointer");
+  AS_REQUIRE(rows > 0 && W2 > 0 && L >= 1 && L <= 4, AS_ERR_BAD_ARG, "corr_pyramid_bwd: bad size (rows %lld, W2 %d, L %d)", rows, W2, L);
+  PyrBwdParams p{};
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(d_levels[i] || (W2 >> i) == 0, AS_ERR_BAD_ARG, "corr_pyramid_bwd: level %d is null", i);
+    p.lv[i] = d_levels[i];
+  }
+  p.out = d_corr0; p.rows = rows; p.W2 = W2; p.L = L;
+  hipLaunchKernelGGL(corr_pyramid_bwd_kernel, dim3((unsigned)as::cdiv64(rows * W2, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("corr_pyramid_bwd");
+}
+
+int as_geo_pyramid_bwd(const float* const* d_levels, float* d_gev, int B, int G, int D, int H, int W, int L, void* stream) {
+  AS_REQUIRE(d_levels && d_gev, AS_ERR_BAD_ARG, "geo_pyramid_bwd: null pointer");
+  AS_REQUIRE(B > 0 && G > 0 && D > 0 && H > 0 && W > 0 && L >= 1 && L <= 4, AS_ERR_BAD_ARG, "geo_pyramid_bwd: bad size");
+  GeoBwdParams p{};
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(d_levels[i] || (D >> i) == 0, AS_ERR_BAD_ARG, "geo_pyramid_bwd: level %d is null", i);
+    p.lv[i] = d_levels[i];
+  }
+  p.out = d_gev; p.B = B; p.G = G; p.D = D; p.H = H; p.W = W; p.L = L;
+  const long long total = (long long)B * G * D * H * W;
+  hipLaunchKernelGGL(geo_pyramid_bwd_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("geo_pyramid_bwd");
+}
+
+int as_gwc_volume_bwd(const float* fl, const float* fr, const float* d_vol, float* d_fl, float* d_fr, int B, int C, int H,
+                      int W, int D, int G, void* stream) {
+  AS_REQUIRE(fl && fr && d_vol && d_fl && d_fr, AS_ERR_BAD_ARG, "gwc_volume_bwd: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && D > 0 && G > 0, AS_ERR_BAD_ARG, "gwc_volume_bwd: non-positive size");
+  AS_REQUIRE(C % G == 0, AS_ERR_BAD_SHAPE, "gwc_volume_bwd: C=%d not divisible by G=%d", C, G);
+  const long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(gwc_bwd_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), fl, fr, d_vol,
+                     d_fl, d_fr, B, C, H, W, D, G);
+  return as::check_launch("gwc_volume_bwd");
+}
+
+int as_disparity_regression_bwd(const float* cost, const float* d_out, float* d_cost, int B, int D, int H, int W,
+                                int apply_softmax, void* stream) {
+  AS_REQUIRE(cost && d_out && d_cost, AS_ERR_BAD_ARG, "disparity_regression_bwd: null pointer");
+  AS_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "disparity_regression_bwd: non-positive size");
+  hipLaunchKernelGGL(dispreg_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * H * W, 256)), dim3(256), 0, as::as_stream(stream),
+                     cost, d_out, d_cost, B, D, H, W, apply_softmax);
+  return as::check_launch("disparity_regression_bwd");
+}
+
+int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat, int B, int C, int H, int W, int Q,
+                       int lat_ctot, int lat_coff, void* stream) {
+  AS_REQUIRE(d_latent && coord && d_feat, AS_ERR_BAD_ARG, "liif_gather_bwd: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Q > 0, AS_ERR_BAD_ARG, "liif_gather_bwd: non-positive size");
+  AS_REQUIRE(lat_coff >= 0 && lat_coff + C <= lat_ctot, AS_ERR_BAD_SHAPE, "liif_gather_bwd: latent channel window outside %d", lat_ctot);
+  hipError_t e = hipMemsetAsync(d_feat, 0, sizeof(float) * (size_t)B * C * H * W, as::as_stream(stream));
+  if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "liif_gather_bwd: memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(liif_gather_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream),
+                     d_latent, coord, d_feat, B, C, H, W, Q, lat_ctot, lat_coff, (float)(-1.0 + 1e-6), (float)(1.0 - 1e-6));
+  return as::check_launch("liif_gather_bwd");
+}
+
+int as_convex_upsample_bwd(const float* disp, const float* scale, const float* mask, const float* coord, const float* d_out,
+                           float* d_mask, float* d_disp, int B, int H, int W, int Q, int mask_is_logits, void* stream) {
+  AS_REQUIRE(disp && mask && coord && d_out && d_mask, AS_ERR_BAD_ARG, "convex_upsample_bwd: null pointer");
+  AS_REQUIRE(B > 0 && H > 0 && W > 0 && Q > 0, AS_ERR_BAD_ARG, "convex_upsample_bwd: non-positive size");
+  if (d_disp) {
+    hipError_t e = hipMemsetAsync(d_disp, 0, sizeof(float) * (size_t)B * H * W, as::as_stream(stream));
+    if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "convex_upsample_bwd: memset: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(convex_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream),
+                     disp, scale, mask, coord, d_out, d_mask, d_disp, B, H, W, Q, mask_is_logits, (float)(-1.0 + 1e-6),
+                     (float)(1.0 - 1e-6));
+  return as::check_launch("convex_upsample_bwd");
+}
+
+}  // extern "C"

@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--no-batched", action="store_true", help="skip the extra 4-pairs-per-forward throughput measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="run the GRU loop eagerly instead of as a captured hipGraph")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = the headline benchmark (default); train = cfg 4: DDP training steps at 160x320, 16 GRU iterations")
+    ap.add_argument("--batch-per-gpu", type=int, default=4, help="train mode: samples per rank (global batch 32 = 4 x 8)")
+    ap.add_argument("--train-iters", type=int, default=16)
     return ap.parse_args()
 
 
@@ -69,8 +73,73 @@ def algorithmic(B, h, w, Q, iters, C=96, L=2, G=8, D=48, r=4):
     }
 
 
+def train_main(a):
+    """SURVEY.md §8d cfg 4: IGEV training, 4 samples per GPU at 160x320 network input, 51 200 HR queries per sample, 16 GRU
+    iterations with the LIIF upsampler every iteration, AdamW + OneCycleLR; one process per GPU, DDP over RCCL.  A step =
+    zero_grad + forward + loss + backward (+ bucketed gradient all-reduce) + clip + optimizer + scheduler step."""
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from anystereo import _lib
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer, synthetic_train_batch
+    from anystereo.models import __models__, default_args
+    _lib.load()
+    args = default_args("continuous_IGEVStereo")
+    model = __models__["continuous_IGEVStereo"](args)
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(dev)
+    tr = Trainer(model, train_iters=a.train_iters, max_disp=args.max_disp)
+    h, w = (160, 320) if (a.height, a.width) == (540, 960) else (a.height, a.width)
+    batch = synthetic_train_batch(a.batch_per_gpu, h, w, seed=rank, device=dev)
+    losses = []
+    for _ in range(a.warmup):
+        losses.append(float(tr.step(batch)[0]))
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _ = tr.step(batch)
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses.append(float(loss))
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        nparam = sum(p.numel() for p in model.parameters())
+        print(json.dumps({
+            "metric": "train_samples_per_s", "value": round(world * a.batch_per_gpu * a.steps / dt, 3), "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg4 continuous_IGEVStereo training {h}x{w}, {a.train_iters} GRU iters, LIIF every iter, "
+                                   f"Q={batch[2].shape[1]} queries/sample, AdamW+OneCycleLR, clip 1.0",
+                       "global_batch": world * a.batch_per_gpu, "parallelism": f"ddp x{world} (RCCL all-reduce of {nparam} fp32 grads)"},
+            "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+            "backward": "HIP kernels for the volume/lookup/gwc/LIIF-gather/convex-upsample transposes; conv dgrad/wgrad on MIOpen",
+            "roofline": None, "cpu_baseline": None}))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.mode == "train":
+        return train_main(a)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))

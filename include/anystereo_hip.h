@@ -238,6 +238,33 @@ int as_liif_gather_mlp1(const float* u0, const float* u1, const float* coord, co
 int as_convex_upsample(const float* disp, const float* scale, const float* mask, const float* coord,
                        float* out, int B, int H, int W, int Q, int mask_is_logits, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward (training, cfg 4: train_continuous_IGEV.py:214-239) of the HBM-bound operators above — what autograd
+ * derives for the reference's Python call sites.  All fp32, every destination element is written (no zero-fill
+ * contract) — the two scatters (liif_gather_bwd's d_feat, convex_upsample_bwd's d_disp) clear their destination on
+ * `stream` and accumulate with float atomics, like ATen's grid_sample backward.
+ *   a2^T  as_corr_pyramid_bwd: d_levels[i] [rows, W2>>i] (rows = B*H*W1) -> d_corr0 [rows, W2] = sum_i 2^-i d_levels[i][r, x>>i]
+ *         (avg_pool2d([1,2]) chain, geometry.py:27-29 / corePrune_RAFT/geometry.py:16-19).  d(f1), d(f2) then are two plain
+ *         batched GEMMs of d_corr0 with f2 / f1 (einsum 'aijk,aijh->ajkh', geometry.py:70) — left to rocBLAS by the binding.
+ *   a2^T  as_geo_pyramid_bwd: d_levels[i] [B,H,W,D>>i,G] -> d_gev [B,G,D,H,W] (geometry.py:17-25).
+ *   a4^T  as_gwc_volume_bwd: d_vol [B,G,D,H,W] -> d_fl, d_fr [B,C,H,W] (submodule.py:253-271).
+ *   a5^T  as_disparity_regression_bwd: d_out [B,1,H,W] -> d_cost [B,D,H,W]; apply_softmax as in the forward.
+ *   a14^T as_liif_gather_bwd: d_latent [B,lat_ctot,Q] channels [lat_coff, lat_coff+C) -> d_feat [B,C,H,W]
+ *         (grid_sample nearest backward, liif.py:122-125; the relative coordinates carry no gradient to feat).
+ *   a16/a17^T as_convex_upsample_bwd: d_out [B,1,Q] -> d_mask [B,9,Q] (w.r.t. the logits when mask_is_logits) and
+ *         d_disp [B,1,H,W] (may be NULL) w.r.t. the UNscaled disparity when scale != NULL.
+ * ------------------------------------------------------------------------------------------- */
+int as_corr_pyramid_bwd(const float* const* d_levels, float* d_corr0, long long rows, int W2, int L, void* stream);
+int as_geo_pyramid_bwd(const float* const* d_levels, float* d_gev, int B, int G, int D, int H, int W, int L, void* stream);
+int as_gwc_volume_bwd(const float* fl, const float* fr, const float* d_vol, float* d_fl, float* d_fr,
+                      int B, int C, int H, int W, int D, int G, void* stream);
+int as_disparity_regression_bwd(const float* cost, const float* d_out, float* d_cost, int B, int D, int H, int W,
+                                int apply_softmax, void* stream);
+int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat,
+                       int B, int C, int H, int W, int Q, int lat_ctot, int lat_coff, void* stream);
+int as_convex_upsample_bwd(const float* disp, const float* scale, const float* mask, const float* coord, const float* d_out,
+                           float* d_mask, float* d_disp, int B, int H, int W, int Q, int mask_is_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,7 @@ ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 REF = "/root/reference"
 sys.path.insert(0, os.path.join(ROOT, "any-stereo_amd"))
 
-from anystereo.harness.synthetic import det_uniform, fill_module_deterministic, synthetic_pair  # noqa: E402
+from anystereo.harness.synthetic import det_uniform, fill_module_deterministic, synthetic_pair, tiny_train_case  # noqa: E402
 from anystereo.models.base import default_args  # noqa: E402
 from anystereo.nn.encoders import MobileNetV2Trunk  # noqa: E402
 
@@ -57,7 +57,44 @@ def save(name, **arrs):
     print(f"wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
-def main():
+# parameters whose full gradient is stored (the rest: L2 norms only) — one per hot-path operator family + the
+# backbone tensors that receive their gradient THROUGH the volume build / gwc / lookup backward
+TRAIN_FULL = {
+    "igev": ["update_block.encoder.convc1.bias", "update_block.encoder.convd1.weight", "update_block.gru04.convq.bias",
+             "update_block.gru16.convz.bias", "update_block.disp_head.conv2.weight", "liif_up.imnet.layers.0.weight",
+             "liif_up.imnet.layers.6.weight", "desc.bias", "corr_stem.bn.weight", "corr_stem.conv.weight",
+             "context_zqr_convs.0.bias", "stem_2.head.1.bias"],
+    "raft": ["update_block.encoder.convc1.bias", "update_block.encoder.convd1.weight", "update_block.gru04.convq.bias",
+             "update_block.disp_head.conv2.weight", "liif_up.imnet.layers.0.weight", "liif_up.imnet.layers.6.weight",
+             "context_zqr_convs.0.bias", "fnet.conv2.bias"],
+}
+
+
+def golden_train(RefIGEV, RefRAFT, ns2):
+    """G8: one training forward/backward of the imported reference — loss and parameter gradients."""
+    torch.set_grad_enabled(True)
+    for name, Ref in (("igev", RefIGEV), ("raft", RefRAFT)):
+        args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
+        model = Ref(args)
+        fill_module_deterministic(model, base_seed=1)
+        model.train()
+        model.freeze_bn()  # train_continuous_IGEV.py:189
+        H, W, img1, img2, coord, gt, scale = tiny_train_case(name)
+        res = model(img1, img2, iters=3, hr_coord=coord.clone(), scale=scale)
+        preds = res[1] if name == "igev" else res
+        loss, met = ns2["sequence_loss_multiscale"](preds, gt, ((gt < 512) & (gt > 0)).float(), max_disp=args.max_disp)
+        loss.backward()
+        named = dict(model.named_parameters())
+        names = sorted(n for n, p in named.items() if p.grad is not None)
+        norms = np.array([float(named[n].grad.double().norm()) for n in names])
+        full = {f"g{i}": named[n].grad for i, n in enumerate(TRAIN_FULL[name])}
+        save(f"train_{name}", loss=loss, names=np.array(names), norms=norms, full_names=np.array(TRAIN_FULL[name]),
+             last_pred=preds[-1], **full)
+        print(name, "train loss", float(loss), "params with grad", len(names), "max norm", norms.max())
+    torch.set_grad_enabled(False)
+
+
+def main(only=None):
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     import_reference()
@@ -69,6 +106,14 @@ def main():
     import models.coreContinuous_IGEV.liif as rliif
     from models.coreContinuous_IGEV.continuous_IGEVstereo import continuous_IGEVStereo as RefIGEV
     from models.corePrune_RAFT.prune_raft_stereo import continuous_RaftStereo as RefRAFT
+    if only == "train":
+        import ast
+        import torch.nn.functional as F
+        tree = ast.parse(open(os.path.join(REF, "train_continuous_IGEV.py")).read())
+        fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "sequence_loss_multiscale"][0]
+        ns2 = {"torch": torch, "F": F}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), "train_continuous_IGEV.py", "exec"), ns2)
+        return golden_train(RefIGEV, RefRAFT, ns2)
 
     # ---- G1/G2/G3: correlation, pyramids, lookup (IGEV: L=2,G=8; RAFT: L=4,G=0) ------------------
     for tag, (b, c, h, w, w2) in {"even": (2, 96, 3, 20, 20), "odd": (1, 96, 2, 21, 21)}.items():
@@ -231,7 +276,11 @@ def main():
          epe_m=met["epe"], px1=met["1px"], px3=met["3px"],
          EPE=rmet.EPE_metric(est, g3, m3), D1=rmet.D1_metric(est, g3, m3), Thres2=rmet.Thres_metric(est, g3, m3, 2.0))
 
+    # ---- G8: training step (loss + parameter gradients) -------------------------------------------
+    golden_train(RefIGEV, RefRAFT, ns2)
+
 
 if __name__ == "__main__":
-    argparse.ArgumentParser().parse_args()
-    main()
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", choices=["train"], default=None, help="regenerate only the G8 training-step fixtures")
+    main(ap.parse_args().only)

@@ -531,3 +531,157 @@ def test_ops_reject_cpu_tensors():
         ops.corr_build_pyramid(torch.zeros(1, 4, 2, 8), torch.zeros(1, 4, 2, 8), 2)
     with pytest.raises(RuntimeError):
         ops.pool2x(torch.zeros(1, 1, 4, 4))
+
+
+# ---------------------------------------------------------------------------------------------
+# training (cfg 4): backward kernels vs autograd of the oracle; one training step vs the reference's gradients (G8)
+# ---------------------------------------------------------------------------------------------
+
+def _leaf(t, dev=None, dt=None):
+    t = t.clone()
+    if dt is not None:
+        t = t.to(dt)
+    if dev is not None:
+        t = t.to(dev)
+    return t.requires_grad_(True)
+
+
+@pytest.mark.parametrize("b,c,h,w1,w2,L", [(2, 96, 3, 20, 20, 2), (1, 64, 2, 21, 21, 2), (1, 32, 2, 37, 37, 4), (2, 33, 3, 70, 45, 3)])
+def test_corr_build_backward(b, c, h, w1, w2, L):
+    from anystereo import grad as G
+    f1, f2 = U((b, c, h, w1), 401), U((b, c, h, w2), 402)
+    gs = [U((b, h, w1, w2 >> i), 410 + i) for i in range(L)]
+    a1, a2 = _leaf(f1, DEV), _leaf(f2, DEV)
+    lv = G.CorrBuildPyramid.apply(a1, a2, L)
+    torch.autograd.backward(lv, [g.to(DEV) for g in gs])
+    r1, r2 = _leaf(f1, dt=torch.float64), _leaf(f2, dt=torch.float64)
+    ref = O.corr_pyramid(O.all_pairs_corr(r1, r2), L)
+    torch.autograd.backward(ref, [g.double().view_as(r) for g, r in zip(gs, ref)])
+    close(a1.grad, r1.grad, 2e-5, 1e-6, "d f1")
+    close(a2.grad, r2.grad, 2e-5, 1e-6, "d f2")
+    # only the coarsest level receives a gradient (the others arrive as None)
+    a1.grad = None
+    lv = G.CorrBuildPyramid.apply(a1, a2.detach(), L)
+    lv[-1].backward(gs[-1].to(DEV))
+    r1.grad = None
+    ref = O.corr_pyramid(O.all_pairs_corr(r1, r2.detach()), L)
+    ref[-1].backward(gs[-1].double().view_as(ref[-1]))
+    close(a1.grad, r1.grad, 2e-5, 1e-6, "d f1 (last level only)")
+
+
+@pytest.mark.parametrize("b,g,d,h,w,L", [(2, 8, 48, 3, 20, 2), (1, 4, 17, 2, 9, 3), (1, 8, 48, 5, 33, 2)])
+def test_geo_pyramid_backward(b, g, d, h, w, L):
+    from anystereo import grad as G
+    gev = U((b, g, d, h, w), 420)
+    gs = [U((b, h, w, d >> i, g), 421 + i) for i in range(L)]
+    a = _leaf(gev, DEV)
+    torch.autograd.backward(G.GeoPyramid.apply(a, L), [t.to(DEV) for t in gs])
+    r = _leaf(gev, dt=torch.float64)
+    torch.autograd.backward(O.geo_pyramid(r, L), [t.double().permute(0, 1, 2, 4, 3) for t in gs])
+    close(a.grad, r.grad, 1e-6, 1e-7, "d gev")
+
+
+@pytest.mark.parametrize("b,c,h,w,D,G_", [(2, 96, 3, 60, 48, 8), (1, 32, 2, 20, 48, 4), (1, 96, 5, 37, 12, 8)])
+def test_gwc_backward(b, c, h, w, D, G_):
+    from anystereo import grad as G
+    fl, fr = U((b, c, h, w), 430), U((b, c, h, w), 431)
+    gv = U((b, G_, D, h, w), 432)
+    a1, a2 = _leaf(fl, DEV), _leaf(fr, DEV)
+    G.GwcVolume.apply(a1, a2, D, G_).backward(gv.to(DEV))
+    r1, r2 = _leaf(fl, dt=torch.float64), _leaf(fr, dt=torch.float64)
+    O.gwc_volume(r1, r2, D, G_).backward(gv.double())
+    close(a1.grad, r1.grad, 2e-5, 1e-6, "d fl")
+    close(a2.grad, r2.grad, 2e-5, 1e-6, "d fr")
+
+
+def test_disparity_regression_backward():
+    from anystereo import grad as G
+    cost = U((2, 48, 5, 33), 440, -4, 4)
+    g = U((2, 1, 5, 33), 441)
+    for softmax in (True, False):
+        a = _leaf(cost, DEV)
+        G.DisparityRegression.apply(a, softmax).backward(g.to(DEV))
+        r = _leaf(cost, dt=torch.float64)
+        O.disparity_regression(torch.softmax(r, 1) if softmax else r, 48).backward(g.double())
+        close(a.grad, r.grad, 2e-5, 1e-6, f"d cost (softmax={softmax})")
+
+
+@pytest.mark.parametrize("scale", [1.0, 1.5, 2.95])
+def test_liif_gather_and_convex_backward(scale):
+    """Scatter-add transposes (float atomics: summation order varies, tolerance covers it)."""
+    from anystereo import grad as G
+    from anystereo.nn.liif import make_coord
+    b, c, h, w = 2, 40, 6, 10
+    feat = U((b, c, h, w), 450)
+    grid = make_coord([round(4 * h * scale), round(4 * w * scale)])
+    coord = grid[None].repeat(b, 1, 1).contiguous()
+    coord[0, :3] = torch.tensor([[-1.0, -1.0], [1.0, 1.0], [0.0, 0.0]])
+    q = coord.shape[1]
+    # a13 + a14
+    a = _leaf(feat, DEV)
+    lat = G.LiifGather.apply(G.StructureFeature.apply(a), coord.to(DEV))
+    gl = U((b, c + 8 + 2, q), 451)
+    lat.backward(gl.to(DEV))
+    r = _leaf(feat, dt=torch.float64)
+    rel, qf = O.liif_query(O.structure_feature_v2isu(r), coord.double())
+    torch.cat([qf, rel], -1).permute(0, 2, 1).backward(gl.double())
+    close(lat, torch.cat([qf, rel], -1).permute(0, 2, 1), 2e-5, 2e-5, "latent")
+    close(a.grad, r.grad, 1e-4, 1e-5, "d feat")
+    # a16/a17, logits + scale (the model's call) and the reference function's own contract
+    disp, logits, gout = U((b, 1, h, w), 452, 0, 30), U((b, 9, q), 453, -3, 3), U((b, 1, q), 454)
+    sc = torch.tensor([scale, 1.0 + 0.5 * scale])
+    ad, am = _leaf(disp, DEV), _leaf(logits, DEV)
+    out = G.ConvexUpsample.apply(ad, am, coord.to(DEV), sc.to(DEV), True)
+    out.backward(gout.to(DEV))
+    rd, rm = _leaf(disp, dt=torch.float64), _leaf(logits, dt=torch.float64)
+    ref = O.convex_upsample(rd * 4.0 * sc.double().view(-1, 1, 1, 1), torch.softmax(rm, 1), coord.double()).unsqueeze(1)
+    ref.backward(gout.double())
+    close(out, ref, 2e-5, 2e-5, "convex fwd")
+    close(am.grad, rm.grad, 5e-5, 1e-5, "d logits")
+    close(ad.grad, rd.grad, 1e-4, 1e-5, "d disp")
+    ad, am = _leaf(disp, DEV), _leaf(torch.softmax(logits, 1), DEV)
+    G.ConvexUpsample.apply(ad, am, coord.to(DEV), None, False).backward(gout.to(DEV))
+    rd, rm = _leaf(disp, dt=torch.float64), _leaf(torch.softmax(logits, 1), dt=torch.float64)
+    O.convex_upsample(rd, rm, coord.double()).unsqueeze(1).backward(gout.double())
+    close(am.grad, rm.grad, 5e-5, 1e-5, "d mask")
+    close(ad.grad, rd.grad, 1e-4, 1e-5, "d disp (plain)")
+
+
+@pytest.mark.parametrize("name", ["igev", "raft"])
+def test_training_step_vs_reference(name):
+    """One training forward/backward of the product model (train mode, frozen BatchNorm2d, 3 GRU iterations with the
+    LIIF upsampler every iteration, sequence_loss_multiscale) on the GPU vs the loss and parameter gradients captured
+    from the imported reference (tests/golden/train_*.npz, G8)."""
+    import numpy as np
+    from anystereo.harness.metrics import sequence_loss_multiscale
+    from anystereo.harness.synthetic import fill_module_deterministic, tiny_train_case
+    from anystereo.models import __models__, default_args
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}.npz"))
+    args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
+    model = __models__[args.model](args)
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV).train()
+    model.freeze_bn()
+    h, w, img1, img2, coord, gt, scale = tiny_train_case(name)
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        res = model(img1.to(DEV), img2.to(DEV), iters=3, hr_coord=coord.to(DEV), scale=scale.to(DEV))
+        preds = res[1] if name == "igev" else res
+        gtd = gt.to(DEV)
+        loss, _ = sequence_loss_multiscale(preds, gtd, ((gtd < 512) & (gtd > 0)).float(), max_disp=args.max_disp)
+        loss.backward()
+    finally:
+        torch.backends.cudnn.deterministic = prev
+    assert abs(loss.item() - float(z["loss"])) < 1e-3 * abs(float(z["loss"])), (loss.item(), float(z["loss"]))
+    assert (preds[-1].detach().cpu() - torch.from_numpy(z["last_pred"])).abs().mean().item() < 1e-3
+    named = dict(model.named_parameters())
+    names = [str(n) for n in z["names"]]
+    assert sorted(n for n, p in named.items() if p.grad is not None) == names
+    norms = np.array([float(named[n].grad.double().norm()) for n in names])
+    rel = np.abs(norms - z["norms"]) / (z["norms"] + 1e-6 * z["norms"].max())
+    assert rel.max() < 2e-2, f"{name}: grad-norm mismatch {rel.max():.3e} at {names[int(rel.argmax())]}"
+    # element-wise, on one tensor per operator family; 2 % of the tensor's max: the BatchNorm3d scale/shift gradients of
+    # the cost aggregation are sums of large cancelling terms and move by ~1 % between CPU and MIOpen batch statistics
+    for i, n in enumerate(str(x) for x in z["full_names"]):
+        close(named[n].grad, torch.from_numpy(z[f"g{i}"]), rtol=2e-2, atol=1e-6, what=n)

@@ -2,9 +2,13 @@
 reference (tests/golden/make_golden.py).  Tolerances are fp32 rounding-order tolerances; the lookup
 additionally absorbs grid_sample's normalise/denormalise round trip (utils.py:64, SURVEY.md A3:
 ~3e-6 relative to the coordinate, i.e. ~1e-5 of the local volume slope)."""
+import os
+
 import torch
 
 from oracle import ops as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def close(a, b, rtol=1e-5, atol=1e-5):
@@ -150,3 +154,31 @@ def test_whole_model_vs_reference(golden):
                 close(res[0], g["init_disp"], 1e-4, 1e-4)
             for i, p in enumerate(preds):
                 assert (p - g[f"pred_{i}"]).abs().mean().item() < 1e-3
+
+
+def test_training_step_vs_reference(golden):
+    """G8: loss and parameter gradients of one training forward/backward (train mode, frozen BatchNorm2d, LIIF every
+    iteration, sequence_loss_multiscale) of the oracle model vs the imported reference."""
+    import numpy as np
+    from anystereo.harness.metrics import sequence_loss_multiscale
+    from anystereo.harness.synthetic import tiny_train_case
+    for name in ("igev", "raft"):
+        z = np.load(f"{GOLDEN}/train_{name}.npz")
+        model, _ = _whole(name)
+        model.train()
+        model.freeze_bn()
+        h, w, img1, img2, coord, gt, scale = tiny_train_case(name)
+        res = model(img1, img2, iters=3, hr_coord=coord.clone(), scale=scale)
+        preds = res[1] if name == "igev" else res
+        loss, _ = sequence_loss_multiscale(preds, gt, ((gt < 512) & (gt > 0)).float(), max_disp=model.args.max_disp)
+        loss.backward()
+        assert abs(loss.item() - float(z["loss"])) < 1e-3 * abs(float(z["loss"]))
+        assert (preds[-1].detach() - torch.from_numpy(z["last_pred"])).abs().mean().item() < 1e-3
+        named = dict(model.named_parameters())
+        names = [str(n) for n in z["names"]]
+        assert sorted(n for n, p in named.items() if p.grad is not None) == names
+        norms = np.array([float(named[n].grad.double().norm()) for n in names])
+        rel = np.abs(norms - z["norms"]) / (z["norms"] + 1e-6 * z["norms"].max())
+        assert rel.max() < 2e-2, f"{name}: grad-norm mismatch {rel.max():.3e} at {names[int(rel.argmax())]}"
+        for i, n in enumerate(str(x) for x in z["full_names"]):
+            close(named[n].grad, torch.from_numpy(z[f"g{i}"]), rtol=2e-3, atol=1e-6)
