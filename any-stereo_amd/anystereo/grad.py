@@ -157,12 +157,44 @@ class LiifGather(torch.autograd.Function):
     def backward(ctx, d_lat):
         coord = ctx.coord
         b, c, h, w = ctx.shape
-        d_lat = _c(d_lat)
-        d_feat = torch.empty(ctx.shape, device=d_lat.device, dtype=torch.float32)
-        with torch.cuda.device(d_lat.device):
-            L.check(L.load().as_liif_gather_bwd(_p(d_lat), _p(coord), _p(d_feat), b, c, h, w, coord.shape[1], c + 2, 0, _stream()),
-                    "liif_gather_bwd")
-        return d_feat, None
+        return ops.liif_scatter_add(_c(d_lat), coord, c, h, w), None
+
+
+# ---- a14 + first Linear/ReLU of a15 through the low-resolution identity (csrc/liif.hip, as_liif_gather_mlp1) -----
+class LiifGatherMlp1(torch.autograd.Function):
+    """h1[b,:,q] = relu(u0[b,:,n0(q)] + u1[b,:,n1(q)] + wrel·rel(q) + bias).  Backward: the ReLU mask, two scatter-adds
+    (HIP) and two small reductions over the queries for wrel / bias."""
+
+    @staticmethod
+    def forward(ctx, u0, u1, coord, wrel, bias):
+        h1 = ops.liif_gather_mlp1(u0, u1, coord, wrel, bias)
+        ctx.save_for_backward(h1)
+        ctx.coord = coord  # see LiifGather
+        ctx.s0 = tuple(u0.shape)
+        ctx.s1 = None if u1 is None else tuple(u1.shape)
+        ctx.has_bias = bias is not None
+        return h1
+
+    @staticmethod
+    def backward(ctx, d_h1):
+        (h1,) = ctx.saved_tensors
+        coord = ctx.coord
+        d_pre = (d_h1 * (h1 > 0)).contiguous()
+        b, c, h0, w0 = ctx.s0
+        d_u0 = ops.liif_scatter_add(d_pre, coord, c, h0, w0) if ctx.needs_input_grad[0] else None
+        d_u1 = None
+        sizes = [(h0, w0)]
+        if ctx.s1 is not None:
+            sizes.append(ctx.s1[2:])
+            if ctx.needs_input_grad[1]:
+                d_u1 = ops.liif_scatter_add(d_pre, coord, c, ctx.s1[2], ctx.s1[3])
+        d_wrel = d_bias = None
+        if ctx.needs_input_grad[3]:
+            rel, _ = ops.liif_rel_key(coord, sizes)
+            d_wrel = torch.matmul(d_pre, rel.transpose(1, 2)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            d_bias = d_pre.sum((0, 2))
+        return d_u0, d_u1, None, d_wrel, d_bias
 
 
 # ---- a16/a17: (softmax +) convex 3x3 upsampling at the queries (submodule.py:357-372) ---------------------------

@@ -76,13 +76,44 @@ class ContinuousStereoBase(nn.Module):
 
     def _hot_upsample(self, disp, x, stem_2x, hr_coord, scale_vec):
         feats = [x, stem_2x] if stem_2x is not None else [x]
+        disp = disp.float().contiguous()
+        if G.needs_grad(disp, x, *self.liif_up.parameters()):
+            return self._hot_upsample_train(disp, feats, hr_coord, scale_vec)
         logits = self.liif_up(feats, hr_coord, scale_vec)  # [B,9,Q]
         hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)  # side effect of context_upsample_multiscale_train (submodule.py:366)
-        disp = disp.float().contiguous()
         with scope("convex_upsample"):
-            if G.needs_grad(disp, logits):
-                return G.ConvexUpsample.apply(disp, logits.contiguous(), hr_coord, scale_vec, True)
             return ops.convex_upsample(disp, logits, hr_coord, scale=scale_vec, mask_is_logits=True)
+
+    # Training: the queries are random samples of the HR grid (stereo_datasets.py:190-193), ~16 per 1/4-res pixel.  The whole
+    # per-query stage (gather, MLP, softmax, convex combination) is order-independent, so it runs on the queries SORTED by
+    # source pixel — the gathers read coalesced and the scatter-add backward pre-sums each pixel's run inside a wave instead
+    # of issuing one contended atomic per element (csrc/backward.hip) — and the result is put back in the caller's order.
+    # The permutation is computed once per forward (`_iterate` clears it): hr_coord is the same tensor in every iteration.
+    sort_queries = True
+
+    def _query_order(self, hr_coord, sizes):
+        cache = self.__dict__.setdefault("_qorder", {})
+        k = (hr_coord.data_ptr(), tuple(hr_coord.shape), tuple(sizes))
+        if k not in cache:
+            _, key = ops.liif_rel_key(hr_coord, sizes, want_rel=False, want_key=True)
+            perm = torch.argsort(key, dim=1)
+            inv = torch.empty_like(perm)
+            inv.scatter_(1, perm, torch.arange(perm.shape[1], device=perm.device).expand_as(perm))
+            cache.clear()
+            cache[k] = (perm, inv)
+        return cache[k]
+
+    def _hot_upsample_train(self, disp, feats, hr_coord, scale_vec):
+        sizes = [tuple(f.shape[2:]) for f in feats]
+        order = self._query_order(hr_coord, sizes) if (self.sort_queries and len(feats) <= 2) else None
+        hr = hr_coord if order is None else torch.gather(hr_coord, 1, order[0].unsqueeze(-1).expand(-1, -1, 2))
+        logits = self.liif_up(feats, hr, scale_vec)
+        hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)  # reference side effect (submodule.py:366)
+        if order is not None:
+            hr = hr.clamp(-1 + 1e-6, 1 - 1e-6)
+        with scope("convex_upsample"):
+            out = G.ConvexUpsample.apply(disp, logits.contiguous(), hr, scale_vec, True)
+        return out if order is None else torch.gather(out, 2, order[1].unsqueeze(1))
 
     # ---- whole-forward hipGraph ---------------------------------------------------------------
     # A 32-iteration forward is ~2000 short launches; replaying it as ONE captured graph removes the host
@@ -190,6 +221,7 @@ class ContinuousStereoBase(nn.Module):
         disp_preds = []
         disp_up = None
         ub = self.update_block
+        self.__dict__.pop("_qorder", None)
         if (test_mode and iters > 0 and a.n_gru_layers == 3 and not a.slow_fast_gru and disp.is_cuda
                 and not torch.is_grad_enabled() and getattr(ub, "parallel_encoder", False)
                 and type(self)._hot_update is ContinuousStereoBase._hot_update and self.pipelined_loop):

@@ -107,7 +107,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
             if B.fused_ok(geo_encoding_volume, self) and B.conv3d_k3_ok(self.classifier):
                 cost = B.conv3d_fused(self, self.classifier, None, geo_encoding_volume, 0)
             else:
-                cost = self.classifier(geo_encoding_volume)
+                cost = B.conv3d_train(self.classifier, geo_encoding_volume)
             init_disp = self._hot_init_disp(cost.squeeze(1))
             del gwc_volume
             cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)

@@ -68,6 +68,47 @@ def conv3d_fused(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int)
     return ops.conv3d_k3(x.contiguous(), w, b, conv.stride[0], act)
 
 
+class _SearchedConv(torch.autograd.Function):
+    """aten.convolution / convolution_backward with MIOpen's solver SEARCH enabled for these calls only.
+    Without a tuning database MIOpen's immediate mode serves the hourglass' 3-D convolutions (17 configurations) with
+    naive reference kernels in training — 223 ms of a 359 ms cfg-4 step, 4.6 ms after a search (tools/conv_bwd_times.py) —
+    while turning `cudnn.benchmark` on globally makes it search every 2-D configuration of the model too (> 8 min)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, cfg):
+        ctx.save_for_backward(x, w)
+        ctx.cfg, ctx.bias_sizes = cfg, None if bias is None else list(bias.shape)
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = True
+        try:
+            return torch.ops.aten.convolution(x, w, bias, *cfg)
+        finally:
+            torch.backends.cudnn.benchmark = prev
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = True
+        try:
+            gx, gw, gb = torch.ops.aten.convolution_backward(
+                gy.contiguous(), x, w, ctx.bias_sizes, *ctx.cfg,
+                [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]])
+        finally:
+            torch.backends.cudnn.benchmark = prev
+        return gx, gw, gb, None
+
+
+def conv3d_train(conv, x):
+    """conv(x) for an nn.Conv3d / nn.ConvTranspose3d; under autograd on the GPU through _SearchedConv."""
+    if not (x.is_cuda and x.dim() == 5 and torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
+        return conv(x)
+    transposed = isinstance(conv, nn.ConvTranspose3d)
+    cfg = (list(conv.stride), list(conv.padding), list(conv.dilation), transposed,
+           list(conv.output_padding) if transposed else [0, 0, 0], conv.groups)
+    return _SearchedConv.apply(x, conv.weight, conv.bias, cfg)
+
+
 def _conv_nd(is_3d: bool, deconv: bool):
     if is_3d:
         return nn.ConvTranspose3d if deconv else nn.Conv3d
@@ -100,7 +141,7 @@ class _ConvNormAct(nn.Module):
         if fused_ok(x, self) and x.dim() == 4 and _plain_instance_norm(norm):
             # conv (library kernel where it applies, else MIOpen) -> fused InstanceNorm + LeakyReLU
             return ops.instance_norm_act(conv2d_plain(self, self.conv, x), norm.eps, L.ACT_LEAKY if self.relu else L.ACT_NONE)
-        x = self.conv(x)
+        x = conv3d_train(self.conv, x) if x.dim() == 5 else self.conv(x)
         if self.use_norm:
             x = norm(x)
         return F.leaky_relu(x, 0.01) if self.relu else x

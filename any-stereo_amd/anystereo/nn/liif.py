@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import grad as G
@@ -177,10 +178,23 @@ class liif_out_multi_scale_Training(nn.Module):
         return us, wrel, None if lin0.bias is None else lin0.bias.detach().float().contiguous()
 
     def _mask_logits_train(self, sfs, coord):
-        """Differentiable form: HIP gather (+ scatter-add backward) per source, the MLP as plain library GEMMs over the
-        channel-major latent [B,228,Q] (liif.py:652-678)."""
-        x = torch.cat([G.LiifGather.apply(s, coord) for s in sfs], dim=1)
+        """Differentiable form (liif.py:652-678).  With <= 2 sources the first Linear layer is applied at LOW resolution
+        (two library 1x1 convs under autograd) and the per-query stage is the fused HIP gather + add + ReLU with its HIP
+        scatter-add backward (grad.LiifGatherMlp1); otherwise the latent [B,228,Q] is gathered per source.  The remaining
+        layers are plain library GEMMs over the channel-major activations."""
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
+        if self.fused_first_layer and len(sfs) <= 2 and len(lin) > 1:
+            w1, off, us, rel_cols = lin[0].weight, 0, [], []
+            for s in sfs:
+                c = s.shape[1]
+                us.append(F.conv2d(s, w1[:, off:off + c, None, None]))
+                rel_cols.append(w1[:, off + c:off + c + 2])
+                off += c + 2
+            x = G.LiifGatherMlp1.apply(us[0].contiguous(), us[1].contiguous() if len(us) > 1 else None, coord,
+                                       torch.cat(rel_cols, dim=1).contiguous(), lin[0].bias)
+            lin = lin[1:]
+        else:
+            x = torch.cat([G.LiifGather.apply(s, coord) for s in sfs], dim=1)
         for i, m in enumerate(lin):
             x = torch.matmul(m.weight, x)
             if m.bias is not None:

@@ -588,6 +588,32 @@ def liif_gather_mlp1(u0, u1, coord, wrel, bias):
     return out
 
 
+def liif_rel_key(coord, sizes, want_rel=True, want_key=False):
+    """Relative coordinates [B, 2*n_src, Q] of the queries w.r.t. the nearest cell of each source (liif.py:127-129) and/or the
+    int32 sort key [B,Q] of the training path.  sizes = [(H0,W0)] or [(H0,W0),(H1,W1)]."""
+    _req(coord, "coord")
+    b, q = coord.shape[:2]
+    n = len(sizes)
+    if n not in (1, 2) or tuple(coord.shape) != (b, q, 2):
+        raise RuntimeError("liif_rel_key: coord must be [B,Q,2] and 1 or 2 sources")
+    rel = torch.empty((b, 2 * n, q), device=coord.device, dtype=torch.float32) if want_rel else None
+    key = torch.empty((b, q), device=coord.device, dtype=torch.int32) if want_key else None
+    (h0, w0), (h1, w1) = sizes[0], (sizes[1] if n > 1 else (0, 0))
+    with torch.cuda.device(coord.device):
+        L.check(L.load().as_liif_rel_key(_p(coord), _p(rel), _p(key), b, q, n, h0, w0, h1, w1, _stream()), "liif_rel_key")
+    return rel, key
+
+
+def liif_scatter_add(d_rows, coord, c, h, w, coff=0):
+    """Transpose of the nearest gather: d_rows [B,Ctot,Q] channels [coff, coff+c) summed into [B,c,h,w]."""
+    _req(d_rows, "d_rows"), _req(coord, "coord")
+    b, ctot, q = d_rows.shape
+    out = torch.empty((b, c, h, w), device=d_rows.device, dtype=torch.float32)
+    with torch.cuda.device(d_rows.device):
+        L.check(L.load().as_liif_gather_bwd(_p(d_rows), _p(coord), _p(out), b, c, h, w, q, ctot, coff, _stream()), "liif_gather_bwd")
+    return out
+
+
 def convex_upsample(disp, mask, coord, scale=None, mask_is_logits=False):
     """(softmax(mask) ·) disp[3x3 nbr of the nearest low-res pixel] -> [B,1,Q]; with `scale` [B] the
     disparity is multiplied by 4*scale_b on the fly

@@ -123,19 +123,78 @@ __device__ __forceinline__ int nearest_idx_b(float c, int n) {
   return (int)rintf(u);
 }
 
+// Scatter-add of per-query rows into the low-resolution map.  Lanes whose queries fall into the same source pixel are
+// first summed inside the wave (segmented suffix sum over runs of equal keys, 6 shuffle steps) and only the head of
+// each run issues the atomic: with the queries sorted by source pixel (the training path sorts them once per step,
+// models/base.py) this cuts the atomics by the number of queries per pixel (16 at scale 1); on unsorted queries every
+// lane is (almost always) its own run and the kernel degenerates to one atomic per element — correct either way.
 __global__ __launch_bounds__(256) void liif_gather_bwd_kernel(const float* __restrict__ dlat, const float* __restrict__ coord,
                                                              float* __restrict__ dfeat, int B, int C, int H, int W, int Q,
                                                              int lat_ctot, int lat_coff, float lo, float hi) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)B * Q) return;
-  const long long b = t / Q, q = t - b * Q;
-  const int iy = nearest_idx_b(fminf(fmaxf(coord[t * 2 + 0], lo), hi), H);
-  const int ix = nearest_idx_b(fminf(fmaxf(coord[t * 2 + 1], lo), hi), W);
-  if (iy < 0 || iy >= H || ix < 0 || ix >= W) return;
+  const bool valid = t < (long long)B * Q;  // no early return: every lane takes part in the shuffles
+  const long long tt = valid ? t : 0;
+  const long long b = tt / Q, q = tt - b * Q;
+  const int iy = nearest_idx_b(fminf(fmaxf(coord[tt * 2 + 0], lo), hi), H);
+  const int ix = nearest_idx_b(fminf(fmaxf(coord[tt * 2 + 1], lo), hi), W);
+  const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
   const long long plane = (long long)H * W;
+  const int key = ok ? (int)(b * plane + (long long)iy * W + ix) : -1;
+  const int lane = threadIdx.x & 63;
+  // runs = maximal stretches of CONSECUTIVE lanes with equal keys (equal keys further apart are separate runs, each with
+  // its own atomic): lane + 2^k belongs to this lane's run iff no run starts in (lane, lane + 2^k]
+  const int prev = __shfl_up(key, 1);
+  const bool starts = lane == 0 || prev != key;
+  const unsigned long long heads = __ballot(starts);
+  const unsigned long long after = (heads >> lane) >> 1;
+  unsigned same = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (lane + (1 << k) < 64 && (after & ((1ull << (1 << k)) - 1ull)) == 0ull) same |= 1u << k;
+  const bool head = ok && starts;
   float* fp = dfeat + b * C * plane + (long long)iy * W + ix;
   const float* lp = dlat + (b * lat_ctot + lat_coff) * Q + q;
-  for (int c = 0; c < C; ++c) atomicAdd(fp + (long long)c * plane, lp[(long long)c * Q]);
+  for (int c = 0; c < C; ++c) {
+    float v = ok ? lp[(long long)c * Q] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float o = __shfl_down(v, 1 << k);
+      v += ((same >> k) & 1u) ? o : 0.f;
+    }
+    if (head) atomicAdd(fp + (long long)c * plane, v);
+  }
+}
+
+// relative coordinates of a14 alone: out[b, 2s+{0,1}, q] = (coord - centre of the nearest cell of source s) * (H_s, W_s)
+// and the sort key of the training path: (nearest pixel of source 0) * 4 + parity of the nearest pixel of source 1
+struct RelParams {
+  const float* coord;
+  float* rel;   // [B, 2*n_src, Q] or null
+  int* key;     // [B, Q] or null
+  int B, Q, n_src;
+  int H[2], W[2];
+  float lo, hi;
+  float c0y[2], sy[2], c0x[2], sx[2];
+};
+
+__global__ __launch_bounds__(256) void liif_rel_key_kernel(RelParams p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)p.B * p.Q) return;
+  const long long b = t / p.Q, q = t - b * p.Q;
+  const float cr = p.coord[t * 2 + 0], cc = p.coord[t * 2 + 1];
+  int key = 0;
+  for (int s = 0; s < p.n_src; ++s) {
+    const int iy = nearest_idx_b(fminf(fmaxf(cr, p.lo), p.hi), p.H[s]);
+    const int ix = nearest_idx_b(fminf(fmaxf(cc, p.lo), p.hi), p.W[s]);
+    if (p.rel) {
+      const float qy = __fadd_rn(p.c0y[s], __fmul_rn(p.sy[s], (float)iy));
+      const float qx = __fadd_rn(p.c0x[s], __fmul_rn(p.sx[s], (float)ix));
+      p.rel[(b * 2 * p.n_src + 2 * s) * p.Q + q] = __fmul_rn(__fsub_rn(cr, qy), (float)p.H[s]);
+      p.rel[(b * 2 * p.n_src + 2 * s + 1) * p.Q + q] = __fmul_rn(__fsub_rn(cc, qx), (float)p.W[s]);
+    }
+    key = s == 0 ? (iy * p.W[0] + ix) * 4 : key + ((iy & 1) << 1) + (ix & 1);
+  }
+  if (p.key) p.key[t] = key;
 }
 
 // ---- a16/a17ᵀ: (softmax +) convex 3x3 combination at the nearest low-res pixel (submodule.py:357-372) -----------
@@ -240,11 +299,29 @@ int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat,
   AS_REQUIRE(d_latent && coord && d_feat, AS_ERR_BAD_ARG, "liif_gather_bwd: null pointer");
   AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Q > 0, AS_ERR_BAD_ARG, "liif_gather_bwd: non-positive size");
   AS_REQUIRE(lat_coff >= 0 && lat_coff + C <= lat_ctot, AS_ERR_BAD_SHAPE, "liif_gather_bwd: latent channel window outside %d", lat_ctot);
+  AS_REQUIRE((long long)B * H * W < 2147483647ll, AS_ERR_BAD_SHAPE, "liif_gather_bwd: B*H*W too large for a 32-bit run key");
   hipError_t e = hipMemsetAsync(d_feat, 0, sizeof(float) * (size_t)B * C * H * W, as::as_stream(stream));
   if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "liif_gather_bwd: memset: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(liif_gather_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream),
                      d_latent, coord, d_feat, B, C, H, W, Q, lat_ctot, lat_coff, (float)(-1.0 + 1e-6), (float)(1.0 - 1e-6));
   return as::check_launch("liif_gather_bwd");
+}
+
+int as_liif_rel_key(const float* coord, float* rel, int* key, int B, int Q, int n_src, int H0, int W0, int H1, int W1, void* stream) {
+  AS_REQUIRE(coord && (rel || key), AS_ERR_BAD_ARG, "liif_rel_key: null pointer");
+  AS_REQUIRE(B > 0 && Q > 0 && (n_src == 1 || n_src == 2) && H0 > 0 && W0 > 0 && (n_src == 1 || (H1 > 0 && W1 > 0)), AS_ERR_BAD_ARG,
+             "liif_rel_key: bad size");
+  AS_REQUIRE((long long)H0 * W0 * 4 < 2147483647ll, AS_ERR_BAD_SHAPE, "liif_rel_key: source 0 too large for a 32-bit key");
+  RelParams p{};
+  p.coord = coord; p.rel = rel; p.key = key; p.B = B; p.Q = Q; p.n_src = n_src;
+  p.H[0] = H0; p.W[0] = W0; p.H[1] = n_src > 1 ? H1 : 1; p.W[1] = n_src > 1 ? W1 : 1;
+  p.lo = (float)(-1.0 + 1e-6); p.hi = (float)(1.0 - 1e-6);
+  for (int s = 0; s < 2; ++s) {
+    p.c0y[s] = (float)(-1.0 + 1.0 / p.H[s]); p.sy[s] = (float)(2.0 * (1.0 / p.H[s]));
+    p.c0x[s] = (float)(-1.0 + 1.0 / p.W[s]); p.sx[s] = (float)(2.0 * (1.0 / p.W[s]));
+  }
+  hipLaunchKernelGGL(liif_rel_key_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("liif_rel_key");
 }
 
 int as_convex_upsample_bwd(const float* disp, const float* scale, const float* mask, const float* coord, const float* d_out,

@@ -262,6 +262,11 @@ int as_disparity_regression_bwd(const float* cost, const float* d_out, float* d_
                                 int apply_softmax, void* stream);
 int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat,
                        int B, int C, int H, int W, int Q, int lat_ctot, int lat_coff, void* stream);
+/* relative coordinates of a14 alone and the query sort key of the training path: rel [B, 2*n_src, Q] (rows
+ *   rel_row_s, rel_col_s as in as_liif_gather; may be NULL), key [B,Q] int32 = (nearest pixel of source 0) * 4 + parity of
+ *   the nearest pixel of source 1 (may be NULL).  Sorting the queries by key makes the scatter of as_liif_gather_bwd
+ *   run-coherent (it pre-sums runs of equal source pixels inside a wave before the atomics). */
+int as_liif_rel_key(const float* coord, float* rel, int* key, int B, int Q, int n_src, int H0, int W0, int H1, int W1, void* stream);
 int as_convex_upsample_bwd(const float* disp, const float* scale, const float* mask, const float* coord, const float* d_out,
                            float* d_mask, float* d_disp, int B, int H, int W, int Q, int mask_is_logits, void* stream);
 

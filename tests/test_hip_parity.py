@@ -685,3 +685,32 @@ def test_training_step_vs_reference(name):
     # the cost aggregation are sums of large cancelling terms and move by ~1 % between CPU and MIOpen batch statistics
     for i, n in enumerate(str(x) for x in z["full_names"]):
         close(named[n].grad, torch.from_numpy(z[f"g{i}"]), rtol=2e-2, atol=1e-6, what=n)
+
+
+@pytest.mark.parametrize("sort", [False, True])
+def test_liif_gather_mlp1_backward(sort):
+    """Fused gather + first Linear/ReLU and its backward (scatter-adds with in-wave run pre-summation), on random queries
+    as drawn in training and on the same queries sorted by source pixel."""
+    from anystereo import grad as G, ops
+    from anystereo.nn.liif import make_coord
+    b, c, h0, w0 = 2, 24, 5, 9
+    grid = make_coord([4 * h0 * 2, 4 * w0 * 2])
+    idx = (U((b, 700), 470, 0.0, 1.0) * grid.shape[0]).long().clamp(max=grid.shape[0] - 1)
+    coord = torch.stack([grid[i] for i in idx]).contiguous()
+    if sort:
+        _, key = ops.liif_rel_key(coord.to(DEV), [(h0, w0), (2 * h0, 2 * w0)], want_rel=False, want_key=True)
+        perm = torch.argsort(key, dim=1).cpu()
+        coord = torch.gather(coord, 1, perm.unsqueeze(-1).expand(-1, -1, 2)).contiguous()
+    u0, u1 = U((b, c, h0, w0), 471), U((b, c, 2 * h0, 2 * w0), 472)
+    wrel, bias, gout = U((c, 4), 473), U((c,), 474), U((b, c, coord.shape[1]), 475)
+    a = [_leaf(t, DEV) for t in (u0, u1, wrel, bias)]
+    out = G.LiifGatherMlp1.apply(a[0], a[1], coord.to(DEV), a[2], a[3])
+    out.backward(gout.to(DEV))
+    r = [_leaf(t, dt=torch.float64) for t in (u0, u1, wrel, bias)]
+    rel0, q0 = O.liif_query(r[0], coord.double())
+    rel1, q1 = O.liif_query(r[1], coord.double())
+    ref = torch.relu(q0 + q1 + torch.cat([rel0, rel1], -1) @ r[2].t() + r[3]).permute(0, 2, 1)
+    ref.backward(gout.double())
+    close(out, ref, 2e-5, 2e-5, "h1")
+    for x, y, n in zip(a, r, ("d u0", "d u1", "d wrel", "d bias")):
+        close(x.grad, y.grad, 1e-4, 1e-5, n)
