@@ -108,6 +108,7 @@ def train_main(a):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        torch.cuda._sleep(2000)  # ~1 us `spin_kernel`: step marker for tools/profile_train.sh (separates MIOpen's search in warm-up)
         loss, _ = tr.step(batch)
     torch.cuda.synchronize()
     if dist:

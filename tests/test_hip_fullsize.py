@@ -247,3 +247,41 @@ def test_conv1x1_many_pixels(mode):
             assert (big[:, :1] == 7.0).all() and (big[:, 1 + cout:] == 7.0).all()
     finally:
         ops.set_precision(prev)
+
+
+def test_cfg4_training_steps_fullsize():
+    """cfg 4 at full size (4 x 160x320, 51 200 queries per sample, 16 GRU iterations): three optimisation steps on one batch.
+    Size-independent properties: finite loss that decreases on a repeated batch, finite gradients on every parameter that
+    takes part in the loss, the global gradient norm clipped to 1, sorted-query and caller-order upsampling agree."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer, synthetic_train_batch
+    from anystereo.models import __models__, default_args
+    args = default_args("continuous_IGEVStereo")
+    model = __models__["continuous_IGEVStereo"](args)
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV)
+    tr = Trainer(model, num_steps=100, train_iters=16, max_disp=args.max_disp)
+    batch = synthetic_train_batch(4, 160, 320, seed=3, device=DEV)
+    assert batch[2].shape == (4, 51200, 2)
+    losses = []
+    for _ in range(3):
+        loss, met = tr.step(batch)
+        losses.append(float(loss))
+        assert torch.isfinite(loss) and set(met) == {"epe", "1px", "3px"}
+    assert losses[2] < losses[0], losses
+    with_grad = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+    assert len(with_grad) >= 430
+    assert all(torch.isfinite(p.grad).all() for _, p in with_grad)
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in with_grad)).item()
+    assert total <= 1.0 + 1e-4, f"gradient norm after clipping {total}"
+    # the per-query stage is order-independent: sorted (training default) == caller order
+    model.eval()
+    img1, img2, coord, _, scale = (t[:1] for t in batch)
+    outs = []
+    for flag in (True, False):
+        model.sort_queries = flag
+        with torch.enable_grad():
+            _, preds = model(img1, img2, iters=2, hr_coord=coord.clone(), scale=scale)
+        outs.append(preds[-1].detach())
+    model.sort_queries = True
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-3
