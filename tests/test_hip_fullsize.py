@@ -250,9 +250,13 @@ def test_conv1x1_many_pixels(mode):
 
 
 def test_cfg4_training_steps_fullsize():
-    """cfg 4 at full size (4 x 160x320, 51 200 queries per sample, 16 GRU iterations): three optimisation steps on one batch.
-    Size-independent properties: finite loss that decreases on a repeated batch, finite gradients on every parameter that
-    takes part in the loss, the global gradient norm clipped to 1, sorted-query and caller-order upsampling agree."""
+    """cfg 4 at full size (4 x 160x320, 51 200 queries per sample, 16 GRU iterations).  Size-independent properties:
+    finite losses and gradients over optimisation steps, the global gradient norm clipped to 1; the training forward
+    (library convs, autograd Functions) and the inference kernels under no_grad give the same loss; a small step against the
+    gradient lowers it (no first-order magnitude check: the reference detaches `disp` every iteration,
+    continuous_IGEVstereo.py:285, so its gradient is a truncated one by design — the exact pin is G8 in
+    test_hip_parity.py); sorted-query and caller-order upsampling agree."""
+    from anystereo.harness.metrics import sequence_loss_multiscale
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.harness.train import Trainer, synthetic_train_batch
     from anystereo.models import __models__, default_args
@@ -260,28 +264,45 @@ def test_cfg4_training_steps_fullsize():
     model = __models__["continuous_IGEVStereo"](args)
     fill_module_deterministic(model, base_seed=1)
     model = model.to(DEV)
-    tr = Trainer(model, num_steps=100, train_iters=16, max_disp=args.max_disp)
+    tr = Trainer(model, lr=1e-5, num_steps=100, train_iters=16, max_disp=args.max_disp, lr_fixed=True)
     batch = synthetic_train_batch(4, 160, 320, seed=3, device=DEV)
     assert batch[2].shape == (4, 51200, 2)
-    losses = []
-    for _ in range(3):
+    for _ in range(2):
         loss, met = tr.step(batch)
-        losses.append(float(loss))
         assert torch.isfinite(loss) and set(met) == {"epe", "1px", "3px"}
-    assert losses[2] < losses[0], losses
     with_grad = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
     assert len(with_grad) >= 430
     assert all(torch.isfinite(p.grad).all() for _, p in with_grad)
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in with_grad)).item()
     assert total <= 1.0 + 1e-4, f"gradient norm after clipping {total}"
+
+    img1, img2, coord, gt, scale = batch
+
+    def loss_of(grad):
+        with torch.set_grad_enabled(grad):
+            _, preds = model(img1, img2, iters=16, hr_coord=coord.clone(), scale=scale)
+            return sequence_loss_multiscale(preds, gt, ((gt < 512) & (gt > 0)).float(), max_disp=args.max_disp)[0]
+
+    model.zero_grad()
+    l0 = loss_of(True)
+    l0_inf = loss_of(False).item()
+    assert abs(l0.item() - l0_inf) < 1e-4 * abs(l0_inf), (l0.item(), l0_inf)
+    l0.backward()
+    params = [p for p in model.parameters() if p.grad is not None]
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)).item()
+    eps = 2e-3
+    with torch.no_grad():
+        for p in params:
+            p.add_(p.grad, alpha=-eps / gnorm)
+    l1 = loss_of(False).item()
+    assert l1 < l0.item() - 0.5 * eps * gnorm, (l0.item(), l1, eps * gnorm)
+
     # the per-query stage is order-independent: sorted (training default) == caller order
-    model.eval()
-    img1, img2, coord, _, scale = (t[:1] for t in batch)
     outs = []
     for flag in (True, False):
         model.sort_queries = flag
         with torch.enable_grad():
-            _, preds = model(img1, img2, iters=2, hr_coord=coord.clone(), scale=scale)
+            _, preds = model(img1[:1], img2[:1], iters=2, hr_coord=coord[:1].clone(), scale=scale[:1])
         outs.append(preds[-1].detach())
     model.sort_queries = True
     assert (outs[0] - outs[1]).abs().max().item() < 1e-3
