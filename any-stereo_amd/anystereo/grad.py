@@ -197,6 +197,38 @@ class LiifGatherMlp1(torch.autograd.Function):
         return d_u0, d_u1, None, d_wrel, d_bias
 
 
+# ---- remaining Linear/ReLU layers of a15 over channel-major activations (liif.py:9-25) ---------------------------
+class PointwiseLinear(torch.autograd.Function):
+    """y[b,:,q] = act(W x[b,:,q] + bias), x [B,C,Q].  Forward and dgrad run on the implicit-GEMM conv kernel (1x1, the
+    dgrad with W^T); wgrad and the bias gradient are library reductions over the queries."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, pack_f, pack_b):
+        b, c, q = x.shape
+        y = ops.conv2d([x.view(b, c, 1, q)], pack_f.get([weight], [bias]), act=L.ACT_RELU if relu else L.ACT_NONE).view(b, -1, q)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.pack_b, ctx.has_bias = pack_b, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, weight, y = ctx.saved_tensors
+        b, c, q = x.shape
+        d = _c(d_y if y is None else d_y * (y > 0))
+        d_x = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            if weight.shape[0] >= 16:
+                pk = ctx.pack_b.get([weight], [None], transform=lambda w: w.t().contiguous())
+                d_x = ops.conv2d([d.view(b, -1, 1, q)], pk).view(b, c, q)
+            else:  # a handful of output channels (the 9 mask logits): not worth a K-padded MFMA launch
+                d_x = torch.matmul(weight.t(), d)
+        if ctx.needs_input_grad[1]:
+            d_w = torch.matmul(d, x.transpose(1, 2)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_b = d.sum((0, 2))
+        return d_x, d_w, d_b, None, None, None
+
+
 # ---- a16/a17: (softmax +) convex 3x3 upsampling at the queries (submodule.py:357-372) ---------------------------
 class ConvexUpsample(torch.autograd.Function):
     @staticmethod

@@ -181,7 +181,7 @@ class liif_out_multi_scale_Training(nn.Module):
         """Differentiable form (liif.py:652-678).  With <= 2 sources the first Linear layer is applied at LOW resolution
         (two library 1x1 convs under autograd) and the per-query stage is the fused HIP gather + add + ReLU with its HIP
         scatter-add backward (grad.LiifGatherMlp1); otherwise the latent [B,228,Q] is gathered per source.  The remaining
-        layers are plain library GEMMs over the channel-major activations."""
+        layers run forward and dgrad as 1x1 convs on the implicit-GEMM kernel (grad.PointwiseLinear)."""
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
         if self.fused_first_layer and len(sfs) <= 2 and len(lin) > 1:
             w1, off, us, rel_cols = lin[0].weight, 0, [], []
@@ -195,12 +195,10 @@ class liif_out_multi_scale_Training(nn.Module):
             lin = lin[1:]
         else:
             x = torch.cat([G.LiifGather.apply(s, coord) for s in sfs], dim=1)
+        packs = self.__dict__.setdefault("_train_packs", {})
         for i, m in enumerate(lin):
-            x = torch.matmul(m.weight, x)
-            if m.bias is not None:
-                x = x + m.bias[None, :, None]
-            if i + 1 < len(lin):
-                x = torch.relu(x)
+            pf, pb = packs.setdefault(id(m), (ops.PackedConv(), ops.PackedConv()))
+            x = G.PointwiseLinear.apply(x.contiguous(), m.weight, m.bias, i + 1 < len(lin), pf, pb)
         return x
 
     def _mask_logits(self, sfs, coord, ctot, pre=None):

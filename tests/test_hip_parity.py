@@ -714,3 +714,23 @@ def test_liif_gather_mlp1_backward(sort):
     close(out, ref, 2e-5, 2e-5, "h1")
     for x, y, n in zip(a, r, ("d u0", "d u1", "d wrel", "d bias")):
         close(x.grad, y.grad, 1e-4, 1e-5, n)
+
+
+def test_pointwise_linear_backward(precision):
+    """MLP layer on the conv kernel: forward + dgrad (W^T as a 1x1 conv) + library wgrad vs autograd of F.linear in fp64."""
+    from anystereo import grad as G, ops
+    b, q = 2, 1500
+    for cin, cout, relu in ((128, 64, True), (64, 64, True), (64, 9, False)):
+        x, w, bias, g = U((b, cin, q), 480), U((cout, cin), 481, -0.2, 0.2), U((cout,), 482), U((b, cout, q), 483)
+        a = [_leaf(t, DEV) for t in (x, w, bias)]
+        y = G.PointwiseLinear.apply(a[0], a[1], a[2], relu, ops.PackedConv(), ops.PackedConv())
+        y.backward(g.to(DEV))
+        r = [_leaf(t, dt=torch.float64) for t in (x, w, bias)]
+        ref = torch.matmul(r[1], r[0]) + r[2][None, :, None]
+        ref = torch.relu(ref) if relu else ref
+        ref.backward(g.double())
+        tol = 2e-5 if precision == "fp32" else 5e-5
+        close(y, ref, tol, 1e-5, "y")
+        close(a[0].grad, r[0].grad, tol, 1e-5, "d x")
+        close(a[1].grad, r[1].grad, 1e-4, 1e-5, "d w")
+        close(a[2].grad, r[2].grad, 1e-4, 1e-5, "d b")
