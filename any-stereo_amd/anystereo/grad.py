@@ -229,6 +229,41 @@ class PointwiseLinear(torch.autograd.Function):
         return d_x, d_w, d_b, None, None, None
 
 
+# ---- a6/a7/a9: stride-1 "same" convolutions of the update block (update.py:16-92) -------------------------------
+class Conv2dSame(torch.autograd.Function):
+    """y = act(conv(x, W) + bias), 1x1 or 3x3, stride 1, zero "same" padding.  Forward and dgrad run on the implicit-GEMM
+    kernel (dgrad = the same kernel on W transposed and flipped); wgrad / bias gradient on the library (MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, pack_f, pack_b):
+        y = ops.conv2d([x], pack_f.get([weight], [bias]), act=L.ACT_RELU if relu else L.ACT_NONE)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.pack_b, ctx.bias_sizes = pack_b, None if bias is None else list(bias.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, weight, y = ctx.saved_tensors
+        d = _c(d_y if y is None else d_y * (y > 0))
+        k = weight.shape[2]
+        d_x = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            pk = ctx.pack_b.get([weight], [None], transform=lambda w: w.transpose(0, 1).flip(2, 3).contiguous())
+            d_x = ops.conv2d([d], pk)
+        want_w, want_b = ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]
+        if want_w or want_b:
+            _, d_w, d_b = torch.ops.aten.convolution_backward(d, x, weight, ctx.bias_sizes, [1, 1], [k // 2, k // 2], [1, 1], False,
+                                                              [0, 0], 1, [False, want_w, want_b])
+        return d_x, d_w, d_b, None, None, None
+
+
+def conv2d_same(mod, name, x, weight, bias, relu=False):
+    """Conv2dSame with the forward / dgrad weight packs cached on `mod` under `name`."""
+    packs = mod.__dict__.setdefault("_train_packs", {})
+    pf, pb = packs.setdefault(name, (ops.PackedConv(), ops.PackedConv()))
+    return Conv2dSame.apply(_c(x), weight, bias, relu, pf, pb)
+
+
 # ---- a16/a17: (softmax +) convex 3x3 upsampling at the queries (submodule.py:357-372) ---------------------------
 class ConvexUpsample(torch.autograd.Function):
     @staticmethod

@@ -27,10 +27,12 @@ def _f(t):
     return t.float().contiguous()
 
 
-# Training (gradients required): the dense convolutions of this file run as the nn.Conv2d children themselves (library
-# forward + dgrad/wgrad under autograd) in exactly the reference's formulation; the fused HIP epilogues are the
-# inference path.  Hand-written dgrad/wgrad for the GRU is the next step.
+# Training (gradients required): the reference's formulation op for op (gates as separate pointwise ops under autograd);
+# the 3x3 / 1x1 convolutions run forward and dgrad on the implicit-GEMM kernel (grad.Conv2dSame; convz and convr as ONE
+# conv over concatenated weights), wgrad on the library.  The 7x7 one-channel conv and the 256 -> 1 head conv stay nn.Conv2d.
+# The fused GRU epilogues are the inference path; their backward is the next step.
 _train = G.needs_grad
+_cs = G.conv2d_same
 
 
 class DispHead(nn.Module):
@@ -46,7 +48,7 @@ class DispHead(nn.Module):
         """delta = conv2(relu(conv1(x))) (update.py:23-24); with `addend` the result is addend + delta (the loop's
         `disp = disp + delta_disp`, fused into the last kernel)."""
         if _train(x, self.conv1.weight):
-            out = self.conv2(self.relu(self.conv1(x)))  # update.py:23-24
+            out = self.conv2(_cs(self, "conv1", x, self.conv1.weight, self.conv1.bias, relu=True))  # update.py:23-24
             return out if addend is None else addend + out
         with scope("disp_head_conv1"):
             t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
@@ -98,9 +100,11 @@ class ConvGRU(nn.Module):
         if _train(h, cz, cr, cq, self.convz.weight, *x_list):  # update.py:33-41
             x = torch.cat(x_list, dim=1)
             hx = torch.cat([h, x], dim=1)
-            z = torch.sigmoid(self.convz(hx) + cz)
-            r = torch.sigmoid(self.convr(hx) + cr)
-            q = torch.tanh(self.convq(torch.cat([r * h, x], dim=1)) + cq)
+            zr = _cs(self, "zr", hx, torch.cat([self.convz.weight, self.convr.weight]), torch.cat([self.convz.bias, self.convr.bias]))
+            hid = h.shape[1]
+            z = torch.sigmoid(zr[:, :hid] + cz)
+            r = torch.sigmoid(zr[:, hid:] + cr)
+            q = torch.tanh(_cs(self, "q", torch.cat([r * h, x], dim=1), self.convq.weight, self.convq.bias) + cq)
             return (1 - z) * h + z * q
         h = _f(h)
         xs = [_f(x) for x in x_list]
@@ -130,9 +134,10 @@ class BasicMotionEncoder(nn.Module):
 
     def forward(self, disp, corr):
         if _train(disp, corr, self.convc1.weight):  # update.py:84-92
-            cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
-            dsp = F.relu(self.convd2(F.relu(self.convd1(disp))))
-            out = F.relu(self.conv(torch.cat([cor, dsp], dim=1)))
+            cor = _cs(self, "c1", corr, self.convc1.weight, self.convc1.bias, relu=True)
+            cor = _cs(self, "c2", cor, self.convc2.weight, self.convc2.bias, relu=True)
+            dsp = _cs(self, "d2", F.relu(self.convd1(disp)), self.convd2.weight, self.convd2.bias, relu=True)
+            out = _cs(self, "c", torch.cat([cor, dsp], dim=1), self.conv.weight, self.conv.bias, relu=True)
             return torch.cat([out, disp], dim=1)
         disp, corr = _f(disp), _f(corr)
         cd, out = self.new_buffer(disp), self.new_output(disp)

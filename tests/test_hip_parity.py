@@ -734,3 +734,26 @@ def test_pointwise_linear_backward(precision):
         close(a[0].grad, r[0].grad, tol, 1e-5, "d x")
         close(a[1].grad, r[1].grad, 1e-4, 1e-5, "d w")
         close(a[2].grad, r[2].grad, 1e-4, 1e-5, "d b")
+
+
+@pytest.mark.parametrize("cin,cout,k,relu", [(384, 256, 3, False), (128, 127, 3, True), (162, 64, 1, True), (64, 64, 3, True)])
+def test_conv2d_same_backward(cin, cout, k, relu, precision):
+    """Update-block conv in training: forward + dgrad on the implicit-GEMM kernel (transposed, flipped weights), library
+    wgrad, vs autograd of F.conv2d in fp64."""
+    import torch.nn.functional as F
+    from anystereo import grad as G, ops
+    b, h, w = 2, 9, 21
+    x, wt = U((b, cin, h, w), 490), U((cout, cin, k, k), 491, -0.05, 0.05)
+    bias, g = U((cout,), 492), U((b, cout, h, w), 493)
+    a = [_leaf(t, DEV) for t in (x, wt, bias)]
+    y = G.Conv2dSame.apply(a[0], a[1], a[2], relu, ops.PackedConv(), ops.PackedConv())
+    y.backward(g.to(DEV))
+    r = [_leaf(t, dt=torch.float64) for t in (x, wt, bias)]
+    ref = F.conv2d(r[0], r[1], r[2], padding=k // 2)
+    ref = torch.relu(ref) if relu else ref
+    ref.backward(g.double())
+    tol = 2e-5 if precision == "fp32" else 5e-5
+    close(y, ref, tol, 1e-5, "y")
+    close(a[0].grad, r[0].grad, tol, 1e-5, "d x")
+    close(a[1].grad, r[1].grad, 2e-4, 1e-5, "d w")
+    close(a[2].grad, r[2].grad, 2e-4, 1e-5, "d b")
