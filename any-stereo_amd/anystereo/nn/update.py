@@ -191,6 +191,7 @@ def pool2x(x):
 
 def interp(x, dest):
     if _train(x):
+        # (a HIP forward + aten.upsample_bilinear2d_backward pair measured SLOWER than this on the same box: 124 vs 116 ms/step)
         return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)  # update.py:100-102
     with scope("interp"):
         return ops.interp(_f(x), dest.shape[2], dest.shape[3])

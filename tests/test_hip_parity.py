@@ -757,3 +757,4 @@ def test_conv2d_same_backward(cin, cout, k, relu, precision):
     close(a[0].grad, r[0].grad, tol, 1e-5, "d x")
     close(a[1].grad, r[1].grad, 2e-4, 1e-5, "d w")
     close(a[2].grad, r[2].grad, 2e-4, 1e-5, "d b")
+
