@@ -130,7 +130,7 @@ def train_main(a):
                                    f"Q={batch[2].shape[1]} queries/sample, AdamW+OneCycleLR, clip 1.0",
                        "global_batch": world * a.batch_per_gpu, "parallelism": f"ddp x{world} (RCCL all-reduce of {nparam} fp32 grads)"},
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
-            "backward": "HIP kernels for the volume/lookup/gwc/LIIF-gather/convex-upsample transposes; conv dgrad/wgrad on MIOpen",
+            "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample transposes and the update-block/MLP dgrad; wgrad and backbone convs on MIOpen/rocBLAS",
             "roofline": None, "cpu_baseline": None}))
     if dist:
         td.barrier()
