@@ -188,6 +188,9 @@ class ContinuousStereoBase(nn.Module):
     # (Measured and not kept: a third stream for the encoder's disparity branch — 0.70 vs 0.60 ms per iteration under
     # graph replay; and a stream that waits on a stream which waited on it crashes capture on this stack.)
     pipelined_loop = os.environ.get("ANYSTEREO_PIPELINED_LOOP", "1") != "0"
+    # Measured and not kept (off by default): issuing the h-part of gru04's gate conv at the top of the iteration
+    # (ConvGRU.pre_zr) to fill the CUs the small kernels leave idle — 0.66 vs 0.60 ms per iteration on the same box.
+    split_gate_conv = os.environ.get("ANYSTEREO_SPLIT_GATE_CONV", "0") != "0"
 
     def _iterate_pipelined(self, lookup_fn, net, inp, disp, coords, iters):
         from ..nn.update import interp, pool2x
@@ -199,12 +202,13 @@ class ContinuousStereoBase(nn.Module):
         with torch.cuda.stream(side):
             mf = ub.encoder(disp, lookup_fn(disp, coords))
         for itr in range(iters):
+            pre = ub.gru04.pre_zr(net[0], *(inp[0])) if self.split_gate_conv else None
             net[2] = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
             net[1] = ub.gru08(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
             up = interp(net[1], net[0])
             main.wait_stream(side)  # motion features (and the disparity they were computed from) are ready
             mf.record_stream(main)
-            net[0] = ub.gru04(net[0], *(inp[0]), mf, up)
+            net[0] = ub.gru04(net[0], *(inp[0]), mf, up, pre_zr=pre)
             net[0].record_stream(side)
             side.wait_stream(main)
             with torch.cuda.stream(side):

@@ -93,10 +93,11 @@ class ConvGRU(nn.Module):
         self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
         self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=pad)
         self._pzr = ops.PackedConv()
+        self._pzr_h, self._pzr_x = ops.PackedConv(), ops.PackedConv()
         self._pq = ops.PackedConv()
         self.tag = "gru"  # timing label; BasicMultiUpdateBlock renames it gru04 / gru08 / gru16
 
-    def forward(self, h, cz, cr, cq, *x_list):
+    def forward(self, h, cz, cr, cq, *x_list, pre_zr=None):
         if _train(h, cz, cr, cq, self.convz.weight, *x_list):  # update.py:33-41
             x = torch.cat(x_list, dim=1)
             hx = torch.cat([h, x], dim=1)
@@ -110,12 +111,30 @@ class ConvGRU(nn.Module):
         xs = [_f(x) for x in x_list]
         ctx, coff = _context_window(cz, cr, cq)
         hid = h.shape[1]
-        pzr = self._pzr.get([self.convz.weight, self.convr.weight], [self.convz.bias, self.convr.bias])
         pq = self._pq.get([self.convq.weight], [self.convq.bias])
-        with scope(self.tag + "_zr_conv"):
-            z, rh = ops.conv2d([h] + xs, pzr, add=ctx, add_coff=coff, epilogue=L.EPI_GRU_ZR, h=h)
+        if pre_zr is None:
+            pzr = self._pzr.get([self.convz.weight, self.convr.weight], [self.convz.bias, self.convr.bias])
+            with scope(self.tag + "_zr_conv"):
+                z, rh = ops.conv2d([h] + xs, pzr, add=ctx, add_coff=coff, epilogue=L.EPI_GRU_ZR, h=h)
+        else:
+            pzx = self._pzr_x.get([self.convz.weight, self.convr.weight], [None, None], transform=lambda w: w[:, hid:])
+            with scope(self.tag + "_zr_conv"):
+                z, rh = ops.conv2d(xs, pzx, add=pre_zr, add_coff=0, epilogue=L.EPI_GRU_ZR, h=h)
         with scope(self.tag + "_q_conv"):
             return ops.conv2d([rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z)
+
+    def pre_zr(self, h, cz, cr, cq):
+        """The part of convz‖convr that needs only the hidden state: conv([h], W[:, :hidden]) + bias + [cz‖cr].  The inference
+        schedule (models/base.py) issues it at the top of an iteration, while the motion features are still being computed
+        on the other stream; forward(..., pre_zr=) then finishes the gates with the x-part of the weights (one fp32 add of two
+        partial sums instead of one K loop: same arithmetic up to summation order)."""
+        h = _f(h)
+        ctx, coff = _context_window(cz, cr, cq)
+        hid = h.shape[1]
+        pzh = self._pzr_h.get([self.convz.weight, self.convr.weight], [self.convz.bias, self.convr.bias],
+                              transform=lambda w: w[:, :hid])
+        with scope(self.tag + "_zr_pre"):
+            return ops.conv2d([h], pzh, add=ctx, add_coff=coff)
 
 
 class BasicMotionEncoder(nn.Module):

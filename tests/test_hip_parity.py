@@ -269,9 +269,12 @@ def test_conv_gru_fused(h, w, precision):
         out = gru(hh.to(DEV), cz, cr, cq, x1.to(DEV), x2.to(DEV))
         # non-view context tensors take the concat fallback and must agree
         out2 = gru(hh.to(DEV), cz.clone(), cr.clone(), cq.clone(), x1.to(DEV), x2.to(DEV))
+        # the h-part of the gate conv issued ahead (inference schedule of models/base.py)
+        out3 = gru(hh.to(DEV), cz, cr, cq, x1.to(DEV), x2.to(DEV), pre_zr=gru.pre_zr(hh.to(DEV), cz, cr, cq))
         ref = O.conv_gru(gru.cpu().double(), hh.double(), *ctx.double().split(128, dim=1), x1.double(), x2.double())
     close(out, ref, 1e-5, 1e-5, "convgru")
     close(out2, ref, 1e-5, 1e-5, "convgru (cat fallback)")
+    close(out3, ref, 1e-5, 1e-5, "convgru (h-part of the gates ahead)")
 
 
 @pytest.mark.parametrize("cin,cout,stride,h,w", [(64, 64, 1, 18, 37), (64, 96, 2, 18, 36), (128, 128, 1, 7, 129)])
