@@ -6,6 +6,8 @@ as models/coreContinuous_IGEV/continuous_IGEVstereo.py:91-305, with the hot path
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -70,20 +72,52 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         return self.geo_block(match_left.float(), match_right.float(), gev.float(), radius=self.args.corr_radius,
                               num_levels=self.args.corr_levels)
 
+    parallel_context = os.environ.get("ANYSTEREO_PARALLEL_CONTEXT", "1") != "0"
+    parallel_stems = os.environ.get("ANYSTEREO_PARALLEL_STEMS", "1") != "0"
+
+    def _context(self, image1):
+        """Hidden-state initialisation and the per-level context terms (continuous_IGEVstereo.py:270-273)."""
+        cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
+        net_list = [torch.tanh(x[0]) for x in cnet_list]
+        inp_list = [torch.relu(x[1]) for x in cnet_list]
+        return net_list, [_plain_conv(self, conv, i) for i, conv in zip(inp_list, self.context_zqr_convs)]
+
     def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
         """Estimate disparity between a pair of frames (images are 0..255 float)."""
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda):
-            if B.fused_ok(image1, self):
+            fast = B.fused_ok(image1, self)
+            side = None
+            if fast:
                 # inference: left and right image as ONE batch through the (per-sample) feature net, stems and
                 # descriptor head — same arithmetic per sample, half the launches, twice the blocks per launch
                 n = image1.shape[0]
                 both = torch.cat((image1, image2), 0)
+            if fast and self.parallel_context and image1.is_cuda:
+                # the stems and the context network do not depend on the feature trunk, and most of the trunk / cost-aggregation
+                # kernels at 1/8 .. 1/32 resolution leave CUs idle: run them on the second stream (captured as a parallel
+                # branch); the main stream picks the stems up before the descriptor head and the context before the GRU loop
+                main = torch.cuda.current_stream(image1.device)
+                side = self.update_block._side_stream(image1.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    if self.parallel_stems:
+                        stem_2b = self.stem_2(both)
+                        stem_4b = self.stem_4(stem_2b)
+                        stems_done = torch.cuda.Event()
+                        stems_done.record(side)
+                    net_list, ctx_list = self._context(image1)
+            if fast:
                 feats = self.feature(both)
-                stem_2b = self.stem_2(both)
-                stem_4b = self.stem_4(stem_2b)
+                if side is not None and self.parallel_stems:
+                    main.wait_event(stems_done)
+                    stem_2b.record_stream(main)
+                    stem_4b.record_stream(main)
+                else:
+                    stem_2b = self.stem_2(both)
+                    stem_4b = self.stem_4(stem_2b)
                 feats[0] = torch.cat((feats[0], stem_4b), 1)
                 match = self.desc(self.conv(feats[0]))
                 features_left = [f[:n] for f in feats]
@@ -110,10 +144,12 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 cost = B.conv3d_train(self.classifier, geo_encoding_volume)
             init_disp = self._hot_init_disp(cost.squeeze(1))
             del gwc_volume
-            cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
-            net_list = [torch.tanh(x[0]) for x in cnet_list]
-            inp_list = [torch.relu(x[1]) for x in cnet_list]
-            ctx_list = [_plain_conv(self, conv, i) for i, conv in zip(inp_list, self.context_zqr_convs)]
+            if side is None:
+                net_list, ctx_list = self._context(image1)
+            else:
+                main.wait_stream(side)
+                for t in net_list + ctx_list:
+                    t.record_stream(main)
         net_list = [n.float() for n in net_list]
         # cz, cr, cq stay VIEWS of one [B,3*hidden,h,w] tensor: the GRU kernels index it in place
         inp_list = [list(c.float().split(split_size=c.shape[1] // 3, dim=1)) for c in ctx_list]
