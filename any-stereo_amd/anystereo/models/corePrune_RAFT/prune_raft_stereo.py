@@ -3,6 +3,8 @@ models/corePrune_RAFT/prune_raft_stereo.py:92-297, with the hot path on HIP (no 
 volume: correlation pyramid of 4 levels, zero initial disparity)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -59,21 +61,40 @@ class continuous_RaftStereo(ContinuousStereoBase):
         return self.corr_block(match_left.float(), match_right.float(), radius=self.args.corr_radius,
                                num_levels=self.args.corr_levels)
 
+    parallel_context = os.environ.get("ANYSTEREO_PARALLEL_CONTEXT", "1") != "0"
+
+    def _context(self, image1):
+        a = self.args
+        cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
+        net_list = [torch.tanh(x[0]) for x in cnet_list]
+        inp_list = [torch.relu(x[1]) for x in cnet_list]
+        ctx_list = [conv(i) for i, conv in zip(inp_list, self.context_zqr_convs)]
+        stem_2x = stem_4x = None
+        if self._has_stems:
+            stem_2x = self.stem_2(image1)
+            stem_4x = self.stem_4(stem_2x)
+        return net_list, ctx_list, stem_2x, stem_4x
+
     def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=False):
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda):
+            side = None
+            if B.fused_ok(image1, self) and self.parallel_context and image1.is_cuda:
+                # context network (+ stems) on the second stream while the feature network runs (see continuous_IGEVStereo)
+                main = torch.cuda.current_stream(image1.device)
+                side = self.update_block._side_stream(image1.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    net_list, ctx_list, stem_2x, stem_4x = self._context(image1)
             match_left, match_right = self.fnet([image1, image2])
-            cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
-            net_list = [torch.tanh(x[0]) for x in cnet_list]
-            inp_list = [torch.relu(x[1]) for x in cnet_list]
-            ctx_list = [conv(i) for i, conv in zip(inp_list, self.context_zqr_convs)]
-            if self._has_stems:
-                stem_2x = self.stem_2(image1)
-                stem_4x = self.stem_4(stem_2x)
+            if side is None:
+                net_list, ctx_list, stem_2x, stem_4x = self._context(image1)
             else:
-                stem_4x = stem_2x = None
+                main.wait_stream(side)
+                for t in net_list + ctx_list + [t for t in (stem_2x, stem_4x) if t is not None]:
+                    t.record_stream(main)
         net_list = [n.float() for n in net_list]
         inp_list = [list(c.float().split(split_size=c.shape[1] // 3, dim=1)) for c in ctx_list]
 
