@@ -257,6 +257,59 @@ class Conv2dSame(torch.autograd.Function):
         return d_x, d_w, d_b, None, None, None
 
 
+# ---- a7: ConvGRU gate math as two fused stages (update.py:36-41) ---------------------------------------------------
+class GruGatesZR(torch.autograd.Function):
+    """(z, r*h) from the convz‖convr output; cz, cr are passed for the autograd graph, the kernel reads them in place from
+    the context tensor they are views of (`base`, channel offset `coff`)."""
+
+    @staticmethod
+    def forward(ctx, lin, cz, cr, h, base, coff):
+        b, c, hh, ww = h.shape
+        z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            L.check(L.load().as_gru_gates_zr(_p(lin), _p(base), base.shape[1], coff, _p(h), _p(z), _p(r), _p(rh), b, c, hh, ww,
+                                             _stream()), "gru_gates_zr")
+        ctx.save_for_backward(z, r, h)
+        return z, rh
+
+    @staticmethod
+    def backward(ctx, d_z, d_rh):
+        z, r, h = ctx.saved_tensors
+        b, c, hh, ww = h.shape
+        d_z = None if d_z is None else _c(d_z)
+        d_rh = None if d_rh is None else _c(d_rh)
+        d_lin = torch.empty((b, 2 * c, hh, ww), device=h.device, dtype=torch.float32)
+        d_h = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            L.check(L.load().as_gru_gates_zr_bwd(_p(d_z), _p(d_rh), _p(z), _p(r), _p(h), _p(d_lin), _p(d_h), b, c, hh, ww, _stream()),
+                    "gru_gates_zr_bwd")
+        return d_lin, d_lin[:, :c], d_lin[:, c:], d_h, None, None
+
+
+class GruGatesQ(torch.autograd.Function):
+    """h' = (1 - z) h + z tanh(lin + cq)."""
+
+    @staticmethod
+    def forward(ctx, lin, cq, z, h, base, coff):
+        b, c, hh, ww = h.shape
+        out, t = torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            L.check(L.load().as_gru_gates_q(_p(lin), _p(base), base.shape[1], coff, _p(z), _p(h), _p(out), _p(t), b, c, hh, ww,
+                                            _stream()), "gru_gates_q")
+        ctx.save_for_backward(z, t, h)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        z, t, h = ctx.saved_tensors
+        b, c, hh, ww = h.shape
+        d_lin, d_z, d_h = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            L.check(L.load().as_gru_gates_q_bwd(_p(_c(d_out)), _p(z), _p(t), _p(h), _p(d_lin), _p(d_z), _p(d_h), b, c, hh, ww,
+                                                _stream()), "gru_gates_q_bwd")
+        return d_lin, d_lin, d_z, d_h, None, None
+
+
 def conv2d_same(mod, name, x, weight, bias, relu=False):
     """Conv2dSame with the forward / dgrad weight packs cached on `mod` under `name`."""
     packs = mod.__dict__.setdefault("_train_packs", {})

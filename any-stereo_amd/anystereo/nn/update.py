@@ -95,6 +95,7 @@ class ConvGRU(nn.Module):
         self._pzr = ops.PackedConv()
         self._pzr_h, self._pzr_x = ops.PackedConv(), ops.PackedConv()
         self._pq = ops.PackedConv()
+        self.fused_gates = __import__("os").environ.get("ANYSTEREO_FUSED_GATES", "1") != "0"  # training: gate math as two HIP stages (grad.GruGatesZR / GruGatesQ) instead of ~30 pointwise ops
         self.tag = "gru"  # timing label; BasicMultiUpdateBlock renames it gru04 / gru08 / gru16
 
     def forward(self, h, cz, cr, cq, *x_list, pre_zr=None):
@@ -103,6 +104,12 @@ class ConvGRU(nn.Module):
             hx = torch.cat([h, x], dim=1)
             zr = _cs(self, "zr", hx, torch.cat([self.convz.weight, self.convr.weight]), torch.cat([self.convz.bias, self.convr.bias]))
             hid = h.shape[1]
+            if zr.is_cuda and self.fused_gates:
+                base, coff = _context_window(cz, cr, cq)
+                hc = _f(h)
+                z, rh = G.GruGatesZR.apply(zr, cz, cr, hc, base, coff)
+                ql = _cs(self, "q", torch.cat([rh, x], dim=1), self.convq.weight, self.convq.bias)
+                return G.GruGatesQ.apply(ql, cq, z, hc, base, coff + 2 * hid)
             z = torch.sigmoid(zr[:, :hid] + cz)
             r = torch.sigmoid(zr[:, hid:] + cr)
             q = torch.tanh(_cs(self, "q", torch.cat([r * h, x], dim=1), self.convq.weight, self.convq.bias) + cq)

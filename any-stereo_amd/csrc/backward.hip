@@ -243,9 +243,137 @@ __global__ __launch_bounds__(256) void convex_bwd_kernel(const float* __restrict
   for (int k = 0; k < 9; ++k) gm[(long long)k * Q] = logits ? g * l[k] * (dk[k] - out) : g * dk[k];
 }
 
+// ---- a7: ConvGRU gate math (update.py:33-41) as two fused pointwise stages with their transposes --------------------
+// stage ZR:  z = sigmoid(lin[:, :C] + cz), r = sigmoid(lin[:, C:] + cr), rh = r * h        (lin = convz‖convr output [B,2C,H,W])
+// stage Q :  t = tanh(lin + cq), h' = (1 - z) h + z t
+// cz, cr, cq are channel windows of one context tensor [B, ctx_ctot, H, W] (continuous_IGEVstereo.py:273).
+struct GateParams {
+  const float* lin;
+  const float* ctx;
+  const float* h;
+  const float* z;     // stage Q: input
+  float* o0;          // ZR: z        Q: h'
+  float* o1;          // ZR: r        Q: t
+  float* o2;          // ZR: r*h
+  long long plane, total;  // H*W, B*C*H*W
+  int C, ctx_ctot, ctx_coff;
+};
+
+__global__ __launch_bounds__(256) void gru_gates_zr_kernel(GateParams p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.total) return;
+  const long long pix = t % p.plane;
+  const long long bc = t / p.plane;
+  const int c = (int)(bc % p.C);
+  const long long b = bc / p.C;
+  const float* lin = p.lin + (b * 2 * p.C) * p.plane + pix;
+  const float* cx = p.ctx + (b * p.ctx_ctot + p.ctx_coff) * p.plane + pix;
+  const float z = 1.f / (1.f + expf(-(lin[(long long)c * p.plane] + cx[(long long)c * p.plane])));
+  const float r = 1.f / (1.f + expf(-(lin[(long long)(p.C + c) * p.plane] + cx[(long long)(p.C + c) * p.plane])));
+  p.o0[t] = z;
+  p.o1[t] = r;
+  p.o2[t] = r * p.h[t];
+}
+
+struct GateBwdParams {
+  const float* g0;   // ZR: d z       Q: d h'
+  const float* g1;   // ZR: d (r*h)
+  const float* z;
+  const float* r;    // ZR: r         Q: t
+  const float* h;
+  float* d_lin;      // ZR: [B,2C,H,W]  Q: [B,C,H,W]     (also the gradient of the context window)
+  float* d_h;        // partial d h of this stage
+  float* d_z;        // Q only
+  long long plane, total;
+  int C;
+};
+
+__global__ __launch_bounds__(256) void gru_gates_zr_bwd_kernel(GateBwdParams p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.total) return;
+  const long long pix = t % p.plane;
+  const long long bc = t / p.plane;
+  const int c = (int)(bc % p.C);
+  const long long b = bc / p.C;
+  const float z = p.z[t], r = p.r[t], h = p.h[t];
+  const float dz = p.g0 ? p.g0[t] : 0.f, drh = p.g1 ? p.g1[t] : 0.f;
+  float* dl = p.d_lin + (b * 2 * p.C) * p.plane + pix;
+  dl[(long long)c * p.plane] = dz * z * (1.f - z);
+  dl[(long long)(p.C + c) * p.plane] = drh * h * r * (1.f - r);
+  p.d_h[t] = drh * r;
+}
+
+__global__ __launch_bounds__(256) void gru_gates_q_kernel(GateParams p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.total) return;
+  const long long pix = t % p.plane;
+  const long long bc = t / p.plane;
+  const int c = (int)(bc % p.C);
+  const long long b = bc / p.C;
+  const float q = tanhf(p.lin[t] + p.ctx[(b * p.ctx_ctot + p.ctx_coff + c) * p.plane + pix]);
+  const float z = p.z[t];
+  p.o0[t] = (1.f - z) * p.h[t] + z * q;
+  p.o1[t] = q;
+}
+
+__global__ __launch_bounds__(256) void gru_gates_q_bwd_kernel(GateBwdParams p) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.total) return;
+  const float g = p.g0[t], z = p.z[t], q = p.r[t], h = p.h[t];
+  p.d_lin[t] = g * z * (1.f - q * q);
+  p.d_z[t] = g * (q - h);
+  p.d_h[t] = g * (1.f - z);
+}
+
 }  // namespace
 
 extern "C" {
+
+int as_gru_gates_zr(const float* lin, const float* ctx, int ctx_ctot, int ctx_coff, const float* h, float* z, float* r, float* rh,
+                    int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(lin && ctx && h && z && r && rh, AS_ERR_BAD_ARG, "gru_gates_zr: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "gru_gates_zr: non-positive size");
+  AS_REQUIRE(ctx_coff >= 0 && ctx_coff + 2 * C <= ctx_ctot, AS_ERR_BAD_SHAPE, "gru_gates_zr: context window [%d,%d) outside %d", ctx_coff, ctx_coff + 2 * C, ctx_ctot);
+  GateParams p{};
+  p.lin = lin; p.ctx = ctx; p.h = h; p.o0 = z; p.o1 = r; p.o2 = rh;
+  p.plane = (long long)H * W; p.total = p.plane * B * C; p.C = C; p.ctx_ctot = ctx_ctot; p.ctx_coff = ctx_coff;
+  hipLaunchKernelGGL(gru_gates_zr_kernel, dim3((unsigned)as::cdiv64(p.total, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("gru_gates_zr");
+}
+
+int as_gru_gates_zr_bwd(const float* d_z, const float* d_rh, const float* z, const float* r, const float* h, float* d_lin,
+                        float* d_h, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(z && r && h && d_lin && d_h, AS_ERR_BAD_ARG, "gru_gates_zr_bwd: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "gru_gates_zr_bwd: non-positive size");
+  GateBwdParams p{};
+  p.g0 = d_z; p.g1 = d_rh; p.z = z; p.r = r; p.h = h; p.d_lin = d_lin; p.d_h = d_h;
+  p.plane = (long long)H * W; p.total = p.plane * B * C; p.C = C;
+  hipLaunchKernelGGL(gru_gates_zr_bwd_kernel, dim3((unsigned)as::cdiv64(p.total, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("gru_gates_zr_bwd");
+}
+
+int as_gru_gates_q(const float* lin, const float* ctx, int ctx_ctot, int ctx_coff, const float* z, const float* h, float* out,
+                   float* t, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(lin && ctx && z && h && out && t, AS_ERR_BAD_ARG, "gru_gates_q: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "gru_gates_q: non-positive size");
+  AS_REQUIRE(ctx_coff >= 0 && ctx_coff + C <= ctx_ctot, AS_ERR_BAD_SHAPE, "gru_gates_q: context window [%d,%d) outside %d", ctx_coff, ctx_coff + C, ctx_ctot);
+  GateParams p{};
+  p.lin = lin; p.ctx = ctx; p.h = h; p.z = z; p.o0 = out; p.o1 = t;
+  p.plane = (long long)H * W; p.total = p.plane * B * C; p.C = C; p.ctx_ctot = ctx_ctot; p.ctx_coff = ctx_coff;
+  hipLaunchKernelGGL(gru_gates_q_kernel, dim3((unsigned)as::cdiv64(p.total, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("gru_gates_q");
+}
+
+int as_gru_gates_q_bwd(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
+                       int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(d_out && z && t && h && d_lin && d_z && d_h, AS_ERR_BAD_ARG, "gru_gates_q_bwd: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "gru_gates_q_bwd: non-positive size");
+  GateBwdParams p{};
+  p.g0 = d_out; p.z = z; p.r = t; p.h = h; p.d_lin = d_lin; p.d_z = d_z; p.d_h = d_h;
+  p.plane = (long long)H * W; p.total = p.plane * B * C; p.C = C;
+  hipLaunchKernelGGL(gru_gates_q_bwd_kernel, dim3((unsigned)as::cdiv64(p.total, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("gru_gates_q_bwd");
+}
 
 int as_corr_pyramid_bwd(const float* const* d_levels, float* d_corr0, long long rows, int W2, int L, void* stream) {
   AS_REQUIRE(d_levels && d_corr0, AS_ERR_BAD_ARG, "corr_pyramid_bwd: null pointer");

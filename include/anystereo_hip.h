@@ -262,6 +262,21 @@ int as_disparity_regression_bwd(const float* cost, const float* d_out, float* d_
                                 int apply_softmax, void* stream);
 int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat,
                        int B, int C, int H, int W, int Q, int lat_ctot, int lat_coff, void* stream);
+/* a7 in training: the ConvGRU gate math (update.py:33-41) as two fused pointwise stages and their transposes (the convs
+ *   run through as_conv2d with the LINEAR epilogue; inference uses the fused GRU epilogues instead).
+ *   ZR: lin [B,2C,H,W] = convz||convr output, ctx [B,ctx_ctot,H,W] with [cz||cr] at channel ctx_coff, h [B,C,H,W]
+ *       -> z, r, rh = r*h.   bwd: d_z, d_rh (either may be NULL = zero) -> d_lin [B,2C,H,W] (= gradient of the context window
+ *       as well) and this stage's contribution d_h.
+ *   Q : lin [B,C,H,W] = convq output, cq at channel ctx_coff -> t = tanh(lin + cq), out = (1-z) h + z t.
+ *       bwd: d_out -> d_lin (= d cq), d_z, d_h (this stage's contribution). */
+int as_gru_gates_zr(const float* lin, const float* ctx, int ctx_ctot, int ctx_coff, const float* h, float* z, float* r, float* rh,
+                    int B, int C, int H, int W, void* stream);
+int as_gru_gates_zr_bwd(const float* d_z, const float* d_rh, const float* z, const float* r, const float* h, float* d_lin,
+                        float* d_h, int B, int C, int H, int W, void* stream);
+int as_gru_gates_q(const float* lin, const float* ctx, int ctx_ctot, int ctx_coff, const float* z, const float* h, float* out,
+                   float* t, int B, int C, int H, int W, void* stream);
+int as_gru_gates_q_bwd(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
+                       int B, int C, int H, int W, void* stream);
 /* relative coordinates of a14 alone and the query sort key of the training path: rel [B, 2*n_src, Q] (rows
  *   rel_row_s, rel_col_s as in as_liif_gather; may be NULL), key [B,Q] int32 = (nearest pixel of source 0) * 4 + parity of
  *   the nearest pixel of source 1 (may be NULL).  Sorting the queries by key makes the scatter of as_liif_gather_bwd

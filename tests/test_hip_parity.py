@@ -761,3 +761,30 @@ def test_conv2d_same_backward(cin, cout, k, relu, precision):
     close(a[1].grad, r[1].grad, 2e-4, 1e-5, "d w")
     close(a[2].grad, r[2].grad, 2e-4, 1e-5, "d b")
 
+
+
+def test_conv_gru_training_fused_gates():
+    """ConvGRU under autograd: conv kernel + the two fused gate stages (forward and backward) vs autograd of the fp64 oracle,
+    with the context passed as views of one tensor (the model's layout) — gradients to h, x, the context and all weights."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn.update import ConvGRU
+    b, h, w = 2, 9, 14
+    gru = ConvGRU(128, 256)
+    fill_module_deterministic(gru, 3)
+    hh, ctx = torch.tanh(U((b, 128, h, w), 500, -2, 2)), U((b, 384, h, w), 501)
+    x1, x2, g = U((b, 128, h, w), 502), U((b, 128, h, w), 503), U((b, 128, h, w), 504)
+    ref_m = ConvGRU(128, 256).double()
+    ref_m.load_state_dict(gru.state_dict())
+    r = [_leaf(t, dt=torch.float64) for t in (hh, ctx, x1, x2)]
+    O.conv_gru(ref_m, r[0], *r[1].split(128, dim=1), r[2], r[3]).backward(g.double())
+    gru = gru.to(DEV).train()
+    for fused in (True, False):
+        gru.fused_gates = fused
+        gru.zero_grad()
+        a = [_leaf(t, DEV) for t in (hh, ctx, x1, x2)]
+        out = gru(a[0], *a[1].split(128, dim=1), a[2], a[3])
+        out.backward(g.to(DEV))
+        for x, y, n in zip(a, r, ("d h", "d ctx", "d x1", "d x2")):
+            close(x.grad, y.grad, 5e-5, 1e-6, f"{n} (fused_gates={fused})")
+        for (n, p), (_, q) in zip(gru.named_parameters(), ref_m.named_parameters()):
+            close(p.grad, q.grad, 2e-4, 1e-6, f"d {n} (fused_gates={fused})")
