@@ -9,6 +9,8 @@ per sample in [1, 2.95].
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as td
 
@@ -52,18 +54,22 @@ class Trainer:
     harness.metrics.train_step and returns (loss, metrics)."""
 
     def __init__(self, model, lr: float = 2e-4, wdecay: float = 1e-5, num_steps: int = 100000, train_iters: int = 16,
-                 max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int = 25):
+                 max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int = 25,
+                 force_ddp: bool = False):
         model.train()
         model.freeze_bn()  # train_continuous_IGEV.py:203
         self.model = model
         self.module = model
-        if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        if td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or force_ddp):
             p = next(model.parameters())
             ids = [p.device.index] if p.is_cuda else None
             # the IGEV classifier (and everything else that only feeds init_disp) gets no gradient from
-            # sequence_loss_multiscale: DDP has to be told that some parameters stay unused
-            self.module = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=True,
-                                                                    bucket_cap_mb=bucket_cap_mb)
+            # sequence_loss_multiscale: DDP has to be told that some parameters stay unused (measured on one MI355X rank through
+            # RCCL: 139 vs 129 ms per step without the wrapper).  ANYSTEREO_DDP_STATIC=1 tries `static_graph` instead of the
+            # per-step graph walk; it works with gloo on CPU but raised on the GPU box in round 1 — left opt-in.
+            static = os.environ.get("ANYSTEREO_DDP_STATIC", "0") != "0"
+            self.module = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=not static,
+                                                                    static_graph=static, bucket_cap_mb=bucket_cap_mb)
         self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed)
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
         self.train_iters, self.max_disp = train_iters, max_disp

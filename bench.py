@@ -80,7 +80,7 @@ def train_main(a):
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = world > 1
+    dist = world > 1 or "RANK" in os.environ  # under torchrun even one rank goes through RCCL + DDP
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -96,7 +96,7 @@ def train_main(a):
     model = __models__["continuous_IGEVStereo"](args)
     fill_module_deterministic(model, base_seed=1)
     model = model.to(dev)
-    tr = Trainer(model, train_iters=a.train_iters, max_disp=args.max_disp)
+    tr = Trainer(model, train_iters=a.train_iters, max_disp=args.max_disp, force_ddp=dist)
     h, w = (160, 320) if (a.height, a.width) == (540, 960) else (a.height, a.width)
     batch = synthetic_train_batch(a.batch_per_gpu, h, w, seed=rank, device=dev)
     losses = []
