@@ -670,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   constexpr int WCHUNK = NTAPE * 4 * WSEG;   // bytes of one unit's weight image
   constexpr int NWD = WCHUNK / 16 / 256;     // 16-B LDS-DMA pieces per loader thread per chunk
   constexpr int PATCHT = NSUB * PATCHP;      // patch pixels of the block (sub-tile patches back to back)
-  constexpr int NPI = (8 * PATCHT + 255) / 256;  // (channel pair, patch pixel) items per loader thread and sub-chunk
+  constexpr int NPI = (2 * PATCHT + 255) / 256;  // (k-half, patch pixel) items per loader thread and sub-chunk
   constexpr int PIMG = 4 * PATCHT * 16;      // bytes of one sub-chunk's patch image [comp][h][pixel][8]
   constexpr int WPX = 256 / BN;              // consumer waves along the pixel dimension (4 consumers = (BN/64) x WPX)
   constexpr int PTW = BM / (WPX * 32);       // pixel MFMA tiles per consumer wave
@@ -732,20 +732,25 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     // =========================== LOADER WAVES ===========================
     const int ltid = tid - 256;
     const int lwave = wave - 4;
-    unsigned p_voff[NPI];  // byte offset of channel 2*cp of the chunk at this patch pixel, or OOB sentinel
+    // A patch item is (k-half hh, patch pixel): the lane fetches the 8 channels 8 hh .. 8 hh + 7 of its pixel and
+    // commits them as ONE ds_write_b128 per component — the fragment layout [comp][h][pixel][8] makes a pixel's 8
+    // channels 16 contiguous bytes, and a wave's 64 pixels 1 KB: full-rate, conflict-free LDS writes.  (Items of
+    // (channel pair, pixel) with 4-B writes at a 16-B lane stride were 4-way bank conflicted: 4 x the instructions at a
+    // quarter of the rate, on the LDS port the consumers' operand reads already keep 2/3 busy.)
+    unsigned p_voff[NPI];  // byte offset of channel 8*hh of the chunk at this patch pixel, or OOB sentinel
     int p_lds[NPI];        // byte offset inside one comp image of the patch buffer
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
       int idx = ltid + i * 256;
-      const bool slot = idx < 8 * PATCHT;
-      if (!slot) idx = 8 * PATCHT - 1;
-      const int cp = idx / PATCHT, ppt = idx - cp * PATCHT;
+      const bool slot = idx < 2 * PATCHT;
+      if (!slot) idx = 2 * PATCHT - 1;
+      const int hh = idx / PATCHT, ppt = idx - hh * PATCHT;
       const int su = ppt / PATCHP, pp = ppt - su * PATCHP;
       const int py = pp / PW, px = pp - py * PW;
       const int gy = (NSUB > 1 && su ? sy0[NSUB - 1] : sy0[0]) * S - PAD + py, gx = (NSUB > 1 && su ? sx0[NSUB - 1] : sx0[0]) * S - PAD + px;
       const bool in = slot && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
-      p_voff[i] = in ? (unsigned)(((long long)(2 * cp) * plane + (long long)gy * p.Wi + gx) * 4) : 0x7FFFFFF0u;
-      p_lds[i] = slot ? (cp >> 2) * (PATCHT * 16) + ppt * 16 + (cp & 3) * 4 : -1;
+      p_voff[i] = in ? (unsigned)(((long long)(8 * hh) * plane + (long long)gy * p.Wi + gx) * 4) : 0x7FFFFFF0u;
+      p_lds[i] = slot ? hh * (PATCHT * 16) + ppt * 16 : -1;
     }
     // piece i of this thread is 16-B unit (ltid + 256 i) of the chunk image = segment (ltid + 256 i) / BN,
     // column (ltid + 256 i) % BN; the global pack has the same order, so the DMA destination is linear
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + n0 + (long long)(ltid / BN) * p.Cout_pad + (ltid % BN);
     const long long wstep16 = (long long)SEG_PER_STEP * p.Cout_pad;
     const long long wchunk16 = (long long)NTAPE * 4 * p.Cout_pad;  // 16-B units of one pipeline unit in the pack
-    half2v c_hi[NSC][NPI], c_lo[NSC][NPI];
+    half8 c_hi[NSC][NPI], c_lo[NSC][NPI];
 
     // weights: plain 16-B global loads into registers, then ds_write_b128 (an LDS-DMA instruction costs the
     // issuing wave ~150-180 cycles per 1-KB piece on a busy CU — 18 of them per chunk made the loaders
@@ -782,18 +787,18 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     const int recs = left > 0 ? (int)((long long)left * plane * 4) : 0;                                \
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
     const unsigned pl4 = (unsigned)(plane * 4);                                                       \
-    float v0[NPI], v1[NPI];                                                                           \
+    float v[NPI][8];                                                                                  \
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
       const unsigned o0 = p_voff[i];                                                                  \
-      const unsigned o1 = o0 == 0x7FFFFFF0u ? o0 : o0 + pl4;                                           \
-      v0[i] = as_bload(rs, o0);                                                                       \
-      v1[i] = as_bload(rs, o1);                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                    \
+        v[i][j] = as_bload(rs, o0 == 0x7FFFFFF0u ? o0 : o0 + (unsigned)j * pl4);                       \
     }                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
-      const _Float16 h0 = (_Float16)v0[i], h1 = (_Float16)v1[i];                                       \
-      c_hi[sc_][i][0] = h0; c_hi[sc_][i][1] = h1;                                                     \
-      c_lo[sc_][i][0] = (_Float16)((v0[i] - (float)h0) * 2048.f);                                      \
-      c_lo[sc_][i][1] = (_Float16)((v1[i] - (float)h1) * 2048.f);                                      \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                  \
+        const _Float16 hj = (_Float16)v[i][j];                                                        \
+        c_hi[sc_][i][j] = hj;                                                                         \
+        c_lo[sc_][i][j] = (_Float16)((v[i][j] - (float)hj) * 2048.f);                                  \
+      }                                                                                               \
     }                                                                                                 \
   }
 #define AS_SPLIT_COMMIT_P()                                                                           \
@@ -801,8 +806,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     unsigned char* pd = lds + 2 * WCHUNK + sc_ * PIMG;                                                 \
     _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
       if (p_lds[i] >= 0) {                                                                            \
-        *reinterpret_cast<half2v*>(pd + p_lds[i]) = c_hi[sc_][i];                                      \
-        *reinterpret_cast<half2v*>(pd + 2 * PATCHT * 16 + p_lds[i]) = c_lo[sc_][i];                    \
+        *reinterpret_cast<half8*>(pd + p_lds[i]) = c_hi[sc_][i];                                       \
+        *reinterpret_cast<half8*>(pd + 2 * PATCHT * 16 + p_lds[i]) = c_lo[sc_][i];                     \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -867,8 +872,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                      \
     acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);   \
     acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
-    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0);   \
-  }
+  }                                                                                                     \
+  _Pragma("unroll") for (int q = 0; q < PTW; ++q)  /* second cross term: not back to back with the first on the same accumulator */ \
+    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0);
 #define AS_SPLIT_STEP(TAP)                                                                              \
   if constexpr ((TAP) < NTAPE) {                                                                        \
     AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
