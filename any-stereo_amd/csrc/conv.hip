@@ -642,6 +642,33 @@ constexpr int kSplitKC = 16;
 typedef __attribute__((address_space(3))) void as_lds_void;
 typedef __attribute__((address_space(1))) const void as_gbl_void;
 
+// Diagnostic builds only (tools/conv_variant.sh): never defined in the product build.
+//   -DAS_CONV_STAMPS  s_memtime brackets around the segments of the chunk loop, summed in scalar registers by the first
+//                     consumer and the first loader wave of each block and stored to a buffer of their own after the loop
+//   -DAS_ABL_NO_W / -DAS_ABL_NO_P   timing-only: the loaders skip the global loads of the weight image / the halo patch
+//                     after the first unit (stale registers are stored instead: results are wrong, the instruction
+//                     stream, LDS traffic and barriers stay)
+#ifdef AS_CONV_STAMPS
+constexpr int kStampBlocks = 1024, kStampSlots = 16;
+__device__ unsigned long long as_conv_stamp_buf[kStampBlocks * kStampSlots];
+#define AS_STAMP(T)                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory");            \
+  __builtin_amdgcn_sched_barrier(0);
+#define AS_STAMP_DECL unsigned long long st_a = 0, st_b = 0, st_sum[6] = {0, 0, 0, 0, 0, 0};
+#define AS_STAMP_BEGIN AS_STAMP(st_a)
+#define AS_STAMP_SEG(I) { AS_STAMP(st_b) st_sum[I] += st_b - st_a; st_a = st_b; }
+#define AS_STAMP_FLUSH(ROLE)                                                             \
+  if (blockIdx.x < kStampBlocks && lane == 0 && (wave & 3) == 0) {                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) as_conv_stamp_buf[blockIdx.x * kStampSlots + (ROLE) * 8 + i_] = st_sum[i_]; \
+  }
+#else
+#define AS_STAMP_DECL
+#define AS_STAMP_BEGIN
+#define AS_STAMP_SEG(I)
+#define AS_STAMP_FLUSH(ROLE)
+#endif
+
 // Wave specialisation (8 waves, 2 per SIMD): waves 0-3 are CONSUMERS — their instruction stream is only
 // ds_read_b128 + MFMA; waves 4-7 are LOADERS — weight-image DMA, halo-patch fetch, fp32 -> hi/lo split and
 // the LDS commit.  Measured on the single-role version: an LDS-DMA instruction costs the issuing wave
@@ -816,19 +843,32 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     AS_SPLIT_STORE_W(0)
     AS_SPLIT_COMMIT_P()
     __syncthreads();
+    AS_STAMP_DECL
+    AS_STAMP_BEGIN
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
       const bool more = chunk + 1 < chunk_hi;
       if (more) {
+#ifndef AS_ABL_NO_W
         AS_SPLIT_LOAD_W(chunk + 1)
+#endif
+        AS_STAMP_SEG(5)  // weight loads issued
+#ifndef AS_ABL_NO_P
         AS_SPLIT_FETCH_SPLIT_P(chunk + 1)
+#endif
+        AS_STAMP_SEG(0)  // patch loads issued, returned, split
         AS_SPLIT_STORE_W(((chunk - chunk_lo) & 1) ^ 1)  // the other W image is free while the consumers work on this one
+        AS_STAMP_SEG(1)  // weight image stored
       }
       __syncthreads();  // consumers finished chunk: patch and W image `cur` are free
+      AS_STAMP_SEG(2)    // waited for the consumers
       if (more) {
         AS_SPLIT_COMMIT_P()
+        AS_STAMP_SEG(3)  // patch committed
         __syncthreads();
+        AS_STAMP_SEG(4)
       }
     }
+    AS_STAMP_FLUSH(1)
 #undef AS_SPLIT_LOAD_W
 #undef AS_SPLIT_STORE_W
 #undef AS_SPLIT_FETCH_SPLIT_P
@@ -850,6 +890,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc_h[c][q][r] = 0.f; acc_x[c][q][r] = 0.f; }
     __syncthreads();
+    AS_STAMP_DECL
+    AS_STAMP_BEGIN
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
       const bool more = chunk + 1 < chunk_hi;
       const unsigned char* wb = lds + ((chunk - chunk_lo) & 1) * WCHUNK + wlane;
@@ -890,9 +932,15 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
 #undef AS_SPLIT_STEP
 #undef AS_SPLIT_MFMA_C
 #undef AS_SPLIT_LDOPS
+      AS_STAMP_SEG(0)  // operand reads + MFMAs of the chunk
       __syncthreads();
-      if (more) __syncthreads();
+      AS_STAMP_SEG(1)  // waited for the loaders (next weight image stored, next patch fetched)
+      if (more) {
+        __syncthreads();
+        AS_STAMP_SEG(2)  // waited for the patch commit
+      }
     }
+    AS_STAMP_FLUSH(0)
   }
 
   // ---- epilogue (consumer waves hold the accumulators) ----
@@ -1036,6 +1084,17 @@ int conv_cout_pad(int Cout) { return ((Cout + kBN - 1) / kBN) * kBN; }
 }  // namespace
 
 extern "C" {
+
+#ifdef AS_CONV_STAMPS
+// diagnostic build only: copy the stamp sums [block][16] (slots 0-5 consumer, 8-13 loader) to the host and clear them
+int as_debug_conv_stamps(unsigned long long* out, int n) {
+  if (!out || n <= 0 || n > kStampBlocks * kStampSlots) return AS_ERR_BAD_ARG;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(as_conv_stamp_buf), sizeof(unsigned long long) * n) != hipSuccess) return AS_ERR_LAUNCH;
+  static unsigned long long zeros[kStampBlocks * kStampSlots];
+  if (hipMemcpyToSymbol(HIP_SYMBOL(as_conv_stamp_buf), zeros, sizeof(zeros)) != hipSuccess) return AS_ERR_LAUNCH;
+  return AS_OK;
+}
+#endif
 
 int64_t as_conv_pack_size(int Cin, int Cout, int KS) {
   if (Cin <= 0 || Cout <= 0 || (KS != 1 && KS != 3)) return -1;

@@ -1,0 +1,75 @@
+"""Read the in-kernel stamps of the diagnostic conv build (tools/conv_variant.sh stamps -DAS_CONV_STAMPS -> lib/stamps.so) on the GPU box:
+    python tools/conv_stamps.py [gru_zr|gru_q|head1|liif_l2|cnet_l1]
+Prints, per segment of conv_split_kernel's chunk loop, the mean cycles per chunk over all blocks (SHARES matter, not totals:
+the stamps' fences forbid overlaps the product kernel has)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+os.environ["ANYSTEREO_LIB"] = os.path.join(ROOT, "any-stereo_amd", "anystereo", "lib", "stamps.so")
+sys.path.insert(0, os.path.join(ROOT, "any-stereo_amd"))
+import torch  # noqa: E402
+
+from anystereo import _lib as Lb, ops  # noqa: E402
+from anystereo.harness.synthetic import det_uniform  # noqa: E402
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "gru_zr"
+    dev, b, h, w = "cuda:0", 1, 136, 240
+    U = lambda shape, seed, lo=-1.0, hi=1.0: det_uniform(shape, seed, lo, hi).to(dev)  # noqa: E731
+    if which == "gru_zr":
+        xs = [U((b, 128, h, w), 10 + i) for i in range(3)]
+        ctx = U((b, 384, h, w), 20)
+        pk = ops.PackedConv().get([U((256, 384, 3, 3), 30, -0.02, 0.02)], [U((256,), 31)])
+        fn, chunks = (lambda: ops.conv2d(xs, pk, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=xs[0])), 24
+    elif which == "gru_q":
+        xs = [U((b, 128, h, w), 10 + i) for i in range(3)]
+        ctx = U((b, 384, h, w), 20)
+        z = U((b, 128, h, w), 21, 0.0, 1.0)
+        pk = ops.PackedConv().get([U((128, 384, 3, 3), 30, -0.02, 0.02)], [U((128,), 31)])
+        fn, chunks = (lambda: ops.conv2d(xs, pk, add=ctx, add_coff=256, epilogue=Lb.EPI_GRU_Q, h=xs[0], z=z)), 24
+    elif which == "head1":
+        x = U((b, 128, h, w), 10)
+        pk = ops.PackedConv().get([U((256, 128, 3, 3), 30, -0.02, 0.02)], [U((256,), 31)])
+        fn, chunks = (lambda: ops.conv2d([x], pk, act=Lb.ACT_RELU)), 8
+    elif which == "cnet_l1":
+        x = U((1, 64, 4 * h, 4 * w), 61)
+        pk = ops.PackedConv().get([U((64, 64, 3, 3), 62, -0.05, 0.05)], [U((64,), 63)])
+        fn, chunks = (lambda: ops.conv2d([x], pk, act=Lb.ACT_RELU)), 4
+    else:
+        x = U((1, 128, 1, 16 * h * w), 64)
+        pk = ops.PackedConv().get([U((64, 128, 1, 1), 65, -0.05, 0.05)], [U((64,), 66)])
+        fn, chunks = (lambda: ops.conv2d([x], pk, act=Lb.ACT_RELU)), 2
+    lib = Lb.load()
+    dbg = lib.as_debug_conv_stamps
+    dbg.restype, dbg.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    n = 1024 * 16
+    buf = (C.c_ulonglong * n)()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    assert dbg(buf, n) == 0
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    torch.cuda.synchronize()
+    assert dbg(buf, n) == 0
+    t = torch.tensor(list(buf), dtype=torch.float64).view(1024, 16)
+    used = t[(t.sum(1) > 0)]
+    print(f"{which}: {used.shape[0]} blocks stamped, launch {s.elapsed_time(e) * 1e3:.1f} us (diagnostic build), {chunks} chunks/block")
+    names = {0: "consumer: operand reads + MFMAs", 1: "consumer: barrier 1 (waits for loaders)", 2: "consumer: barrier 2 (patch commit)",
+             13: "loader: weight loads issued", 8: "loader: patch loads issued+returned+split", 9: "loader: weight image store", 10: "loader: barrier 1 (waits for consumers)",
+             11: "loader: patch commit", 12: "loader: barrier 2"}
+    for role, slots in (("consumer", (0, 1, 2)), ("loader", (13, 8, 9, 10, 11, 12))):
+        tot = sum(used[:, i].mean().item() for i in slots)
+        for i in slots:
+            m = used[:, i].mean().item()
+            print(f"  {names[i]:45s} {m / chunks:9.0f} ticks/chunk  {100 * m / tot:5.1f} %   (min {used[:, i].min().item() / chunks:.0f}, max {used[:, i].max().item() / chunks:.0f})")
+        print(f"  {role} total {tot / chunks:.0f} ticks/chunk")
+
+
+if __name__ == "__main__":
+    main()

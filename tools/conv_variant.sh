@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build a DIAGNOSTIC library any-stereo_amd/anystereo/lib/<name>.so from the working tree with extra defines for conv.hip:
+#   tools/conv_variant.sh stamps -DAS_CONV_STAMPS          (read with tools/conv_stamps.py on the GPU box)
+#   tools/conv_variant.sh now    -DAS_ABL_NO_W             (timing-only ablations: ANYSTEREO_LIB=... tools/kbench.py gru_zr)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+tmp=$(mktemp -d)
+objs=""
+for f in any-stereo_amd/csrc/*.hip; do
+  o=$tmp/$(basename ${f%.hip}).o
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 "$@" -c $f -o $o 2>/dev/null &
+  objs="$objs $o"
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o any-stereo_amd/anystereo/lib/$name.so
+rm -rf $tmp
+echo built any-stereo_amd/anystereo/lib/$name.so
