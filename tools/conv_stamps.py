@@ -65,6 +65,8 @@ def main():
              11: "loader: patch commit", 12: "loader: barrier 2"}
     for role, slots in (("consumer", (0, 1, 2)), ("loader", (13, 8, 9, 10, 11, 12))):
         tot = sum(used[:, i].mean().item() for i in slots)
+        if tot == 0:
+            continue  # the interleaved loader pipeline carries no stamps
         for i in slots:
             m = used[:, i].mean().item()
             print(f"  {names[i]:45s} {m / chunks:9.0f} ticks/chunk  {100 * m / tot:5.1f} %   (min {used[:, i].min().item() / chunks:.0f}, max {used[:, i].max().item() / chunks:.0f})")
