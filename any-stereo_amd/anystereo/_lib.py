@@ -37,6 +37,8 @@ class ConvDesc(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("KS", C.c_int),
         ("act", C.c_int), ("epilogue", C.c_int), ("precision", C.c_int),
         ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("stride", C.c_int),
+        ("src_bs", C.c_int * AS_MAX_SRCS), ("out_bs", C.c_void_p), ("out_bs_ctot", C.c_int), ("out_bs_coff", C.c_int),
+        ("bs_only", C.c_int),
     ]
 
 
@@ -61,10 +63,12 @@ SIGNATURES = {
     "as_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv_pack_size_split": (C.c_int64, [_i, _i, _i]),
     "as_conv_pack_weights_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "as_pool2x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_pool2x_bs": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_interp_bilinear_ac_bs": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_dwconv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_conv3d_k3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_deconv3d_k4s2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -210,6 +210,9 @@ class ContinuousStereoBase(nn.Module):
             mf.record_stream(main)
             net[0] = ub.gru04(net[0], *(inp[0]), mf, up, pre_zr=pre)
             net[0].record_stream(side)
+            twin = getattr(net[0], "_as_bs", None)  # blocked twin of the hidden state: read by the head on the side stream
+            if twin is not None:
+                twin.t.record_stream(side)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 disp = ub.disp_head(net[0], addend=disp)

@@ -27,6 +27,21 @@ def _f(t):
     return t.float().contiguous()
 
 
+def _links() -> bool:
+    """Conv -> conv links as blocked split-fp16 tensors (ops.BS8: bit-identical results, a quarter of the consumer's patch
+    loads): only the split-precision kernel reads / writes them.  ANYSTEREO_BS_LINKS=0 keeps fp32 links (A/B timing)."""
+    return _LINKS_ENV and ops.get_precision() == "split"
+
+
+_LINKS_ENV = __import__("os").environ.get("ANYSTEREO_BS_LINKS", "1") != "0"
+
+
+def _twin(t):
+    """The blocked twin a producer attached to its fp32 result (same values), or the tensor itself."""
+    bs = getattr(t, "_as_bs", None)
+    return bs if (bs is not None and _links() and tuple(bs.shape) == tuple(t.shape)) else t
+
+
 # Training (gradients required): the reference's formulation op for op (gates as separate pointwise ops under autograd);
 # the 3x3 / 1x1 convolutions run forward and dgrad on the implicit-GEMM kernel (grad.Conv2dSame; convz and convr as ONE
 # conv over concatenated weights), wgrad on the library.  The 7x7 one-channel conv and the 256 -> 1 head conv stay nn.Conv2d.
@@ -50,8 +65,14 @@ class DispHead(nn.Module):
         if _train(x, self.conv1.weight):
             out = self.conv2(_cs(self, "conv1", x, self.conv1.weight, self.conv1.bias, relu=True))  # update.py:23-24
             return out if addend is None else addend + out
+        links = _links()
         with scope("disp_head_conv1"):
-            t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
+            if links:  # hidden layer handed to conv2 as a blocked tensor only
+                b, _, hh, ww = x.shape
+                t = ops.BS8.empty(b, self.conv1.out_channels, hh, ww, x.device)
+                ops.conv2d([_twin(_f(x))], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU, out_bs=t, bs_only=True)
+            else:
+                t = ops.conv2d([_f(x)], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU)
         if self.conv2.out_channels == 1:
             # 3x3, 256 -> 1 as (1x1, 256 -> 9 tap planes on the MFMA path) + a 9-tap shifted sum
             with scope("disp_head_conv2"):
@@ -114,21 +135,33 @@ class ConvGRU(nn.Module):
             r = torch.sigmoid(zr[:, hid:] + cr)
             q = torch.tanh(_cs(self, "q", torch.cat([r * h, x], dim=1), self.convq.weight, self.convq.bias) + cq)
             return (1 - z) * h + z * q
+        hsrc = _twin(h) if isinstance(h, torch.Tensor) else h  # blocked twin written by the previous step's q conv
         h = _f(h)
-        xs = [_f(x) for x in x_list]
+        xs = [x if isinstance(x, ops.BS8) else _twin(_f(x)) for x in x_list]
         ctx, coff = _context_window(cz, cr, cq)
         hid = h.shape[1]
+        links = _links()
+        b, _, hh, ww = h.shape
+        # r*h goes to the q conv as a blocked tensor only; the new hidden state gets a blocked twin for its conv consumers
+        # (next step's gate conv, the disparity head) next to the fp32 tensor the epilogues / resamplers read
+        rbs = ops.BS8.empty(b, hid, hh, ww, h.device) if links else None
+        hbs = ops.BS8.empty(b, hid, hh, ww, h.device) if links else None
         pq = self._pq.get([self.convq.weight], [self.convq.bias])
         if pre_zr is None:
             pzr = self._pzr.get([self.convz.weight, self.convr.weight], [self.convz.bias, self.convr.bias])
             with scope(self.tag + "_zr_conv"):
-                z, rh = ops.conv2d([h] + xs, pzr, add=ctx, add_coff=coff, epilogue=L.EPI_GRU_ZR, h=h)
+                z, rh = ops.conv2d([hsrc if links else h] + xs, pzr, add=ctx, add_coff=coff, epilogue=L.EPI_GRU_ZR, h=h,
+                                   out_bs=rbs, bs_only=links)
         else:
             pzx = self._pzr_x.get([self.convz.weight, self.convr.weight], [None, None], transform=lambda w: w[:, hid:])
             with scope(self.tag + "_zr_conv"):
-                z, rh = ops.conv2d(xs, pzx, add=pre_zr, add_coff=0, epilogue=L.EPI_GRU_ZR, h=h)
+                z, rh = ops.conv2d(xs, pzx, add=pre_zr, add_coff=0, epilogue=L.EPI_GRU_ZR, h=h, out_bs=rbs, bs_only=links)
         with scope(self.tag + "_q_conv"):
-            return ops.conv2d([rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z)
+            out = ops.conv2d([rbs if links else rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z,
+                             out_bs=hbs)
+        if links:
+            out._as_bs = hbs
+        return out
 
     def pre_zr(self, h, cz, cr, cq):
         """The part of convz‖convr that needs only the hidden state: conv([h], W[:, :hidden]) + bias + [cz‖cr].  The inference
@@ -176,17 +209,30 @@ class BasicMotionEncoder(nn.Module):
     # [64,128) = disparity branch (the reference's torch.cat, update.py:90, never materialised separately).
     def new_buffer(self, disp):
         b, _, h, w = disp.shape
+        if _links():  # the two branches meet in a blocked tensor that only the last conv reads
+            return ops.BS8.empty(b, 128, h, w, disp.device)
         return torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
 
     def new_output(self, disp):
         b, _, h, w = disp.shape
+        if _links():  # the motion features only feed gru04's two convolutions
+            return ops.BS8.empty(b, 128, h, w, disp.device)
         return torch.empty((b, 128, h, w), device=disp.device, dtype=torch.float32)
 
     def corr_branch(self, corr, cd):
+        bs = isinstance(cd, ops.BS8)
         with scope("enc_convc1"):
-            cor = ops.conv2d([_f(corr)], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
+            if bs:
+                b, _, h, w = corr.shape
+                cor = ops.BS8.empty(b, 64, h, w, corr.device)
+                ops.conv2d([_f(corr)], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU, out_bs=cor, bs_only=True)
+            else:
+                cor = ops.conv2d([_f(corr)], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
         with scope("enc_convc2"):
-            ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out=cd, out_coff=0)
+            if bs:
+                ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out_bs=cd, out_bs_coff=0, bs_only=True)
+            else:
+                ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out=cd, out_coff=0)
 
     def disp_branch(self, disp, cd, out=None):
         """convd1 -> convd2 into cd[:, 64:]; with `out` the disparity itself is also placed in out[:, 127] (update.py:91)."""
@@ -194,16 +240,24 @@ class BasicMotionEncoder(nn.Module):
             d1 = ops.conv7x7_c1_relu(_f(disp), _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()),
                                      copy_out=out, copy_coff=127)
         with scope("enc_convd2"):
-            ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out=cd, out_coff=64)
+            if isinstance(cd, ops.BS8):
+                ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out_bs=cd, out_bs_coff=64, bs_only=True)
+            else:
+                ops.conv2d([d1], self._pd2.get([self.convd2.weight], [self.convd2.bias]), act=L.ACT_RELU, out=cd, out_coff=64)
 
     def merge(self, cd, disp, out=None):
         """relu(conv(cd)) into channels [0,127) and disp in channel 127; `out` given = disp_branch already placed disp."""
         have_disp = out is not None
         if out is None:
-            out = torch.empty_like(cd)
+            out = self.new_output(disp)
         with scope("enc_conv"):
-            ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out=out, out_coff=0)
+            if isinstance(out, ops.BS8):  # channels [0,127) here, channel 127 (disp) by the 7x7 kernel's pass-through
+                ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out_bs=out, out_bs_coff=0, bs_only=True)
+            else:
+                ops.conv2d([cd], self._pc.get([self.conv.weight], [self.conv.bias]), act=L.ACT_RELU, out=out, out_coff=0)
         if not have_disp:
+            if isinstance(out, ops.BS8):
+                raise RuntimeError("BasicMotionEncoder.merge: a blocked output needs disp_branch(..., out=) to place the disparity")
             out[:, 127:128].copy_(_f(disp))
         return out
 
@@ -212,7 +266,7 @@ def pool2x(x):
     if _train(x):
         return F.avg_pool2d(x, 3, stride=2, padding=1)  # update.py:94-95
     with scope("pool2x"):
-        return ops.pool2x(_f(x))
+        return ops.pool2x_bs(_f(x)) if _links() else ops.pool2x(_f(x))  # the pooled / resized maps only feed GRU convs
 
 
 def interp(x, dest):
@@ -220,6 +274,8 @@ def interp(x, dest):
         # (a HIP forward + aten.upsample_bilinear2d_backward pair measured SLOWER than this on the same box: 124 vs 116 ms/step)
         return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)  # update.py:100-102
     with scope("interp"):
+        if _links():
+            return ops.interp_bs(_f(x), dest.shape[2], dest.shape[3])
         return ops.interp(_f(x), dest.shape[2], dest.shape[3])
 
 

@@ -7,6 +7,7 @@ fp32 contiguous tensors and raises RuntimeError otherwise — no silent fallback
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -270,12 +271,49 @@ def fold_bn(conv, bn, out_dim: int = 0):
     return w, ((b0 - mean) * s + beta).float()
 
 
+class BS8:
+    """Blocked split-fp16 activation tensor, the link format between two split-precision convolutions
+    (include/anystereo_hip.h, as_conv_desc.src_bs / out_bs): t [B, 2, ceil(C/8), H, W, 8] float16 holds a plane set of hi parts
+    and one of lo parts of x = hi + lo/2048, the 8 channels of a block contiguous per pixel — what the consuming kernel's
+    loaders would compute from the fp32 tensor, so results are bit-identical to passing that tensor while a loader item is
+    2 coalesced 16-B loads instead of 8 dword loads and the split."""
+
+    __slots__ = ("t", "c")
+
+    def __init__(self, t: torch.Tensor, c: int):
+        self.t, self.c = t, c
+
+    @staticmethod
+    def empty(b: int, c: int, h: int, w: int, device) -> "BS8":
+        return BS8(torch.empty((b, 2, (c + 7) // 8, h, w, 8), device=device, dtype=torch.float16), c)
+
+    @property
+    def shape(self):  # logical NCHW shape
+        return (self.t.shape[0], self.c, self.t.shape[3], self.t.shape[4])
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def record_stream(self, stream) -> None:
+        self.t.record_stream(stream)
+
+    def float(self) -> torch.Tensor:
+        """The fp32 tensor the record pairs stand for (tests / debugging)."""
+        b, _, c8, h, w, _ = self.t.shape
+        v = self.t[:, 0].float() + self.t[:, 1].float() / 2048.0
+        return v.permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, h, w)[:, :self.c].contiguous()
+
+
 def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE, add: Optional[torch.Tensor] = None,
            add_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0, epilogue: int = L.EPI_LINEAR,
            h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-           stride: int = 1):
+           stride: int = 1, out_bs: Optional[BS8] = None, out_bs_coff: int = 0, bs_only: bool = False):
     """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue.
-    stride 2: 3x3 / padding 1 / LINEAR epilogue in split precision only; outputs are [(H-1)//2+1, (W-1)//2+1]."""
+    stride 2: 3x3 / padding 1 / LINEAR epilogue in split precision only; outputs are [(H-1)//2+1, (W-1)//2+1].
+    Split precision only: a source may be a BS8 (blocked split-fp16 link tensor); `out_bs` receives such a copy of the result
+    (LINEAR / GRU_Q: of out; GRU_ZR: of r*h) in channels [out_bs_coff, ...); with `bs_only` the fp32 form of that result is
+    not written and None is returned in its place."""
     b, _, hin, win = srcs[0].shape
     if stride not in (1, 2):
         raise RuntimeError("conv2d: stride must be 1 or 2")
@@ -283,16 +321,22 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     kc = 16 if pack.split else (8 if pack.ks == 3 else 32)  # channels per K chunk of the kernel (csrc/conv.hip)
     if any(s.shape[1] % kc for s in srcs[:-1]):
         # a K chunk must not straddle two tensors: materialise the concat for odd splits (never on the model path)
-        srcs = [torch.cat(list(srcs), dim=1)]
+        srcs = [torch.cat([s.float() if isinstance(s, BS8) else s for s in srcs], dim=1)]
+    if (out_bs is not None or any(isinstance(s, BS8) for s in srcs)) and not (pack.split and stride == 1):
+        raise RuntimeError("conv2d: blocked split-fp16 tensors need the split-precision kernel at stride 1")
     d = L.ConvDesc()
     cin = 0
     if len(srcs) > L.AS_MAX_SRCS:
         raise RuntimeError(f"conv2d: at most {L.AS_MAX_SRCS} sources")
     for i, s in enumerate(srcs):
-        _req(s, f"src[{i}]")
+        if isinstance(s, BS8):
+            _req(s.t, f"src[{i}]", torch.float16)
+            d.src_bs[i] = 1
+        else:
+            _req(s, f"src[{i}]")
         if s.shape[0] != b or tuple(s.shape[2:]) != (hin, win):
             raise RuntimeError(f"conv2d: src[{i}] shape {tuple(s.shape)} does not match {(b, '*', hin, win)}")
-        d.src[i] = s.data_ptr()
+        d.src[i] = s.t.data_ptr() if isinstance(s, BS8) else s.data_ptr()
         d.src_c[i] = s.shape[1]
         cin += s.shape[1]
     if cin != pack.cin:
@@ -307,11 +351,22 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
             raise RuntimeError("conv2d: add shape mismatch")
         d.add, d.add_ctot, d.add_coff = add.data_ptr(), add.shape[1], add_coff
     dev = srcs[0].device
-    if epilogue == L.EPI_LINEAR:
+    if out_bs is not None:
+        _req(out_bs.t, "out_bs", torch.float16)
+        cres = cout // 2 if epilogue == L.EPI_GRU_ZR else cout
+        if out_bs.shape[0] != b or tuple(out_bs.shape[2:]) != (hh, ww) or out_bs_coff % 8 or out_bs_coff + cres > (out_bs.c + 7) // 8 * 8:
+            raise RuntimeError("conv2d: out_bs does not fit the result")
+        d.out_bs, d.out_bs_ctot, d.out_bs_coff, d.bs_only = out_bs.t.data_ptr(), out_bs.c, out_bs_coff, 1 if bs_only else 0
+    elif bs_only:
+        raise RuntimeError("conv2d: bs_only without out_bs")
+    if epilogue == L.EPI_LINEAR and bs_only:
+        out = None
+    elif epilogue == L.EPI_LINEAR:
         if out is None:
             out = torch.empty((b, cout, hh, ww), device=dev, dtype=torch.float32)
         _req(out, "out")
         d.out, d.out_ctot, d.out_coff = out.data_ptr(), out.shape[1], out_coff
+    if epilogue == L.EPI_LINEAR:
         if h is not None:  # residual tail: out = relu(h + act(conv))
             _req(h, "h")
             if tuple(h.shape) != (b, cout, hh, ww):
@@ -322,13 +377,16 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
         _req(h, "h")
         if out is None:
             out = torch.empty((b, ch, hh, ww), device=dev, dtype=torch.float32)
-        if out2 is None:
+        if out2 is None and not bs_only:
             out2 = torch.empty((b, ch, hh, ww), device=dev, dtype=torch.float32)
-        _req(out, "out"), _req(out2, "out2")
-        for t in (h, out, out2):
+        _req(out, "out")
+        for t in (h, out) + (() if bs_only else (out2,)):
+            _req(t, "h/out/out2")
             if tuple(t.shape) != (b, ch, hh, ww):
                 raise RuntimeError("conv2d(GRU_ZR): h/out/out2 must be [B,Cout/2,H,W]")
-        d.h, d.out, d.out2 = h.data_ptr(), out.data_ptr(), out2.data_ptr()
+        d.h, d.out, d.out2 = h.data_ptr(), out.data_ptr(), (0 if bs_only else out2.data_ptr())
+        if bs_only:
+            out2 = None
     else:
         _req(h, "h"), _req(z, "z")
         if out is None:
@@ -368,20 +426,24 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
         out = torch.empty((b, cout, h, w), device=x.device, dtype=torch.float32)
     _req(out, "out")
     key = (weight.data_ptr(), weight._version, weight.device)
-    wt = _TAPMAJOR.get(key)
+    ent = _TAPMAJOR.get(key)
+    # the entry must belong to THIS tensor: a freed weight's address (and version 0) is reused by the caching allocator
+    wt = ent[1] if (ent is not None and ent[0]() is weight) else None
     if wt is None:  # tap-major copy, rebuilt when the weight changes (one entry per live weight tensor)
         if len(_TAPMAJOR) > 64:
             _TAPMAJOR.clear()
         wt = torch.zeros((49, (cout + 63) // 64 * 64), device=weight.device, dtype=torch.float32)
         wt[:, :cout] = weight.detach().reshape(cout, 49).t()
-        _TAPMAJOR[key] = wt
+        _TAPMAJOR[key] = (weakref.ref(weight), wt)
     with torch.cuda.device(x.device):
+        cbs = isinstance(copy_out, BS8)
         if copy_out is not None:
-            _req(copy_out, "copy_out")
+            _req(copy_out.t if cbs else copy_out, "copy_out", torch.float16 if cbs else torch.float32)
             if copy_out.shape[0] != b or tuple(copy_out.shape[2:]) != (h, w):
                 raise RuntimeError("conv7x7_c1_relu: copy_out shape mismatch")
         L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(wt), _p(bias), _p(out), b, h, w, cout, out.shape[1], out_coff, 1,
-                                            _p(copy_out), 0 if copy_out is None else copy_out.shape[1], copy_coff, _stream()),
+                                            _p(copy_out.t if cbs else copy_out), 0 if copy_out is None else copy_out.shape[1], copy_coff,
+                                            1 if cbs else 0, _stream()),
                 "conv7x7_c1_relu")
     return out
 
@@ -421,6 +483,26 @@ def pool2x(x):
     out = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         L.check(L.load().as_pool2x(_p(x), _p(out), b, c, h, w, _stream()), "pool2x")
+    return out
+
+
+def pool2x_bs(x) -> "BS8":
+    """pool2x with a blocked split-fp16 result (for maps that only feed split-precision convolutions)."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    out = BS8.empty(b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_pool2x_bs(_p(x), _p(out.t), b, c, h, w, _stream()), "pool2x_bs")
+    return out
+
+
+def interp_bs(x, ho: int, wo: int) -> "BS8":
+    """Bilinear align_corners=True resize with a blocked split-fp16 result."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    out = BS8.empty(b, c, ho, wo, x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.load().as_interp_bilinear_ac_bs(_p(x), _p(out.t), b, c, h, w, ho, wo, _stream()), "interp_bs")
     return out
 
 

@@ -157,7 +157,8 @@ def _motion_encoder(disp, corr, weights, biases):
         # cor_planes = corr_levels * 9 * (geo_channels + 1): any factorisation builds the same module
         return BasicMotionEncoder(argparse.Namespace(corr_levels=1, corr_radius=4), geo_channels=weights[0].shape[1] // 9 - 1).to(disp.device)
     m = _cached("enc", list(weights) + list(biases), build)
-    return _call(m, ["convc1", "convc2", "convd1", "convd2", "conv"], weights, biases, "motion_encoder", disp, corr)
+    out = _call(m, ["convc1", "convc2", "convd1", "convd2", "conv"], weights, biases, "motion_encoder", disp, corr)
+    return out.float() if isinstance(out, ops.BS8) else out  # inside the models the features stay a blocked link tensor
 
 
 def _convgru_step(h, cz, cr, cq, x, weights, biases):

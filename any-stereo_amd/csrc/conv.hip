@@ -28,6 +28,10 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using half4v = __attribute__((ext_vector_type(4))) _Float16;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 struct ConvParams {
   const float* src[AS_MAX_SRCS];
@@ -46,6 +50,14 @@ struct ConvParams {
   int B, H, W, Cin, Cout, Cout_pad, act;  // H, W: OUTPUT plane (= input plane for stride 1)
   int Hi, Wi;                             // input plane (conv_split_kernel with stride 2)
   int tiles_x, tiles_y, n_tiles, chunks;
+  // Blocked split-fp16 tensors ("BS8", conv_split_kernel only): [B][2][ceil(C/8)][H][W][8 halves] = a plane set of hi parts and
+  // one of lo parts of the operand split, 8 channels of a pixel contiguous — exactly the 16-B units of the kernel's LDS patch
+  // image, so a loader item is two fully coalesced 16-B loads and no arithmetic instead of eight dword loads and the split.
+  int src_bs[AS_MAX_SRCS];     // 1: src[i] is such a tensor (src_c[i] logical channels)
+  _Float16* out_bs;            // optional blocked copy of the result (LINEAR: out, GRU_Q: out, GRU_ZR: out2 = r*h)
+  int out_bs_c8tot, out_bs_coff8;  // blocks of the destination tensor per batch element; first block of the window
+  int out_bs_ctot;             // logical channels of the destination tensor (slots past them are zero-filled, never another producer's)
+  int bs_only;                 // 1: the fp32 copy of that result is not written
   int xcd_map;  // conv_split_kernel: XCD-aware block order (channel tiles of one pixel tile on the same XCD)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
@@ -86,8 +98,11 @@ __device__ __forceinline__ void as_bstore(__amdgpu_buffer_rsrc_t r, unsigned off
 }
 
 struct EpiCtx {
-  __amdgpu_buffer_rsrc_t r_add, r_out, r_h, r_z;
-  bool has_add;
+  __amdgpu_buffer_rsrc_t r_add, r_out, r_h, r_z, r_bs, r_bsl;
+  bool has_add, has_bs, skip_out;
+  int cvalid;        // valid output channels of this block's tile
+  int cend;          // blocked copy: channels from the tile's first to the destination tensor's logical end (slots past it are zeroed;
+                     // slots in [cvalid, cend) belong to another producer and are left untouched)
   unsigned plane4;   // bytes per channel plane
 };
 
@@ -131,6 +146,27 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
     e.r_h = __builtin_amdgcn_make_buffer_rsrc((void*)(p.h + o), 0, recs, 0x00020000);
     e.r_z = __builtin_amdgcn_make_buffer_rsrc((void*)(p.z + o), 0, recs, 0x00020000);
   }
+  // blocked split-fp16 copy: window of this block's channel tile (n0 and the window offset are multiples of 8)
+  e.has_bs = false;
+  e.skip_out = false;
+  e.cvalid = cvalid;
+  e.cend = cvalid;
+  e.r_bs = e.r_out;
+  e.r_bsl = e.r_out;
+  if (EPI != kEpiPartial && p.out_bs) {
+    int c0 = n0;
+    bool on = true;
+    if (EPI == AS_EPI_GRU_ZR) { const int ch = p.Cout >> 1; on = n0 >= ch; c0 = n0 - ch; }
+    if (on) {
+      const int nblk = cvalid > 0 ? (cvalid + 7) / 8 : 0;
+      _Float16* dst = p.out_bs + (((long long)b * 2 * p.out_bs_c8tot + p.out_bs_coff8 + (c0 >> 3)) * plane) * 8;
+      e.r_bs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)((long long)nblk * plane * 16), 0x00020000);
+      e.r_bsl = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (long long)p.out_bs_c8tot * plane * 8), 0, (int)((long long)nblk * plane * 16), 0x00020000);
+      e.has_bs = true;
+      e.cend = p.out_bs_ctot - (p.out_bs_coff8 * 8 + c0);
+      e.skip_out = p.bs_only != 0;
+    }
+  }
   return e;
 }
 
@@ -160,7 +196,8 @@ __device__ __forceinline__ void epi_load(const EpiCtx& e, int col0, int half, un
 
 template <int EPI>
 __device__ __forceinline__ void epi_finish(const ConvParams& p, const EpiCtx& e, const f32x16& v, int col0, int half, int g,
-                                           const float* bias_s, bool is_r, const EpiRegs& R) {
+                                           const float* bias_s, bool is_r, const EpiRegs& R, unsigned poff = 0x7FFFFFF0u) {
+  float ov[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = g * 8 + i;
@@ -178,7 +215,41 @@ __device__ __forceinline__ void epi_finish(const ConvParams& p, const EpiCtx& e,
     } else {
       o = (1.f - R.zv[i]) * R.hv[i] + R.zv[i] * tanhf(x);
     }
-    as_bstore(e.r_out, R.off[i], o);
+    if (!e.skip_out) as_bstore(e.r_out, R.off[i], o);
+    ov[i] = o;
+  }
+  if (EPI != kEpiPartial && e.has_bs) {
+    // rows g*8 .. g*8+7 of the tile = channels [8 m + 4 half, +4) of blocks m = col0/8 + 2g, 2g+1: this lane's 8-B share of
+    // the block's 16-B pixel unit in the hi and in the lo plane set (the lane with the other `half` writes the other share)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      half4v hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float o = ov[m * 4 + k];
+        const _Float16 hk = (_Float16)o;
+        hi[k] = hk;
+        lo[k] = (_Float16)((o - (float)hk) * 2048.f);
+      }
+      const unsigned blk = (unsigned)(col0 >> 3) + 2u * g + m;
+      const unsigned off = poff == 0x7FFFFFF0u ? poff : blk * (e.plane4 * 4u) + poff * 4u + (unsigned)half * 8u;
+      const int crel = (int)blk * 8 + 4 * half;  // first of this lane's four channels, relative to the tile
+      if (crel + 4 <= e.cvalid) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), e.r_bs, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), e.r_bsl, (int)off, 0, 0);
+      } else {  // the result's last channels end inside or before this group: 2-B stores
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool own = crel + k < e.cvalid, pad = crel + k >= e.cend;
+          if (own || pad) {
+            const unsigned ok = off == 0x7FFFFFF0u ? off : off + 2u * k;
+            const _Float16 zero = (_Float16)0.f;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, own ? hi[k] : zero), e.r_bs, (int)ok, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, own ? lo[k] : zero), e.r_bsl, (int)ok, 0, 0);
+          }
+        }
+      }
+    }
   }
 }
 
@@ -213,7 +284,7 @@ __device__ __forceinline__ void epilogue_block(const ConvParams& p, const EpiCtx
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
     }
-    epi_finish<EPI>(p, e, v, co_base + c * 32, half, g, bias_s, is_r, R[i & 1]);
+    epi_finish<EPI>(p, e, v, co_base + c * 32, half, g, bias_s, is_r, R[i & 1], poff[q]);
   }
 }
 
@@ -480,7 +551,7 @@ template <int CO>
 __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int H, int W, int Cout, int CP, int out_ctot, int out_coff,
-                                                            float* __restrict__ copy_out, int copy_ctot, int copy_coff) {
+                                                            float* __restrict__ copy_out, int copy_ctot, int copy_coff, int copy_bs) {
   __shared__ float patch[22 * 22];
   const int groups = CP / CO;
   const int b = blockIdx.z / groups;
@@ -516,7 +587,18 @@ __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restr
     for (int j = 0; j < CO; ++j)
       if (c0 + j < Cout) o[(long long)j * plane] = fmaxf(acc[j] + (bias ? bias[c0 + j] : 0.f), 0.f);
     // optional pass-through of the input plane (the `cat([out, disp])` of the motion encoder, update.py:91)
-    if (copy_out && c0 == 0) copy_out[((long long)b * copy_ctot + copy_coff) * plane + (long long)gy * W + gx] = patch[(ly + 3) * 22 + lx + 3];
+    if (copy_out && c0 == 0) {
+      const float v = patch[(ly + 3) * 22 + lx + 3];
+      if (copy_bs) {  // copy_out is a blocked split-fp16 tensor (ConvParams' BS8 comment): slot copy_coff % 8 of its block
+        const int c8 = (copy_ctot + 7) >> 3;
+        _Float16* rec = reinterpret_cast<_Float16*>(copy_out) + (((long long)b * 2 * c8 + (copy_coff >> 3)) * plane + (long long)gy * W + gx) * 8 + (copy_coff & 7);
+        const _Float16 hk = (_Float16)v;
+        rec[0] = hk;
+        rec[(long long)c8 * plane * 8] = (_Float16)((v - (float)hk) * 2048.f);
+      } else {
+        copy_out[((long long)b * copy_ctot + copy_coff) * plane + (long long)gy * W + gx] = v;
+      }
+    }
   }
 }
 
@@ -576,15 +658,7 @@ __global__ __launch_bounds__(256) void tap_shift_sum_kernel(const float* __restr
 }
 
 // pool2x: 3x3 mean, stride 2, zero pad 1, divisor 9 (update.py:94-95)
-__global__ __launch_bounds__(256) void pool2x_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
-                                                     int Ho, int Wo, long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int xo = (int)(idx % Wo);
-  long long t = idx / Wo;
-  const int yo = (int)(t % Ho);
-  const long long bc = t / Ho;
-  const float* xp = x + bc * H * W;
+__device__ __forceinline__ float pool2x_at(const float* __restrict__ xp, int yo, int xo, int H, int W) {
   float s = 0.f;
 #pragma unroll
   for (int dy = 0; dy < 3; ++dy) {
@@ -596,10 +670,67 @@ __global__ __launch_bounds__(256) void pool2x_kernel(const float* __restrict__ x
       if (xx >= 0 && xx < W) s += xp[(long long)yy * W + xx];
     }
   }
-  out[idx] = s / 9.f;
+  return s / 9.f;
+}
+
+__global__ __launch_bounds__(256) void pool2x_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
+                                                     int Ho, int Wo, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int xo = (int)(idx % Wo);
+  long long t = idx / Wo;
+  const int yo = (int)(t % Ho);
+  const long long bc = t / Ho;
+  out[idx] = pool2x_at(x + bc * H * W, yo, xo, H, W);
+}
+
+// Blocked split-fp16 output (ConvParams' BS8 comment): one thread per (8-channel block, output pixel) writes the 16-B unit of
+// the hi plane set and the one of the lo plane set.  Same per-element arithmetic as the fp32 kernels (shared helpers).
+__device__ __forceinline__ void bs8_store(_Float16* __restrict__ out_bs, long long b, int c8tot, int blk, long long plane,
+                                          long long pix, const float (&v)[8]) {
+  half8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 hj = (_Float16)v[j];
+    hi[j] = hj;
+    lo[j] = (_Float16)((v[j] - (float)hj) * 2048.f);
+  }
+  _Float16* rec = out_bs + ((b * 2 * c8tot + blk) * plane + pix) * 8;
+  *reinterpret_cast<half8*>(rec) = hi;
+  *reinterpret_cast<half8*>(rec + (long long)c8tot * plane * 8) = lo;
+}
+
+__global__ __launch_bounds__(256) void pool2x_bs_kernel(const float* __restrict__ x, _Float16* __restrict__ out_bs, int C, int H, int W,
+                                                        int Ho, int Wo, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (C + 7) >> 3;
+  const int xo = (int)(idx % Wo);
+  long long t = idx / Wo;
+  const int yo = (int)(t % Ho);
+  t /= Ho;
+  const int blk = (int)(t % c8);
+  const long long b = t / c8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = blk * 8 + j;
+    v[j] = c < C ? pool2x_at(x + (b * C + c) * H * W, yo, xo, H, W) : 0.f;
+  }
+  bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v);
 }
 
 // interp: bilinear, align_corners=True (update.py:100-102)
+__device__ __forceinline__ float interp_at(const float* __restrict__ xp, int yo, int xo, int H, int W, float sy, float sx) {
+  const float fy = sy * (float)yo, fx = sx * (float)xo;
+  const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ty = fy - (float)y0, tx = fx - (float)x0;
+  const float top = (1.f - tx) * xp[(long long)y0 * W + x0] + tx * xp[(long long)y0 * W + x1];
+  const float bot = (1.f - tx) * xp[(long long)y1 * W + x0] + tx * xp[(long long)y1 * W + x1];
+  return (1.f - ty) * top + ty * bot;
+}
+
 __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W,
                                                      int Ho, int Wo, float sy, float sx, long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -608,14 +739,27 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x
   long long t = idx / Wo;
   const int yo = (int)(t % Ho);
   const long long bc = t / Ho;
-  const float fy = sy * (float)yo, fx = sx * (float)xo;
-  const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
-  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-  const float ty = fy - (float)y0, tx = fx - (float)x0;
-  const float* xp = x + bc * H * W;
-  const float top = (1.f - tx) * xp[(long long)y0 * W + x0] + tx * xp[(long long)y0 * W + x1];
-  const float bot = (1.f - tx) * xp[(long long)y1 * W + x0] + tx * xp[(long long)y1 * W + x1];
-  out[idx] = (1.f - ty) * top + ty * bot;
+  out[idx] = interp_at(x + bc * H * W, yo, xo, H, W, sy, sx);
+}
+
+__global__ __launch_bounds__(256) void interp_bs_kernel(const float* __restrict__ x, _Float16* __restrict__ out_bs, int C, int H, int W,
+                                                        int Ho, int Wo, float sy, float sx, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (C + 7) >> 3;
+  const int xo = (int)(idx % Wo);
+  long long t = idx / Wo;
+  const int yo = (int)(t % Ho);
+  t /= Ho;
+  const int blk = (int)(t % c8);
+  const long long b = t / c8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = blk * 8 + j;
+    v[j] = c < C ? interp_at(x + (b * C + c) * H * W, yo, xo, H, W, sy, sx) : 0.f;
+  }
+  bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v);
 }
 
 // ================================================================================================
@@ -634,7 +778,6 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x
 // Pipeline unit = one kernel row (KS taps) of a 16-channel chunk: weights double-buffered per unit,
 // the halo patch double-buffered per chunk; next unit/chunk is fetched into registers under the MFMAs.
 // ================================================================================================
-using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int kSplitKC = 16;
@@ -765,6 +908,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     // (channel pair, pixel) with 4-B writes at a 16-B lane stride were 4-way bank conflicted: 4 x the instructions at a
     // quarter of the rate, on the LDS port the consumers' operand reads already keep 2/3 busy.)
     unsigned p_voff[NPI];  // byte offset of channel 8*hh of the chunk at this patch pixel, or OOB sentinel
+    unsigned p_boff[NPI];  // the same position inside a plane set of a blocked split-fp16 source (16-B pixel units)
     int p_lds[NPI];        // byte offset inside one comp image of the patch buffer
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
@@ -777,6 +921,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       const int gy = (NSUB > 1 && su ? sy0[NSUB - 1] : sy0[0]) * S - PAD + py, gx = (NSUB > 1 && su ? sx0[NSUB - 1] : sx0[0]) * S - PAD + px;
       const bool in = slot && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
       p_voff[i] = in ? (unsigned)(((long long)(8 * hh) * plane + (long long)gy * p.Wi + gx) * 4) : 0x7FFFFFF0u;
+      p_boff[i] = in ? (unsigned)(((long long)hh * plane + (long long)gy * p.Wi + gx) * 16) : 0x7FFFFFF0u;
       p_lds[i] = slot ? hh * (PATCHT * 16) + ppt * 16 : -1;
     }
     // piece i of this thread is 16-B unit (ltid + 256 i) of the chunk image = segment (ltid + 256 i) / BN,
@@ -805,26 +950,43 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   _Pragma("unroll") for (int sc_ = 0; sc_ < NSC; ++sc_) {                                              \
     const int cb = ((CHUNK) * NSC + sc_) * kSplitKC;                                                  \
     const float* sp = p.src[0];                                                                       \
-    int sc = p.src_c[0], sb = 0;                                                                      \
-    if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; }      \
-    if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; }      \
-    if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; }      \
+    int sc = p.src_c[0], sb = 0, sbs = p.src_bs[0];                                                   \
+    if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; sbs = p.src_bs[1]; } \
+    if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; sbs = p.src_bs[2]; } \
+    if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; sbs = p.src_bs[3]; } \
     const int left = sc - (cb - sb);  /* channels of the source from this chunk on; <= 0 in the zero padding of the last unit */ \
-    const float* spb = sp + ((long long)b * sc + (left > 0 ? cb - sb : 0)) * plane;                    \
-    const int recs = left > 0 ? (int)((long long)left * plane * 4) : 0;                                \
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
-    const unsigned pl4 = (unsigned)(plane * 4);                                                       \
-    float v[NPI][8];                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
-      const unsigned o0 = p_voff[i];                                                                  \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                    \
-        v[i][j] = as_bload(rs, o0 == 0x7FFFFFF0u ? o0 : o0 + (unsigned)j * pl4);                       \
-    }                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                  \
-        const _Float16 hj = (_Float16)v[i][j];                                                        \
-        c_hi[sc_][i][j] = hj;                                                                         \
-        c_lo[sc_][i][j] = (_Float16)((v[i][j] - (float)hj) * 2048.f);                                  \
+    if (sbs) {  /* blocked split-fp16 source: a k-half of a pixel is one 16-B unit of the hi and one of the lo plane set */ \
+      const int c8 = (sc + 7) >> 3, blk = (cb - sb) >> 3;                                              \
+      const _Float16* spb = reinterpret_cast<const _Float16*>(sp) + ((long long)b * 2 * c8 + (left > 0 ? blk : 0)) * plane * 8; \
+      const int recs = left > 0 ? (int)((long long)(c8 - blk) * plane * 16) : 0;                       \
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
+      const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(spb + (long long)c8 * plane * 8), 0, recs, 0x00020000); \
+      u32x4 qh[NPI], ql[NPI];                                                                         \
+      _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                \
+        qh[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)p_boff[i], 0, 0);                       \
+        ql[i] = __builtin_amdgcn_raw_buffer_load_b128(rsl, (int)p_boff[i], 0, 0);                      \
+      }                                                                                               \
+      _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                \
+        c_hi[sc_][i] = __builtin_bit_cast(half8, qh[i]);                                              \
+        c_lo[sc_][i] = __builtin_bit_cast(half8, ql[i]);                                              \
+      }                                                                                               \
+    } else {                                                                                          \
+      const float* spb = sp + ((long long)b * sc + (left > 0 ? cb - sb : 0)) * plane;                  \
+      const int recs = left > 0 ? (int)((long long)left * plane * 4) : 0;                              \
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
+      const unsigned pl4 = (unsigned)(plane * 4);                                                     \
+      float v[NPI][8];                                                                                \
+      _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                \
+        const unsigned o0 = p_voff[i];                                                                \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                  \
+          v[i][j] = as_bload(rs, o0 == 0x7FFFFFF0u ? o0 : o0 + (unsigned)j * pl4);                     \
+      }                                                                                               \
+      _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
+          const _Float16 hj = (_Float16)v[i][j];                                                      \
+          c_hi[sc_][i][j] = hj;                                                                       \
+          c_lo[sc_][i][j] = (_Float16)((v[i][j] - (float)hj) * 2048.f);                                \
+        }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -988,32 +1150,49 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16*
 template <int EPI>
 __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   const long long plane = (long long)p.H * p.W;
-  const long long total = (long long)p.B * p.Cout * plane;
+  // with a blocked split-fp16 copy the channel range is walked to the end of its last 8-block (the pad slots are zeroed)
+  const int cwalk = p.out_bs ? ((EPI == AS_EPI_GRU_ZR) ? p.Cout : (p.Cout + 7) / 8 * 8) : p.Cout;
+  const long long total = (long long)p.B * cwalk * plane;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const long long pix = idx % plane;
-  const int co = (int)((idx / plane) % p.Cout);
-  const int b = (int)(idx / (plane * p.Cout));
-  float x = 0.f;
-  for (int ks = 0; ks < p.ksplit; ++ks) x += p.ws[(((long long)ks * p.B + b) * p.Cout_pad + co) * plane + pix];
-  if (p.bias) x += p.bias[co];
-  if (p.add) x += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pix];
-  if (EPI == AS_EPI_LINEAR) {
-    float o = act_apply(x, p.act);
-    if (p.h) o = fmaxf(o + p.h[((long long)b * p.Cout + co) * plane + pix], 0.f);
-    p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pix] = o;
-  } else if (EPI == AS_EPI_GRU_ZR) {
-    const int ch = p.Cout >> 1;
-    const float g = 1.f / (1.f + expf(-x));
-    if (co < ch) p.out[((long long)b * ch + co) * plane + pix] = g;
-    else {
-      const long long o = ((long long)b * ch + (co - ch)) * plane + pix;
-      p.out2[o] = g * p.h[o];
+  const int co = (int)((idx / plane) % cwalk);
+  const int b = (int)(idx / (plane * cwalk));
+  float o = 0.f;
+  bool to_bs = p.out_bs != nullptr;
+  if (co >= p.Cout && p.out_bs_coff8 * 8 + co < p.out_bs_ctot) to_bs = false;  // another producer's slot, not padding
+  int cb_ = co;  // channel inside the mirrored tensor
+  if (co < p.Cout) {
+    float x = 0.f;
+    for (int ks = 0; ks < p.ksplit; ++ks) x += p.ws[(((long long)ks * p.B + b) * p.Cout_pad + co) * plane + pix];
+    if (p.bias) x += p.bias[co];
+    if (p.add) x += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pix];
+    if (EPI == AS_EPI_LINEAR) {
+      o = act_apply(x, p.act);
+      if (p.h) o = fmaxf(o + p.h[((long long)b * p.Cout + co) * plane + pix], 0.f);
+      if (!p.bs_only) p.out[((long long)b * p.out_ctot + p.out_coff + co) * plane + pix] = o;
+    } else if (EPI == AS_EPI_GRU_ZR) {
+      const int ch = p.Cout >> 1;
+      const float g = 1.f / (1.f + expf(-x));
+      if (co < ch) { p.out[((long long)b * ch + co) * plane + pix] = g; to_bs = false; }
+      else {
+        const long long oo = ((long long)b * ch + (co - ch)) * plane + pix;
+        o = g * p.h[oo];
+        if (!p.bs_only) p.out2[oo] = o;
+        cb_ = co - ch;
+      }
+    } else {
+      const long long oo = ((long long)b * p.Cout + co) * plane + pix;
+      const float zz = p.z[oo];
+      o = (1.f - zz) * p.h[oo] + zz * tanhf(x);
+      p.out[oo] = o;
     }
-  } else {
-    const long long o = ((long long)b * p.Cout + co) * plane + pix;
-    const float zz = p.z[o];
-    p.out[o] = (1.f - zz) * p.h[o] + zz * tanhf(x);
+  }
+  if (to_bs) {
+    _Float16* rec = p.out_bs + (((long long)b * 2 * p.out_bs_c8tot + p.out_bs_coff8 + (cb_ >> 3)) * plane + pix) * 8 + (cb_ & 7);
+    const _Float16 hk = (_Float16)o;
+    rec[0] = hk;
+    rec[(long long)p.out_bs_c8tot * plane * 8] = (_Float16)((o - (float)hk) * 2048.f);
   }
 }
 
@@ -1042,7 +1221,8 @@ int launch_conv_split(const ConvParams& p, int epi, hipStream_t s) {
   if (p.ksplit > 1) {
     int rc = launch_conv_split_epi<KS, TW, BN, kEpiPartial>(p, s);
     if (rc != AS_OK) return rc;
-    const long long total = (long long)p.B * p.Cout * p.H * p.W;
+    const int cwalk = (p.out_bs && epi != AS_EPI_GRU_ZR) ? (p.Cout + 7) / 8 * 8 : p.Cout;  // conv_finish_kernel's channel walk
+    const long long total = (long long)p.B * cwalk * p.H * p.W;
     const dim3 g((unsigned)as::cdiv64(total, 256));
     if (epi == AS_EPI_LINEAR) hipLaunchKernelGGL(conv_finish_kernel<AS_EPI_LINEAR>, g, dim3(256), 0, s, p);
     else if (epi == AS_EPI_GRU_ZR) hipLaunchKernelGGL(conv_finish_kernel<AS_EPI_GRU_ZR>, g, dim3(256), 0, s, p);
@@ -1143,7 +1323,10 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(d->KS == 1 || d->KS == 3, AS_ERR_BAD_ARG, "conv2d: KS=%d (supported: 1, 3)", d->KS);
   AS_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, AS_ERR_BAD_ARG, "conv2d: non-positive size");
   AS_REQUIRE(d->n_src >= 1 && d->n_src <= AS_MAX_SRCS, AS_ERR_BAD_ARG, "conv2d: n_src=%d", d->n_src);
-  AS_REQUIRE(d->wpack && d->out, AS_ERR_BAD_ARG, "conv2d: null wpack/out");
+  AS_REQUIRE(d->wpack, AS_ERR_BAD_ARG, "conv2d: null wpack");
+  const bool bs_only = d->out_bs && d->bs_only;
+  // the fp32 result may be omitted only where the blocked copy replaces it (LINEAR: out; GRU_ZR: out2)
+  AS_REQUIRE(d->out || (bs_only && d->epilogue == AS_EPI_LINEAR), AS_ERR_BAD_ARG, "conv2d: null out");
   AS_REQUIRE((reinterpret_cast<uintptr_t>(d->wpack) & 15) == 0, AS_ERR_BAD_ARG, "conv2d: wpack not 16-B aligned");
   ConvParams p{};
   int csum = 0;
@@ -1153,6 +1336,24 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.src_c[i] = d->src_c[i];
     csum += d->src_c[i];
     p.src_end[i] = csum;
+    p.src_bs[i] = d->src_bs[i] ? 1 : 0;
+    AS_REQUIRE(!d->src_bs[i] || (d->precision == 1 && (d->stride == 0 || d->stride == 1)), AS_ERR_BAD_ARG,
+               "conv2d: blocked split-fp16 sources need the split-precision kernel, stride 1");
+    AS_REQUIRE(!d->src_bs[i] || (reinterpret_cast<uintptr_t>(d->src[i]) & 15) == 0, AS_ERR_BAD_ARG, "conv2d: blocked source %d not 16-B aligned", i);
+  }
+  if (d->out_bs) {
+    AS_REQUIRE(d->precision == 1 && (d->stride == 0 || d->stride == 1), AS_ERR_BAD_ARG, "conv2d: out_bs needs the split-precision kernel, stride 1");
+    AS_REQUIRE((reinterpret_cast<uintptr_t>(d->out_bs) & 15) == 0, AS_ERR_BAD_ARG, "conv2d: out_bs not 16-B aligned");
+    const int cres = d->epilogue == AS_EPI_GRU_ZR ? d->Cout / 2 : d->Cout;
+    const int ctot = d->out_bs_ctot > 0 ? d->out_bs_ctot : cres;
+    AS_REQUIRE(d->out_bs_coff >= 0 && d->out_bs_coff % 8 == 0 && d->out_bs_coff + cres <= (ctot + 7) / 8 * 8, AS_ERR_BAD_SHAPE,
+               "conv2d: out_bs channel window [%d,%d) must start at a multiple of 8 inside %d channels", d->out_bs_coff, d->out_bs_coff + cres, ctot);
+    AS_REQUIRE(d->epilogue != AS_EPI_GRU_Q || !d->bs_only, AS_ERR_BAD_ARG, "conv2d(GRU_Q): the fp32 hidden state is always written");
+    p.out_bs = reinterpret_cast<_Float16*>(d->out_bs);
+    p.out_bs_c8tot = (ctot + 7) / 8;
+    p.out_bs_ctot = ctot;
+    p.out_bs_coff8 = d->out_bs_coff / 8;
+    p.bs_only = d->bs_only ? 1 : 0;
   }
   AS_REQUIRE(csum == d->Cin, AS_ERR_BAD_SHAPE, "conv2d: sources hold %d channels, Cin=%d", csum, d->Cin);
   AS_REQUIRE(d->precision == 0 || d->precision == 1, AS_ERR_BAD_ARG, "conv2d: precision=%d", d->precision);
@@ -1176,7 +1377,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     AS_REQUIRE(p.out_coff >= 0 && p.out_coff + d->Cout <= p.out_ctot, AS_ERR_BAD_SHAPE, "conv2d: out channel window outside out_ctot");
     AS_REQUIRE(d->act >= AS_ACT_NONE && d->act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "conv2d: act=%d", d->act);
   } else if (epi == AS_EPI_GRU_ZR) {
-    AS_REQUIRE(d->h && d->out2 && (d->Cout % (2 * kBN)) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and Cout %% 128 == 0");
+    AS_REQUIRE(d->h && (d->out2 || bs_only) && (d->Cout % (2 * kBN)) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and Cout %% 128 == 0");
   } else if (epi == AS_EPI_GRU_Q) {
     AS_REQUIRE(d->h && d->z, AS_ERR_BAD_ARG, "conv2d(GRU_Q): needs h and z");
   } else {
@@ -1278,7 +1479,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
 
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out, int B, int H, int W,
                        int Cout, int out_ctot, int out_coff, int tap_major, float* copy_out, int copy_ctot, int copy_coff,
-                       void* stream) {
+                       int copy_bs, void* stream) {
   AS_REQUIRE(x && weight && out, AS_ERR_BAD_ARG, "conv7x7_c1: null pointer");
   AS_REQUIRE((long long)H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "conv7x7_c1: plane too large");
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, AS_ERR_BAD_ARG, "conv7x7_c1: non-positive size");
@@ -1291,7 +1492,7 @@ int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, f
     const dim3 g3(grid.x, grid.y, (unsigned)(B * (CP / 8)));
     AS_REQUIRE(!copy_out || (copy_coff >= 0 && copy_coff < copy_ctot), AS_ERR_BAD_SHAPE, "conv7x7_c1: copy channel outside copy_ctot");
     hipLaunchKernelGGL(conv7x7_c1_tm_kernel<8>, g3, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, CP, out_ctot, out_coff,
-                       copy_out, copy_ctot, copy_coff);
+                       copy_out, copy_ctot, copy_coff, copy_bs);
   } else {
     AS_REQUIRE(!copy_out, AS_ERR_BAD_ARG, "conv7x7_c1: the input pass-through needs tap_major weights");
     hipLaunchKernelGGL(conv7x7_c1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, out_ctot, out_coff);
@@ -1333,6 +1534,30 @@ int as_interp_bilinear_ac(const float* x, float* out, int B, int C, int H, int W
   const long long total = (long long)B * C * Ho * Wo;
   hipLaunchKernelGGL(interp_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x, out, H, W, Ho, Wo, sy, sx, total);
   return as::check_launch("interp_bilinear_ac");
+}
+
+/* pool2x / interp with a blocked split-fp16 result (as_conv_desc.src_bs): the resampled map only feeds convolutions */
+int as_pool2x_bs(const float* x, void* out_bs, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(x && out_bs, AS_ERR_BAD_ARG, "pool2x_bs: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "pool2x_bs: non-positive size");
+  AS_REQUIRE((reinterpret_cast<uintptr_t>(out_bs) & 15) == 0, AS_ERR_BAD_ARG, "pool2x_bs: out_bs not 16-B aligned");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)B * ((C + 7) / 8) * Ho * Wo;
+  hipLaunchKernelGGL(pool2x_bs_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x,
+                     reinterpret_cast<_Float16*>(out_bs), C, H, W, Ho, Wo, total);
+  return as::check_launch("pool2x_bs");
+}
+
+int as_interp_bilinear_ac_bs(const float* x, void* out_bs, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
+  AS_REQUIRE(x && out_bs, AS_ERR_BAD_ARG, "interp_bs: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, AS_ERR_BAD_ARG, "interp_bs: non-positive size");
+  AS_REQUIRE((reinterpret_cast<uintptr_t>(out_bs) & 15) == 0, AS_ERR_BAD_ARG, "interp_bs: out_bs not 16-B aligned");
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long long total = (long long)B * ((C + 7) / 8) * Ho * Wo;
+  hipLaunchKernelGGL(interp_bs_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x,
+                     reinterpret_cast<_Float16*>(out_bs), C, H, W, Ho, Wo, sy, sx, total);
+  return as::check_launch("interp_bilinear_ac_bs");
 }
 
 }  // extern "C"

@@ -144,6 +144,14 @@ typedef struct {
   int64_t ws_elems;   /* capacity of ws in floats; as_conv_ws_elems() gives the useful maximum; 0/NULL = never split K */
   int stride;         /* 0 or 1: 'same' conv, output H x W.  2 (KS 3, precision 1, AS_EPI_LINEAR): padding 1, H and W are the INPUT
                          plane, out / add / h are [.., (H-1)/2+1, (W-1)/2+1] — the stride-2 convs of the encoders (extractor.py:14,83) */
+  /* Blocked split-fp16 tensors (precision 1, stride 1): [B][2][ceil(C/8)][H][W][8] fp16 = a plane set of hi parts and one of lo
+     parts of the kernel's operand split (x = hi + lo/2048), the 8 channels of a block contiguous per pixel — the 16-B units
+     of its LDS patch image, so the loader fetches a k-half of a pixel with two coalesced 16-B loads and no arithmetic.  Written by one as_conv2d (out_bs), read by the next (src_bs):
+     an internal link format between convolutions, bit-identical in effect to passing the fp32 tensor. */
+  int src_bs[AS_MAX_SRCS];   /* != 0: src[s] points to such a tensor holding src_c[s] logical channels */
+  void* out_bs;       /* optional blocked copy of the result: AS_EPI_LINEAR / AS_EPI_GRU_Q: of out; AS_EPI_GRU_ZR: of out2 (r*h) */
+  int out_bs_ctot, out_bs_coff;  /* the copy goes to channels [out_bs_coff, +Cout) (multiple of 8) of a blocked tensor of out_bs_ctot channels (0: Cout) */
+  int bs_only;        /* != 0: do not write the fp32 form of that result (LINEAR: out may be NULL; GRU_ZR: out2 may be NULL) */
 } as_conv_desc;
 int as_conv2d(const as_conv_desc* d, void* stream);
 /* floats of split-K scratch worth passing in as_conv_desc.ws for this problem (0: the problem is large enough) */
@@ -163,7 +171,8 @@ int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Co
  *   `torch.cat([out, disp])` tail of BasicMotionEncoder (update.py:91) without a copy kernel. */
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out,
                        int B, int H, int W, int Cout, int out_ctot, int out_coff, int tap_major,
-                       float* copy_out, int copy_ctot, int copy_coff, void* stream);
+                       float* copy_out, int copy_ctot, int copy_coff, int copy_bs /* != 0: copy_out is a blocked split-fp16 tensor of copy_ctot channels (as_conv_desc.src_bs) */,
+                       void* stream);
 int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float* out,
                    int B, int Cin, int H, int W, void* stream);
 
@@ -177,6 +186,10 @@ int as_tap_shift_sum(const float* S, const float* bias, const float* addend /* [
  *     resize (update.py:100-102).  x [B,C,H,W] -> out [B,C,Ho,Wo].                                */
 int as_pool2x(const float* x, float* out, int B, int C, int H, int W, void* stream);
 int as_interp_bilinear_ac(const float* x, float* out, int B, int C, int H, int W, int Ho, int Wo, void* stream);
+/* the same resamplers with a blocked split-fp16 result [B][2][ceil(C/8)][Ho][Wo][8] (as_conv_desc.src_bs) for maps that only
+ * feed convolutions (pool2x(net) and interp(net) inside BasicMultiUpdateBlock.forward, update.py:124-131) */
+int as_pool2x_bs(const float* x, void* out_bs, int B, int C, int H, int W, void* stream);
+int as_interp_bilinear_ac_bs(const float* x, void* out_bs, int B, int C, int H, int W, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * f4  backbone-side one-shot operators, direct convolutions with fused bias + activation;

@@ -428,7 +428,8 @@ def test_update_block_golden(golden, precision):
         net = [g["net0"].to(DEV), g["net1"].to(DEV), g["net2"].to(DEV)]
         inp = [list(g[f"ctx{i}"].to(DEV).split(128, dim=1)) for i in range(3)]
         with torch.no_grad():
-            close(ub.encoder(g["disp"].to(DEV), g["corr"].to(DEV)), g["motion"], 2e-5, 2e-5, "motion encoder")
+            mf = ub.encoder(g["disp"].to(DEV), g["corr"].to(DEV))
+            close(mf if torch.is_tensor(mf) else mf.float(), g["motion"], 2e-5, 2e-5, "motion encoder")  # blocked link tensor in split mode
             close(ub.disp_head(net[0]), g["head"], 2e-5, 2e-5, "disp head")
             out, delta = ub([n.clone() for n in net], inp, g["corr"].to(DEV), g["disp"].to(DEV))
             for i in range(3):
@@ -788,3 +789,148 @@ def test_conv_gru_training_fused_gates():
             close(x.grad, y.grad, 5e-5, 1e-6, f"{n} (fused_gates={fused})")
         for (n, p), (_, q) in zip(gru.named_parameters(), ref_m.named_parameters()):
             close(p.grad, q.grad, 2e-4, 1e-6, f"d {n} (fused_gates={fused})")
+
+
+# ---------------------------------------------------------------------------------------------
+# blocked split-fp16 link tensors between convolutions (as_conv_desc.src_bs / out_bs)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("h,w", [(9, 14), (136, 240)])  # split-K + finish kernel / the MFMA epilogue
+def test_conv_blocked_split_link_is_bit_identical(h, w):
+    """A conv -> conv link through a BS8 tensor gives exactly the result of the fp32 link (the record pairs are what the
+    consumer's loaders would compute), incl. a channel count that is no multiple of 8, a channel window written by two
+    producers, a 1x1 consumer and mixed fp32 / BS8 sources."""
+    from anystereo import _lib as Lb, ops
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        x = U((1, 48, h, w), 301).to(DEV)
+        p1 = ops.PackedConv().get([(U((40, 48, 3, 3), 302) * 0.1).to(DEV)], [U((40,), 303).to(DEV)])
+        p2 = ops.PackedConv().get([(U((64, 40, 3, 3), 304) * 0.1).to(DEV)], [U((64,), 305).to(DEV)])
+        p2k1 = ops.PackedConv().get([(U((24, 40, 1, 1), 306) * 0.1).to(DEV)], [None])
+        y = ops.conv2d([x], p1, act=Lb.ACT_RELU)
+        ybs = ops.BS8.empty(1, 40, h, w, DEV)
+        y_again = ops.conv2d([x], p1, act=Lb.ACT_RELU, out_bs=ybs)
+        assert torch.equal(y, y_again)
+        close(ybs.float(), y, 0, 2.0 ** -21 * y.abs().max().item(), "BS8 record pairs")
+        assert ops.conv2d([x], p1, act=Lb.ACT_RELU, out_bs=ybs, bs_only=True) is None
+        assert torch.equal(ops.conv2d([ybs], p2, act=Lb.ACT_TANH), ops.conv2d([y], p2, act=Lb.ACT_TANH))
+        assert torch.equal(ops.conv2d([ybs], p2k1), ops.conv2d([y], p2k1))
+        # two producers into one blocked tensor (channel windows 0 and 64), one mixed-source consumer
+        pa = ops.PackedConv().get([(U((64, 48, 3, 3), 310) * 0.1).to(DEV)], [U((64,), 311).to(DEV)])
+        pb = ops.PackedConv().get([(U((64, 48, 1, 1), 312) * 0.1).to(DEV)], [U((64,), 313).to(DEV)])
+        pc = ops.PackedConv().get([(U((127, 176, 3, 3), 314) * 0.05).to(DEV)], [U((127,), 315).to(DEV)])
+        cat = torch.empty((1, 128, h, w), device=DEV)
+        cbs = ops.BS8.empty(1, 128, h, w, DEV)
+        ops.conv2d([x], pa, act=Lb.ACT_RELU, out=cat, out_coff=0)
+        ops.conv2d([x], pb, act=Lb.ACT_RELU, out=cat, out_coff=64)
+        ops.conv2d([x], pa, act=Lb.ACT_RELU, out_bs=cbs, out_bs_coff=0, bs_only=True)
+        ops.conv2d([x], pb, act=Lb.ACT_RELU, out_bs=cbs, out_bs_coff=64, bs_only=True)
+        assert torch.equal(ops.conv2d([cbs, x], pc, act=Lb.ACT_RELU), ops.conv2d([cat, x], pc, act=Lb.ACT_RELU))
+        assert torch.equal(ops.conv2d([x, cbs], pc_swap(ops, DEV), act=Lb.ACT_RELU), ops.conv2d([x, cat], pc_swap(ops, DEV), act=Lb.ACT_RELU))
+        # GRU: r*h handed to the q conv as a blocked tensor only; the new hidden state with a blocked twin
+        hs, xs = U((1, 128, h, w), 320).to(DEV), U((1, 128, h, w), 321).to(DEV)
+        ctx = U((1, 384, h, w), 322).to(DEV)
+        pzr = ops.PackedConv().get([(U((256, 256, 3, 3), 323) * 0.03).to(DEV)], [U((256,), 324).to(DEV)])
+        pq = ops.PackedConv().get([(U((128, 256, 3, 3), 325) * 0.03).to(DEV)], [U((128,), 326).to(DEV)])
+        z, rh = ops.conv2d([hs, xs], pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=hs)
+        hn = ops.conv2d([rh, xs], pq, add=ctx, add_coff=256, epilogue=Lb.EPI_GRU_Q, h=hs, z=z)
+        rbs, hbs = ops.BS8.empty(1, 128, h, w, DEV), ops.BS8.empty(1, 128, h, w, DEV)
+        z2, none = ops.conv2d([hs, xs], pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=hs, out_bs=rbs, bs_only=True)
+        assert none is None and torch.equal(z, z2)
+        hn2 = ops.conv2d([rbs, xs], pq, add=ctx, add_coff=256, epilogue=Lb.EPI_GRU_Q, h=hs, z=z2, out_bs=hbs)
+        assert torch.equal(hn, hn2)
+        z3, rh3 = ops.conv2d([hbs, xs], pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=hn2)
+        z4, rh4 = ops.conv2d([hn, xs], pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=hn)
+        assert torch.equal(z3, z4) and torch.equal(rh3, rh4)
+    finally:
+        ops.set_precision(prev)
+
+
+def pc_swap(ops, dev):
+    return ops.PackedConv().get([(U((127, 176, 3, 3), 316) * 0.05).to(dev)], [U((127,), 317).to(dev)])
+
+
+def test_resamplers_blocked_split_output():
+    """pool2x / interp with a BS8 result hold exactly the split of the fp32 kernels' values (C not a multiple of 8 too)."""
+    from anystereo import ops
+    for c in (16, 13):
+        x = U((2, c, 9, 14), 330 + c).to(DEV)
+        for bs, ref in ((ops.pool2x_bs(x), ops.pool2x(x)), (ops.interp_bs(x, 18, 27), ops.interp(x, 18, 27))):
+            assert tuple(bs.shape) == tuple(ref.shape)
+            hi = ref.half()
+            lo = ((ref - hi.float()) * 2048.0).half()
+            b, _, c8, h, w, _ = bs.t.shape
+            got_hi = bs.t[:, 0].permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, h, w)
+            got_lo = bs.t[:, 1].permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, h, w)
+            assert torch.equal(got_hi[:, :c], hi) and torch.equal(got_lo[:, :c], lo)
+            assert (got_hi[:, c:] == 0).all() and (got_lo[:, c:] == 0).all()
+
+
+def test_update_block_links_on_off_bit_identical(monkeypatch):
+    """The whole update block with blocked split-fp16 links == with fp32 links, bit for bit."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.models.base import default_args
+    from anystereo.nn import update as UP
+    from anystereo import ops
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        args = default_args("continuous_IGEVStereo")
+        ub = UP.BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims, geo_channels=8).eval()
+        fill_module_deterministic(ub, base_seed=7)
+        ub = ub.to(DEV)
+        h, w = 24, 40
+        net0 = [U((1, 128, h >> i, w >> i), 340 + i).to(DEV) for i in range(3)]
+        inp = [list(U((1, 384, h >> i, w >> i), 350 + i).to(DEV).split(128, dim=1)) for i in range(3)]
+        corr, disp = U((1, 162, h, w), 360).to(DEV), U((1, 1, h, w), 361, 0.0, 30.0).to(DEV)
+        outs = []
+        for on in (True, False):
+            monkeypatch.setattr(UP, "_LINKS_ENV", on)
+            with torch.no_grad():
+                net = [n.clone() for n in net0]
+                for _ in range(2):  # second pass consumes the hidden states' blocked twins
+                    net, delta = ub(net, inp, corr, disp)
+                outs.append([t.clone() for t in net] + [delta.clone()])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_precision(prev)
+
+
+@pytest.mark.parametrize("h,w", [(9, 14), (136, 240)])
+def test_blocked_split_partial_block_and_passthrough(h, w):
+    """A 127-channel result + the 7x7 kernel's input pass-through in slot 127 of the same blocked tensor (the motion
+    features, update.py:91), and a 43-channel result whose pad slots must read as zeros."""
+    from anystereo import _lib as Lb, ops
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        x = U((1, 128, h, w), 401).to(DEV)
+        disp = U((1, 1, h, w), 402, -3.0, 40.0).to(DEV)
+        w7, b7 = (U((64, 1, 7, 7), 403) * 0.2).to(DEV), (U((64,), 404) * 0.1).to(DEV)
+        pe = ops.PackedConv().get([(U((127, 128, 3, 3), 405) * 0.05).to(DEV)], [U((127,), 406).to(DEV)])
+        pz = ops.PackedConv().get([(U((64, 128, 3, 3), 407) * 0.05).to(DEV)], [U((64,), 408).to(DEV)])
+        ref = torch.empty((1, 128, h, w), device=DEV)
+        d1 = ops.conv7x7_c1_relu(disp, w7, b7, copy_out=ref, copy_coff=127)
+        ops.conv2d([x], pe, act=Lb.ACT_RELU, out=ref, out_coff=0)
+        for order in (0, 1):  # the two producers in either order
+            bs = ops.BS8.empty(1, 128, h, w, DEV)
+            bs.t.fill_(float("nan"))
+            if order == 0:
+                d2 = ops.conv7x7_c1_relu(disp, w7, b7, copy_out=bs, copy_coff=127)
+            ops.conv2d([x], pe, act=Lb.ACT_RELU, out_bs=bs, out_bs_coff=0, bs_only=True)
+            if order == 1:
+                d2 = ops.conv7x7_c1_relu(disp, w7, b7, copy_out=bs, copy_coff=127)
+            assert torch.equal(d1, d2)
+            assert torch.isfinite(bs.t.float()).all()
+            assert torch.equal(ops.conv2d([bs], pz, act=Lb.ACT_TANH), ops.conv2d([ref], pz, act=Lb.ACT_TANH))
+        p43 = ops.PackedConv().get([(U((43, 128, 1, 1), 409) * 0.05).to(DEV)], [U((43,), 410).to(DEV)])
+        b43 = ops.BS8.empty(1, 43, h, w, DEV)
+        b43.t.fill_(float("nan"))
+        y43 = ops.conv2d([x], p43, act=Lb.ACT_SIGMOID, out_bs=b43)
+        full = b43.t[:, 0].permute(0, 1, 4, 2, 3).reshape(1, 48, h, w)
+        assert torch.isfinite(b43.t.float()).all() and (full[:, 43:] == 0).all()
+        close(b43.float(), y43, 0, 2.0 ** -21, "43-channel blocked copy")
+    finally:
+        ops.set_precision(prev)

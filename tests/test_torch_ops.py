@@ -87,7 +87,7 @@ def test_torch_ops_update_block_golden(golden):
         _close(T.disp_head(g["net0"].to(DEV), *wb(ub.disp_head.conv1, ub.disp_head.conv2)), g["head"], 3e-5, "disp_head")
         net = [g[f"net{i}"].to(DEV) for i in range(3)]
         cz, cr, cq = g["ctx2"].to(DEV).split(128, dim=1)
-        h16 = T.convgru_step(net[2], cz, cr, cq, [anystereo.nn.update.pool2x(net[1])], *wb(ub.gru16.convz, ub.gru16.convr, ub.gru16.convq))
+        h16 = T.convgru_step(net[2], cz, cr, cq, [anystereo.ops.pool2x(net[1])], *wb(ub.gru16.convz, ub.gru16.convr, ub.gru16.convq))
         assert torch.equal(h16, ub.gru16(net[2], cz, cr, cq, anystereo.nn.update.pool2x(net[1])))
         _close(h16, g["gru16"], 3e-5, "convgru_step")
 

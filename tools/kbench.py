@@ -53,6 +53,13 @@ def main():
         xs = [det_uniform((b, 128, hh, ww), 40 + i).to(dev) for i in range(3)]
         cx = det_uniform((b, 384, hh, ww), 50).to(dev)
         return lambda: ops.conv2d(xs, pzr, add=cx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=xs[0])
+    def to_bs(x):  # fp32 [B,C,H,W] -> ops.BS8 holding the same split the kernel's loaders compute
+        bb, cc, hh, ww = x.shape
+        hi = x.half()
+        lo = ((x - hi.float()) * 2048.0).half()
+        t = torch.stack([hi, lo], 1).view(bb, 2, cc // 8, 8, hh, ww).permute(0, 1, 2, 4, 5, 3).contiguous()
+        return ops.BS8(t, cc)
+    x128bs = [to_bs(x) for x in x128]
     fns = {
         "corr_build": lambda: ops.corr_build_pyramid(f1, f2, L),
         "geo_pyramid": (lambda: ops.geo_pyramid(gev, L)) if g else None,
@@ -65,6 +72,8 @@ def main():
         "conv3d_stem": (lambda: ops.conv3d_k3(gev, w3d, None, 1, 5)) if g else None,
         "gru08_zr": zr_at(2),
         "gru16_zr": zr_at(4),
+        "gru_zr_bs": lambda: ops.conv2d(x128bs, pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=x128[0]),
+        "gru_zr_bs1": lambda: ops.conv2d([x128bs[0], x128[1], x128[2]], pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=x128[0]),
         "gru_zr": lambda: ops.conv2d(x128, pzr, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=x128[0]),
     }
     for k in a.kernels:
