@@ -39,6 +39,8 @@ class ConvDesc(C.Structure):
         ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("stride", C.c_int),
         ("src_bs", C.c_int * AS_MAX_SRCS), ("out_bs", C.c_void_p), ("out_bs_ctot", C.c_int), ("out_bs_coff", C.c_int),
         ("bs_only", C.c_int),
+        ("dual", C.c_int), ("src2", C.c_void_p), ("src2_bs", C.c_int), ("wpack2", C.c_void_p), ("bias2", C.c_void_p),
+        ("out_coff2", C.c_int), ("out_bs_coff2", C.c_int),
     ]
 
 

@@ -200,9 +200,31 @@ class BasicMotionEncoder(nn.Module):
             return torch.cat([out, disp], dim=1)
         disp, corr = _f(disp), _f(corr)
         cd, out = self.new_buffer(disp), self.new_output(disp)
+        if self.dual_branches and ops.get_precision() == "split":
+            # convc1 and convd1, then convc2 and convd2 (same shape, independent inputs) as ONE launch into the two halves of cd
+            bs = isinstance(cd, ops.BS8)
+            b, _, h, w = disp.shape
+            with scope("enc_convc1"):
+                if bs:
+                    cor = ops.BS8.empty(b, 64, h, w, corr.device)
+                    ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU, out_bs=cor, bs_only=True)
+                else:
+                    cor = ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
+            with scope("enc_convd1"):
+                d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()), copy_out=out, copy_coff=127)
+            with scope("enc_convc2"):
+                second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
+                pc2 = self._pc2.get([self.convc2.weight], [self.convc2.bias])
+                if bs:
+                    ops.conv2d([cor], pc2, act=L.ACT_RELU, out_bs=cd, out_bs_coff=0, bs_only=True, dual=second)
+                else:
+                    ops.conv2d([cor], pc2, act=L.ACT_RELU, out=cd, out_coff=0, dual=second)
+            return self.merge(cd, disp, out)
         self.corr_branch(corr, cd)
         self.disp_branch(disp, cd, out)
         return self.merge(cd, disp, out)
+
+    dual_branches = __import__("os").environ.get("ANYSTEREO_DUAL_BRANCHES", "1") != "0"
 
     # The three pieces of forward(), exposed so the inference schedule (models/base.py::_iterate_pipelined) can run
     # the two independent branches on different streams.  cd [B,128,h,w]: channels [0,64) = correlation branch,

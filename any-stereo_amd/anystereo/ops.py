@@ -308,12 +308,14 @@ class BS8:
 def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE, add: Optional[torch.Tensor] = None,
            add_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0, epilogue: int = L.EPI_LINEAR,
            h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-           stride: int = 1, out_bs: Optional[BS8] = None, out_bs_coff: int = 0, bs_only: bool = False):
+           stride: int = 1, out_bs: Optional[BS8] = None, out_bs_coff: int = 0, bs_only: bool = False, dual: Optional[dict] = None):
     """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue.
     stride 2: 3x3 / padding 1 / LINEAR epilogue in split precision only; outputs are [(H-1)//2+1, (W-1)//2+1].
     Split precision only: a source may be a BS8 (blocked split-fp16 link tensor); `out_bs` receives such a copy of the result
     (LINEAR / GRU_Q: of out; GRU_ZR: of r*h) in channels [out_bs_coff, ...); with `bs_only` the fp32 form of that result is
-    not written and None is returned in its place."""
+    not written and None is returned in its place.
+    dual = {"src": tensor | BS8, "pack": PackedConv, "out_coff": int, "out_bs_coff": int}: a second convolution of the same
+    shape in the same launch, writing its own channel window of out / out_bs (LINEAR epilogue, one source, no add / residual)."""
     b, _, hin, win = srcs[0].shape
     if stride not in (1, 2):
         raise RuntimeError("conv2d: stride must be 1 or 2")
@@ -396,6 +398,22 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
             if tuple(t.shape) != (b, cout, hh, ww):
                 raise RuntimeError("conv2d(GRU_Q): h/z/out must be [B,Cout,H,W]")
         d.h, d.z, d.out = h.data_ptr(), z.data_ptr(), out.data_ptr()
+    if dual is not None:
+        s2, p2 = dual["src"], dual["pack"]
+        if (epilogue != L.EPI_LINEAR or len(srcs) != 1 or add is not None or h is not None or stride != 1
+                or (p2.cin, p2.cout, p2.ks, p2.split) != (pack.cin, pack.cout, pack.ks, pack.split) or tuple(s2.shape) != tuple(srcs[0].shape)):
+            raise RuntimeError("conv2d(dual): needs two LINEAR single-source convolutions of one shape")
+        if isinstance(s2, BS8):
+            _req(s2.t, "dual src", torch.float16)
+        else:
+            _req(s2, "dual src")
+        d.dual, d.src2, d.src2_bs = 1, (s2.t if isinstance(s2, BS8) else s2).data_ptr(), 1 if isinstance(s2, BS8) else 0
+        d.wpack2, d.bias2 = p2.wpack.data_ptr(), (0 if p2.bias is None else p2.bias.data_ptr())
+        d.out_coff2, d.out_bs_coff2 = int(dual.get("out_coff", 0)), int(dual.get("out_bs_coff", 0))
+        if out is not None and d.out_coff2 + cout > out.shape[1]:
+            raise RuntimeError("conv2d(dual): second output window outside out")
+        if out_bs is not None and (d.out_bs_coff2 % 8 or d.out_bs_coff2 + cout > (out_bs.c + 7) // 8 * 8):
+            raise RuntimeError("conv2d(dual): second output window outside out_bs")
     d.B, d.H, d.W, d.Cin, d.Cout, d.KS = b, hin, win, cin, cout, pack.ks
     d.stride = stride
     d.act, d.epilogue = act, epilogue

@@ -58,6 +58,15 @@ struct ConvParams {
   int out_bs_c8tot, out_bs_coff8;  // blocks of the destination tensor per batch element; first block of the window
   int out_bs_ctot;             // logical channels of the destination tensor (slots past them are zero-filled, never another producer's)
   int bs_only;                 // 1: the fp32 copy of that result is not written
+  // Dual launch (conv_split_kernel, LINEAR epilogue, one source): a second convolution of the same shape rides in the same grid
+  // as extra output-channel tiles [n_tiles/2, n_tiles) with its own source, weights, bias and output channel window — the two
+  // 64 -> 64 branch convs of the motion encoder (update.py:86,88) are one launch instead of two on the loop's critical stream.
+  int dual;
+  const float* src2;
+  int src2_bs;
+  const float* wpack2;
+  const float* bias2;
+  int out_coff2, out_bs_coff8_2;
   int xcd_map;  // conv_split_kernel: XCD-aware block order (channel tiles of one pixel tile on the same XCD)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
@@ -108,7 +117,7 @@ struct EpiCtx {
 
 // n0: first output channel of the block, bn: channels per block (descriptor windows start at channel n0)
 template <int EPI>
-__device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n0, int bn) {
+__device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n0, int bn, bool second = false) {
   EpiCtx e;
   const long long plane = (long long)p.H * p.W;
   const int cvalid = min(p.Cout - n0, bn);
@@ -127,7 +136,7 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
     e.r_h = e.r_out;
     e.r_z = e.r_out;
   } else if (EPI == AS_EPI_LINEAR) {
-    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + ((long long)b * p.out_ctot + p.out_coff + n0) * plane), 0, recs, 0x00020000);
+    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + ((long long)b * p.out_ctot + (second ? p.out_coff2 : p.out_coff) + n0) * plane), 0, recs, 0x00020000);
     // optional residual (ResidualBlock tail, extractor.py:56-62): out = relu(h + act(...)); 0 records when absent
     const float* res = p.h ? p.h + ((long long)b * p.Cout + n0) * plane : p.out;
     e.r_h = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, p.h ? recs : 0, 0x00020000);
@@ -159,11 +168,12 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
     if (EPI == AS_EPI_GRU_ZR) { const int ch = p.Cout >> 1; on = n0 >= ch; c0 = n0 - ch; }
     if (on) {
       const int nblk = cvalid > 0 ? (cvalid + 7) / 8 : 0;
-      _Float16* dst = p.out_bs + (((long long)b * 2 * p.out_bs_c8tot + p.out_bs_coff8 + (c0 >> 3)) * plane) * 8;
+      const int coff8 = second ? p.out_bs_coff8_2 : p.out_bs_coff8;
+      _Float16* dst = p.out_bs + (((long long)b * 2 * p.out_bs_c8tot + coff8 + (c0 >> 3)) * plane) * 8;
       e.r_bs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)((long long)nblk * plane * 16), 0x00020000);
       e.r_bsl = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (long long)p.out_bs_c8tot * plane * 8), 0, (int)((long long)nblk * plane * 16), 0x00020000);
       e.has_bs = true;
-      e.cend = p.out_bs_ctot - (p.out_bs_coff8 * 8 + c0);
+      e.cend = p.out_bs_ctot - (coff8 * 8 + c0);
       e.skip_out = p.bs_only != 0;
     }
   }
@@ -890,6 +900,12 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     sx0[u] = (t % p.tiles_x) * TW;
     sy0[u] = t < ntile ? (t / p.tiles_x) * TH : p.H + PAD + 1;
   }
+  const bool second = p.dual && nt >= (p.n_tiles >> 1);  // block-uniform: this block belongs to the dual launch's second conv
+  if (second) nt -= p.n_tiles >> 1;
+  const float* const src0 = second ? p.src2 : p.src[0];
+  const int src0_bs = second ? p.src2_bs : p.src_bs[0];
+  const float* const wpack_sel = second ? p.wpack2 : p.wpack;
+  const float* const bias_sel = second ? p.bias2 : p.bias;
   const int n0 = nt * BN;
   const long long plane = (long long)p.Hi * p.Wi;  // INPUT plane: source addressing of the loader waves
 
@@ -927,7 +943,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     // piece i of this thread is 16-B unit (ltid + 256 i) of the chunk image = segment (ltid + 256 i) / BN,
     // column (ltid + 256 i) % BN; the global pack has the same order, so the DMA destination is linear
     constexpr int SEG_PER_STEP = 256 / BN;
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wpack) + n0 + (long long)(ltid / BN) * p.Cout_pad + (ltid % BN);
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wpack_sel) + n0 + (long long)(ltid / BN) * p.Cout_pad + (ltid % BN);
     const long long wstep16 = (long long)SEG_PER_STEP * p.Cout_pad;
     const long long wchunk16 = (long long)NTAPE * 4 * p.Cout_pad;  // 16-B units of one pipeline unit in the pack
     half8 c_hi[NSC][NPI], c_lo[NSC][NPI];
@@ -949,8 +965,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
 #define AS_SPLIT_FETCH_SPLIT_P(CHUNK)                                                                 \
   _Pragma("unroll") for (int sc_ = 0; sc_ < NSC; ++sc_) {                                              \
     const int cb = ((CHUNK) * NSC + sc_) * kSplitKC;                                                  \
-    const float* sp = p.src[0];                                                                       \
-    int sc = p.src_c[0], sb = 0, sbs = p.src_bs[0];                                                   \
+    const float* sp = src0;                                                                           \
+    int sc = p.src_c[0], sb = 0, sbs = src0_bs;                                                       \
     if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; sbs = p.src_bs[1]; } \
     if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; sbs = p.src_bs[2]; } \
     if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; sbs = p.src_bs[3]; } \
@@ -1107,10 +1123,10 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
 
   // ---- epilogue (consumer waves hold the accumulators) ----
   float* bias_s = reinterpret_cast<float*>(lds);  // the weight images are dead after the last barrier
-  if (tid < BN) bias_s[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;
+  if (tid < BN) bias_s[tid] = (bias_sel && n0 + tid < p.Cout) ? bias_sel[n0 + tid] : 0.f;
   __syncthreads();
   if (!loader) {
-    const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN);
+    const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);
     const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
     unsigned poff[PTW];
 #pragma unroll
@@ -1261,6 +1277,18 @@ void conv_pick_ksplit(ConvParams& p, const as_conv_desc* d) {
 }
 int conv_cout_pad(int Cout) { return ((Cout + kBN - 1) / kBN) * kBN; }
 
+// second convolution of a dual launch: twice the channel tiles, the upper half addressed to the second problem
+void conv_apply_dual(ConvParams& p, const as_conv_desc* d) {
+  p.dual = 1;
+  p.n_tiles *= 2;
+  p.src2 = d->src2;
+  p.src2_bs = d->src2_bs ? 1 : 0;
+  p.wpack2 = d->wpack2;
+  p.bias2 = d->bias2;
+  p.out_coff2 = d->out_coff2;
+  p.out_bs_coff8_2 = d->out_bs_coff2 / 8;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1318,8 +1346,27 @@ int64_t as_conv_ws_elems(int B, int Cout, int H, int W) {
   return ks > 1 ? (int64_t)ks * B * cpad * H * W : 0;
 }
 
+int as_conv2d(const as_conv_desc* d, void* stream);
+static int conv2d_dual_sequential(const as_conv_desc* d, void* stream) {
+  as_conv_desc a = *d;
+  a.dual = 0;
+  const int rc = as_conv2d(&a, stream);
+  if (rc != AS_OK) return rc;
+  a.src[0] = d->src2; a.src_bs[0] = d->src2_bs; a.wpack = d->wpack2; a.bias = d->bias2;
+  a.out_coff = d->out_coff2; a.out_bs_coff = d->out_bs_coff2;
+  return as_conv2d(&a, stream);
+}
+
 int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(d, AS_ERR_BAD_ARG, "conv2d: null descriptor");
+  if (d->dual) {
+    AS_REQUIRE(d->n_src == 1 && d->epilogue == AS_EPI_LINEAR && !d->add && !d->h && (d->stride == 0 || d->stride == 1), AS_ERR_BAD_ARG,
+               "conv2d(dual): one source, LINEAR epilogue, no add / residual, stride 1");
+    AS_REQUIRE(d->src2 && d->wpack2 && (reinterpret_cast<uintptr_t>(d->wpack2) & 15) == 0, AS_ERR_BAD_ARG, "conv2d(dual): null / misaligned src2 / wpack2");
+    AS_REQUIRE(!d->src2_bs || (reinterpret_cast<uintptr_t>(d->src2) & 15) == 0, AS_ERR_BAD_ARG, "conv2d(dual): blocked src2 not 16-B aligned");
+    AS_REQUIRE(d->out_coff2 >= 0 && d->out_bs_coff2 >= 0 && d->out_bs_coff2 % 8 == 0, AS_ERR_BAD_SHAPE, "conv2d(dual): bad second output window");
+    if (d->precision != 1) return conv2d_dual_sequential(d, stream);
+  }
   AS_REQUIRE(d->KS == 1 || d->KS == 3, AS_ERR_BAD_ARG, "conv2d: KS=%d (supported: 1, 3)", d->KS);
   AS_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, AS_ERR_BAD_ARG, "conv2d: non-positive size");
   AS_REQUIRE(d->n_src >= 1 && d->n_src <= AS_MAX_SRCS, AS_ERR_BAD_ARG, "conv2d: n_src=%d", d->n_src);
@@ -1374,7 +1421,8 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   if (epi == AS_EPI_LINEAR) {
     p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
     p.out_coff = d->out_coff;
-    AS_REQUIRE(p.out_coff >= 0 && p.out_coff + d->Cout <= p.out_ctot, AS_ERR_BAD_SHAPE, "conv2d: out channel window outside out_ctot");
+    AS_REQUIRE(bs_only || (p.out_coff >= 0 && p.out_coff + d->Cout <= p.out_ctot), AS_ERR_BAD_SHAPE, "conv2d: out channel window outside out_ctot");
+    AS_REQUIRE(!d->dual || bs_only || d->out_coff2 + d->Cout <= p.out_ctot, AS_ERR_BAD_SHAPE, "conv2d(dual): second out channel window outside out_ctot");
     AS_REQUIRE(d->act >= AS_ACT_NONE && d->act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "conv2d: act=%d", d->act);
   } else if (epi == AS_EPI_GRU_ZR) {
     AS_REQUIRE(d->h && (d->out2 || bs_only) && (d->Cout % (2 * kBN)) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and Cout %% 128 == 0");
@@ -1421,6 +1469,10 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
       p.tiles_y = 1;
       AS_REQUIRE((long long)p.B * p.tiles_x * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
       conv_pick_ksplit(p, d);
+      if (d->dual) {
+        if (p.ksplit > 1) return conv2d_dual_sequential(d, stream);
+        conv_apply_dual(p, d);
+      }
       return bn == 128 ? launch_conv_split<1, 128, 128>(p, epi, s) : launch_conv_split<1, 128, 64>(p, epi, s);
     }
     p.H = d->H;
@@ -1433,6 +1485,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     p.tiles_y = as::cdiv(p.H, 128 / tw);
     AS_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
     conv_pick_ksplit(p, d);
+    if (d->dual && p.ksplit > 1) return conv2d_dual_sequential(d, stream);
     // big maps: 256-pixel x 64-channel blocks (two sub-tiles) pull 30 % fewer bytes per MFMA through the CU's L1
     static const int wide_mode = getenv("AS_CONV_WIDE") ? atoi(getenv("AS_CONV_WIDE")) : 1;
     const long long wide_blocks = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, 2) * (p.Cout_pad / 64);
@@ -1441,8 +1494,10 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
                                    : wide_blocks >= 2 * kNumCU;  // bn == 64: a wide block is twice the work of a current one
     if (wide_mode && p.ksplit == 1 && wide_ok) {
       p.n_tiles = p.Cout_pad / 64;
+      if (d->dual) conv_apply_dual(p, d);
       return tw == 16 ? launch_conv_split<3, 16, 64, 2>(p, epi, s) : launch_conv_split<3, 32, 64, 2>(p, epi, s);
     }
+    if (d->dual) conv_apply_dual(p, d);
     if (tw == 16) return bn == 128 ? launch_conv_split<3, 16, 128>(p, epi, s) : launch_conv_split<3, 16, 64>(p, epi, s);
     return bn == 128 ? launch_conv_split<3, 32, 128>(p, epi, s) : launch_conv_split<3, 32, 64>(p, epi, s);
   }

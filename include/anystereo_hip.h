@@ -152,6 +152,16 @@ typedef struct {
   void* out_bs;       /* optional blocked copy of the result: AS_EPI_LINEAR / AS_EPI_GRU_Q: of out; AS_EPI_GRU_ZR: of out2 (r*h) */
   int out_bs_ctot, out_bs_coff;  /* the copy goes to channels [out_bs_coff, +Cout) (multiple of 8) of a blocked tensor of out_bs_ctot channels (0: Cout) */
   int bs_only;        /* != 0: do not write the fp32 form of that result (LINEAR: out may be NULL; GRU_ZR: out2 may be NULL) */
+  /* Dual launch (AS_EPI_LINEAR, n_src == 1, no add / residual, stride 1): a second convolution of the SAME shape (Cin, Cout, KS,
+     act, plane) runs in the same grid with its own source, weights, bias and output channel window inside out / out_bs — the two
+     64 -> 64 branch convolutions of BasicMotionEncoder (update.py:86,88) as one launch.  Equivalent to two calls (and executed as
+     two where the fused form does not apply: fp32 precision, split-K). */
+  int dual;
+  const float* src2;
+  int src2_bs;
+  const float* wpack2;
+  const float* bias2;
+  int out_coff2, out_bs_coff2;
 } as_conv_desc;
 int as_conv2d(const as_conv_desc* d, void* stream);
 /* floats of split-K scratch worth passing in as_conv_desc.ws for this problem (0: the problem is large enough) */

@@ -934,3 +934,29 @@ def test_blocked_split_partial_block_and_passthrough(h, w):
         close(b43.float(), y43, 0, 2.0 ** -21, "43-channel blocked copy")
     finally:
         ops.set_precision(prev)
+
+
+@pytest.mark.parametrize("h,w", [(9, 14), (136, 240)])  # sequential fallback (split-K) / the fused grid
+def test_conv_dual_launch_equals_two_launches(h, w, precision):
+    """as_conv_desc.dual: two same-shape convolutions in one launch == the two launches, bit for bit (fp32 and blocked outputs,
+    fp32 and blocked second source)."""
+    from anystereo import _lib as Lb, ops
+    xa, xb = U((1, 64, h, w), 501).to(DEV), U((1, 64, h, w), 502).to(DEV)
+    pa = ops.PackedConv().get([(U((64, 64, 3, 3), 503) * 0.1).to(DEV)], [U((64,), 504).to(DEV)])
+    pb = ops.PackedConv().get([(U((64, 64, 3, 3), 505) * 0.1).to(DEV)], [U((64,), 506).to(DEV)])
+    ref = torch.empty((1, 128, h, w), device=DEV)
+    ops.conv2d([xa], pa, act=Lb.ACT_RELU, out=ref, out_coff=0)
+    ops.conv2d([xb], pb, act=Lb.ACT_RELU, out=ref, out_coff=64)
+    got = torch.empty((1, 128, h, w), device=DEV)
+    ops.conv2d([xa], pa, act=Lb.ACT_RELU, out=got, out_coff=0, dual={"src": xb, "pack": pb, "out_coff": 64})
+    assert torch.equal(got, ref)
+    if precision == "split":
+        bs_ref, bs_got = ops.BS8.empty(1, 128, h, w, DEV), ops.BS8.empty(1, 128, h, w, DEV)
+        xbb = ops.BS8.empty(1, 64, h, w, DEV)
+        pid = ops.PackedConv().get([torch.eye(64, device=DEV).view(64, 64, 1, 1).contiguous()], [None])
+        ops.conv2d([xb], pid, out_bs=xbb, bs_only=True)  # xb as a blocked tensor
+        ops.conv2d([xa], pa, act=Lb.ACT_RELU, out_bs=bs_ref, out_bs_coff=0, bs_only=True)
+        ops.conv2d([xb], pb, act=Lb.ACT_RELU, out_bs=bs_ref, out_bs_coff=64, bs_only=True)
+        ops.conv2d([xa], pa, act=Lb.ACT_RELU, out_bs=bs_got, out_bs_coff=0, bs_only=True,
+                   dual={"src": xbb, "pack": pb, "out_bs_coff": 64})
+        assert torch.equal(bs_got.t, bs_ref.t)
