@@ -17,7 +17,7 @@ AS_MAX_LEVELS = 4
 AS_MAX_SRCS = 4
 AS_F32, AS_F16, AS_F64 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_RELU6, ACT_LEAKY, ACT_GELU = 0, 1, 2, 3, 4, 5, 6
-EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q, EPI_RELU_TAPS = 0, 1, 2, 4
 
 # ANYSTEREO_LIB selects another build of the same library (A/B timing of kernel variants); default = the in-tree build
 LIB_PATH = os.environ.get("ANYSTEREO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libanystereo_hip.so")
@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("ws", C.c_void_p), ("ws_elems", C.c_int64), ("stride", C.c_int),
         ("src_bs", C.c_int * AS_MAX_SRCS), ("out_bs", C.c_void_p), ("out_bs_ctot", C.c_int), ("out_bs_coff", C.c_int),
         ("bs_only", C.c_int),
-        ("dual", C.c_int), ("src2", C.c_void_p), ("src2_bs", C.c_int), ("wpack2", C.c_void_p), ("bias2", C.c_void_p),
+        ("tap_w", C.c_void_p), ("dual", C.c_int), ("src2", C.c_void_p), ("src2_bs", C.c_int), ("wpack2", C.c_void_p), ("bias2", C.c_void_p),
         ("out_coff2", C.c_int), ("out_bs_coff2", C.c_int),
     ]
 
@@ -67,7 +67,7 @@ SIGNATURES = {
     "as_conv_pack_weights_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_pool2x": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "as_pool2x_bs": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "as_interp_bilinear_ac_bs": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -66,6 +66,14 @@ class DispHead(nn.Module):
             out = self.conv2(_cs(self, "conv1", x, self.conv1.weight, self.conv1.bias, relu=True))  # update.py:23-24
             return out if addend is None else addend + out
         links = _links()
+        if self.fused_head and self.conv2.out_channels == 1 and ops.get_precision() == "split":
+            # conv2 (3x3, 256 -> 1) folded into conv1's epilogue: per 64-channel tile the nine per-tap channel reductions of
+            # relu(conv1) — the 256-channel hidden layer is never written — then the shifted 9-tap sum over the four tiles
+            with scope("disp_head_conv1"):
+                taps = ops.conv2d([_twin(_f(x))], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU,
+                                  epilogue=L.EPI_RELU_TAPS, tap_w=self._tap_weights())
+            with scope("disp_head_conv2"):
+                return ops.tap_shift_sum(taps, _f(self.conv2.bias.detach()), None if addend is None else _f(addend))
         with scope("disp_head_conv1"):
             if links:  # hidden layer handed to conv2 as a blocked tensor only
                 b, _, hh, ww = x.shape
@@ -81,6 +89,19 @@ class DispHead(nn.Module):
                 return ops.tap_shift_sum(taps, _f(self.conv2.bias.detach()), None if addend is None else _f(addend))
         out = ops.conv2d([t], self._p2.get([self.conv2.weight], [self.conv2.bias]))
         return out if addend is None else addend + out
+
+
+    fused_head = __import__("os").environ.get("ANYSTEREO_FUSED_HEAD", "1") != "0"
+
+    def _tap_weights(self):
+        """conv2.weight [1, C, 3, 3] as [C, 9] (tap = ky*3+kx), cached per weight version."""
+        w = self.conv2.weight
+        key = (w.data_ptr(), w._version, w.device)
+        ent = self.__dict__.get("_tapw")
+        if ent is None or ent[0] != key:
+            ent = (key, w.detach()[0].reshape(w.shape[1], 9).float().contiguous())
+            self.__dict__["_tapw"] = ent
+        return ent[1]
 
 
 class FlowHead(DispHead):

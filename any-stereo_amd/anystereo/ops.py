@@ -308,7 +308,8 @@ class BS8:
 def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE, add: Optional[torch.Tensor] = None,
            add_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0, epilogue: int = L.EPI_LINEAR,
            h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-           stride: int = 1, out_bs: Optional[BS8] = None, out_bs_coff: int = 0, bs_only: bool = False, dual: Optional[dict] = None):
+           stride: int = 1, out_bs: Optional[BS8] = None, out_bs_coff: int = 0, bs_only: bool = False, dual: Optional[dict] = None,
+           tap_w: Optional[torch.Tensor] = None):
     """Implicit-GEMM conv over the channel concat of `srcs` (never materialised) with fused epilogue.
     stride 2: 3x3 / padding 1 / LINEAR epilogue in split precision only; outputs are [(H-1)//2+1, (W-1)//2+1].
     Split precision only: a source may be a BS8 (blocked split-fp16 link tensor); `out_bs` receives such a copy of the result
@@ -361,7 +362,15 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
         d.out_bs, d.out_bs_ctot, d.out_bs_coff, d.bs_only = out_bs.t.data_ptr(), out_bs.c, out_bs_coff, 1 if bs_only else 0
     elif bs_only:
         raise RuntimeError("conv2d: bs_only without out_bs")
-    if epilogue == L.EPI_LINEAR and bs_only:
+    if epilogue == L.EPI_RELU_TAPS:
+        # act(conv) feeds a following 3x3, Cout -> 1 convolution with weights tap_w [Cout, 9]: the result is that convolution's
+        # per-tap channel reductions, one set of 9 planes per 64-channel tile (finish with tap_shift_sum)
+        _req(tap_w, "tap_w")
+        if tuple(tap_w.shape) != (cout, 9) or not pack.split or pack.ks != 3 or stride != 1:
+            raise RuntimeError("conv2d(RELU_TAPS): tap_w must be [Cout, 9]; 3x3 split-precision convolution at stride 1")
+        out = torch.empty((b, (cout + 63) // 64 * 9, hh, ww), device=dev, dtype=torch.float32)
+        d.out, d.tap_w = out.data_ptr(), tap_w.data_ptr()
+    elif epilogue == L.EPI_LINEAR and bs_only:
         out = None
     elif epilogue == L.EPI_LINEAR:
         if out is None:
@@ -374,6 +383,8 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
             if tuple(h.shape) != (b, cout, hh, ww):
                 raise RuntimeError("conv2d(LINEAR): residual h must be [B,Cout,H,W]")
             d.h = h.data_ptr()
+    elif epilogue == L.EPI_RELU_TAPS:
+        pass
     elif epilogue == L.EPI_GRU_ZR:
         ch = cout // 2
         _req(h, "h")
@@ -485,12 +496,12 @@ def tap_shift_sum(s, bias, addend=None):
         _req(addend, "addend")
         if tuple(addend.shape) != (s.shape[0], 1, s.shape[2], s.shape[3]):
             raise RuntimeError("tap_shift_sum: addend must be [B,1,H,W]")
-    b, nine, h, w = s.shape
-    if nine != 9:
-        raise RuntimeError("tap_shift_sum: expects [B,9,H,W]")
+    b, planes, h, w = s.shape
+    if planes % 9:
+        raise RuntimeError("tap_shift_sum: expects [B, groups*9, H, W]")
     out = torch.empty((b, 1, h, w), device=s.device, dtype=torch.float32)
     with torch.cuda.device(s.device):
-        L.check(L.load().as_tap_shift_sum(_p(s), _p(bias), _p(addend), _p(out), b, h, w, _stream()), "tap_shift_sum")
+        L.check(L.load().as_tap_shift_sum(_p(s), _p(bias), _p(addend), _p(out), b, h, w, planes // 9, _stream()), "tap_shift_sum")
     return out
 
 

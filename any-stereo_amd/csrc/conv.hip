@@ -67,6 +67,9 @@ struct ConvParams {
   const float* wpack2;
   const float* bias2;
   int out_coff2, out_bs_coff8_2;
+  // AS_EPI_RELU_TAPS: [Cout][9] weights of a following 3x3, Cout -> 1 convolution whose per-tap channel reductions this
+  // conv's epilogue accumulates instead of storing its own result (out = [B][n_tiles * 9][H][W])
+  const float* tap_w;
   int xcd_map;  // conv_split_kernel: XCD-aware block order (channel tiles of one pixel tile on the same XCD)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
@@ -74,6 +77,7 @@ struct ConvParams {
 
 constexpr int kNumCU = 256;   // MI355X
 constexpr int kEpiPartial = 3;  // internal: store the raw partial sums of a K slice into p.ws
+constexpr int kEpiTaps = AS_EPI_RELU_TAPS;
 
 template <int KS> struct ConvCfg;
 template <> struct ConvCfg<3> { static constexpr int KC = 8; };
@@ -649,19 +653,21 @@ __global__ __launch_bounds__(256) void conv3x3_to1_kernel(const float* __restric
 // Cin -> 1 convolution whose per-tap channel reductions S were produced by a 1x1 MFMA conv (Cin -> 9).
 __global__ __launch_bounds__(256) void tap_shift_sum_kernel(const float* __restrict__ S, const float* __restrict__ bias,
                                                             const float* __restrict__ addend, float* __restrict__ out, int H,
-                                                            int W, long long P) {
+                                                            int W, long long P, int groups) {
   const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
   if (pix >= P) return;
   const long long plane = (long long)H * W;
   const long long b = pix / plane;
   const int rem = (int)(pix - b * plane);
   const int y = rem / W, x = rem - y * W;
-  const float* sp = S + b * 9 * plane;
+  const float* sp = S + b * groups * 9 * plane;
   float acc = 0.f;
+  for (int g = 0; g < groups; ++g, sp += 9 * plane) {  // channel-tile partials of the fused form (AS_EPI_RELU_TAPS), fixed order
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += sp[(long long)t * plane + (long long)yy * W + xx];
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += sp[(long long)t * plane + (long long)yy * W + xx];
+    }
   }
   const float delta = acc + (bias ? bias[0] : 0.f);
   out[pix] = addend ? addend[pix] + delta : delta;  // disp + delta_disp of the GRU loop fused (continuous_IGEVstereo.py:296)
@@ -1125,7 +1131,55 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   float* bias_s = reinterpret_cast<float*>(lds);  // the weight images are dead after the last barrier
   if (tid < BN) bias_s[tid] = (bias_sel && n0 + tid < p.Cout) ? bias_sel[n0 + tid] : 0.f;
   __syncthreads();
-  if (!loader) {
+  if constexpr (EPI == kEpiTaps) {
+    // act(conv + bias) is consumed on the spot by the NEXT layer's 3x3, Cout -> 1 convolution (DispHead.conv2, update.py:19,24):
+    // per tap t the reduction sum_c w2[c][t] act(.)[c] over this block's 64 channels -> plane (n0/64)*9 + t of out; the
+    // shifted 9-tap sum over all channel tiles is as_tap_shift_sum's.  The 256-channel hidden layer never exists in memory.
+    static_assert(EPI != kEpiTaps || BN == 64, "tap reduction: one consumer wave must hold all channels of the tile");
+    float* w2s = bias_s + 64;  // [64][12]
+    for (int i = tid; i < 64 * 9; i += 512) {
+      const int c = i / 9, t = i - c * 9;
+      w2s[c * 12 + t] = (n0 + c < p.Cout) ? p.tap_w[(long long)(n0 + c) * 9 + t] : 0.f;
+    }
+    __syncthreads();
+    // stage relu(acc + bias) as fp32 [64 channels][BM pixels] in LDS (the operand images are dead), then one thread per pixel
+    // walks the 64 channels: no accumulator registers are live next to the nine tap sums, the summation order is fixed
+    float* stage = bias_s + 1024;
+    if (!loader) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int col = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            stage[col * BM + px_base + q * 32 + l31] = fmaxf(acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f) + bias_s[col], 0.f);
+          }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      float ta[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) ta[t] = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) {
+        const float o = stage[c * BM + tid];
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + c * 12), wb = *reinterpret_cast<const f32x4*>(w2s + c * 12 + 4);
+        const float wc = w2s[c * 12 + 8];
+        ta[0] += wa[0] * o; ta[1] += wa[1] * o; ta[2] += wa[2] * o; ta[3] += wa[3] * o;
+        ta[4] += wb[0] * o; ta[5] += wb[1] * o; ta[6] += wb[2] * o; ta[7] += wb[3] * o;
+        ta[8] += wc * o;
+      }
+      const int su = tid >> 7, m = tid & 127;
+      const int gy = ((NSUB > 1 && su) ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = ((NSUB > 1 && su) ? sx0[NSUB - 1] : sx0[0]) + m % TW;
+      if (gy < p.H && gx < p.W) {
+        const long long oplane = (long long)p.H * p.W;
+        float* outp = p.out + ((long long)b * p.n_tiles + nt) * 9 * oplane + (long long)gy * p.W + gx;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) outp[(long long)t * oplane] = ta[t];
+      }
+    }
+  } else if (!loader) {
     const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);
     const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
     unsigned poff[PTW];
@@ -1247,6 +1301,10 @@ int launch_conv_split(const ConvParams& p, int epi, hipStream_t s) {
   }
   if (epi == AS_EPI_LINEAR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_LINEAR, NSUB>(p, s);
   if (epi == AS_EPI_GRU_ZR) return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_ZR, NSUB>(p, s);
+  if (epi == AS_EPI_RELU_TAPS) {
+    if constexpr (BN == 64 && KS == 3) return launch_conv_split_epi<KS, TW, BN, kEpiTaps, NSUB>(p, s);
+    else return as::fail(AS_ERR_BAD_ARG, "conv2d(RELU_TAPS): 3x3, 64-channel tiles only");
+  }
   return launch_conv_split_epi<KS, TW, BN, AS_EPI_GRU_Q, NSUB>(p, s);
 }
 
@@ -1428,6 +1486,11 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     AS_REQUIRE(d->h && (d->out2 || bs_only) && (d->Cout % (2 * kBN)) == 0, AS_ERR_BAD_ARG, "conv2d(GRU_ZR): needs h, out2 and Cout %% 128 == 0");
   } else if (epi == AS_EPI_GRU_Q) {
     AS_REQUIRE(d->h && d->z, AS_ERR_BAD_ARG, "conv2d(GRU_Q): needs h and z");
+  } else if (epi == AS_EPI_RELU_TAPS) {
+    AS_REQUIRE(d->tap_w && d->out && !d->add && !d->h && !d->out_bs && !d->dual && d->precision == 1 && d->KS == 3 && (d->stride == 0 || d->stride == 1),
+               AS_ERR_BAD_ARG, "conv2d(RELU_TAPS): needs tap_w and out; 3x3, split precision, stride 1, no add / residual / blocked copy / dual");
+    AS_REQUIRE(d->act == AS_ACT_RELU, AS_ERR_BAD_ARG, "conv2d(RELU_TAPS): act must be AS_ACT_RELU");
+    p.tap_w = d->tap_w;
   } else {
     return as::fail(AS_ERR_BAD_ARG, "conv2d: epilogue=%d", epi);
   }
@@ -1486,6 +1549,14 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     AS_REQUIRE((long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d: grid too large");
     conv_pick_ksplit(p, d);
     if (d->dual && p.ksplit > 1) return conv2d_dual_sequential(d, stream);
+    if (epi == AS_EPI_RELU_TAPS) {  // 64-channel tiles, whole K per block (the reduction is over a tile's channels)
+      p.ksplit = 1;
+      p.ws = nullptr;
+      p.n_tiles = p.Cout_pad / 64;
+      const long long groups2 = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, 2) * p.n_tiles;
+      if (groups2 >= 2 * kNumCU) return tw == 16 ? launch_conv_split<3, 16, 64, 2>(p, epi, s) : launch_conv_split<3, 32, 64, 2>(p, epi, s);
+      return tw == 16 ? launch_conv_split<3, 16, 64>(p, epi, s) : launch_conv_split<3, 32, 64>(p, epi, s);
+    }
     // big maps: 256-pixel x 64-channel blocks (two sub-tiles) pull 30 % fewer bytes per MFMA through the CU's L1
     static const int wide_mode = getenv("AS_CONV_WIDE") ? atoi(getenv("AS_CONV_WIDE")) : 1;
     const long long wide_blocks = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, 2) * (p.Cout_pad / 64);
@@ -1564,11 +1635,11 @@ int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float
   return as::check_launch("conv3x3_to1");
 }
 
-int as_tap_shift_sum(const float* S, const float* bias, const float* addend, float* out, int B, int H, int W, void* stream) {
+int as_tap_shift_sum(const float* S, const float* bias, const float* addend, float* out, int B, int H, int W, int groups, void* stream) {
   AS_REQUIRE(S && out, AS_ERR_BAD_ARG, "tap_shift_sum: null pointer");
-  AS_REQUIRE(B > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "tap_shift_sum: non-positive size");
+  AS_REQUIRE(B > 0 && H > 0 && W > 0 && groups > 0, AS_ERR_BAD_ARG, "tap_shift_sum: non-positive size");
   const long long P = (long long)B * H * W;
-  hipLaunchKernelGGL(tap_shift_sum_kernel, dim3((unsigned)as::cdiv64(P, 256)), dim3(256), 0, as::as_stream(stream), S, bias, addend, out, H, W, P);
+  hipLaunchKernelGGL(tap_shift_sum_kernel, dim3((unsigned)as::cdiv64(P, 256)), dim3(256), 0, as::as_stream(stream), S, bias, addend, out, H, W, P, groups);
   return as::check_launch("tap_shift_sum");
 }
 

@@ -51,6 +51,9 @@ extern "C" {
 #define AS_EPI_LINEAR 0 /* out = act(acc + bias + add); with h != NULL: out = relu(h + act(...))    (extractor.py:56-62) */
 #define AS_EPI_GRU_ZR 1 /* co <  Cout/2: z  = sigmoid(acc+bias+add)        -> out  [B,Cout/2,H,W]
                            co >= Cout/2: rh = sigmoid(acc+bias+add) * h    -> out2 [B,Cout/2,H,W]  */
+#define AS_EPI_RELU_TAPS 4 /* act(acc+bias) is not stored: per 64-channel tile g and tap t, out[b][g*9+t] = sum_{c in tile} tap_w[c][t] * act(.)[c]
+                              — the channel reductions of a FOLLOWING 3x3, Cout -> 1 convolution (DispHead: conv1 -> relu -> conv2,
+                              update.py:23-24), finished by as_tap_shift_sum(groups = ceil(Cout/64)).  3x3, precision 1, stride 1. */
 #define AS_EPI_GRU_Q 2  /* out = (1-z)*h + z*tanh(acc+bias+add)            (update.py:39-40)      */
 
 /* Matrix-core arithmetic of the GEMM-shaped kernels (as_corr_build_pyramid, as_conv2d):
@@ -156,6 +159,7 @@ typedef struct {
      act, plane) runs in the same grid with its own source, weights, bias and output channel window inside out / out_bs — the two
      64 -> 64 branch convolutions of BasicMotionEncoder (update.py:86,88) as one launch.  Equivalent to two calls (and executed as
      two where the fused form does not apply: fp32 precision, split-K). */
+  const float* tap_w; /* AS_EPI_RELU_TAPS: [Cout][9] fp32 weights of the following Cout -> 1 convolution (tap = ky*3+kx); out is [B, ceil(Cout/64)*9, H, W] */
   int dual;
   const float* src2;
   int src2_bs;
@@ -189,8 +193,8 @@ int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float
 /* second stage of the MFMA form of a 3x3, Cin -> 1 convolution: S [B,9,H,W] holds, per tap t = ky*3+kx,
  * the channel reduction sum_c w[c,ky,kx]*x[c] (a 1x1 as_conv2d with the 9 taps as output channels);
  * out[b,0,y,x] = bias + sum_t S[b,t,y+ky-1,x+kx-1] with zero padding — DispHead.conv2 (update.py:19,24). */
-int as_tap_shift_sum(const float* S, const float* bias, const float* addend /* [B,1,H,W] or NULL: out = addend + (...) */,
-                     float* out, int B, int H, int W, void* stream);
+int as_tap_shift_sum(const float* S /* [B, groups*9, H, W] */, const float* bias, const float* addend /* [B,1,H,W] or NULL: out = addend + (...) */,
+                     float* out, int B, int H, int W, int groups /* channel-tile partials summed in order (1: the plain form) */, void* stream);
 
 /* a8  pool2x = avg_pool2d(3,stride 2,pad 1) (update.py:94-95); interp = bilinear align_corners=True
  *     resize (update.py:100-102).  x [B,C,H,W] -> out [B,C,Ho,Wo].                                */

@@ -960,3 +960,27 @@ def test_conv_dual_launch_equals_two_launches(h, w, precision):
         ops.conv2d([xa], pa, act=Lb.ACT_RELU, out_bs=bs_got, out_bs_coff=0, bs_only=True,
                    dual={"src": xbb, "pack": pb, "out_bs_coff": 64})
         assert torch.equal(bs_got.t, bs_ref.t)
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w", [(1, 128, 256, 136, 240), (2, 32, 100, 9, 14), (1, 16, 64, 24, 40)])
+def test_conv_relu_taps_epilogue(b, cin, cout, h, w):
+    """AS_EPI_RELU_TAPS + as_tap_shift_sum(groups) == conv3x3(relu(conv3x3(x))) with a 1-channel second conv (DispHead)."""
+    from anystereo import _lib as Lb, ops
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        x = U((b, cin, h, w), 601)
+        w1, b1 = U((cout, cin, 3, 3), 602) * 0.05, U((cout,), 603) * 0.1
+        w2, b2 = U((1, cout, 3, 3), 604) * 0.05, U((1,), 605)
+        add = U((b, 1, h, w), 606)
+        p1 = ops.PackedConv().get([w1.to(DEV)], [b1.to(DEV)])
+        taps = ops.conv2d([x.to(DEV)], p1, act=Lb.ACT_RELU, epilogue=Lb.EPI_RELU_TAPS, tap_w=w2[0].reshape(cout, 9).contiguous().to(DEV))
+        assert tuple(taps.shape) == (b, (cout + 63) // 64 * 9, h, w)
+        got = ops.tap_shift_sum(taps, b2.to(DEV), add.to(DEV))
+        ref = add.double() + _ref_conv(torch.relu(_ref_conv(x, w1, b1, 1)), w2, b2, 1)
+        close(got, ref, 2e-5, 2e-5, "fused head")
+        again = ops.tap_shift_sum(ops.conv2d([x.to(DEV)], p1, act=Lb.ACT_RELU, epilogue=Lb.EPI_RELU_TAPS,
+                                             tap_w=w2[0].reshape(cout, 9).contiguous().to(DEV)), b2.to(DEV), add.to(DEV))
+        assert torch.equal(got, again)  # fixed summation order
+    finally:
+        ops.set_precision(prev)
