@@ -662,12 +662,26 @@ __global__ __launch_bounds__(256) void tap_shift_sum_kernel(const float* __restr
   const int y = rem / W, x = rem - y * W;
   const float* sp = S + b * groups * 9 * plane;
   float acc = 0.f;
-  for (int g = 0; g < groups; ++g, sp += 9 * plane) {  // channel-tile partials of the fused form (AS_EPI_RELU_TAPS), fixed order
+  // channel-tile partials of the fused form (AS_EPI_RELU_TAPS) summed in a fixed order; four groups' 36 loads in flight together
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sp, 0, (int)((long long)groups * 9 * plane * 4), 0x00020000);
+  unsigned toff[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += sp[(long long)t * plane + (long long)yy * W + xx];
-    }
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    toff[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (unsigned)(((long long)t * plane + (long long)yy * W + xx) * 4) : 0x7FFFFFF0u;
+  }
+  const unsigned gstep = (unsigned)(9 * plane * 4);
+  for (int g0 = 0; g0 < groups; g0 += 4) {
+    float v[4][9];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        v[g][t] = as_bload(rs, (toff[t] == 0x7FFFFFF0u || g0 + g >= groups) ? 0x7FFFFFF0u : toff[t] + (unsigned)(g0 + g) * gstep);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc += v[g][t];  // out-of-image taps and missing groups read 0
   }
   const float delta = acc + (bias ? bias[0] : 0.f);
   out[pix] = addend ? addend[pix] + delta : delta;  // disp + delta_disp of the GRU loop fused (continuous_IGEVstereo.py:296)
