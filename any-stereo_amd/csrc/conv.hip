@@ -741,11 +741,30 @@ __global__ __launch_bounds__(256) void pool2x_bs_kernel(const float* __restrict_
   t /= Ho;
   const int blk = (int)(t % c8);
   const long long b = t / c8;
+  // all 72 taps of the thread's 8 channels as unconditional buffer loads (out-of-image taps and channels >= C read 0 through
+  // the range check), summed per channel in pool2x_at's order
+  const long long plane = (long long)H * W;
+  const int nch = min(8, C - blk * 8);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (b * C + blk * 8) * plane), 0, (int)(nch * plane * 4), 0x00020000);
+  unsigned off[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = 2 * yo - 1 + k / 3, xx = 2 * xo - 1 + k % 3;
+    off[k] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (unsigned)(((long long)yy * W + xx) * 4) : 0x7FFFFFF0u;
+  }
+  const unsigned pl4 = (unsigned)(plane * 4);
+  float raw[8][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) raw[j][k] = as_bload(rs, off[k] == 0x7FFFFFF0u ? off[k] : off[k] + (unsigned)j * pl4);
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = blk * 8 + j;
-    v[j] = c < C ? pool2x_at(x + (b * C + c) * H * W, yo, xo, H, W) : 0.f;
+    float sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sacc += raw[j][k];
+    v[j] = sacc / 9.f;
   }
   bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v);
 }
