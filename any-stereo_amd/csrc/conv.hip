@@ -58,6 +58,7 @@ struct ConvParams {
   int out_bs_c8tot, out_bs_coff8;  // blocks of the destination tensor per batch element; first block of the window
   int out_bs_ctot;             // logical channels of the destination tensor (slots past them are zero-filled, never another producer's)
   int bs_only;                 // 1: the fp32 copy of that result is not written
+  int all_bs;                  // every source (and a dual launch's second one) is blocked: all-DMA operand staging where it fits
   // Dual launch (conv_split_kernel, LINEAR epilogue, one source): a second convolution of the same shape rides in the same grid
   // as extra output-channel tiles [n_tiles/2, n_tiles) with its own source, weights, bias and output channel window — the two
   // 64 -> 64 branch convs of the motion encoder (update.py:86,88) are one launch instead of two on the loop's critical stream.
@@ -893,6 +894,12 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   constexpr int PIMG = 4 * PATCHT * 16;      // bytes of one sub-chunk's patch image [comp][h][pixel][8]
   constexpr int WPX = 256 / BN;              // consumer waves along the pixel dimension (4 consumers = (BN/64) x WPX)
   constexpr int PTW = BM / (WPX * 32);       // pixel MFMA tiles per consumer wave
+  // All-DMA operand staging: when every source is a blocked split-fp16 tensor, both LDS images of a unit are plain copies of
+  // global memory (weights: the pack's order; patch: 16-B pixel units), so the loaders issue `buffer_load_dwordx4 ... lds` for unit
+  // c+1 into a SECOND patch image while the consumers work on unit c, wait for them to land, and meet the consumers at ONE barrier
+  // per chunk — no VGPR round trip, no LDS write instructions, no commit phase.  Needs room for two patch images (3x3 only).
+  constexpr bool PDB = KS == 3 && 2 * WCHUNK + 2 * NSC * PIMG <= 160 * 1024;
+  const bool dma = PDB && p.all_bs;  // kernel-uniform
   static_assert(PTW == 1 || PTW == 2, "consumer tile is 64 co x 32|64 px");
   static_assert(WCHUNK % (16 * 256) == 0, "weight chunk must split evenly over the loader threads");
   // [W image 0][W image 1][patch image]
@@ -1055,6 +1062,50 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       }                                                                                               \
     }                                                                                                 \
   }
+    if (dma) {
+      if constexpr (PDB) {
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wpack_sel, 0, 0x7FFFFFF0, 0x00020000);
+        const unsigned wvoff = (unsigned)((n0 + (long long)(ltid / BN) * p.Cout_pad + (ltid % BN)) * 16);
+        bool p_slot[NPI];
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) p_slot[i] = p_lds[i] >= 0;
+#define AS_DMA_UNIT(CHUNK, BUF)                                                                       \
+  {                                                                                                   \
+    _Pragma("unroll") for (int g = 0; g < NWD; ++g)                                                    \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (as_lds_void*)(lds + (BUF) * WCHUNK + g * 4096 + lwave * 1024), 16, wvoff, \
+                                               (unsigned)(((long long)(CHUNK) * wchunk16 + (long long)g * wstep16) * 16), 0, 0); \
+    const int cb = (CHUNK) * kSplitKC;                                                                \
+    const float* sp = src0;                                                                           \
+    int sc = p.src_c[0], sb = 0;                                                                      \
+    if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; }      \
+    if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; }      \
+    if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; }      \
+    const int left = sc - (cb - sb);                                                                  \
+    const int c8 = (sc + 7) >> 3, blk = (cb - sb) >> 3;                                                \
+    const _Float16* spb = reinterpret_cast<const _Float16*>(sp) + ((long long)b * 2 * c8 + (left > 0 ? blk : 0)) * plane * 8; \
+    const int recs = left > 0 ? (int)((long long)(c8 - blk) * plane * 16) : 0;                         \
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000); \
+    const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(spb + (long long)c8 * plane * 8), 0, recs, 0x00020000); \
+    const int pimg = 2 * WCHUNK + (BUF) * PIMG;  /* byte offset of the unit's patch image */          \
+    _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                  \
+      const int vo_ = (int)p_boff[i];  /* (a subscript expression as the builtin's voffset silently drops the kernel's host stub) */ \
+      if (p_slot[i]) {  /* lanes past the image's last unit stay out (EXEC) */                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (as_lds_void*)(lds + pimg + (i * 256 + lwave * 64) * 16), 16, vo_, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsl, (as_lds_void*)(lds + pimg + 2 * PATCHT * 16 + (i * 256 + lwave * 64) * 16), 16, vo_, 0, 0, 0); \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+        AS_DMA_UNIT(chunk_lo, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+          if (chunk + 1 < chunk_hi) AS_DMA_UNIT(chunk + 1, ((chunk - chunk_lo) & 1) ^ 1)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();  // unit c+1 landed, consumers finished unit c
+        }
+#undef AS_DMA_UNIT
+      }
+    } else {
     AS_SPLIT_LOAD_W(chunk_lo)
     AS_SPLIT_FETCH_SPLIT_P(chunk_lo)
     AS_SPLIT_STORE_W(0)
@@ -1086,6 +1137,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       }
     }
     AS_STAMP_FLUSH(1)
+    }
 #undef AS_SPLIT_LOAD_W
 #undef AS_SPLIT_STORE_W
 #undef AS_SPLIT_FETCH_SPLIT_P
@@ -1112,7 +1164,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
       const bool more = chunk + 1 < chunk_hi;
       const unsigned char* wb = lds + ((chunk - chunk_lo) & 1) * WCHUNK + wlane;
-      const unsigned char* pb = lds + 2 * WCHUNK;
+      const unsigned char* pb = lds + 2 * WCHUNK + (dma ? ((chunk - chunk_lo) & 1) * PIMG : 0);
       // operand software pipeline: the ds_read_b128 of tap t+1 sit between the two halves of tap t's MFMAs
       half8 a_hi[2][2], a_lo[2][2], b_hi[2][PTW], b_lo[2][PTW];
 #define AS_SPLIT_LDOPS(TAP, S)                                                                          \
@@ -1152,7 +1204,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       AS_STAMP_SEG(0)  // operand reads + MFMAs of the chunk
       __syncthreads();
       AS_STAMP_SEG(1)  // waited for the loaders (next weight image stored, next patch fetched)
-      if (more) {
+      if (more && !dma) {
         __syncthreads();
         AS_STAMP_SEG(2)  // waited for the patch commit
       }
@@ -1303,7 +1355,8 @@ template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1>
 int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   constexpr int TH = 128 / TW, PATCHP = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
   constexpr int NSC = (KS == 1) ? 4 : 1;
-  constexpr size_t lds = 2 * (size_t)(KS * KS * NSC * 4 * BN * 16) + (size_t)NSC * (4 * NSUB * PATCHP * 16);
+  constexpr size_t wimg = (size_t)(KS * KS * NSC * 4 * BN * 16), pimg = (size_t)NSC * (4 * NSUB * PATCHP * 16);
+  constexpr size_t lds = 2 * wimg + ((KS == 3 && 2 * wimg + 2 * pimg <= 160 * 1024) ? 2 : 1) * pimg;  // the kernel's PDB rule
   static_assert(lds <= 160 * 1024, "conv_split: LDS budget");
   static bool configured = false;  // per instantiation; the attribute is idempotent
   if (!configured && lds > 64 * 1024) {
@@ -1502,6 +1555,13 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
                "conv2d: source %d has %d channels; every source but the last must hold a multiple of %d (concatenate first)",
                i, d->src_c[i], kc_req);
   p.n_src = d->n_src;
+  {
+    bool all = d->precision == 1;
+    for (int i = 0; i < d->n_src; ++i) all = all && d->src_bs[i];
+    if (d->dual) all = all && d->src2_bs;
+    static const int dma_mode = getenv("AS_CONV_DMA") ? atoi(getenv("AS_CONV_DMA")) : 1;
+    p.all_bs = (all && dma_mode) ? 1 : 0;
+  }
   p.wpack = d->wpack; p.bias = d->bias; p.add = d->add;
   p.add_ctot = d->add_ctot; p.add_coff = d->add_coff;
   AS_REQUIRE(!d->add || (d->add_coff >= 0 && d->add_coff + d->Cout <= d->add_ctot), AS_ERR_BAD_SHAPE, "conv2d: add channel window [%d,%d) outside %d", d->add_coff, d->add_coff + d->Cout, d->add_ctot);
