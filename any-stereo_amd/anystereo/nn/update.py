@@ -232,7 +232,8 @@ class BasicMotionEncoder(nn.Module):
                 else:
                     cor = ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
             with scope("enc_convd1"):
-                d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()), copy_out=out, copy_coff=127)
+                d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()),
+                                         out=ops.BS8.empty(b, 64, h, w, disp.device) if bs else None, copy_out=out, copy_coff=127)
             with scope("enc_convc2"):
                 second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
                 pc2 = self._pc2.get([self.convc2.weight], [self.convc2.bias])

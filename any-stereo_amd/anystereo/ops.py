@@ -453,7 +453,8 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
         raise RuntimeError("conv7x7_c1_relu: expects x [B,1,H,W] and weight [Cout,1,7,7]")
     if out is None:
         out = torch.empty((b, cout, h, w), device=x.device, dtype=torch.float32)
-    _req(out, "out")
+    obs = isinstance(out, BS8)  # blocked split-fp16 result (feeds a split-precision convolution only)
+    _req(out.t if obs else out, "out", torch.float16 if obs else torch.float32)
     key = (weight.data_ptr(), weight._version, weight.device)
     ent = _TAPMAJOR.get(key)
     # the entry must belong to THIS tensor: a freed weight's address (and version 0) is reused by the caching allocator
@@ -470,9 +471,9 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
             _req(copy_out.t if cbs else copy_out, "copy_out", torch.float16 if cbs else torch.float32)
             if copy_out.shape[0] != b or tuple(copy_out.shape[2:]) != (h, w):
                 raise RuntimeError("conv7x7_c1_relu: copy_out shape mismatch")
-        L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(wt), _p(bias), _p(out), b, h, w, cout, out.shape[1], out_coff, 1,
+        L.check(L.load().as_conv7x7_c1_relu(_p(x), _p(wt), _p(bias), _p(out.t if obs else out), b, h, w, cout, out.shape[1], out_coff, 1,
                                             _p(copy_out.t if cbs else copy_out), 0 if copy_out is None else copy_out.shape[1], copy_coff,
-                                            1 if cbs else 0, _stream()),
+                                            1 if cbs else 0, 1 if obs else 0, _stream()),
                 "conv7x7_c1_relu")
     return out
 

@@ -558,6 +558,22 @@ __global__ __launch_bounds__(256) void conv7x7_c1_kernel(const float* __restrict
   }
 }
 
+// Blocked split-fp16 output (ConvParams' BS8 comment): one thread per (8-channel block, output pixel) writes the 16-B unit of
+// the hi plane set and the one of the lo plane set.  Same per-element arithmetic as the fp32 kernels (shared helpers).
+__device__ __forceinline__ void bs8_store(_Float16* __restrict__ out_bs, long long b, int c8tot, int blk, long long plane,
+                                          long long pix, const float (&v)[8]) {
+  half8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 hj = (_Float16)v[j];
+    hi[j] = hj;
+    lo[j] = (_Float16)((v[j] - (float)hj) * 2048.f);
+  }
+  _Float16* rec = out_bs + ((b * 2 * c8tot + blk) * plane + pix) * 8;
+  *reinterpret_cast<half8*>(rec) = hi;
+  *reinterpret_cast<half8*>(rec + (long long)c8tot * plane * 8) = lo;
+}
+
 // Tap-major variant (the shipped path): weights as wt[49][Cout_pad].  The kernel above walks the output channels in its
 // outer loop and pulls 49 scalar weights per channel (3136 dependent s_load dwords per wave) on 135 blocks — 30 us at
 // 136x240, on the critical stream of the GRU loop.  Here a block owns a 16x16 pixel tile and CO = 8 output channels
@@ -566,7 +582,8 @@ template <int CO>
 __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int H, int W, int Cout, int CP, int out_ctot, int out_coff,
-                                                            float* __restrict__ copy_out, int copy_ctot, int copy_coff, int copy_bs) {
+                                                            float* __restrict__ copy_out, int copy_ctot, int copy_coff, int copy_bs,
+                                                            int out_bs) {
   __shared__ float patch[22 * 22];
   const int groups = CP / CO;
   const int b = blockIdx.z / groups;
@@ -597,10 +614,20 @@ __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restr
   }
   const int gy = y0 + ly, gx = x0 + lx;
   if (gy < H && gx < W) {
-    float* o = out + ((long long)b * out_ctot + out_coff + c0) * plane + (long long)gy * W + gx;
+    if (out_bs) {  // `out` is a blocked split-fp16 tensor of out_ctot channels: the thread's CO = 8 channels are one block's pixel unit
+      static_assert(CO == 8, "blocked output: one 8-channel block per thread");
+      if (c0 < (Cout + 7) / 8 * 8) {
+        float v[8];
 #pragma unroll
-    for (int j = 0; j < CO; ++j)
-      if (c0 + j < Cout) o[(long long)j * plane] = fmaxf(acc[j] + (bias ? bias[c0 + j] : 0.f), 0.f);
+        for (int j = 0; j < CO; ++j) v[j] = (c0 + j < Cout) ? fmaxf(acc[j] + (bias ? bias[c0 + j] : 0.f), 0.f) : 0.f;
+        bs8_store(reinterpret_cast<_Float16*>(out), b, (out_ctot + 7) >> 3, (out_coff + c0) >> 3, plane, (long long)gy * W + gx, v);
+      }
+    } else {
+      float* o = out + ((long long)b * out_ctot + out_coff + c0) * plane + (long long)gy * W + gx;
+#pragma unroll
+      for (int j = 0; j < CO; ++j)
+        if (c0 + j < Cout) o[(long long)j * plane] = fmaxf(acc[j] + (bias ? bias[c0 + j] : 0.f), 0.f);
+    }
     // optional pass-through of the input plane (the `cat([out, disp])` of the motion encoder, update.py:91)
     if (copy_out && c0 == 0) {
       const float v = patch[(ly + 3) * 22 + lx + 3];
@@ -713,22 +740,6 @@ __global__ __launch_bounds__(256) void pool2x_kernel(const float* __restrict__ x
   const int yo = (int)(t % Ho);
   const long long bc = t / Ho;
   out[idx] = pool2x_at(x + bc * H * W, yo, xo, H, W);
-}
-
-// Blocked split-fp16 output (ConvParams' BS8 comment): one thread per (8-channel block, output pixel) writes the 16-B unit of
-// the hi plane set and the one of the lo plane set.  Same per-element arithmetic as the fp32 kernels (shared helpers).
-__device__ __forceinline__ void bs8_store(_Float16* __restrict__ out_bs, long long b, int c8tot, int blk, long long plane,
-                                          long long pix, const float (&v)[8]) {
-  half8 hi, lo;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const _Float16 hj = (_Float16)v[j];
-    hi[j] = hj;
-    lo[j] = (_Float16)((v[j] - (float)hj) * 2048.f);
-  }
-  _Float16* rec = out_bs + ((b * 2 * c8tot + blk) * plane + pix) * 8;
-  *reinterpret_cast<half8*>(rec) = hi;
-  *reinterpret_cast<half8*>(rec + (long long)c8tot * plane * 8) = lo;
 }
 
 __global__ __launch_bounds__(256) void pool2x_bs_kernel(const float* __restrict__ x, _Float16* __restrict__ out_bs, int C, int H, int W,
@@ -1698,11 +1709,12 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
 
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out, int B, int H, int W,
                        int Cout, int out_ctot, int out_coff, int tap_major, float* copy_out, int copy_ctot, int copy_coff,
-                       int copy_bs, void* stream) {
+                       int copy_bs, int out_bs, void* stream) {
   AS_REQUIRE(x && weight && out, AS_ERR_BAD_ARG, "conv7x7_c1: null pointer");
   AS_REQUIRE((long long)H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "conv7x7_c1: plane too large");
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, AS_ERR_BAD_ARG, "conv7x7_c1: non-positive size");
-  AS_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctot, AS_ERR_BAD_SHAPE, "conv7x7_c1: out channel window outside out_ctot");
+  AS_REQUIRE(out_coff >= 0 && out_coff + Cout <= (out_bs ? (out_ctot + 7) / 8 * 8 : out_ctot), AS_ERR_BAD_SHAPE, "conv7x7_c1: out channel window outside out_ctot");
+  AS_REQUIRE(!out_bs || (out_coff % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0), AS_ERR_BAD_ARG, "conv7x7_c1: blocked output window must start at a multiple of 8, 16-B aligned");
   AS_REQUIRE(B <= 65535 && as::cdiv(H, 16) <= 65535, AS_ERR_BAD_SHAPE, "conv7x7_c1: grid too large");
   dim3 grid((unsigned)as::cdiv(W, 16), (unsigned)as::cdiv(H, 16), (unsigned)B);
   if (tap_major) {
@@ -1711,8 +1723,9 @@ int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, f
     const dim3 g3(grid.x, grid.y, (unsigned)(B * (CP / 8)));
     AS_REQUIRE(!copy_out || (copy_coff >= 0 && copy_coff < copy_ctot), AS_ERR_BAD_SHAPE, "conv7x7_c1: copy channel outside copy_ctot");
     hipLaunchKernelGGL(conv7x7_c1_tm_kernel<8>, g3, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, CP, out_ctot, out_coff,
-                       copy_out, copy_ctot, copy_coff, copy_bs);
+                       copy_out, copy_ctot, copy_coff, copy_bs, out_bs);
   } else {
+    AS_REQUIRE(!out_bs, AS_ERR_BAD_ARG, "conv7x7_c1: a blocked output needs tap_major weights");
     AS_REQUIRE(!copy_out, AS_ERR_BAD_ARG, "conv7x7_c1: the input pass-through needs tap_major weights");
     hipLaunchKernelGGL(conv7x7_c1_kernel, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, out, H, W, Cout, out_ctot, out_coff);
   }

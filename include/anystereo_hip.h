@@ -186,6 +186,7 @@ int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Co
 int as_conv7x7_c1_relu(const float* x, const float* weight, const float* bias, float* out,
                        int B, int H, int W, int Cout, int out_ctot, int out_coff, int tap_major,
                        float* copy_out, int copy_ctot, int copy_coff, int copy_bs /* != 0: copy_out is a blocked split-fp16 tensor of copy_ctot channels (as_conv_desc.src_bs) */,
+                       int out_bs /* != 0 (tap_major only): out is a blocked split-fp16 tensor of out_ctot channels, out_coff a multiple of 8 */,
                        void* stream);
 int as_conv3x3_to1(const float* x, const float* weight, const float* bias, float* out,
                    int B, int Cin, int H, int W, void* stream);

@@ -984,3 +984,22 @@ def test_conv_relu_taps_epilogue(b, cin, cout, h, w):
         assert torch.equal(got, again)  # fixed summation order
     finally:
         ops.set_precision(prev)
+
+
+def test_conv7x7_blocked_split_output():
+    """The 7x7 one-channel conv with a BS8 result holds exactly the split of its fp32 result (+ the disparity pass-through)."""
+    from anystereo import ops
+    for cout, h, w in ((64, 20, 37), (13, 9, 14)):
+        disp = U((2, 1, h, w), 701, -2.0, 30.0).to(DEV)
+        w7, b7 = (U((cout, 1, 7, 7), 702) * 0.2).to(DEV), (U((cout,), 703) * 0.1).to(DEV)
+        ref = ops.conv7x7_c1_relu(disp, w7, b7)
+        bs = ops.BS8.empty(2, cout, h, w, DEV)
+        bs.t.fill_(float("nan"))
+        assert ops.conv7x7_c1_relu(disp, w7, b7, out=bs) is bs
+        hi = ref.half()
+        lo = ((ref - hi.float()) * 2048.0).half()
+        b, _, c8, hh, ww, _ = bs.t.shape
+        got_hi = bs.t[:, 0].permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, hh, ww)
+        got_lo = bs.t[:, 1].permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, hh, ww)
+        assert torch.equal(got_hi[:, :cout], hi) and torch.equal(got_lo[:, :cout], lo)
+        assert (got_hi[:, cout:] == 0).all() and (got_lo[:, cout:] == 0).all()
