@@ -83,7 +83,12 @@ class ResidualBlock(nn.Module):
     def _forward_fused(self, x):
         x = x.contiguous()
         if _conv_hip_ok(self.conv1):
-            y = ops.conv2d([x], self._pk1.get_folded(self.conv1, self.norm1), act=L.ACT_RELU, stride=self.conv1.stride[0])
+            if self.conv1.stride[0] == 1 and _bs_links():
+                # conv1 -> conv2 through a blocked split-fp16 tensor only (ops.BS8): same values, conv2 stages its operands by DMA
+                y = ops.BS8.empty(x.shape[0], self.conv1.out_channels, x.shape[2], x.shape[3], x.device)
+                ops.conv2d([x], self._pk1.get_folded(self.conv1, self.norm1), act=L.ACT_RELU, out_bs=y, bs_only=True)
+            else:
+                y = ops.conv2d([x], self._pk1.get_folded(self.conv1, self.norm1), act=L.ACT_RELU, stride=self.conv1.stride[0])
         else:  # stride 2: MIOpen with the folded weights
             w, b = self._f1.get(self.conv1, self.norm1)
             y = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
@@ -92,6 +97,11 @@ class ResidualBlock(nn.Module):
             x = nn.functional.conv2d(x, w, b, self.downsample[0].stride)
         # relu(x + relu(bn2(conv2 y))) in the conv epilogue
         return ops.conv2d([y], self._pk2.get_folded(self.conv2, self.norm2), act=L.ACT_RELU, h=x.contiguous())
+
+
+def _bs_links() -> bool:
+    from .update import _links
+    return _links()
 
 
 def _init_encoder(mod: nn.Module):
