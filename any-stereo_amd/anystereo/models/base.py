@@ -212,7 +212,7 @@ class ContinuousStereoBase(nn.Module):
             net[0].record_stream(side)
             twin = getattr(net[0], "_as_bs", None)  # blocked twin of the hidden state: read by the head on the side stream
             if twin is not None:
-                twin.t.record_stream(side)
+                twin[0].record_stream(side)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 disp = ub.disp_head(net[0], addend=disp)

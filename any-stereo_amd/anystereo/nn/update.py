@@ -37,9 +37,18 @@ _LINKS_ENV = __import__("os").environ.get("ANYSTEREO_BS_LINKS", "1") != "0"
 
 
 def _twin(t):
-    """The blocked twin a producer attached to its fp32 result (same values), or the tensor itself."""
-    bs = getattr(t, "_as_bs", None)
-    return bs if (bs is not None and _links() and tuple(bs.shape) == tuple(t.shape)) else t
+    """The blocked twin a producer attached to its fp32 result (same values), or the tensor itself.  The twin is used only
+    while the fp32 tensor is unmodified since it was attached (same version counter): an in-place update of a hidden state
+    by the caller silently falls back to the fp32 tensor."""
+    ent = getattr(t, "_as_bs", None)
+    if ent is None or not _links():
+        return t
+    bs, ver = ent
+    return bs if (ver == t._version and tuple(bs.shape) == tuple(t.shape)) else t
+
+
+def _attach_twin(t, bs):
+    t._as_bs = (bs, t._version)
 
 
 # Training (gradients required): the reference's formulation op for op (gates as separate pointwise ops under autograd);
@@ -181,7 +190,7 @@ class ConvGRU(nn.Module):
             out = ops.conv2d([rbs if links else rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z,
                              out_bs=hbs)
         if links:
-            out._as_bs = hbs
+            _attach_twin(out, hbs)
         return out
 
     def pre_zr(self, h, cz, cr, cq):

@@ -1003,3 +1003,27 @@ def test_conv7x7_blocked_split_output():
         got_lo = bs.t[:, 1].permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, hh, ww)
         assert torch.equal(got_hi[:, :cout], hi) and torch.equal(got_lo[:, :cout], lo)
         assert (got_hi[:, cout:] == 0).all() and (got_lo[:, cout:] == 0).all()
+
+
+def test_hidden_state_twin_is_dropped_after_inplace_update():
+    """A hidden state modified in place by the caller must not be read through its (now stale) blocked twin."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn import update as UP
+    from anystereo import ops
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        gru = UP.ConvGRU(128, 128).eval()
+        fill_module_deterministic(gru, base_seed=9)
+        gru = gru.to(DEV)
+        h0, x = U((1, 128, 12, 20), 801).to(DEV), U((1, 128, 12, 20), 802).to(DEV)
+        ctx = list(U((1, 384, 12, 20), 803).to(DEV).split(128, dim=1))
+        with torch.no_grad():
+            h1 = gru(h0, *ctx, x)
+            assert UP._twin(h1) is not h1                      # twin attached and valid
+            ref = gru(h1.clone().mul_(0.5), *ctx, x)           # fresh tensor: no twin
+            h1.mul_(0.5)                                       # caller edits the hidden state in place
+            assert UP._twin(h1) is h1                          # stale twin ignored
+            assert torch.equal(gru(h1, *ctx, x), ref)
+    finally:
+        ops.set_precision(prev)
