@@ -19,7 +19,18 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "gru_zr"
     dev, b, h, w = "cuda:0", 1, 136, 240
     U = lambda shape, seed, lo=-1.0, hi=1.0: det_uniform(shape, seed, lo, hi).to(dev)  # noqa: E731
-    if which == "gru_zr":
+    def to_bs(x):  # fp32 [B,C,H,W] -> ops.BS8 holding the split the kernel's loaders compute (all-DMA staging path)
+        bb, cc, hh, ww = x.shape
+        hi = x.half()
+        lo = ((x - hi.float()) * 2048.0).half()
+        return ops.BS8(torch.stack([hi, lo], 1).view(bb, 2, cc // 8, 8, hh, ww).permute(0, 1, 2, 4, 5, 3).contiguous(), cc)
+    if which == "gru_zr_bs":
+        xs = [U((b, 128, h, w), 10 + i) for i in range(3)]
+        ctx = U((b, 384, h, w), 20)
+        pk = ops.PackedConv().get([U((256, 384, 3, 3), 30, -0.02, 0.02)], [U((256,), 31)])
+        xb = [to_bs(x) for x in xs]
+        fn, chunks = (lambda: ops.conv2d(xb, pk, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=xs[0])), 24
+    elif which == "gru_zr":
         xs = [U((b, 128, h, w), 10 + i) for i in range(3)]
         ctx = U((b, 384, h, w), 20)
         pk = ops.PackedConv().get([U((256, 384, 3, 3), 30, -0.02, 0.02)], [U((256,), 31)])
