@@ -285,21 +285,24 @@ __device__ __forceinline__ void epilogue_block(const ConvParams& p, const EpiCtx
                                                const f32x16 (&acc_x)[2][PTW], int co_base, const unsigned (&poff)[PTW],
                                                int half, const float* bias_s, bool is_r) {
   constexpr int NR = PTW * 4;
-  EpiRegs R[2];
+  // operand loads run TWO rounds ahead of the arithmetic + stores (three register sets): with one block per CU nothing else
+  // hides their latency, and the epilogue is ~15 % of a 24-chunk block's life
+  EpiRegs R[3];
   epi_load<EPI>(e, co_base, half, poff[0], 0, R[0]);
+  if (NR > 1) epi_load<EPI>(e, co_base, half, poff[0], 1, R[1]);
   f32x16 v;
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
     const int q = i >> 2, c = (i >> 1) & 1, g = i & 1;
-    if (i + 1 < NR) {
-      const int i1 = i + 1;
-      epi_load<EPI>(e, co_base + ((i1 >> 1) & 1) * 32, half, poff[i1 >> 2], i1 & 1, R[i1 & 1]);
+    if (i + 2 < NR) {
+      const int i2 = i + 2;
+      epi_load<EPI>(e, co_base + ((i2 >> 1) & 1) * 32, half, poff[i2 >> 2], i2 & 1, R[i2 % 3]);
     }
     if (g == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
     }
-    epi_finish<EPI>(p, e, v, co_base + c * 32, half, g, bias_s, is_r, R[i & 1], poff[q]);
+    epi_finish<EPI>(p, e, v, co_base + c * 32, half, g, bias_s, is_r, R[i % 3], poff[q]);
   }
 }
 
