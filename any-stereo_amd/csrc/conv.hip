@@ -1278,6 +1278,93 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
         for (int t = 0; t < 9; ++t) outp[(long long)t * oplane] = ta[t];
       }
     }
+  } else if constexpr (EPI != kEpiPartial) {
+    // Staged epilogue: the consumers park the tile (hh + cross/2048) as fp32 [BN channels][BM pixels] in LDS — the operand
+    // images are dead — and ALL eight waves finish it, one thread per (pixel, 8-channel block) step: with one block per CU
+    // the epilogue's global operand loads (context term, h, z) are pure latency, and the four loader waves double the loads in
+    // flight; a thread owns whole 8-channel blocks of its pixel, so the blocked copy is written as full 16-B units.
+    // Per element the arithmetic is the one of epi_finish (same operations, same order): results are unchanged.
+    float* stage = bias_s + 256;
+    if (!loader) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < PTW; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int col = co_base + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            stage[col * BM + px_base + q * 32 + l31] = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
+          }
+    }
+    __syncthreads();
+    const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);
+    const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
+    constexpr int PG = 512 / BM;           // thread groups along the channel dimension
+    constexpr int NB8 = BN / 8 / PG;       // 8-channel blocks per thread
+    const int mt = tid % BM, cg = tid / BM;
+    const int su = mt >> 7, m = mt & 127;
+    const int gy = ((NSUB > 1 && su) ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = ((NSUB > 1 && su) ? sx0[NSUB - 1] : sx0[0]) + m % TW;
+    const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
+    // operand loads of block k+1 are issued before block k is finished
+    float av[2][8], hv[2][8], zv[2][8];
+#define AS_EPI_LOAD8(K, S)                                                                            \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
+    const int col = (cg * NB8 + (K)) * 8 + j;                                                         \
+    const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff;                 \
+    av[S][j] = as_bload(e.r_add, off);                                                                \
+    if (EPI == AS_EPI_GRU_ZR || EPI == AS_EPI_LINEAR) hv[S][j] = as_bload(e.r_h, off);                 \
+    if (EPI == AS_EPI_GRU_Q) { hv[S][j] = as_bload(e.r_h, off); zv[S][j] = as_bload(e.r_z, off); }     \
+  }
+    AS_EPI_LOAD8(0, 0)
+#pragma unroll
+    for (int k = 0; k < NB8; ++k) {
+      if (k + 1 < NB8) AS_EPI_LOAD8(k + 1, (k + 1) & 1)
+      float ov[8];
+      const int col0 = (cg * NB8 + k) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = col0 + j;
+        const float x = stage[col * BM + mt] + bias_s[col] + av[k & 1][j];
+        float o;
+        if (EPI == AS_EPI_LINEAR) {
+          o = act_apply(x, p.act);
+          if (p.h) o = fmaxf(o + hv[k & 1][j], 0.f);
+        } else if (EPI == AS_EPI_GRU_ZR) {
+          const float gte = 1.f / (1.f + expf(-x));
+          o = is_r ? gte * hv[k & 1][j] : gte;
+        } else {
+          o = (1.f - zv[k & 1][j]) * hv[k & 1][j] + zv[k & 1][j] * tanhf(x);
+        }
+        ov[j] = o;
+        if (!e.skip_out) as_bstore(e.r_out, poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff, o);
+      }
+      if (e.has_bs) {
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const _Float16 hj = (_Float16)ov[j];
+          hi[j] = hj;
+          lo[j] = (_Float16)((ov[j] - (float)hj) * 2048.f);
+        }
+        const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)(col0 >> 3) * (e.plane4 * 4u) + poff * 4u;
+        if (col0 + 8 <= e.cvalid) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), e.r_bs, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), e.r_bsl, (int)off, 0, 0);
+        } else {  // the result's last channels end inside or before this block: own slots + zeroed padding, 2 B each
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bool own = col0 + j < e.cvalid, pad = col0 + j >= e.cend;
+            if (own || pad) {
+              const unsigned ok = off == 0x7FFFFFF0u ? off : off + 2u * j;
+              const _Float16 zero = (_Float16)0.f;
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, own ? hi[j] : zero), e.r_bs, (int)ok, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, own ? lo[j] : zero), e.r_bsl, (int)ok, 0, 0);
+            }
+          }
+        }
+      }
+    }
+#undef AS_EPI_LOAD8
   } else if (!loader) {
     const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);
     const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
