@@ -1419,8 +1419,17 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   if (co >= p.Cout && p.out_bs_coff8 * 8 + co < p.out_bs_ctot) to_bs = false;  // another producer's slot, not padding
   int cb_ = co;  // channel inside the mirrored tensor
   if (co < p.Cout) {
+    // all (<= 8) K-slice partials as unconditional buffer loads in flight together (missing slices read 0 through the range
+    // check), summed in slice order: a run-time trip count made this a chain of dependent load -> add round trips
+    const long long slab = (long long)p.B * p.Cout_pad * plane;  // elements of one K slice
+    const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, (int)((long long)p.ksplit * slab * 4), 0x00020000);
+    const unsigned o0 = (unsigned)((((long long)b * p.Cout_pad + co) * plane + pix) * 4), sl4 = (unsigned)(slab * 4);
+    float part[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) part[ks] = as_bload(rws, ks < p.ksplit ? o0 + (unsigned)ks * sl4 : 0x7FFFFFF0u);
     float x = 0.f;
-    for (int ks = 0; ks < p.ksplit; ++ks) x += p.ws[(((long long)ks * p.B + b) * p.Cout_pad + co) * plane + pix];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) x += part[ks];
     if (p.bias) x += p.bias[co];
     if (p.add) x += p.add[((long long)b * p.add_ctot + p.add_coff + co) * plane + pix];
     if (EPI == AS_EPI_LINEAR) {
