@@ -1771,9 +1771,18 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
       if (d->dual) conv_apply_dual(p, d);
       return tw == 16 ? launch_conv_split<3, 16, 64, 2>(p, epi, s) : launch_conv_split<3, 32, 64, 2>(p, epi, s);
     }
+    // small maps with every source blocked: 64-channel tiles (two patch images fit next to their weight images -> all-DMA
+    // staging) with K split over the blocks that leaves, instead of 128-channel tiles on the register-staged path
+    static const int small_dma = getenv("AS_CONV_SMALL_DMA") ? atoi(getenv("AS_CONV_SMALL_DMA")) : 1;
+    bool use64 = bn == 64;
+    if (small_dma && p.all_bs && bn == 128 && !d->dual) {
+      p.n_tiles = p.Cout_pad / 64;
+      conv_pick_ksplit(p, d);
+      use64 = true;
+    }
     if (d->dual) conv_apply_dual(p, d);
-    if (tw == 16) return bn == 128 ? launch_conv_split<3, 16, 128>(p, epi, s) : launch_conv_split<3, 16, 64>(p, epi, s);
-    return bn == 128 ? launch_conv_split<3, 32, 128>(p, epi, s) : launch_conv_split<3, 32, 64>(p, epi, s);
+    if (tw == 16) return use64 ? launch_conv_split<3, 16, 64>(p, epi, s) : launch_conv_split<3, 16, 128>(p, epi, s);
+    return use64 ? launch_conv_split<3, 32, 64>(p, epi, s) : launch_conv_split<3, 32, 128>(p, epi, s);
   }
   if (d->KS == 1) {
     // no halo: run on the flattened H*W plane

@@ -867,8 +867,12 @@ def test_resamplers_blocked_split_output():
             assert (got_hi[:, c:] == 0).all() and (got_lo[:, c:] == 0).all()
 
 
-def test_update_block_links_on_off_bit_identical(monkeypatch):
-    """The whole update block with blocked split-fp16 links == with fp32 links, bit for bit."""
+def test_update_block_links_on_off_equal(monkeypatch):
+    """The whole update block with blocked split-fp16 links == with fp32 links.  A link tensor holds exactly the operand split
+    the consumer would compute, so every convolution sees identical operands; the only difference is that an all-blocked
+    convolution on a small map runs 64-channel tiles with another split-K factor (fp32 partial sums grouped differently):
+    equal to fp32 rounding of that regrouping, bit for bit where no K split is involved
+    (test_conv_blocked_split_link_is_bit_identical)."""
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.models.base import default_args
     from anystereo.nn import update as UP
@@ -893,7 +897,7 @@ def test_update_block_links_on_off_bit_identical(monkeypatch):
                     net, delta = ub(net, inp, corr, disp)
                 outs.append([t.clone() for t in net] + [delta.clone()])
         for a, b in zip(*outs):
-            assert torch.equal(a, b)
+            close(a, b, 2e-6, 2e-6, "links on vs off")
     finally:
         ops.set_precision(prev)
 
