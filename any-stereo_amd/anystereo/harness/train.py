@@ -51,7 +51,15 @@ def shard_batch(batch, rank: int, world: int):
 
 class Trainer:
     """model.train() + freeze_bn + (DDP when a process group exists) + AdamW/OneCycleLR; `step(batch)` runs
-    harness.metrics.train_step and returns (loss, metrics)."""
+    harness.metrics.train_step and returns (loss, metrics).
+
+    DDP without `find_unused_parameters`: in the `multi_training` branch the loss sees only the GRU predictions
+    (train_continuous_IGEV.py:219), and the loop detaches `disp` at every iteration (continuous_IGEVstereo.py:285), so the
+    parameters that only feed `init_disp` (the IGEV `classifier`) never receive a gradient — in the reference as well, where
+    AdamW simply skips them.  The reducer must not wait for them: the FIRST step therefore runs forward + backward once on the
+    bare module, freezes (`requires_grad_(False)`) every parameter that came back without a gradient, and only then wraps the
+    module — a plain DDP whose autograd graph is the same every step, with no per-step graph walk (find_unused_parameters cost
+    10 ms of a 129 ms step in round 1) and no dependence on `static_graph`."""
 
     def __init__(self, model, lr: float = 2e-4, wdecay: float = 1e-5, num_steps: int = 100000, train_iters: int = 16,
                  max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int = 25,
@@ -60,24 +68,51 @@ class Trainer:
         model.freeze_bn()  # train_continuous_IGEV.py:203
         self.model = model
         self.module = model
-        if td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or force_ddp):
-            p = next(model.parameters())
-            ids = [p.device.index] if p.is_cuda else None
-            # the IGEV classifier (and everything else that only feeds init_disp) gets no gradient from
-            # sequence_loss_multiscale: DDP has to be told that some parameters stay unused (measured on one MI355X rank through
-            # RCCL: 139 vs 129 ms per step without the wrapper).  ANYSTEREO_DDP_STATIC=1 tries `static_graph` instead of the
-            # per-step graph walk; it works with gloo on CPU but raised on the GPU box in round 1 — left opt-in.
-            static = os.environ.get("ANYSTEREO_DDP_STATIC", "0") != "0"
-            self.module = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=not static,
-                                                                    static_graph=static, bucket_cap_mb=bucket_cap_mb)
+        self._want_ddp = td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or force_ddp)
+        self._bucket_cap_mb = bucket_cap_mb
+        self.ddp_mode = "none"
+        self.frozen_unused = []
         self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed)
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
         self.train_iters, self.max_disp = train_iters, max_disp
 
-    def step(self, batch):
-        # DDP wraps in train mode; BatchNorm2d must stay frozen even after a .train() from outside
+    def _wrap_ddp(self, batch):
+        """Probe pass on the bare module -> freeze gradient-less parameters -> wrap (see the class docstring)."""
+        from .metrics import sequence_loss_multiscale
+        model = self.model
+        mode = os.environ.get("ANYSTEREO_DDP", "probe")  # probe (default) | find_unused | static
+        if mode == "probe":
+            model.zero_grad(set_to_none=True)
+            image1, image2, hr_coord, gt, scale = batch
+            res = model(image1, image2, iters=min(2, self.train_iters), hr_coord=hr_coord.clone(), scale=scale)
+            preds = res[1] if isinstance(res, tuple) else res
+            loss, _ = sequence_loss_multiscale(preds, gt, (gt < 512) & (gt > 0.0), max_disp=self.max_disp)
+            loss.backward()
+            for n, p in model.named_parameters():
+                if p.requires_grad and p.grad is None:
+                    p.requires_grad_(False)
+                    self.frozen_unused.append(n)
+            model.zero_grad(set_to_none=True)
+        p = next(model.parameters())
+        ids = [p.device.index] if p.is_cuda else None
+        self.module = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=ids, find_unused_parameters=(mode == "find_unused"), static_graph=(mode == "static"),
+            bucket_cap_mb=self._bucket_cap_mb, gradient_as_bucket_view=True)
+        self.ddp_mode = {"probe": f"plain DDP, {len(self.frozen_unused)} gradient-less parameter tensors frozen after a probe pass",
+                         "find_unused": "find_unused_parameters", "static": "static_graph"}[mode]
+
+    def step(self, batch, sync_grads: bool = True):
+        """One optimisation step.  sync_grads=False (measurement only): DDP's reducer is bypassed (`no_sync`), every rank
+        steps on its local gradient — what a step costs without the all-reduce."""
+        if self._want_ddp and self.module is self.model:
+            self._wrap_ddp(batch)
+        # BatchNorm2d stays frozen whatever the caller did in between (validation's .eval(), a bare .train())
         if not self.module.training:
             self.module.train()
-            self.model.freeze_bn()
+        self.model.freeze_bn()
+        if not sync_grads and self.module is not self.model:
+            with self.module.no_sync():
+                return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
+                                  max_disp=self.max_disp)
         return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
                           max_disp=self.max_disp)

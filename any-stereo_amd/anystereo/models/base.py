@@ -118,11 +118,43 @@ class ContinuousStereoBase(nn.Module):
     # ---- whole-forward hipGraph ---------------------------------------------------------------
     # A 32-iteration forward is ~2000 short launches; replaying it as ONE captured graph removes the host
     # launch path (PyTorch dispatch + ctypes) from the critical path.  Opt-in (`enable_graph(True)`), inference
-    # only, one graph per (input shapes, iters); inputs are copied into static buffers, the result is a clone.
+    # only; inputs are copied into static buffers, the result is a clone.
+    # A replay runs no Python: it reads the packed / BatchNorm-folded weight buffers that existed at capture time.  So a
+    # graph is keyed on (input shapes, iters, device, matrix-core mode, WEIGHTS FINGERPRINT): an optimizer step,
+    # load_state_dict(), .to() / .half() or set_precision() between two calls selects (captures) another graph instead of
+    # replaying stale weights; train() / load_state_dict() / _apply() drop every graph.  Not seen by the fingerprint:
+    # writes through `.data` (they do not bump the version counter) — call `enable_graph(True)` again after such edits.
+    # The cache is an LRU of `graph_cache_size` entries (each holds a private memory pool with a whole forward), so
+    # datasets with per-image sizes (ETH3D, Middlebury) do not grow memory without bound.
+    graph_cache_size = 2
+
     def enable_graph(self, flag: bool = True):
         self._use_graph = bool(flag)
-        if not flag:
-            self._graphs = {}
+        self._graphs = {}
+
+    def _weights_fingerprint(self):
+        ver = ptr = n = 0
+        for t in list(self.parameters()) + list(self.buffers()):
+            ver += t._version
+            ptr ^= t.data_ptr() + 0x9E3779B97F4A7C15 * n & 0xFFFFFFFFFFFFFFFF
+            n += 1
+        return (n, ver, ptr)
+
+    def _drop_graphs(self):
+        if self.__dict__.get("_graphs"):
+            self.__dict__["_graphs"] = {}
+
+    def train(self, mode: bool = True):
+        self._drop_graphs()
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **k):
+        self._drop_graphs()
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_graphs()
+        return super()._apply(fn, *a, **k)
 
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
         """Reference signature (continuous_IGEVstereo.py:239, prune_raft_stereo.py:246)."""
@@ -133,10 +165,13 @@ class ContinuousStereoBase(nn.Module):
                                   hr_coord=hr_coord, scale=scale, output_raw=output_raw)
 
     def _forward_graphed(self, image1, image2, iters, hr_coord, scale):
-        key = (tuple(image1.shape), tuple(hr_coord.shape), tuple(scale.shape), int(iters), image1.device.index)
+        key = (tuple(image1.shape), tuple(hr_coord.shape), tuple(scale.shape), int(iters), image1.device.index,
+               ops.get_precision(), self._weights_fingerprint())
         graphs = self.__dict__.setdefault("_graphs", {})
-        ent = graphs.get(key)
+        ent = graphs.pop(key, None)
         if ent is None:
+            while len(graphs) >= max(1, self.graph_cache_size):  # least recently used first (dict order = recency)
+                graphs.pop(next(iter(graphs)))
             st = [t.detach().clone() for t in (image1, image2, hr_coord, scale)]
             side = torch.cuda.Stream(device=image1.device)
             side.wait_stream(torch.cuda.current_stream())
@@ -150,7 +185,8 @@ class ContinuousStereoBase(nn.Module):
             st[2].copy_(hr_coord)
             with torch.cuda.graph(g):
                 out = self._forward_impl(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
-            ent = graphs[key] = (g, st, out)
+            ent = (g, st, out)
+        graphs[key] = ent  # (re-)insert as most recently used
         g, st, out = ent
         st[0].copy_(image1)
         st[1].copy_(image2)

@@ -1,22 +1,29 @@
-"""Headline benchmark (BASELINE.json): stereo pairs/s and ms per GRU iteration of
-coreContinuous_IGEV inference on a 960x540 SceneFlow-shape synthetic pair, 32 iterations, fp32.
+"""Headline benchmark (BASELINE.json): stereo pairs/s and ms per GRU iteration of coreContinuous_IGEV inference on a
+960x540 SceneFlow-shape synthetic pair, 32 iterations (cfg 2), fp32 storage.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W]            N > 1: this process spawns N ranks itself (one per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (the driver's form)
 
-One process per GPU; every rank runs the same per-GPU workload on its own pair (independent
-units, no data-path collective: "replicas", weak scaling).  A step = one full forward pass
-(backbones on PyTorch-ROCm/MIOpen, hot path on libanystereo_hip.so) with inputs resident in HBM.
-Rank 0 prints ONE JSON line.  Extra objects on that line:
-  roofline      dominant kernel (by time) measured with HIP events on its launch stream in the timed steps
-  rooflines     the same figure for every hot kernel class (north_star quotes build+lookup vs HBM)
-  cpu_baseline  the CPU oracle (oracle/model.py) timed on this host's cores on a bounded sample
+One process per GPU over RCCL; every rank runs the same per-GPU workload on its own pair (independent units, no
+data-path collective: "replicas", weak scaling).  A step = one full forward pass (backbones on PyTorch-ROCm/MIOpen, hot path
+on libanystereo_hip.so) with inputs resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects on that line:
+  roofline        dominant kernel (by time), HIP events on its launch stream
+  rooflines       the same figure for every hot kernel class; HBM-bound ones warm (working set in the Infinity Cache),
+                  cold (operand sets rotated, > 256 MB) and co-scheduled inside the two-stream GRU loop
+  parity          EPE of this run's output against the CPU oracle's output on the same input, split and fp32 mode
+  fp32_mode       the same workload in exact-fp32 MFMA mode (the same-precision figure next to the split-precision headline)
+  other_configs   cfg 3 (KITTI x2.0) and cfg 5 (Middlebury-F x1.5, 48 iterations) pairs/s, N = 1 only
+  cpu_baseline    the CPU oracle (oracle/model.py) timed on this host's cores: cfg 2 (and cfg 1 under `also`)
+`--mode train` = cfg 4 (DDP training step).  Without a visible GPU the launcher protocol alone runs (gloo, "dry_run").
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,66 +32,189 @@ for p in (ROOT, os.path.join(ROOT, "any-stereo_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
+torch = None  # imported by main() in the worker ranks only: the spawning parent never touches torch or the GPU
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16/bf16 MFMA dense peak (~2.5 PF)
+INFINITY_CACHE_MB = 256
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--height", type=int, default=540)
-    ap.add_argument("--width", type=int, default=960)
-    ap.add_argument("--iters", type=int, default=32)
-    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"],
+                    help="workload of `value` (harness/workloads.py); the default is the configuration BASELINE.json's metric is quoted on")
+    ap.add_argument("--height", type=int, default=None, help="custom workload: wanted output height (with --width)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--iters", type=int, default=None)
+    ap.add_argument("--scale", type=float, default=None)
     ap.add_argument("--pairs-per-gpu", type=int, default=1,
                     help="stereo pairs per forward on each GPU (1 = the reference's evaluation protocol; >1 = throughput mode)")
     ap.add_argument("--no-batched", action="store_true", help="skip the extra 4-pairs-per-forward throughput measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip fp32_mode / other_configs / cold-cache timing (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="run the GRU loop eagerly instead of as a captured hipGraph")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline benchmark (default); train = cfg 4: DDP training steps at 160x320, 16 GRU iterations")
     ap.add_argument("--batch-per-gpu", type=int, default=4, help="train mode: samples per rank (global batch 32 = 4 x 8)")
     ap.add_argument("--train-iters", type=int, default=16)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def algorithmic(B, h, w, Q, iters, C=96, L=2, G=8, D=48, r=4):
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun -> N child ranks, one per GPU; the parent touches no GPU
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a) -> int:
+    """Spawn `a.gpus` fresh processes running this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what
+    torch.distributed.run would export).  Rank 0 inherits stdout (the ONE JSON line); the other ranks' stdout goes to
+    stderr.  Exit code = the worst child's."""
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def _dist_init(backend_gpu: bool, local: int):
+    import torch.distributed as td
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend_gpu:
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" IS RCCL on ROCm
+    else:
+        td.init_process_group("gloo")
+    return td
+
+
+def dry_main(a, rank, world):
+    """No GPU visible: rehearse the N-rank protocol only (rendezvous, barrier, timed steps, MAX over ranks, gather of the
+    per-rank values) over gloo.  Nothing of the hot path runs and no throughput is claimed (`value` is null)."""
+    td = _dist_init(False, 0) if world > 1 else None
+    x = torch.ones(64, 64)
+    for _ in range(a.warmup):
+        x = x @ x * 1e-3
+    if td:
+        td.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        x = x @ x * 1e-3
+        time.sleep(0.002)
+    if td:
+        td.barrier()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if td:
+        t = torch.tensor([dt], dtype=torch.float64)
+        gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        td.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        sys.stderr.write("bench.py: no GPU visible - dry run of the launch protocol over gloo; the hot path has no CPU fallback\n")
+        print(json.dumps({"metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)", "value": None,
+                          "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "launch protocol only (no GPU visible)", "parallelism": f"replicas x{world}",
+                                     "backend": "gloo"},
+                          "per_rank_step_s": [round(v / a.steps, 5) for v in per_rank], "roofline": None, "cpu_baseline": None}))
+    if td:
+        td.barrier()
+        td.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# algorithmic work (SURVEY.md §8d)
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def algorithmic(B, h, w, Q, C=96, L=2, G=8, D=48, r=4):
     """Algorithmic bytes / flops per launch."""
     P = B * h * w
     build_b = 4 * (2 * B * C * h * w + sum(P * (w >> i) for i in range(L)))
     geo_b = 4 * (B * G * D * h * w + sum(P * G * (D >> i) for i in range(L)))
     lookup_b = 4 * P * (L * (G + 1) * (2 * r + 2) + 1 + L * (G + 1) * (2 * r + 1))
+    # LIIF: compulsory bytes 4*[B(184+160)hw + 2Q + Bhw + Q]; flops Q*84096 (the product applies the first layer at low
+    # resolution, so it executes fewer — the ALGORITHMIC figure is the reference's)
+    liif_b = 4 * (B * (184 + 160) * h * w + 2 * Q * B + B * h * w + Q * B)
     return {
         "corr_build": {"bound": "hbm", "bytes": build_b, "flops": 2 * C * P * w},
         "geo_pyramid": {"bound": "hbm", "bytes": geo_b},
         "lookup": {"bound": "hbm", "bytes": lookup_b},
+        "lookup_convc1": {"bound": "hbm", "bytes": 4 * P * (L * (G + 1) * (2 * r + 2) + 1) + 4 * P * 64},
         "gwc_volume": {"bound": "hbm", "bytes": 4 * (2 * B * C * h * w + B * G * D * h * w)},
         # 3x3 convs of gru04: zr = (3*128 -> 256), q = (3*128 -> 128)
         "gru04_zr_conv": {"bound": "mfma", "flops": 2 * P * 384 * 9 * 256},
         "gru04_q_conv": {"bound": "mfma", "flops": 2 * P * 384 * 9 * 128},
+        "gru08_zr_conv": {"bound": "mfma", "flops": 2 * (P // 4) * 384 * 9 * 256},
+        "gru16_zr_conv": {"bound": "mfma", "flops": 2 * (P // 16) * 256 * 9 * 256},
         "disp_head_conv1": {"bound": "mfma", "flops": 2 * P * 128 * 9 * 256},
         # layers 2..4 at query resolution (the first Linear layer runs at low resolution: liif_mlp_lowres)
         "liif_mlp": {"bound": "mfma", "flops": 2 * Q * B * (128 * 64 + 64 * 64 + 64 * 9)},
+        "liif_tail": {"bound": "hbm", "bytes": liif_b, "flops": 2 * Q * B * (128 * 64 + 64 * 64 + 64 * 9)},
     }
 
 
-def train_main(a):
+def src_hash() -> str:
+    """Content hash of the kernel sources: ties a committed profile to the code it was taken on (the GPU box has no .git)."""
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "any-stereo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    (profiles/rNN_pmc_traffic.json, produced by tools/profile_round.sh + tools/summarize_pmc.py with the guide's gfx950
+    FETCH_SIZE correction).  NOT measured in this run: the line says so under `traffic_source`."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return {}, None
+    d = json.load(open(files[-1]))
+    meta = d.get("_meta", {})
+    now = src_hash()
+    source = {"file": os.path.relpath(files[-1], ROOT), "measured_in_this_run": False,
+              "profile_src_hash": meta.get("src_hash"), "current_src_hash": now,
+              "kernel_sources_unchanged_since_profile": meta.get("src_hash") == now,
+              "collected": meta.get("collected"), "method": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE "
+              "doubled for kernels whose reads are 16 B/lane (MI355X_MICROARCH.md §HBM)"}
+    return {k: (None if v.get("hbm_bytes") is None else int(v["hbm_bytes"])) for k, v in d.items() if not k.startswith("_")}, source
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cfg 4: training
+# ------------------------------------------------------------------------------------------------------------------
+
+
+def train_main(a, rank, world, local):
     """SURVEY.md §8d cfg 4: IGEV training, 4 samples per GPU at 160x320 network input, 51 200 HR queries per sample, 16 GRU
     iterations with the LIIF upsampler every iteration, AdamW + OneCycleLR; one process per GPU, DDP over RCCL.  A step =
     zero_grad + forward + loss + backward (+ bucketed gradient all-reduce) + clip + optimizer + scheduler step."""
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = world > 1 or "RANK" in os.environ  # under torchrun even one rank goes through RCCL + DDP
-    if dist:
-        import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dist = world > 1 or "RANK" in os.environ  # under a launcher even one rank goes through RCCL + DDP
+    td = _dist_init(True, local) if dist else None
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from anystereo import _lib
@@ -97,29 +227,49 @@ def train_main(a):
     fill_module_deterministic(model, base_seed=1)
     model = model.to(dev)
     tr = Trainer(model, train_iters=a.train_iters, max_disp=args.max_disp, force_ddp=dist)
-    h, w = (160, 320) if (a.height, a.width) == (540, 960) else (a.height, a.width)
+    h, w = (160, 320) if a.height is None else (a.height, a.width)
     batch = synthetic_train_batch(a.batch_per_gpu, h, w, seed=rank, device=dev)
     losses = []
-    for _ in range(a.warmup):
+    for _ in range(max(1, a.warmup)):
         losses.append(float(tr.step(batch)[0]))
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        torch.cuda._sleep(2000)  # ~1 us `spin_kernel`: step marker for tools/profile_train.sh (separates MIOpen's search in warm-up)
-        loss, _ = tr.step(batch)
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def timed(n, sync_grads=True):
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            torch.cuda._sleep(2000)  # ~1 us `spin_kernel`: step marker for tools/profile_train.sh
+            loss, _ = tr.step(batch, sync_grads=sync_grads)
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, loss
+
+    dt, loss = timed(a.steps)
     losses.append(float(loss))
+    per_rank = [dt]
+    overlap = None
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
+        # what the gradient all-reduce costs on the critical path: the same steps with DDP's reducer off (no_sync: every
+        # rank steps on its local gradient) — outside the timed region, reported only
+        n2 = max(2, min(a.steps, 5))
+        dt_ns, _ = timed(n2, sync_grads=False)
+        t2 = torch.tensor([dt_ns], device=dev, dtype=torch.float64)
+        td.all_reduce(t2, op=td.ReduceOp.MAX)
+        ms_sync, ms_nosync = dt / a.steps * 1e3, float(t2.item()) / n2 * 1e3
+        nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
+        overlap = {"ms_per_step_with_allreduce": round(ms_sync, 2), "ms_per_step_no_sync": round(ms_nosync, 2),
+                   "exposed_allreduce_ms": round(ms_sync - ms_nosync, 2), "gradient_bytes": nbytes,
+                   "ddp": tr.ddp_mode}
     if rank == 0:
         nparam = sum(p.numel() for p in model.parameters())
         print(json.dumps({
@@ -129,6 +279,8 @@ def train_main(a):
             "config": {"workload": f"cfg4 continuous_IGEVStereo training {h}x{w}, {a.train_iters} GRU iters, LIIF every iter, "
                                    f"Q={batch[2].shape[1]} queries/sample, AdamW+OneCycleLR, clip 1.0",
                        "global_batch": world * a.batch_per_gpu, "parallelism": f"ddp x{world} (RCCL all-reduce of {nparam} fp32 grads)"},
+            "per_rank_samples_per_s": [round(a.batch_per_gpu * a.steps / v, 3) for v in per_rank],
+            "allreduce_overlap": overlap,
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
             "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample transposes and the update-block/MLP dgrad; wgrad and backbone convs on MIOpen/rocBLAS",
             "roofline": None, "cpu_baseline": None}))
@@ -137,196 +289,339 @@ def train_main(a):
         td.destroy_process_group()
 
 
-def main():
-    a = parse()
-    if a.mode == "train":
-        return train_main(a)
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+# ------------------------------------------------------------------------------------------------------------------
+# inference
+# ------------------------------------------------------------------------------------------------------------------
+
+
+class Runner:
+    """One workload resident on one GPU: model, inputs, step()."""
+
+    def __init__(self, wl, dev, seed, pairs=1, graph=True, model=None, args=None):
+        from anystereo.harness import workloads as WL
+        self.wl, self.dev = wl, dev
+        if model is None:
+            model, args = WL.build_model(wl, device=dev)
+        self.model, self.args = model, args
+        self.cpu_inputs = WL.build_inputs(wl, seed=seed)
+        self.i1, self.i2, self.coord, self.scale = WL.build_inputs(wl, seed=seed, pairs=pairs, device=dev)
+        self.pairs = pairs
+        self.Q = self.coord.shape[1]
+        self.hp, self.wp = self.i1.shape[-2:]
+        self.graph = graph and hasattr(model, "enable_graph")
+        if hasattr(model, "enable_graph"):
+            model.enable_graph(self.graph)
+
+    def step(self, iters=None):
+        with torch.no_grad():
+            return self.model(self.i1, self.i2, iters=iters or self.wl.iters, test_mode=True, hr_coord=self.coord, scale=self.scale)
+
+    def time_steps(self, n, iters=None):
+        self.step(iters)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            out = self.step(iters)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n, out
+
+
+def kernel_stats(run, passes=2, co_scheduled=False):
+    """Per-kernel device times: HIP events on the launch stream around every hot-kernel launch in instrumented EAGER passes
+    of the identical workload (a graph replay has no per-kernel events).  co_scheduled=False: the two-stream loop is
+    serialised so each duration is the kernel alone; True: the loop runs as it does in the timed steps (a kernel's events then
+    include what the other stream's kernels take from it)."""
+    from anystereo.harness import timing
+    model = run.model
+    graphed = run.graph
+    if graphed:
+        model.enable_graph(False)
+    ub = model.update_block
+    par = ub.parallel_encoder
+    ub.parallel_encoder = bool(co_scheduled)
+    run.step()
+    timing.enable(True)
+    for _ in range(passes):
+        # a ~60 ms device-side delay first: the host then enqueues the pass AHEAD of the GPU, so an event pair measures the
+        # kernel between them and not the Python / ctypes time between recording the start event and the launch
+        torch.cuda._sleep(120_000_000)
+        run.step()
+    ks = timing.collect()
+    timing.enable(False)
+    ub.parallel_encoder = par
+    if graphed:
+        model.enable_graph(True)
+    return ks, passes
+
+
+def micro_time_small_kernels(dev, h, w, reps=20, cold=False):
+    """The short HBM-bound kernels (10-60 us) on operands of the workload's shapes (C=96, L=2, G=8, D=48): `reps` launches
+    captured into one hipGraph (the host launch path, ~20 us per call through Python + ctypes, is longer than these kernels)
+    and replayed between one HIP event pair on the launch stream.
+    cold=False: every launch on the SAME operands (120-250 MB: they stay in the 256 MB Infinity Cache).
+    cold=True:  the launches rotate over enough operand sets that > 2 x 256 MB pass between two uses of the same line, so
+    every launch streams from HBM."""
+    from anystereo import ops
+    from anystereo.harness.synthetic import det_uniform
+
+    def make_set(k):
+        f1 = det_uniform((1, 96, h, w), 1 + 10 * k).to(dev)
+        f2 = det_uniform((1, 96, h, w), 2 + 10 * k).to(dev)
+        gev = det_uniform((1, 8, 48, h, w), 3 + 10 * k).to(dev)
+        disp = det_uniform((1, 1, h, w), 4 + 10 * k, 0.0, 40.0).to(dev)
+        return {"f1": f1, "f2": f2, "gev": gev, "disp": disp, "corr": ops.corr_build_pyramid(f1, f2, 2), "geo": ops.geo_pyramid(gev, 2)}
+
+    P = h * w
+    set_mb = {"corr_build": 4 * (2 * 96 * P + P * w * 1.5) / 1e6, "lookup": 4 * (P * 48 * 8 * 1.5 + P * w * 1.5 + 163 * P) / 1e6,
+              "gwc_volume": 4 * (2 * 96 * P + 8 * 48 * P) / 1e6, "geo_pyramid": 4 * (8 * 48 * P * 2.5) / 1e6}
+    nsets = 1
+    if cold:
+        nsets = max(3, int(2.2 * INFINITY_CACHE_MB / min(set_mb.values())) + 1)
+    sets = [make_set(k) for k in range(nsets)]
+    fns = {"corr_build": lambda s: ops.corr_build_pyramid(s["f1"], s["f2"], 2),
+           "lookup": lambda s: ops.geo_corr_lookup(s["geo"], s["corr"], s["disp"], 4),
+           "gwc_volume": lambda s: ops.gwc_volume(s["f1"], s["f2"], 48, 8),
+           "geo_pyramid": lambda s: ops.geo_pyramid(s["gev"], 2)}
+    out = {}
+    for name, fn in fns.items():
+        n = reps if not cold else max(reps, nsets * 2)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for k in range(3):
+                fn(sets[k % nsets])
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for k in range(n):
+                fn(sets[k % nsets])
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        out[name] = {"count": n, "total_ms": s.elapsed_time(e), "operand_sets": nsets,
+                     "bytes_between_reuse_mb": round(set_mb[name] * nsets, 1)}
+        del g
+    return out
+
+
+def roofline_table(kstats, alg, precision, traffic):
+    rooflines = {}
+    for name, st in kstats.items():
+        if name not in alg or st["count"] == 0:
+            continue
+        avg_s = st["total_ms"] / st["count"] * 1e-3
+        e = alg[name]
+        if e["bound"] == "hbm":
+            ach = e["bytes"] / avg_s / 1e9
+            rooflines[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
+                               "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
+        else:
+            ach = e["flops"] / avg_s / 1e12
+            # split precision spends 3 fp16 MFMA products per algorithmic product: the attainable peak for
+            # ALGORITHMIC flops is the fp16 dense peak / 3; in fp32 mode it is the fp32-input MFMA peak
+            peak = MFMA_F16_PEAK_TFLOPS / 3.0 if precision == "split" else MFMA_F32_PEAK_TFLOPS
+            rooflines[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": traffic.get(name),
+                               "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
+    return rooflines
+
+
+def infer_main(a, rank, world, local):
     dist = world > 1
-    if dist:
-        import torch.distributed as td
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    td = _dist_init(True, local) if dist else None
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     from anystereo import _lib
-    from anystereo.harness import timing
-    from anystereo.harness.query import pad_for_multi_train
-    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
-    from anystereo.models import __models__, default_args
-
-    _lib.load()
     from anystereo import ops as _ops
+    from anystereo.harness import workloads as WL
+    _lib.load()
     precision = _ops.get_precision()
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("ANYSTEREO_MIOPEN_BENCHMARK", "0")))
-    args = default_args("continuous_IGEVStereo")
-    model = __models__["continuous_IGEVStereo"](args).eval()
-    fill_module_deterministic(model, base_seed=1)  # random-init weights of the named architecture (no checkpoints offline)
-    model = model.to(dev)
-
-    img1, img2 = synthetic_pair(1, a.height, a.width, shift=8, seed=1234 + rank)
-    i1, i2, coord, _ = pad_for_multi_train(img1, img2, a.scale, divis_by=32)
+    wl = WL.WORKLOADS[a.config]
+    if a.height is not None and a.width is not None:
+        wl = WL.custom(a.height, a.width, a.scale or 1.0, a.iters or 32)
+    elif a.iters is not None or a.scale is not None:
+        wl = WL.Workload(wl.name, wl.model, wl.height, wl.width, a.scale or wl.scale, a.iters or wl.iters, wl.protocol,
+                         wl.divis_by, wl.what)
     nb = max(1, a.pairs_per_gpu)
-    i1, i2 = i1.to(dev).repeat(nb, 1, 1, 1), i2.to(dev).repeat(nb, 1, 1, 1)
-    coord = coord.unsqueeze(0).to(dev).repeat(nb, 1, 1)
-    scale = torch.tensor([[a.scale]] * nb, device=dev)
-    Q = coord.shape[1]
-    hp, wp = i1.shape[-2:]
-    use_graph = not a.no_graph
-    if hasattr(model, "enable_graph"):
-        model.enable_graph(use_graph)
-
-    def step(iters=a.iters):
-        with torch.no_grad():
-            return model(i1, i2, iters=iters, test_mode=True, hr_coord=coord, scale=scale)
+    run = Runner(wl, dev, seed=1234 + rank, pairs=nb, graph=not a.no_graph)
+    model = run.model
 
     for _ in range(a.warmup):
-        out = step()
+        out = run.step()
     torch.cuda.synchronize()
     if dist:
         td.barrier()
     torch.cuda.synchronize()
-    graphed = use_graph and hasattr(model, "enable_graph")
-    if not graphed:
+    from anystereo.harness import timing
+    if not run.graph:
         timing.enable(True)       # HIP events around every hot-kernel launch, on the launch stream
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
+        out = run.step()
     torch.cuda.synchronize()
     if dist:
         td.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if graphed:
-        # the timed steps replay one captured hipGraph (no per-kernel events inside a replay): take the
-        # per-kernel device times from instrumented EAGER passes of the identical workload right after
-        model.enable_graph(False)
-        par = model.update_block.parallel_encoder
-        model.update_block.parallel_encoder = False   # isolated kernel durations: no co-running stream
-        step()
-        timing.enable(True)
-        for _ in range(2):
-            # a ~60 ms device-side delay first: the host then enqueues the pass AHEAD of the GPU, so an event pair measures the
-            # kernel between them and not the Python / ctypes time between recording the start event and the launch (which
-            # inflated the multi-source conv launches by 10-20 % against rocprofv3's durations of the same run)
-            torch.cuda._sleep(120_000_000)
-            step()
-        kstats = timing.collect()
-        timing.enable(False)
-        model.update_block.parallel_encoder = par
-        model.enable_graph(True)
-        ksteps = 2
-    else:
-        kstats = timing.collect()
-        timing.enable(False)
-        ksteps = a.steps
+    out_split = out.float().cpu() if precision == "split" else None
+    out_this = out.float().cpu()
+    per_rank = [dt]
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out).all()
+    if run.graph:
+        kstats, ksteps = kernel_stats(run, passes=2)
+    else:
+        kstats, ksteps = timing.collect(), a.steps
+        timing.enable(False)
 
     # ms per GRU iteration = (t32 - t8) / 24 on the same inputs (SURVEY.md §8d), outside the timed region
-    def timed(iters, reps=3):
-        step(iters)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(reps):
-            step(iters)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t) / reps
-    lo = max(1, a.iters // 4)
-    ms_iter = (timed(a.iters) - timed(lo)) / (a.iters - lo) * 1e3 if a.iters > lo else None
+    lo = max(1, wl.iters // 4)
+    ms_iter = (run.time_steps(3)[0] - run.time_steps(3, lo)[0]) / (wl.iters - lo) * 1e3 if wl.iters > lo else None
 
     # throughput mode (reported next to the headline, never as `value`): 4 pairs per forward fill the 1/8- and
     # 1/16-resolution kernels that leave most CUs idle at one pair; every rank measures, rank 0 reports the job total
     batched = None
     if nb == 1 and not a.no_batched:
         nbb = 4
-        bi1, bi2 = i1.repeat(nbb, 1, 1, 1), i2.repeat(nbb, 1, 1, 1)
-        bcoord, bscale = coord.repeat(nbb, 1, 1), scale.repeat(nbb, 1)
-        with torch.no_grad():
-            for _ in range(2):
-                model(bi1, bi2, iters=a.iters, test_mode=True, hr_coord=bcoord, scale=bscale)
-            torch.cuda.synchronize()
-            if dist:
-                td.barrier()
-            tb = time.perf_counter()
-            for _ in range(3):
-                model(bi1, bi2, iters=a.iters, test_mode=True, hr_coord=bcoord, scale=bscale)
-            torch.cuda.synchronize()
-            if dist:
-                td.barrier()
-            dtb = time.perf_counter() - tb
+        rb = Runner(wl, dev, seed=1234 + rank, pairs=nbb, graph=run.graph, model=model, args=run.args)
+        for _ in range(2):
+            rb.step()
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        tb = time.perf_counter()
+        for _ in range(3):
+            rb.step()
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        dtb = time.perf_counter() - tb
         if dist:
             tt = torch.tensor([dtb], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dtb = float(tt.item())
         batched = {"pairs_per_gpu": nbb, "value": round(world * nbb * 3 / dtb, 4), "unit": "pairs/s",
                    "ms_per_step": round(dtb / 3 * 1e3, 3), "steps": 3}
-        del bi1, bi2, bcoord, bscale
+        del rb
 
     if rank == 0:
-        alg = algorithmic(nb, hp // 4, wp // 4, Q, a.iters)
-        # the short HBM-bound kernels (10-60 us) are re-timed as 20 back-to-back launches (one hipGraph) between ONE
-        # event pair: a start/stop pair around a single launch adds ~3 us of its own (rocprofv3 durations confirm)
-        micro = micro_time_small_kernels(dev, hp // 4, wp // 4)
+        h4, w4 = run.hp // 4, run.wp // 4
+        alg = algorithmic(nb, h4, w4, run.Q)
+        traffic, traffic_source = load_pmc_traffic()
+        # the short HBM-bound kernels are re-timed as back-to-back launches of one hipGraph between ONE event pair: a
+        # start/stop pair around a single launch adds ~3 us of its own (rocprofv3 durations confirm)
+        micro = micro_time_small_kernels(dev, h4, w4)
         for k, v in micro.items():
             kstats[k] = v
-        traffic = load_pmc_traffic()
-        rooflines = {}
-        for name, st in kstats.items():
-            if name not in alg or st["count"] == 0:
-                continue
-            avg_s = st["total_ms"] / st["count"] * 1e-3
-            e = alg[name]
-            if e["bound"] == "hbm":
-                ach = e["bytes"] / avg_s / 1e9
-                rooflines[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
-                                   "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
-            else:
-                ach = e["flops"] / avg_s / 1e12
-                # split precision spends 3 fp16 MFMA products per algorithmic product: the attainable peak for
-                # ALGORITHMIC flops is the fp16 dense peak / 3; in fp32 mode it is the fp32-input MFMA peak
-                peak = MFMA_F16_PEAK_TFLOPS / 3.0 if precision == "split" else MFMA_F32_PEAK_TFLOPS
-                rooflines[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                                   "frac": round(ach / peak, 4), "traffic": traffic.get(name),
-                                   "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
+        rooflines = roofline_table(kstats, alg, precision, traffic)
+        extras = not a.no_extras and world == 1
+        if extras:
+            cold = roofline_table(micro_time_small_kernels(dev, h4, w4, cold=True), alg, precision, {})
+            co, _ = kernel_stats(run, passes=1, co_scheduled=True)
+            co = roofline_table({k: v for k, v in co.items() if k in ("lookup", "lookup_convc1")}, alg, precision, {})
+            for k, r in rooflines.items():
+                if k in cold:
+                    r["cache_state"] = "warm: 20 launches on one operand set (fits the 256 MB Infinity Cache)"
+                    r["frac_cold"], r["avg_us_cold"] = cold[k]["frac"], cold[k]["avg_us"]
+                if k in co:
+                    r["frac_in_loop"], r["avg_us_in_loop"] = co[k]["frac"], co[k]["avg_us"]
         dominant = max(rooflines, key=lambda k: rooflines[k]["total_ms"]) if rooflines else None
         # north_star's own bar: >= 40 % of the HBM roofline on volume build + lookup (a1-a3) — each kernel and the pair together
         ns = None
-        if all(k in rooflines for k in ("corr_build", "geo_pyramid", "lookup")):
-            ks = ("corr_build", "geo_pyramid", "lookup")
-            t_us = sum(rooflines[k]["avg_us"] for k in ks)
-            byt = sum(rooflines[k]["achieved"] * rooflines[k]["avg_us"] for k in ks)  # GB/s * us = kB
-            ns = {"build_plus_lookup_hbm_frac": round(byt / t_us / HBM_PEAK_GBS, 4), "target": 0.40,
+        lk = "lookup" if "lookup" in rooflines else ("lookup_convc1" if "lookup_convc1" in rooflines else None)
+        if lk and all(k in rooflines for k in ("corr_build", "geo_pyramid")):
+            ks = ("corr_build", "geo_pyramid", lk)
+
+            def pooled(fk, uk):
+                t_us = sum(rooflines[k][uk] for k in ks)
+                byt = sum(rooflines[k][fk] * HBM_PEAK_GBS * rooflines[k][uk] for k in ks)
+                return round(byt / t_us / HBM_PEAK_GBS, 4)
+            ns = {"build_plus_lookup_hbm_frac": pooled("frac", "avg_us"), "target": 0.40,
                   "per_kernel": {k: rooflines[k]["frac"] for k in ks},
-                  "note": "one build (all-pairs pyramid + geometry pyramid) + one lookup, algorithmic bytes / measured time / 8 TB/s"}
+                  "note": "one build (all-pairs pyramid + geometry pyramid) + one lookup, algorithmic bytes / measured time / 8 TB/s; "
+                          "warm = operands resident in the Infinity Cache, cold = streamed from HBM"}
+            if all("frac_cold" in rooflines[k] for k in ks):
+                ns["build_plus_lookup_hbm_frac_cold"] = pooled("frac_cold", "avg_us_cold")
+                ns["per_kernel_cold"] = {k: rooflines[k]["frac_cold"] for k in ks}
         cpu = None
+        parity = None
+        oracle_out = None
         if not a.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), bounded sample
-            cpu = cpu_baseline(args, model, img1, img2, a)
+            cpu, oracle_out = cpu_baseline(run)
+            if extras and wl.name == "cfg2":
+                try:
+                    cpu["also"] = {"cfg1": cpu_baseline_cfg1()}
+                except Exception as ex:  # never lose the headline line to the side measurement
+                    cpu["also"] = {"cfg1": {"error": repr(ex)}}
+        fp32_mode = None
+        if extras and precision == "split":
+            fp32_mode, out_fp32 = fp32_mode_run(run, alg, traffic)
+            parity = {"metric": "EPE = mean |disparity - CPU oracle| over all queries of the timed workload, px",
+                      "tolerance": 1e-3, "queries": run.Q * nb, "iters": wl.iters,
+                      "epe_split_vs_fp32": float((out_split - out_fp32).abs().mean())}
+            if oracle_out is not None:
+                parity["epe_vs_oracle"] = {"split": float((out_split - oracle_out).abs().mean()),
+                                           "fp32": float((out_fp32 - oracle_out).abs().mean())}
+                parity["max_abs_vs_oracle"] = {"split": float((out_split - oracle_out).abs().max()),
+                                               "fp32": float((out_fp32 - oracle_out).abs().max())}
+                parity["oracle_mean_abs_disparity"] = float(oracle_out.abs().mean())
+        elif oracle_out is not None:
+            parity = {"metric": "EPE = mean |disparity - CPU oracle| over all queries of the timed workload, px",
+                      "tolerance": 1e-3, "queries": run.Q * nb, "iters": wl.iters,
+                      "epe_vs_oracle": {precision: float((out_this - oracle_out).abs().mean())}}
+        others = None
+        if extras and wl.name == "cfg2":
+            others = {}
+            for name in ("cfg3", "cfg5"):
+                try:
+                    r2 = Runner(WL.WORKLOADS[name], dev, seed=1234, graph=run.graph, model=model, args=run.args)
+                    t_step, o2 = r2.time_steps(3)
+                    lo2 = max(1, r2.wl.iters // 4)
+                    t_lo, _ = r2.time_steps(2, lo2)
+                    others[name] = {"workload": f"{r2.wl.what}, {r2.wl.iters} GRU iters, padded {r2.wp}x{r2.hp}, Q={r2.Q}",
+                                    "value": round(1.0 / t_step, 3), "unit": "pairs/s", "ms_per_step": round(t_step * 1e3, 2),
+                                    "ms_per_gru_iter": round((t_step - t_lo) / (r2.wl.iters - lo2) * 1e3, 4), "steps": 3,
+                                    "finite": bool(torch.isfinite(o2).all())}
+                    del r2, o2
+                    model.enable_graph(run.graph)  # drop that shape's graph pool
+                except Exception as ex:
+                    others[name] = {"error": repr(ex)}
         line = {
             "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",
             "value": round(world * nb * a.steps / dt, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if precision == "fp32" else "f32 (3xf16 split-precision MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": f"coreContinuous_IGEV inference, {a.width}x{a.height} SceneFlow-shape synthetic pair "
-                                   f"(padded {wp}x{hp}), {a.iters} GRU iters, scale {a.scale}, Q={Q} queries, {nb} pair(s) per GPU, "
-                                   f"random-init weights", "pairs_per_gpu": nb, "parallelism": f"replicas x{world}",
-                       "gru_loop": "hipGraph" if use_graph and hasattr(model, "enable_graph") else "eager"},
+            "config": {"workload": f"{wl.what} (padded {run.wp}x{run.hp}), {wl.iters} GRU iters, scale {wl.scale}, Q={run.Q} queries, "
+                                   f"{nb} pair(s) per GPU, random-init weights", "name": wl.name, "pairs_per_gpu": nb,
+                       "parallelism": f"replicas x{world}", "gru_loop": "hipGraph" if run.graph else "eager"},
+            "per_rank_pairs_per_s": [round(nb * a.steps / v, 4) for v in per_rank],
             "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "roofline_source": ("HIP events on the launch stream around each hot-kernel launch, " +
-                                ("2 eager passes of the same workload right after the timed hipGraph replays" if graphed
+                                ("2 eager passes of the same workload right after the timed hipGraph replays" if run.graph
                                  else "inside the timed steps")),
+            "traffic_source": traffic_source,
             "rooflines": rooflines,
             "north_star_roofline": ns,
-            "kernel_times_us": {k: {"avg": round(v["total_ms"] / max(v["count"], 1) * 1e3, 2), "n": v["count"] // ksteps}
+            "kernel_times_us": {k: {"avg": round(v["total_ms"] / max(v["count"], 1) * 1e3, 2), "n": max(1, v["count"] // ksteps)}
                                 for k, v in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
+            "parity": parity,
+            "fp32_mode": fp32_mode,
+            "other_configs": others,
             "throughput_mode": batched,
             "cpu_baseline": cpu,
         }
@@ -336,89 +631,97 @@ def main():
         td.destroy_process_group()
 
 
-def micro_time_small_kernels(dev, h, w, reps=20):
-    """corr_build and lookup on operands of the workload's shapes (C=96, L=2, G=8, D=48): `reps` launches captured
-    into one hipGraph (the host launch path, ~20 us per call through Python + ctypes, is longer than these kernels)
-    and replayed between one HIP event pair on the launch stream."""
+def fp32_mode_run(run, alg, traffic):
+    """The timed workload once more in exact-fp32 MFMA mode (`v_mfma_f32_32x32x2_f32`, peak 157.3 TFLOP/s): the
+    same-precision figure, driver-visible, next to the split-precision headline."""
     from anystereo import ops
-    from anystereo.harness.synthetic import det_uniform
-    f1 = det_uniform((1, 96, h, w), 1).to(dev)
-    f2 = det_uniform((1, 96, h, w), 2).to(dev)
-    gev = det_uniform((1, 8, 48, h, w), 3).to(dev)
-    disp = det_uniform((1, 1, h, w), 4, 0.0, 40.0).to(dev)
-    corr = ops.corr_build_pyramid(f1, f2, 2)
-    geo = ops.geo_pyramid(gev, 2)
-    out = {}
-    for name, fn in (("corr_build", lambda: ops.corr_build_pyramid(f1, f2, 2)),
-                     ("lookup", lambda: ops.geo_corr_lookup(geo, corr, disp, 4)),
-                     ("gwc_volume", lambda: ops.gwc_volume(f1, f2, 48, 8)),
-                     ("geo_pyramid", lambda: ops.geo_pyramid(gev, 2))):
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(reps):
-                fn()
-        g.replay()
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        g.replay()
-        e.record()
-        torch.cuda.synchronize()
-        out[name] = {"count": reps, "total_ms": s.elapsed_time(e)}
-        del g
-    return out
+    ops.set_precision("fp32")
+    try:
+        t_step, out = run.time_steps(3)
+        ks, _ = kernel_stats(run, passes=1)
+        roofs = roofline_table(ks, alg, "fp32", {})
+        keep = {k: roofs[k] for k in ("gru04_zr_conv", "gru04_q_conv", "disp_head_conv1") if k in roofs}
+        dom = max(keep, key=lambda k: keep[k]["total_ms"]) if keep else None
+        res = {"value": round(run.pairs / t_step, 4), "unit": "pairs/s", "ms_per_step": round(t_step * 1e3, 3), "steps": 3,
+               "dtype": "f32 (exact fp32-input MFMA)", "roofline": dict(keep[dom], kernel=dom) if dom else None, "rooflines": keep}
+        return res, out.float().cpu()
+    finally:
+        ops.set_precision("split")
+        run.model.enable_graph(run.graph)
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command (profiles/rNN_pmc_traffic.json, produced by tools/profile_round.sh; gfx950 FETCH_SIZE correction applied)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return {}
-    d = json.load(open(files[-1]))
-    return {k: (None if v.get("hbm_bytes") is None else int(v["hbm_bytes"])) for k, v in d.items() if not k.startswith("_")}
-
-
-def cpu_baseline(args, model, img1, img2, a):
-    """The CPU oracle (same weights) timed on this host: 1 pair of the same workload; if the machine is
-    slow the GRU iteration count of the sample is reduced and the 32-iteration figure extrapolated."""
-    from anystereo.harness.query import pad_for_multi_train
+def cpu_baseline(run):
+    """The CPU oracle (same weights) timed on this host: 1 pair of the same workload; if the machine is slow the GRU
+    iteration count of the sample is reduced and the full figure extrapolated.  Returns (record, oracle output or None):
+    the output of a full-length run is kept so the line can state this run's EPE against it."""
     from oracle.model import OracleIGEV
+    wl = run.wl
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 64))
     torch.set_num_threads(threads)
-    ref = OracleIGEV(args).eval()
-    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
-    i1, i2, coord, _ = pad_for_multi_train(img1, img2, a.scale, divis_by=32)
-    coord = coord.unsqueeze(0)
-    sc = torch.tensor([[a.scale]])
+    ref = OracleIGEV(run.args).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in run.model.state_dict().items()})
+    i1, i2, coord, sc = run.cpu_inputs
 
-    def run(iters):
+    def go(iters):
         t = time.perf_counter()
         with torch.no_grad():
-            ref(i1, i2, iters=iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
-        return time.perf_counter() - t
-    run(1)  # warm-up (thread pools, allocator)
-    t2, t6 = run(2), run(6)
+            o = ref(i1, i2, iters=iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        return time.perf_counter() - t, o
+    go(1)  # warm-up (thread pools, allocator)
+    t2, t6 = go(2)[0], go(6)[0]
     per_iter = max((t6 - t2) / 4, 1e-6)
-    est_full = t2 + per_iter * (a.iters - 2)
+    est_full = t2 + per_iter * (wl.iters - 2)
+    out = None
     if est_full <= 45.0:
-        t_full = run(a.iters)
-        sample = f"1 pair, full workload ({a.iters} iters), fp32, {threads} threads"
+        t_full, out = go(wl.iters)
+        sample = f"1 pair, full workload ({wl.iters} iters), fp32, {threads} threads"
     else:
         t_full = est_full
-        sample = (f"1 pair at 2 and 6 GRU iters ({t2:.1f}s, {t6:.1f}s), extrapolated to {a.iters} iters, fp32, "
+        sample = (f"1 pair at 2 and 6 GRU iters ({t2:.1f}s, {t6:.1f}s), extrapolated to {wl.iters} iters, fp32, "
                   f"{threads} threads")
     return {"value": round(1.0 / t_full, 5), "unit": "pairs/s", "cores": threads, "kind": "port", "sample": sample,
-            "s_per_pair": round(t_full, 3), "ms_per_gru_iter": round(per_iter * 1e3, 2)}
+            "config": wl.name, "s_per_pair": round(t_full, 3), "ms_per_gru_iter": round(per_iter * 1e3, 2)}, \
+        (None if out is None else out.float())
+
+
+def cpu_baseline_cfg1():
+    """BASELINE.md §4 also asks for cfg 1 (corePrune_RAFT, 256x512, 8 GRU iterations) on the host cores."""
+    from anystereo.harness import workloads as WL
+    from oracle.model import OracleRAFT
+    wl = WL.WORKLOADS["cfg1"]
+    model, args = WL.build_model(wl)
+    ref = OracleRAFT(args).eval()
+    ref.load_state_dict(model.state_dict())
+    i1, i2, coord, sc = WL.build_inputs(wl)
+    threads = torch.get_num_threads()
+
+    def go():
+        t = time.perf_counter()
+        with torch.no_grad():
+            ref(i1, i2, iters=wl.iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        return time.perf_counter() - t
+    go()
+    ts = sorted(go() for _ in range(3))
+    return {"value": round(1.0 / ts[1], 4), "unit": "pairs/s", "cores": threads, "kind": "port", "s_per_pair": round(ts[1], 3),
+            "sample": f"{wl.what}, {wl.iters} GRU iters, Q={coord.shape[1]}, median of 3, fp32, {threads} threads"}
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))
+    global torch
+    import torch as _torch
+    torch = _torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        return dry_main(a, rank, world)
+    if a.mode == "train":
+        return train_main(a, rank, world, local)
+    return infer_main(a, rank, world, local)
 
 
 if __name__ == "__main__":

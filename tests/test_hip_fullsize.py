@@ -306,3 +306,120 @@ def test_cfg4_training_steps_fullsize():
         outs.append(preds[-1].detach())
     model.sort_queries = True
     assert (outs[0] - outs[1]).abs().max().item() < 1e-3
+
+
+# ---- whole forward at FULL size against the CPU oracle (same weights, same inputs) -----------------------------
+# The oracle (oracle/model.py, pinned to the imported reference by tests/golden/model_*.npz) finishes cfg 2 / cfg 3 in
+# ~10-15 s on the GPU box's host cores, so the recurrent loop's drift over all 32 iterations is MEASURED, in both
+# matrix-core modes, against north_star's bar: EPE (mean |HIP - oracle| over every query) < 1e-3 px.
+def _oracle_for(wl, model, args):
+    from oracle.model import OracleIGEV, OracleRAFT
+    ref = (OracleIGEV if "IGEV" in wl.model else OracleRAFT)(args).eval()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    return ref
+
+
+def _run_modes(model, inputs, iters, modes=("split", "fp32")):
+    from anystereo import ops
+    i1, i2, coord, sc = inputs
+    prev = ops.get_precision()
+    outs = {}
+    try:
+        for m in modes:
+            ops.set_precision(m)
+            with torch.no_grad():
+                outs[m] = model(i1, i2, iters=iters, test_mode=True, hr_coord=coord.clone(), scale=sc).float().cpu()
+    finally:
+        ops.set_precision(prev)
+    return outs
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_whole_forward_fullsize_vs_oracle(cfg):
+    """cfg 2 (960x540, Q = 518 400) and cfg 3 (KITTI 1242x375 x2.0, Q = 1 863 000), all 32 GRU iterations, split and
+    exact-fp32 mode: EPE vs the CPU oracle < 1e-3 (continuous_IGEVstereo.py:239-305; cfg 3 protocol
+    evaluation_validate.py:92-106)."""
+    from anystereo.harness import workloads as WL
+    wl = WL.WORKLOADS[cfg]
+    model, args = WL.build_model(wl, device=DEV)
+    cpu_in = WL.build_inputs(wl)
+    outs = _run_modes(model, tuple(t.to(DEV) for t in cpu_in), wl.iters)
+    ref = _oracle_for(wl, model, args)
+    torch.set_num_threads(min(64, __import__("os").cpu_count() or 1))
+    with torch.no_grad():
+        want = ref(cpu_in[0], cpu_in[1], iters=wl.iters, test_mode=True, hr_coord=cpu_in[2].clone(), scale=cpu_in[3])
+    q = cpu_in[2].shape[1]
+    assert want.shape == (1, 1, q)
+    for m, got in outs.items():
+        assert got.shape == want.shape and torch.isfinite(got).all()
+        epe = (got - want).abs().mean().item()
+        worst = (got - want).abs().max().item()
+        print(f"[{cfg} {m}] EPE vs oracle {epe:.3e}, max {worst:.3e}, |disp| mean {want.abs().mean().item():.2f}")
+        assert epe < 1e-3, f"{cfg} {m}: EPE vs CPU oracle {epe:.3e} >= 1e-3"
+    assert (outs["split"] - outs["fp32"]).abs().mean().item() < 1e-3
+
+
+def test_cfg5_whole_forward_fullsize():
+    """cfg 5 (Middlebury-F output 2880x1988 at x1.5: 1/4-res map 336x480, 48 iterations, 5 725 440 queries through the real
+    > 2^20-query slab path): finite, bitwise repeatable, hipGraph == eager; and agreement with the CPU oracle on a query
+    subset (every 16th query: the per-query stage is independent of the other queries, so the oracle needs only those)
+    at 12 iterations — the full-length oracle run would take minutes of host time."""
+    from anystereo.harness import workloads as WL
+    wl = WL.WORKLOADS["cfg5"]
+    model, args = WL.build_model(wl, device=DEV)
+    cpu_in = WL.build_inputs(wl)
+    i1, i2, coord, sc = (t.to(DEV) for t in cpu_in)
+    q = coord.shape[1]
+    assert q == 1988 * 2880 and q > model.liif_up.query_chunk
+    prev_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        with torch.no_grad():
+            model(i1, i2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            a = model(i1, i2, iters=wl.iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            b = model(i1, i2, iters=wl.iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            model.enable_graph(True)
+            c = model(i1, i2, iters=wl.iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            model.enable_graph(False)
+            short = model(i1, i2, iters=12, test_mode=True, hr_coord=coord.clone(), scale=sc).cpu()
+    finally:
+        torch.backends.cudnn.deterministic = prev_det
+    assert a.shape == (1, 1, q) and torch.isfinite(a).all()
+    assert torch.equal(a, b), "cfg 5 eager forward is not bitwise repeatable"
+    assert (a - c).abs().max().item() < 1e-3, "cfg 5 hipGraph replay differs from eager"
+    del a, b, c
+    ref = _oracle_for(wl, model, args)
+    sub = torch.arange(0, q, 16)
+    torch.set_num_threads(min(64, __import__("os").cpu_count() or 1))
+    with torch.no_grad():
+        want = ref(cpu_in[0], cpu_in[1], iters=12, test_mode=True, hr_coord=cpu_in[2][:, sub].clone(), scale=cpu_in[3])
+    epe = (short[:, :, sub] - want).abs().mean().item()
+    print(f"[cfg5 split, 12 iters, {sub.numel()} of {q} queries] EPE vs oracle {epe:.3e}")
+    assert epe < 1e-3, f"cfg 5: EPE vs CPU oracle on the query subset {epe:.3e} >= 1e-3"
+
+
+@pytest.mark.parametrize("hw", [(96, 312), (336, 480)])
+def test_gru_convs_cfg3_cfg5_sizes(hw):
+    """The GRU gate convolutions at the 1/4-resolution sizes of cfg 3 (96x312) and cfg 5 (336x480), split mode with
+    blocked links as the model runs them: against the fp64 convolution on row bands (top, middle, bottom: tile and
+    image borders)."""
+    import torch.nn.functional as F
+    from anystereo import _lib as L
+    from anystereo import ops
+    h, w = hw
+    xs = [U((1, 128, h, w), 50 + i, -1.5, 1.5).to(DEV) for i in range(3)]
+    wz = (U((256, 384, 3, 3), 60) * (3.0 / (384 * 9)) ** 0.5).to(DEV)
+    bz = (U((256,), 61) * 0.1).to(DEV)
+    ctx = U((1, 384, h, w), 62).to(DEV)
+    pz = ops.PackedConv().get([wz], [bz])
+    z, rh = ops.conv2d(xs, pz, add=ctx, add_coff=0, epilogue=L.EPI_GRU_ZR, h=xs[0])
+    x64 = torch.cat(xs, 1).double()
+    for r0 in (0, h // 2 - 4, h - 8):
+        lo, hi = max(0, r0 - 1), min(h, r0 + 9)
+        lin = F.conv2d(x64[:, :, lo:hi], wz.double(), bz.double(), padding=1)
+        # rows of the band whose 3x3 support lies inside [lo, hi) or at the true image border
+        keep = slice((r0 - lo), (r0 - lo) + 8)
+        lin = lin[:, :, keep] + ctx[:, :256, r0:r0 + 8].double()
+        zr = torch.sigmoid(lin)
+        assert (z[:, :, r0:r0 + 8].double() - zr[:, :128]).abs().max().item() < 2e-5
+        assert (rh[:, :, r0:r0 + 8].double() - zr[:, 128:] * xs[0][:, :, r0:r0 + 8].double()).abs().max().item() < 4e-5
