@@ -57,6 +57,10 @@ SIGNATURES = {
     "as_geo_pyramid": (_i, [_vp, _pp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_geo_corr_lookup_fwd": (_i, [_pp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_geo_corr_lookup_bwd": (_i, [_vp, _vp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_lookup_convc1_pack_bytes": (C.c_int64, [_i]),
+    "as_lookup_convc1_pack": (_i, [_vp, _i, _vp, _vp]),
+    "as_lookup_convc1_fwd": (_i, [_pp, _pp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_lookup_split_overflow": (C.c_uint, [_i]),
     "as_gwc_volume_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_disparity_regression": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "as_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
@@ -82,6 +86,15 @@ SIGNATURES = {
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_liif_gather_mlp1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_convex_upsample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_affinity": (_i, [_pp, C.POINTER(C.c_int), _i, _vp, _vp, _i, _i, _i, _vp]),
+    "as_liif_affinity_ws_bytes": (C.c_int64, [_i, _i, _i, _i]),
+    "as_liif_lowres_pack_bytes": (C.c_int64, [_i]),
+    "as_liif_lowres_pack": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "as_liif_lowres_cl": (_i, [_pp, C.POINTER(C.c_int), _i, _vp, _vp, _i, _i, _i, _vp]),
+    "as_liif_tail_image_bytes": (C.c_int64, []),
+    "as_liif_tail_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "as_liif_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_split_overflow": (C.c_uint, [_i]),
     "as_corr_pyramid_bwd": (_i, [_pp, _vp, C.c_longlong, _i, _i, _vp]),
     "as_geo_pyramid_bwd": (_i, [_pp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_gwc_volume_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

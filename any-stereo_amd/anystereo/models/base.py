@@ -201,7 +201,6 @@ class ContinuousStereoBase(nn.Module):
         (continuous_IGEVstereo.py:192-237, prune_raft_stereo.py:200-242)."""
         if stem_1x is not None:
             raise NotImplementedError("stem_1x (agg_type 'type2') is not built")
-        x = torch.cat((stem_4x.float(), hidden_layer.float()), 1) if stem_4x is not None else hidden_layer.float()
         b = disp.shape[0]
         if torch.is_tensor(scale):
             scale_vec = scale.reshape(-1).float().to(disp.device)
@@ -211,6 +210,13 @@ class ContinuousStereoBase(nn.Module):
         else:
             scale_vec = torch.full((b,), float(scale), device=disp.device, dtype=torch.float32)
         hr = hr_coord if (hr_coord.dtype == torch.float32 and hr_coord.is_contiguous()) else hr_coord.float().contiguous()
+        parts = [[stem_4x, hidden_layer] if stem_4x is not None else [hidden_layer]] + ([[stem_2x]] if stem_2x is not None else [])
+        if (type(self)._hot_upsample is ContinuousStereoBase._hot_upsample
+                and not G.needs_grad(disp, hidden_layer, *self.liif_up.parameters()) and self.liif_up.fused_ok(parts, hr)):
+            # inference: affinity -> first MLP layer at low resolution -> ONE per-query kernel (gather, MLP, softmax, convex
+            # combination); cat(stem_4x, hidden) (:195), the latent, the hidden layers and the mask never reach HBM
+            return self.liif_up.upsample_fused(parts, hr, disp.float().contiguous(), scale_vec)
+        x = torch.cat((stem_4x.float(), hidden_layer.float()), 1) if stem_4x is not None else hidden_layer.float()
         return self._hot_upsample(disp, x.contiguous(), None if stem_2x is None else stem_2x.float().contiguous(), hr, scale_vec)
 
     # Inference schedule of the GRU loop (same operators, same operands, same results as the loop below).
@@ -235,8 +241,10 @@ class ContinuousStereoBase(nn.Module):
         main = torch.cuda.current_stream(dev)
         side = ub._side_stream(dev)
         side.wait_stream(main)
+        fused = ub.encoder.fused_lookup_ok(lookup_fn)  # lookup -> convc1 as one kernel (no [B,162,h,w] tensor)
+        enc = (lambda d: ub.encoder.forward_fused_lookup(d, lookup_fn)) if fused else (lambda d: ub.encoder(d, lookup_fn(d, coords)))
         with torch.cuda.stream(side):
-            mf = ub.encoder(disp, lookup_fn(disp, coords))
+            mf = enc(disp)
         for itr in range(iters):
             pre = ub.gru04.pre_zr(net[0], *(inp[0])) if self.split_gate_conv else None
             net[2] = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
@@ -253,7 +261,7 @@ class ContinuousStereoBase(nn.Module):
             with torch.cuda.stream(side):
                 disp = ub.disp_head(net[0], addend=disp)
                 if itr + 1 < iters:
-                    mf = ub.encoder(disp, lookup_fn(disp, coords))
+                    mf = enc(disp)
         main.wait_stream(side)
         disp.record_stream(main)
         return disp

@@ -53,6 +53,18 @@ class Combined_Geo_Encoding_Volume:
         with scope("lookup"):
             return ops.geo_corr_lookup(self.geo_volume_pyramid, self.init_corr_pyramid, disp, self.radius)
 
+    def fused_convc1_ok(self) -> bool:
+        """lookup -> convc1 in one kernel: inference, split precision, radius 4 with (G, L) = (8, 2) or (0, 4)."""
+        levels = list(self.geo_volume_pyramid) + list(self.init_corr_pyramid)
+        return (not _needs_grad(*levels) and ops.get_precision() == "split"
+                and ops.lookup_convc1_supported(self.geo_volume_pyramid, self.init_corr_pyramid, self.radius))
+
+    def lookup_convc1(self, disp, pack, out_bs=None, want_f32=False):
+        """relu(convc1(self(disp))) without the [B,162,h,w] tensor (geometry.py:34-60 + update.py:84-85)."""
+        with scope("lookup_convc1"):
+            return ops.lookup_convc1(self.geo_volume_pyramid, self.init_corr_pyramid, disp.float().contiguous(), self.radius, pack,
+                                     out_bs=out_bs, want_f32=want_f32)
+
     @staticmethod
     def corr(fmap1, fmap2):
         """All-pairs correlation only -> [B,h,w1,1,w2] (geometry.py:63-72)."""

@@ -177,6 +177,46 @@ class liif_out_multi_scale_Training(nn.Module):
             wrel = torch.cat([lin0.weight.detach()[:, o:o + 2] for o in rel_cols], dim=1).float().contiguous()
         return us, wrel, None if lin0.bias is None else lin0.bias.detach().float().contiguous()
 
+    # ---- fused inference pipeline (csrc/liif_fused.hip) -----------------------------------------------------------
+    fused_tail = __import__("os").environ.get("ANYSTEREO_FUSED_LIIF", "1") != "0"
+
+    def fused_ok(self, feats_parts, coord) -> bool:
+        """The one-kernel tail exists for the default configuration: <= 2 inputs, MLP 128-64-64-9, split-precision mode,
+        inference.  Everything else takes the staged path (same function)."""
+        lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
+        return (self.fused_tail and coord.is_cuda and not torch.is_grad_enabled() and len(feats_parts) in (1, 2)
+                and [tuple(m.weight.shape) for m in lin[1:]] == [(64, 128), (64, 64), (9, 64)] and lin[0].weight.shape[0] == 128
+                and ops.get_precision() == "split" and all(len(ps) <= 2 for ps in feats_parts)
+                and all(p.shape[1] % 16 == 0 for ps in feats_parts for p in ps))
+
+    def upsample_fused(self, feats_parts, coord, disp, scale_vec, want_logits=False):
+        """feats_parts: per LIIF input the list of NCHW tensors whose channel concat is that input (e.g. [[stem_4x, net0],
+        [stem_2x]]: the concat of continuous_IGEVstereo.py:195 is never materialised).  coord [B,Q,2] is clamped IN PLACE
+        (submodule.py:366).  -> disp_up [B,1,Q] (and the mask logits [B,9,Q], `forward`'s return value, when asked)."""
+        lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
+        w1 = lin[0].weight
+        if not hasattr(self, "_lowres_packs"):
+            self._lowres_packs = [ops.LiifLowresPack() for _ in range(2)]
+        us, sizes, rel_cols, off = [], [], [], 0
+        for parts, lpk in zip(feats_parts, self._lowres_packs):
+            parts = [p_.float().contiguous() for p_ in parts]
+            c = sum(p_.shape[1] for p_ in parts) + 8
+            with scope("structure_feature"):
+                aff = ops.liif_affinity(parts)
+            with scope("liif_mlp_lowres"):
+                us.append(ops.liif_lowres_cl(parts + [aff], lpk.get(w1, off, c)))
+            sizes.append(tuple(parts[0].shape[2:]))
+            rel_cols.append(off + c)
+            off += c + 2
+        if off != w1.shape[1]:
+            raise RuntimeError(f"liif: inputs hold {off} latent channels but the MLP expects {w1.shape[1]}")
+        if not hasattr(self, "_tail_pack"):
+            self._tail_pack = ops.LiifTailPack()
+        pack = self._tail_pack.get(lin, rel_cols)
+        with scope("liif_tail"):
+            return ops.liif_tail(us[0], us[1] if len(us) > 1 else None, sizes, coord, pack, disp, scale_vec,
+                                 clamp_inplace=True, want_logits=want_logits)
+
     def _mask_logits_train(self, sfs, coord):
         """Differentiable form (liif.py:652-678).  With <= 2 sources the first Linear layer is applied at LOW resolution
         (two library 1x1 convs under autograd) and the per-query stage is the fused HIP gather + add + ReLU with its HIP

@@ -256,6 +256,31 @@ class BasicMotionEncoder(nn.Module):
         return self.merge(cd, disp, out)
 
     dual_branches = __import__("os").environ.get("ANYSTEREO_DUAL_BRANCHES", "1") != "0"
+    fused_lookup = __import__("os").environ.get("ANYSTEREO_FUSED_LOOKUP", "1") != "0"
+
+    def fused_lookup_ok(self, lookup_fn) -> bool:
+        return (self.fused_lookup and self.dual_branches and _links() and not torch.is_grad_enabled()
+                and getattr(lookup_fn, "fused_convc1_ok", None) is not None and lookup_fn.fused_convc1_ok()
+                and self.convc1.out_channels == 64 and self.convc1.kernel_size == (1, 1))
+
+    def forward_fused_lookup(self, disp, lookup_fn):
+        """forward(disp, lookup_fn(disp)) with the lookup fused into convc1 (one kernel, blocked split-fp16 result): the
+        [B,162,h,w] correlation features are never written (update.py:84-92 with geometry.py:34-60 inlined)."""
+        disp = _f(disp)
+        cd, out = self.new_buffer(disp), self.new_output(disp)
+        b, _, h, w = disp.shape
+        if not hasattr(self, "_plc1"):
+            self._plc1 = ops.LookupConvPack()
+        cor = ops.BS8.empty(b, 64, h, w, disp.device)
+        lookup_fn.lookup_convc1(disp, self._plc1.get(self.convc1.weight, self.convc1.bias), out_bs=cor)
+        with scope("enc_convd1"):
+            d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()),
+                                     out=ops.BS8.empty(b, 64, h, w, disp.device), copy_out=out, copy_coff=127)
+        with scope("enc_convc2"):
+            second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
+            ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out_bs=cd, out_bs_coff=0,
+                       bs_only=True, dual=second)
+        return self.merge(cd, disp, out)
 
     # The three pieces of forward(), exposed so the inference schedule (models/base.py::_iterate_pipelined) can run
     # the two independent branches on different streams.  cd [B,128,h,w]: channels [0,64) = correlation branch,

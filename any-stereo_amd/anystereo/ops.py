@@ -115,6 +115,72 @@ def geo_corr_lookup(geo: Optional[Sequence[torch.Tensor]], corr: Sequence[torch.
     return out
 
 
+class LookupConvPack:
+    """MFMA fragment image of convc1's weight [64, cin, 1, 1] for the fused lookup + convc1 kernel (rebuilt when the weight
+    or bias changes: identity through weak references + version counters)."""
+
+    def __init__(self):
+        self._key, self._refs, self.image, self.bias = None, None, None, None
+
+    def get(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        ts = [weight, bias]
+        key = tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts)
+        alive = self._refs is not None and all((r is None) == (t is None) and (r is None or r() is t) for r, t in zip(self._refs, ts))
+        if key != self._key or not alive:
+            w = weight.detach().reshape(weight.shape[0], -1).float().contiguous()
+            if w.shape[0] != 64:
+                raise RuntimeError("LookupConvPack: convc1 must have 64 output channels")
+            image = torch.empty(L.load().as_lookup_convc1_pack_bytes(w.shape[1]), device=w.device, dtype=torch.uint8)
+            with torch.cuda.device(w.device):
+                L.check(L.load().as_lookup_convc1_pack(_p(w), w.shape[1], _p(image), _stream()), "lookup_convc1_pack")
+            self.image, self.cin = image, w.shape[1]
+            self.bias = None if bias is None else bias.detach().float().contiguous()
+            self._key, self._refs = key, [None if t is None else weakref.ref(t) for t in ts]
+        return self
+
+
+def lookup_convc1_supported(geo, corr, radius: int) -> bool:
+    g = geo[0].shape[4] if geo else 0
+    return radius == 4 and ((g == 8 and len(corr) == 2) or (g == 0 and len(corr) == 4))
+
+
+def lookup_convc1(geo: Optional[Sequence[torch.Tensor]], corr: Sequence[torch.Tensor], disp: torch.Tensor, radius: int,
+                  pack: LookupConvPack, out_bs: Optional["BS8"] = None, out_bs_coff: int = 0, want_f32: bool = False, relu: bool = True):
+    """relu(convc1(lookup(disp))) in one kernel (geometry.py:34-60 + update.py:84-85): -> fp32 [B,64,H,W] (want_f32) and / or
+    the blocked split-fp16 tensor `out_bs` channels [out_bs_coff, +64)."""
+    _req(disp, "disp")
+    nl = len(corr)
+    b, one, h, w = disp.shape
+    w2 = corr[0].shape[3]
+    for i, t in enumerate(corr):
+        _req(t, f"corr[{i}]")
+        if tuple(t.shape) != (b, h, w, w2 >> i):
+            raise RuntimeError(f"lookup_convc1: corr[{i}] has shape {tuple(t.shape)}, expected {(b, h, w, w2 >> i)}")
+    g = d = 0
+    if geo:
+        d, g = geo[0].shape[3], geo[0].shape[4]
+        for i, t in enumerate(geo):
+            _req(t, f"geo[{i}]")
+            if tuple(t.shape) != (b, h, w, d >> i, g):
+                raise RuntimeError(f"lookup_convc1: geo[{i}] has shape {tuple(t.shape)}")
+    if nl * (2 * radius + 1) * (g + 1) != pack.cin:
+        raise RuntimeError(f"lookup_convc1: the lookup yields {nl * (2 * radius + 1) * (g + 1)} channels, convc1 expects {pack.cin}")
+    out = torch.empty((b, 64, h, w), device=disp.device, dtype=torch.float32) if want_f32 else None
+    if out_bs is None and not want_f32:
+        raise RuntimeError("lookup_convc1: no output requested")
+    if out_bs is not None:
+        _req(out_bs.t, "out_bs", torch.float16)
+        if out_bs.shape[0] != b or tuple(out_bs.shape[2:]) != (h, w):
+            raise RuntimeError("lookup_convc1: out_bs shape mismatch")
+    gp, k1 = L.ptr_array([t.data_ptr() for t in geo]) if geo else (None, None)
+    cp, k2 = L.ptr_array([t.data_ptr() for t in corr])
+    with torch.cuda.device(disp.device):
+        L.check(L.load().as_lookup_convc1_fwd(gp, cp, _p(disp), _p(pack.image), _p(pack.bias), _p(None if out_bs is None else out_bs.t),
+                                              0 if out_bs is None else out_bs.c, out_bs_coff, _p(out), 1 if relu else 0,
+                                              b, h, w, w2, d, g, nl, radius, _stream()), "lookup_convc1_fwd")
+    return out
+
+
 def geo_corr_lookup_backward(disp, d_out, geo_shapes, corr_shapes, radius):
     """Gradients w.r.t. the pyramid levels (transpose of the lookup)."""
     _req(disp, "disp"), _req(d_out, "d_out")
@@ -744,3 +810,128 @@ def convex_upsample(disp, mask, coord, scale=None, mask_is_logits=False):
         L.check(L.load().as_convex_upsample(_p(disp), _p(scale), _p(mask), _p(coord), _p(out), b, h, w, q,
                                             1 if mask_is_logits else 0, _stream()), "convex_upsample")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# LIIF upsampler, fused inference pipeline (csrc/liif_fused.hip)
+# ------------------------------------------------------------------------------------------------
+
+
+def _src_arrays(srcs):
+    ptrs, keep = L.ptr_array([t.data_ptr() for t in srcs])
+    ch = (C.c_int * len(srcs))(*[int(t.shape[1]) for t in srcs])
+    return ptrs, ch, keep
+
+
+def liif_affinity(srcs: Sequence[torch.Tensor]) -> torch.Tensor:
+    """AffinityFeature(cat(srcs, dim=1)) -> [B,8,H,W] without materialising the concat or copying it (liif.py:432-446)."""
+    for i, t in enumerate(srcs):
+        _req(t, f"src[{i}]")
+    b, _, h, w = srcs[0].shape
+    if any(t.shape[0] != b or tuple(t.shape[2:]) != (h, w) for t in srcs) or not 1 <= len(srcs) <= 3:
+        raise RuntimeError("liif_affinity: 1..3 sources of one [B,*,H,W] shape")
+    aff = torch.empty((b, 8, h, w), device=srcs[0].device, dtype=torch.float32)
+    ctot = sum(int(t.shape[1]) for t in srcs)
+    ws = torch.empty(L.load().as_liif_affinity_ws_bytes(b, h, w, (ctot + 7) // 8) // 4, device=srcs[0].device, dtype=torch.float32)
+    ptrs, ch, keep = _src_arrays(srcs)
+    with torch.cuda.device(aff.device):
+        L.check(L.load().as_liif_affinity(ptrs, ch, len(srcs), _p(aff), _p(ws), b, h, w, _stream()), "liif_affinity")
+    return aff
+
+
+class LiifLowresPack:
+    """Split-fp16 MFMA fragments of a column block of the first Linear weight (as_liif_lowres_pack), rebuilt when the weight
+    changes (identity + version counter through a weak reference)."""
+
+    def __init__(self):
+        self._key, self._ref, self.image = None, None, None
+
+    def get(self, weight: torch.Tensor, koff: int, k: int):
+        key = (weight.data_ptr(), weight._version, weight.device, koff, k)
+        if key != self._key or self._ref is None or self._ref() is not weight:
+            w = weight.detach()
+            w = w if (w.dtype == torch.float32 and w.is_contiguous()) else w.float().contiguous()
+            if w.dim() != 2 or w.shape[0] != 128:
+                raise RuntimeError("LiifLowresPack: weight must be [128, in_dim]")
+            image = torch.empty(L.load().as_liif_lowres_pack_bytes(k), device=w.device, dtype=torch.uint8)
+            with torch.cuda.device(w.device):
+                L.check(L.load().as_liif_lowres_pack(_p(w), w.shape[1], koff, k, _p(image), _stream()), "liif_lowres_pack")
+            self.image, self._key, self._ref = image, key, weakref.ref(weight)
+        return self
+
+
+def liif_lowres_cl(srcs: Sequence[torch.Tensor], pack: LiifLowresPack) -> torch.Tensor:
+    """out[b, y*W+x, :] = W1[:, koff:koff+K] @ cat(srcs)[b, :, y, x] -> [B, H*W, 128] channels-last (first MLP layer at low
+    resolution, liif.py:9-25 applied before the nearest gather of liif.py:108-137); pack = LiifLowresPack.get(W1, koff, K)."""
+    for i, t in enumerate(srcs):
+        _req(t, f"src[{i}]")
+    b, _, h, w = srcs[0].shape
+    if sum(int(t.shape[1]) for t in srcs) != pack._key[4]:
+        raise RuntimeError("liif_lowres_cl: sources do not hold the packed column count")
+    out = torch.empty((b, h * w, 128), device=srcs[0].device, dtype=torch.float32)
+    ptrs, ch, keep = _src_arrays(srcs)
+    with torch.cuda.device(out.device):
+        L.check(L.load().as_liif_lowres_cl(ptrs, ch, len(srcs), _p(pack.image), _p(out), b, h, w, _stream()), "liif_lowres_cl")
+    return out
+
+
+class LiifTailPack:
+    """LDS weight image of the fused tail kernel (layers 2-4 + the relative-coordinate columns / bias of layer 1), rebuilt
+    when a source tensor changes (identity + version counter; weak references, so a recycled address cannot alias)."""
+
+    def __init__(self):
+        self._key = None
+        self._refs = None
+        self.image = None
+        self.wrel = None
+
+    def get(self, lin, rel_cols):
+        """lin: the four nn.Linear of the MLP; rel_cols: column index of (rel_row, rel_col) per source in lin[0].weight."""
+        ts = [lin[0].weight, lin[0].bias] + [t for m in lin[1:] for t in (m.weight, m.bias)]
+        key = tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts) + (tuple(rel_cols),)
+        alive = self._refs is not None and all((r is None) == (t is None) and (r is None or r() is t) for r, t in zip(self._refs, ts))
+        if key != self._key or not alive:
+            w1 = lin[0].weight.detach()
+            wrel = torch.cat([w1[:, o:o + 2] for o in rel_cols], dim=1).float().contiguous()
+            f = lambda t: None if t is None else t.detach().float().contiguous()  # noqa: E731
+            w2, w3, w4 = (f(m.weight) for m in lin[1:])
+            if tuple(w2.shape) != (64, 128) or tuple(w3.shape) != (64, 64) or tuple(w4.shape) != (9, 64) or w1.shape[0] != 128:
+                raise RuntimeError("LiifTailPack: the fused tail is built for the default MLP 128-64-64-9")
+            b1, b2, b3, b4 = f(lin[0].bias), f(lin[1].bias), f(lin[2].bias), f(lin[3].bias)
+            image = torch.empty(L.load().as_liif_tail_image_bytes(), device=w1.device, dtype=torch.uint8)
+            with torch.cuda.device(w1.device):
+                L.check(L.load().as_liif_tail_pack(_p(wrel), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(w4), _p(b4),
+                                                   len(rel_cols), _p(image), _stream()), "liif_tail_pack")
+            self.image, self.wrel, self._key = image, wrel, key
+            self._refs = [None if t is None else weakref.ref(t) for t in ts]
+        return self
+
+
+def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_inplace=True, want_logits=False):
+    """The per-query tail: gather + first-layer finish + MLP + softmax + convex upsampling -> [B,1,Q] (and the mask logits
+    [B,9,Q] when asked).  u0 / u1: liif_lowres_cl results; sizes = [(H0,W0)] or [(H0,W0),(H1,W1)]."""
+    _req(u0, "u0"), _req(coord, "coord"), _req(disp, "disp")
+    b, q = coord.shape[:2]
+    (h0, w0), (h1, w1) = sizes[0], (sizes[1] if u1 is not None else (0, 0))
+    if tuple(coord.shape) != (b, q, 2) or tuple(u0.shape) != (b, h0 * w0, 128) or disp.shape[0] != b or disp.shape[1] != 1:
+        raise RuntimeError("liif_tail: shape mismatch")
+    if u1 is not None:
+        _req(u1, "u1")
+        if tuple(u1.shape) != (b, h1 * w1, 128):
+            raise RuntimeError("liif_tail: u1 shape mismatch")
+    if scale is not None:
+        _req(scale, "scale")
+        if scale.numel() != b:
+            raise RuntimeError("liif_tail: scale must hold one value per batch element")
+    out = torch.empty((b, 1, q), device=coord.device, dtype=torch.float32)
+    logits = torch.empty((b, 9, q), device=coord.device, dtype=torch.float32) if want_logits else None
+    with torch.cuda.device(coord.device):
+        L.check(L.load().as_liif_tail(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(disp), _p(scale), _p(out), _p(logits), b, q,
+                                      h0, w0, h1, w1, disp.shape[2], disp.shape[3], 1 if clamp_inplace else 0, _stream()),
+                "liif_tail")
+    return (out, logits) if want_logits else out
+
+
+def split_overflow_count(reset: bool = True) -> int:
+    """Waves in which a split-precision kernel saturated an operand that left the fp16 range (synchronises)."""
+    return int(L.load().as_liif_split_overflow(1 if reset else 0)) + int(L.load().as_lookup_split_overflow(1 if reset else 0))

@@ -252,11 +252,11 @@ __global__ __launch_bounds__(256) void lookup_fwd_coop_kernel(LookupParams p) {
 // correlation window of that level — so floor/frac and the row offset are computed once per lane, all loads are in
 // flight together, and the 36 (+9) results go to the LDS tile [channel][pixel]; the tile leaves as 256-B NCHW rows,
 // eight LDS reads in flight per lane.  Interpolation arithmetic is identical to the kernels above.
+// gather + interpolation of a block's 64 pixels into the LDS tile [CH][65] (shared by the plain and the fused kernel)
 template <int G>
-__global__ __launch_bounds__(256) void lookup_fwd_quad_kernel(LookupParams p) {
+__device__ __forceinline__ void quad_fill_tile(const LookupParams& p, float* tile) {
   constexpr int R = 4, K = 9, NW = 10;
   constexpr int PX = 64, TS = PX + 1;
-  extern __shared__ float tile[];  // [CH][TS]
   const int tid = threadIdx.x;
   const int px = tid >> 2, sub = tid & 3;
   const long long pix0 = (long long)blockIdx.x * PX;
@@ -326,6 +326,15 @@ __global__ __launch_bounds__(256) void lookup_fwd_quad_kernel(LookupParams p) {
       t[k * TS] = a * cw[k] + c * cw[k + 1];
     }
   }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void lookup_fwd_quad_kernel(LookupParams p) {
+  constexpr int PX = 64, TS = PX + 1;
+  extern __shared__ float tile[];  // [CH][TS]
+  const int tid = threadIdx.x;
+  const long long pix0 = (long long)blockIdx.x * PX;
+  quad_fill_tile<G>(p, tile);
   __syncthreads();
   // coalesced NCHW rows: lane = pixel, wave w takes channels w, w+4, ...; 8 LDS reads in flight per lane
   const int lx = tid & 63;
@@ -347,6 +356,133 @@ __global__ __launch_bounds__(256) void lookup_fwd_quad_kernel(LookupParams p) {
     }
     for (; ch < p.CH; ch += 4, o += step, t += 4 * TS) *o = *t;
   }
+}
+
+// ---- lookup fused with the motion encoder's first correlation conv (update.py:84-85: relu(convc1(corr))) -------------------
+// The [B, L*9*(G+1), h, w] lookup result (21 MB at 960x540, written and re-read every GRU iteration) never leaves the CU:
+// the quad kernel's LDS tile [CH][64 px] is the B operand of a 1x1 convolution CH -> 64 on the matrix cores (split
+// precision: 3 x v_mfma_f32_32x32x16_f16 per product), bias + ReLU in the epilogue, and the result goes out as a blocked
+// split-fp16 link tensor (conv.hip, `out_bs`) — what the next convolution's loaders stage by LDS-DMA — and / or as fp32 NCHW.
+// Wave w: output channels [32 (w&1), +32) x pixels [32 (w>>1), +32); its 22 weight fragments (16 B per lane, packed by
+// frag_pack_kernel) are fetched at kernel entry, so they are in flight during the gather.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half4v = __attribute__((ext_vector_type(4))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+struct FusedParams {
+  const _Float16* wimg;  // [ks][mt(2)][hi|lo][lane][8]
+  const float* bias;     // [64] or null
+  _Float16* out_bs;      // blocked split-fp16 tensor [B][2][cb_tot][H][W][8] or null
+  int cb_tot, cb_off;    // 8-channel blocks of that tensor, first block of this result
+  float* out_f32;        // [B][64][H][W] or null
+  int relu;
+};
+
+__device__ unsigned g_split_overflow_lookup;
+
+template <int G>
+__global__ __launch_bounds__(256, 2) void lookup_convc1_kernel(LookupParams p, FusedParams f) {
+  constexpr int PX = 64, TS = PX + 1;
+  constexpr int CH = (G ? 2 : 4) * 9 * (G + 1);
+  constexpr int KS = (CH + 15) / 16;
+  extern __shared__ float tile[];  // [KS*16][TS]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 1, nt = wave >> 1;
+  const int c = lane & 31, half = lane >> 5;
+  half8 ah[KS], al[KS];
+  {
+    const half8* wi = reinterpret_cast<const half8*>(f.wimg);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      ah[ks] = wi[((ks * 2 + mt) * 2) * 64 + lane];
+      al[ks] = wi[((ks * 2 + mt) * 2 + 1) * 64 + lane];
+    }
+  }
+  for (int i = tid; i < (KS * 16 - CH) * TS; i += 256) tile[CH * TS + i] = 0.f;  // padded channels of the last k-step
+  quad_fill_tile<G>(p, tile);
+  __syncthreads();
+  f32x16 acc_h, acc_x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    acc_h[i] = f.bias ? f.bias[32 * mt + (i & 3) + 8 * (i >> 2) + 4 * half] : 0.f;
+    acc_x[i] = 0.f;
+  }
+  float amax = 0.f;
+  const float* tp = tile + 8 * half * TS + 32 * nt + c;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tp[(16 * ks + j) * TS];
+    half8 bh, bl;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) amax = fmaxf(amax, fmaxf(fabsf(v[j]), fabsf(v[j + 1])));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+      const _Float16 hk = (_Float16)x;
+      bh[j] = hk;
+      bl[j] = (_Float16)((x - (float)hk) * 2048.f);
+    }
+    acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc_h, 0, 0, 0);
+    acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc_x, 0, 0, 0);
+    acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc_x, 0, 0, 0);
+  }
+  const long long pix = (long long)blockIdx.x * PX + 32 * nt + c;
+  if (pix < p.P) {
+    const int b = (int)(pix / p.HW);
+    const int rem = (int)(pix - (long long)b * p.HW);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float x = acc_h[4 * qd + k] + acc_x[4 * qd + k] * (1.f / 2048.f);
+        o[k] = f.relu ? fmaxf(x, 0.f) : x;
+      }
+      const int ch = 32 * mt + 8 * qd + 4 * half;  // this lane's four channels of block (4 mt + qd)
+      if (f.out_f32) {
+        float* op = f.out_f32 + ((long long)b * 64 + ch) * p.HW + rem;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) op[(long long)k * p.HW] = o[k];
+      }
+      if (f.out_bs) {
+        half4v hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          amax = fmaxf(amax, fabsf(o[k]));
+          const float x = __builtin_amdgcn_fmed3f(o[k], -65504.f, 65504.f);
+          const _Float16 hk = (_Float16)x;
+          hi[k] = hk;
+          lo[k] = (_Float16)((x - (float)hk) * 2048.f);
+        }
+        const long long blk = f.cb_off + 4 * mt + qd;
+        const long long e_hi = ((((long long)b * 2 + 0) * f.cb_tot + blk) * p.HW + rem) * 8 + 4 * half;
+        const long long e_lo = ((((long long)b * 2 + 1) * f.cb_tot + blk) * p.HW + rem) * 8 + 4 * half;
+        *reinterpret_cast<u32x2*>(f.out_bs + e_hi) = __builtin_bit_cast(u32x2, hi);
+        *reinterpret_cast<u32x2*>(f.out_bs + e_lo) = __builtin_bit_cast(u32x2, lo);
+      }
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(!(amax < 65504.f)) != 0ull && lane == 0) atomicAdd(&g_split_overflow_lookup, 1u);
+}
+
+// [Cout][ldw] fp32 weight columns [koff, koff+K) -> split-fp16 MFMA fragments [ks][tile of 32 rows][hi|lo][lane][8]:
+// lane (r = l&31, h = l>>5) element j = W[32 tile + r][koff + 16 ks + 8 h + j] (zero beyond K)
+__global__ __launch_bounds__(256) void frag_pack_kernel(const float* w, int cout, int ldw, int koff, int K, int ksteps, _Float16* img) {
+  const int tiles = cout / 32;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ksteps * tiles * 2 * 512) return;
+  const int blk = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7;
+  const int hl = blk & 1, t = (blk >> 1) % tiles, ks = (blk >> 1) / tiles;
+  const int k = 16 * ks + 8 * (lane >> 5) + j;
+  const float v = k < K ? w[(long long)(32 * t + (lane & 31)) * ldw + koff + k] : 0.f;
+  const float x = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  const _Float16 hk = (_Float16)x;
+  img[idx] = hl == 0 ? hk : (_Float16)((x - (float)hk) * 2048.f);
 }
 
 // Backward w.r.t. the volumes: the transpose of the above.  Each (pixel, task) owns a private
@@ -623,6 +759,57 @@ int as_corr_sampler_bwd(const float* coords, const void* corr_grad, void* volume
   else
     hipLaunchKernelGGL(sampler_bwd_kernel<double>, grid, dim3(256), 0, s, coords, (const double*)corr_grad, (double*)volume_grad, H1, W1, W2, radius, coords_channels, P);
   return as::check_launch("corr_sampler_bwd");
+}
+
+
+int64_t as_lookup_convc1_pack_bytes(int cin) { return (long long)((cin + 15) / 16) * 2 * 2 * 1024; }
+
+int as_lookup_convc1_pack(const float* w, int cin, void* image, void* stream) {
+  AS_REQUIRE(w && image && cin > 0, AS_ERR_BAD_ARG, "lookup_convc1_pack: bad argument");
+  const int ks = (cin + 15) / 16;
+  hipLaunchKernelGGL(frag_pack_kernel, dim3(as::cdiv(ks * 2 * 2 * 512, 256)), dim3(256), 0, as::as_stream(stream), w, 64, cin, 0, cin, ks,
+                     (_Float16*)image);
+  return as::check_launch("lookup_convc1_pack");
+}
+
+int as_lookup_convc1_fwd(const float* const* geo, const float* const* corr, const float* disp, const void* wimage, const float* bias,
+                         void* out_bs, int out_bs_ctot, int out_bs_coff, float* out_f32, int relu,
+                         int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream) {
+  LookupParams p{};
+  int rc = fill_common(p, B, H, W, W2, D, G, L, radius);
+  if (rc != AS_OK) return rc;
+  AS_REQUIRE(corr && disp && wimage && (out_bs || out_f32) && (G == 0 || geo), AS_ERR_BAD_ARG, "lookup_convc1: null pointer");
+  AS_REQUIRE(radius == 4 && ((G == 8 && L == 2) || (G == 0 && L == 4)), AS_ERR_BAD_ARG,
+             "lookup_convc1: built for radius 4 with (G, L) = (8, 2) or (0, 4); got r=%d G=%d L=%d", radius, G, L);
+  AS_REQUIRE(!out_bs || (out_bs_coff % 8 == 0 && out_bs_coff + 64 <= (out_bs_ctot + 7) / 8 * 8), AS_ERR_BAD_SHAPE,
+             "lookup_convc1: channel window [%d,%d) outside the blocked tensor's %d channels", out_bs_coff, out_bs_coff + 64, out_bs_ctot);
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(corr[i] && (G == 0 || geo[i]), AS_ERR_BAD_ARG, "lookup_convc1: null level %d", i);
+    p.corr[i] = corr[i];
+    p.geo[i] = G ? geo[i] : nullptr;
+    AS_REQUIRE(G == 0 || (reinterpret_cast<uintptr_t>(geo[i]) & 15) == 0, AS_ERR_BAD_ARG, "lookup_convc1: geo[%d] not 16-B aligned", i);
+    const long long cb = p.P * (W2 >> i) * 4, gb = p.P * (long long)(D >> i) * G * 4;
+    AS_REQUIRE(cb < 0x7FFFFFF0ll && gb < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "lookup_convc1: pyramid level %d exceeds 2 GiB", i);
+    p.corr_bytes[i] = (int)cb;
+    p.geo_bytes[i] = (int)gb;
+  }
+  p.disp = disp;
+  FusedParams f{(const _Float16*)wimage, bias, (_Float16*)out_bs, (out_bs_ctot + 7) / 8, out_bs_coff / 8, out_f32, relu};
+  const size_t lds = (size_t)((p.CH + 15) / 16 * 16 * 65) * sizeof(float);
+  const dim3 grid((unsigned)as::cdiv64(p.P, 64));
+  if (G == 8) hipLaunchKernelGGL((lookup_convc1_kernel<8>), grid, dim3(256), lds, as::as_stream(stream), p, f);
+  else hipLaunchKernelGGL((lookup_convc1_kernel<0>), grid, dim3(256), lds, as::as_stream(stream), p, f);
+  return as::check_launch("lookup_convc1_fwd");
+}
+
+unsigned as_lookup_split_overflow(int reset) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_overflow_lookup), sizeof(v)) != hipSuccess) return 0xFFFFFFFFu;
+  if (reset && v) {
+    const unsigned z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_overflow_lookup), &z, sizeof(z));
+  }
+  return v;
 }
 
 }  // extern "C"

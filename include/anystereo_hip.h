@@ -107,6 +107,21 @@ int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, co
 int as_geo_corr_lookup_bwd(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr,
                            int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
 
+/* a3 + the first conv of a6 fused (csrc/lookup.hip): out = act(convc1(lookup(disp))) — replaces
+ *   `corr = geo_fn(disp, coords)` (continuous_IGEVstereo.py:286 -> geometry.py:34-60) followed by
+ *   `F.relu(self.convc1(corr))` (update.py:84-85); the [B, L*9*(G+1), H, W] lookup result stays in LDS.
+ *   Built for radius 4 with (G, L) = (8, 2) [IGEV] or (0, 4) [RAFT]; convc1 = 1x1, L*9*(G+1) -> 64 channels.
+ *   wimage = as_lookup_convc1_pack(weight [64][cin] fp32) (as_lookup_convc1_pack_bytes(cin) bytes); bias [64]|NULL.
+ *   Results (either or both): out_bs = blocked split-fp16 link tensor [B][2][ceil(ctot/8)][H][W][8] fp16 (as_conv_desc.out_bs),
+ *   channels [coff, coff+64); out_f32 [B,64,H,W].  Split-precision arithmetic.  as_lookup_split_overflow: see
+ *   as_liif_split_overflow. */
+int64_t as_lookup_convc1_pack_bytes(int cin);
+int as_lookup_convc1_pack(const float* w, int cin, void* image, void* stream);
+int as_lookup_convc1_fwd(const float* const* geo, const float* const* corr, const float* disp, const void* wimage, const float* bias,
+                         void* out_bs, int out_bs_ctot, int out_bs_coff, float* out_f32, int relu,
+                         int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
+unsigned as_lookup_split_overflow(int reset);
+
 /* ---------------------------------------------------------------------------------------------
  * a4  group-wise correlation volume — replaces build_gwc_volume / groupwise_correlation
  *   (coreContinuous_IGEV/submodule.py:253-271).  fl, fr [B,C,H,W]; out [B,G,D,H,W]; C % G == 0.
@@ -265,6 +280,47 @@ int as_liif_gather_mlp1(const float* u0, const float* u1, const float* coord, co
                         int B, int C, int H0, int W0, int H1, int W1, int Q, void* stream);
 int as_convex_upsample(const float* disp, const float* scale, const float* mask, const float* coord,
                        float* out, int B, int H, int W, int Q, int mask_is_logits, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a12-a17 fused for inference (csrc/liif_fused.hip): the whole `upsample_disp` tail
+ *   (continuous_IGEVstereo.py:192-214 / prune_raft_stereo.py:200-226: StructureFeature -> liif_feat_multiscale_train ->
+ *   MLP -> softmax -> context_upsample_multiscale_train; liif.py:432-446,:496-499,:108-137,:9-25,:644-678;
+ *   submodule.py:357-372) with no per-query intermediate in HBM.  Same function as the staged entry points above.
+ *
+ * as_liif_affinity   aff [B,8,H,W] = AffinityFeature(cat(srcs)) for up to 3 NCHW sources (never concatenated; every
+ *                    source but the last needs a multiple of 8 channels); ws = scratch of
+ *                    as_liif_affinity_ws_bytes(B, H, W, ceil(sum of channels / 8)) bytes (per-channel-group partial sums).
+ * as_liif_lowres_pack  W1[:, koff : koff+K] ([128][ldw] fp32, K <= 192) as split-fp16 MFMA fragments
+ *                    (as_liif_lowres_pack_bytes(K) bytes).
+ * as_liif_lowres_cl  out[b][y*W+x][0..128) = W1[:, koff : koff+K] . cat(srcs)[b,:,y,x]  — the first Linear layer's feature
+ *                    block applied per LOW-resolution pixel (it commutes with the nearest gather), result channels-last so
+ *                    that a query's 128-vector is one 512-B run.  wimage = as_liif_lowres_pack of that column block;
+ *                    K = sum of the source channels; every source but the last needs a multiple of 16 channels.
+ * as_liif_tail_pack  the 128->64->64->9 layers + the relative-coordinate columns / bias of the first layer as the tail
+ *                    kernel's LDS weight image (as_liif_tail_image_bytes() bytes, split fp16 fragments in MFMA order).
+ *                    wrel [128][2*n_src] (rel_row, rel_col per source), b1 [128]|NULL, w2 [64][128], w3 [64][64], w4 [9][64].
+ * as_liif_tail       per query: relu(u0[n0(q)] + u1[n1(q)] + wrel.rel(q) + b1) -> MLP -> softmax -> sum_k p_k * d[3x3 nbr k of
+ *                    the nearest pixel of disp], d = disp * 4 * scale_b (scale == NULL: disp as given) -> out [B,1,Q].
+ *                    u0 [B][H0*W0][128], u1 [B][H1*W1][128]|NULL (as_liif_lowres_cl); disp [B,1,Hd,Wd]; coord [B,Q,2]
+ *                    (row, col); clamp_inplace != 0 writes the clamped coordinates back (the reference's in-place
+ *                    `hr_coord.clamp_`, submodule.py:366); logits [B,9,Q]|NULL also receives the mask logits (`liif_up`'s
+ *                    return value).  Split-precision arithmetic (3 x fp16 MFMA per product, fp32 accumulate).
+ * as_liif_split_overflow  number of waves (since the last reset) in which an operand of these kernels left the fp16
+ *                    range and was saturated to +-65504 (synchronises; diagnostics only).
+ * ------------------------------------------------------------------------------------------- */
+int64_t as_liif_affinity_ws_bytes(int B, int H, int W, int n_chunks);
+int as_liif_affinity(const float* const* srcs, const int* channels, int n_src, float* aff, float* ws, int B, int H, int W, void* stream);
+int64_t as_liif_lowres_pack_bytes(int K);
+int as_liif_lowres_pack(const float* w, int ldw, int koff, int K, void* image, void* stream);
+int as_liif_lowres_cl(const float* const* srcs, const int* channels, int n_src, const void* wimage, float* out,
+                      int B, int H, int W, void* stream);
+int64_t as_liif_tail_image_bytes(void);
+int as_liif_tail_pack(const float* wrel, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* w4, const float* b4, int n_src, void* image, void* stream);
+int as_liif_tail(const float* u0, const float* u1, float* coord, const void* image, const float* disp, const float* scale,
+                 float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd, int clamp_inplace,
+                 void* stream);
+unsigned as_liif_split_overflow(int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward (training, cfg 4: train_continuous_IGEV.py:214-239) of the HBM-bound operators above — what autograd

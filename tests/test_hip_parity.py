@@ -1031,3 +1031,137 @@ def test_hidden_state_twin_is_dropped_after_inplace_update():
             assert torch.equal(gru(h1, *ctx, x), ref)
     finally:
         ops.set_precision(prev)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused LIIF inference pipeline (csrc/liif_fused.hip): affinity without the copy, first layer at low resolution with a
+# channels-last result, ONE per-query kernel (gather + MLP + softmax + convex combination)
+# ---------------------------------------------------------------------------------------------
+
+def _liif_module(seed=7, two=True):
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn.liif import liif_out_multi_scale_Training
+    up = liif_out_multi_scale_Training(encoder_dim=208 if two else 176, mlphidden_list=[128, 64, 64], pos_dim=0, unfold="with_v2ISU",
+                                       affinity_settings={"win_w": 3, "win_h": 3, "dilation": [1, 2, 4, 8]},
+                                       number_input=2 if two else 1, chanels=[176, 32] if two else [176]).eval()
+    fill_module_deterministic(up, base_seed=seed, gain=2.0)
+    return up.to(DEV)
+
+
+def test_liif_fused_pipeline_golden(golden):
+    """Against the reference's own outputs (G6: liif.npz): affinity, mask logits (`liif_up`'s return value) and the convex
+    upsampling result of the fused pipeline; the caller's coordinates come back clamped (submodule.py:366)."""
+    from anystereo import ops
+    g = golden("liif")
+    x4, x2 = g["x4"].to(DEV), g["x2"].to(DEV)
+    close(ops.liif_affinity([g["feat"].to(DEV)]), g["aff"], 1e-5, 2e-6, "affinity (tile kernel)")
+    f = g["feat"].to(DEV)
+    close(ops.liif_affinity([f[:, :8].contiguous(), f[:, 8:].contiguous()]), g["aff"], 1e-5, 2e-6, "affinity, two sources")
+    up = _liif_module()
+    coord = g["coord"].clone().to(DEV)
+    sv = torch.tensor([1.5], device=DEV)
+    with torch.no_grad():
+        assert up.fused_ok([[x4[:, :48], x4[:, 48:]], [x2]], coord) or ops.get_precision() != "split"
+        prev = ops.get_precision()
+        ops.set_precision("split")
+        try:
+            out, logits = up.upsample_fused([[x4[:, :48].contiguous(), x4[:, 48:].contiguous()], [x2]], coord, g["dlow"].to(DEV), sv,
+                                            want_logits=True)
+        finally:
+            ops.set_precision(prev)
+    close(logits, g["mask"], 2e-5, 2e-5, "fused tail: mask logits")
+    close(out[:, 0], g["convex"], 2e-5, 2e-5, "fused tail: upsampled disparity")
+    assert torch.equal(coord.cpu(), g["coord"].clamp(-1 + 1e-6, 1 - 1e-6)), "coordinates are clamped in place"
+
+
+@pytest.mark.parametrize("two,b,h,w,s,nq", [(True, 2, 9, 14, 1.5, None), (False, 1, 7, 11, 2.95, None), (True, 1, 12, 20, 1.0, 1000),
+                                             (True, 3, 5, 9, 2.0, 33)])
+def test_liif_fused_tail_vs_staged(two, b, h, w, s, nq):
+    """The fused pipeline against the fp64 oracle and against the staged HIP path on the same module: batch > 1 (tiles that
+    straddle batch elements), a ragged query count (last tile partly empty), one and two inputs, scales 1 .. 2.95, queries
+    exactly on +-1 (clamp) and on cell borders."""
+    from anystereo import ops
+    up = _liif_module(seed=11, two=two)
+    x4 = U((b, 176, h, w), 201, -1.5, 1.5).to(DEV)
+    x2 = U((b, 32, 2 * h, 2 * w), 202, -1.5, 1.5).to(DEV)
+    grid = O.make_coord([round(4 * h * s), round(4 * w * s)])
+    if nq is not None:
+        idx = (U((nq,), 203, 0.0, 1.0) * grid.shape[0]).long().clamp(max=grid.shape[0] - 1)
+        grid = grid[idx]
+        grid[0] = torch.tensor([-1.0, 1.0])
+        grid[1] = torch.tensor([1.0, -1.0])
+    coord = grid.view(1, -1, 2).repeat(b, 1, 1).contiguous()
+    disp = U((b, 1, h, w), 204, 0.0, 40.0).to(DEV)
+    sv = torch.full((b,), float(s), device=DEV)
+    feats = [x4, x2] if two else [x4]
+    parts = [[x4[:, :48].contiguous(), x4[:, 48:].contiguous()]] + ([[x2]] if two else [])
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        with torch.no_grad():
+            c1 = coord.clone().to(DEV)
+            out, logits = up.upsample_fused(parts, c1, disp, sv, want_logits=True)
+            c2 = coord.clone().to(DEV)
+            staged_logits = up(feats, c2, sv.view(-1, 1))
+            staged = ops.convex_upsample(disp, staged_logits, c2.clamp(-1 + 1e-6, 1 - 1e-6), scale=sv, mask_is_logits=True)
+    finally:
+        ops.set_precision(prev)
+    assert out.shape == (b, 1, coord.shape[1]) and torch.isfinite(out).all()
+    close(logits, staged_logits, 3e-5, 3e-5, "fused vs staged logits")
+    close(out, staged, 3e-5, 3e-5, "fused vs staged disparity")
+    up64 = up.cpu().double()
+    want_mask = O.liif_up_mask(up64, [t.cpu().double() for t in feats], coord.double())
+    d = disp.cpu().double() * 4.0 * s
+    want = O.convex_upsample(d, torch.softmax(want_mask, 1), coord.double().clamp(-1 + 1e-6, 1 - 1e-6)).unsqueeze(1)
+    close(logits, want_mask, 3e-5, 3e-5, "fused logits vs fp64 oracle")
+    close(out, want, 3e-5, 3e-5, "fused disparity vs fp64 oracle")
+    up.float().to(DEV)
+
+
+def test_liif_lowres_channels_last():
+    """First MLP layer at low resolution, channels-last: against the fp64 product; three sources, a column window of the
+    weight, pixel counts that are not multiples of 32."""
+    from anystereo import ops
+    b, h, w = 2, 7, 13
+    srcs = [U((b, c, h, w), 210 + i).to(DEV) for i, c in enumerate((48, 128, 8))]
+    wt = (U((128, 228), 215) * 0.2).to(DEV)
+    got = ops.liif_lowres_cl(srcs, ops.LiifLowresPack().get(wt, 0, 184))
+    x = torch.cat(srcs, 1).double().permute(0, 2, 3, 1).reshape(b, h * w, 184)
+    want = x @ wt[:, :184].double().t()
+    close(got, want, 2e-5, 2e-5, "lowres first layer (K = 184)")
+    srcs = [U((1, c, 2 * h, 2 * w), 220 + i).to(DEV) for i, c in enumerate((32, 8))]
+    got = ops.liif_lowres_cl(srcs, ops.LiifLowresPack().get(wt, 186, 40))
+    x = torch.cat(srcs, 1).double().permute(0, 2, 3, 1).reshape(1, 4 * h * w, 40)
+    close(got, x @ wt[:, 186:226].double().t(), 2e-5, 2e-5, "lowres first layer (K = 40, column offset)")
+
+
+@pytest.mark.parametrize("b,h,w,g,d,L", [(2, 3, 20, 8, 48, 2), (1, 5, 37, 0, 0, 4), (1, 7, 70, 8, 48, 2), (1, 136, 240, 8, 48, 2)])
+def test_lookup_convc1_fused(b, h, w, g, d, L):
+    """lookup -> convc1 -> ReLU as one kernel (geometry.py:34-60 + update.py:84-85) against the fp64 oracle: both model
+    geometries, zero-pad edges, pixel counts that do not fill the last 64-pixel block, batch 2; the blocked split-fp16
+    result carries the same values as the fp32 one."""
+    from anystereo import ops
+    f1, f2 = U((b, 32, h, w), 301).to(DEV), U((b, 32, h, w), 302).to(DEV)
+    corr = ops.corr_build_pyramid(f1, f2, L)
+    geo = ops.geo_pyramid(U((b, g, d, h, w), 303).to(DEV), L) if g else None
+    disp = U((b, 1, h, w), 304, -6.0, w + 6.0).to(DEV)
+    disp[:, :, 0, :4] = torch.tensor([0.0, 1.5, 3.0, float(w - 1)], device=DEV)
+    cin = L * 9 * (g + 1)
+    wt = (U((64, cin, 1, 1), 305) * (3.0 / cin) ** 0.5).to(DEV)
+    bias = (U((64,), 306) * 0.1).to(DEV)
+    pack = ops.LookupConvPack().get(wt, bias)
+    bs = ops.BS8.empty(b, 64, h, w, DEV)
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        out = ops.lookup_convc1(geo, corr, disp, 4, pack, out_bs=bs, want_f32=True)
+        lk = ops.geo_corr_lookup(geo, corr, disp, 4)
+    finally:
+        ops.set_precision(prev)
+    want = torch.relu(torch.einsum("oc,bchw->bohw", wt[:, :, 0, 0].double(), lk.double()) + bias.double().view(1, -1, 1, 1))
+    close(out, want, 2e-5, 2e-5, "fused lookup + convc1")
+    assert (bs.float() - out).abs().max().item() <= 2e-6 * max(1.0, out.abs().max().item()), "blocked split-fp16 copy"
+    geo64 = [t.permute(0, 1, 2, 4, 3).double().cpu() for t in geo] if g else None
+    ref = O.geo_corr_lookup(geo64, [t.double().cpu() for t in corr], disp.double().cpu(), 4)
+    want2 = torch.relu(torch.einsum("oc,bchw->bohw", wt[:, :, 0, 0].double().cpu(), ref) + bias.double().cpu().view(1, -1, 1, 1))
+    close(out, want2, 3e-5, 3e-5, "fused lookup + convc1 vs the oracle's lookup")
