@@ -61,6 +61,8 @@ SIGNATURES = {
     "as_lookup_convc1_pack": (_i, [_vp, _i, _vp, _vp]),
     "as_lookup_convc1_fwd": (_i, [_pp, _pp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_lookup_split_overflow": (C.c_uint, [_i]),
+    "as_conv_split_overflow": (C.c_uint, [_i]),
+    "as_volumes_split_overflow": (C.c_uint, [_i]),
     "as_gwc_volume_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_disparity_regression": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "as_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),

@@ -157,6 +157,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         geo_fn = self._hot_lookup_fn(match_left, match_right, geo_encoding_volume)
         b, c, h, w = match_left.shape
         coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+        coords._as_pixel_grid = True  # the kernels regenerate this grid: mark it so the lookup need not compare it
         disp, disp_up, disp_preds = self._iterate(geo_fn, net_list, inp_list, init_disp.float(), coords, iters, test_mode,
                                                   stem_4x, stem_2x, hr_coord, scale)
         if test_mode:

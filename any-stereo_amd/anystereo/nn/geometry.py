@@ -41,12 +41,30 @@ class Combined_Geo_Encoding_Volume:
                 else:
                     self.geo_volume_pyramid = ops.geo_pyramid(gev, num_levels)
 
+    def _check_coords(self, coords, disp):
+        """`coords` must be the pixel-column grid arange(w) the reference always passes (continuous_IGEVstereo.py:280,
+        prune_raft_stereo.py:272): the kernels regenerate it.  Grids built by this package's models carry a mark; any other
+        tensor is compared once per (tensor, version) — anything else raises instead of giving silently different numbers."""
+        b, _, h, w = disp.shape
+        if tuple(coords.shape) != (b, h, w, 1):
+            raise RuntimeError(f"lookup: coords must be [B,h,w,1] = {(b, h, w, 1)}, got {tuple(coords.shape)}")
+        if getattr(coords, "_as_pixel_grid", False):
+            return
+        key = (coords.data_ptr(), coords._version, tuple(coords.shape))
+        if key == getattr(self, "_coords_ok", None):
+            return
+        if coords.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("lookup: an unverified `coords` tensor inside a stream capture — call once eagerly first")
+        want = torch.arange(w, device=coords.device, dtype=coords.dtype).view(1, 1, w, 1)
+        if not torch.equal(coords, want.expand(b, h, w, 1)):
+            raise RuntimeError("lookup: only coords == arange(w) per row (the grid of continuous_IGEVstereo.py:280) is supported; "
+                               "the lookup position is x - disp with x the pixel column")
+        self._coords_ok = key
+
     def __call__(self, disp, coords=None):
         disp = disp.float().contiguous()
         if coords is not None:
-            b, _, h, w = disp.shape
-            if tuple(coords.shape) != (b, h, w, 1):
-                raise RuntimeError(f"lookup: coords must be [B,h,w,1] = {(b, h, w, 1)}, got {tuple(coords.shape)}")
+            self._check_coords(coords, disp)
         levels = list(self.geo_volume_pyramid) + list(self.init_corr_pyramid)
         if _needs_grad(*levels):
             return G.Lookup.apply(disp, self.radius, len(self.geo_volume_pyramid), *levels)

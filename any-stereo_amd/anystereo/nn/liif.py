@@ -180,6 +180,14 @@ class liif_out_multi_scale_Training(nn.Module):
     # ---- fused inference pipeline (csrc/liif_fused.hip) -----------------------------------------------------------
     fused_tail = __import__("os").environ.get("ANYSTEREO_FUSED_LIIF", "1") != "0"
 
+    parallel_inputs = __import__("os").environ.get("ANYSTEREO_LIIF_PARALLEL", "1") != "0"
+
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault("_streams", {})
+        if device not in streams:
+            streams[device] = torch.cuda.Stream(device=device)
+        return streams[device]
+
     def fused_ok(self, feats_parts, coord) -> bool:
         """The one-kernel tail exists for the default configuration: <= 2 inputs, MLP 128-64-64-9, split-precision mode,
         inference.  Everything else takes the staged path (same function)."""
@@ -198,16 +206,31 @@ class liif_out_multi_scale_Training(nn.Module):
         if not hasattr(self, "_lowres_packs"):
             self._lowres_packs = [ops.LiifLowresPack() for _ in range(2)]
         us, sizes, rel_cols, off = [], [], [], 0
-        for parts, lpk in zip(feats_parts, self._lowres_packs):
+        # the per-input chains (affinity -> first layer at low resolution) are independent, small and latency-bound: the
+        # second input's chain runs on a side stream (a parallel branch of the captured graph) and joins before the tail
+        main = torch.cuda.current_stream(coord.device)
+        side = self._side_stream(coord.device) if (self.parallel_inputs and len(feats_parts) > 1) else None
+        for i, (parts, lpk) in enumerate(zip(feats_parts, self._lowres_packs)):
             parts = [p_.float().contiguous() for p_ in parts]
             c = sum(p_.shape[1] for p_ in parts) + 8
-            with scope("structure_feature"):
-                aff = ops.liif_affinity(parts)
-            with scope("liif_mlp_lowres"):
-                us.append(ops.liif_lowres_cl(parts + [aff], lpk.get(w1, off, c)))
+            pk = lpk.get(w1, off, c)
+            on_side = side is not None and i == 1
+            if on_side:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if on_side else main):
+                with scope("structure_feature"):
+                    aff = ops.liif_affinity(parts)
+                with scope("liif_mlp_lowres"):
+                    us.append(ops.liif_lowres_cl(parts + [aff], pk))
+            if on_side:
+                for t_ in parts:
+                    t_.record_stream(side)
             sizes.append(tuple(parts[0].shape[2:]))
             rel_cols.append(off + c)
             off += c + 2
+        if side is not None:
+            main.wait_stream(side)
+            us[1].record_stream(main)
         if off != w1.shape[1]:
             raise RuntimeError(f"liif: inputs hold {off} latent channels but the MLP expects {w1.shape[1]}")
         if not hasattr(self, "_tail_pack"):

@@ -272,10 +272,24 @@ class PackedConv:
 
     def __init__(self):
         self._key = None
+        self._refs = None
         self.wpack = None
         self.bias = None
         self.cin = self.cout = self.ks = 0
         self.split = False
+
+    def invalidate(self):
+        """Force a rebuild at the next use (after edits through `.data`, which do not bump version counters)."""
+        self._key = None
+
+    def _alive(self, ts) -> bool:
+        # the key holds (address, version): a freed tensor's address (version 0 again) can be recycled by the caching
+        # allocator, so the pack also remembers WHICH tensor objects it was built from
+        return self._refs is not None and len(self._refs) == len(ts) and all(
+            (r is None) == (t is None) and (r is None or r() is t) for r, t in zip(self._refs, ts))
+
+    def _remember(self, ts):
+        self._refs = [None if t is None else weakref.ref(t) for t in ts]
 
     def get_folded(self, conv, bn):
         """Pack of `bn(conv(x))` for an eval-mode BatchNorm: w' = w * g/sqrt(var+eps), b' = (b - mean) * g/sqrt(var+eps) + beta
@@ -283,18 +297,21 @@ class PackedConv:
         split = L.load().as_get_precision() == 1
         ts = [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
         key = ("bn", split) + tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts)
-        if key != self._key:
+        if key != self._key or not self._alive(ts):
             w, b = fold_bn(conv, bn)
             self._build([w], [b], split, key)
+            self._remember(ts)
         return self
 
     def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], transform=None):
         split = L.load().as_get_precision() == 1
         key = (split,) + tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
             tuple((None if b is None else (b.data_ptr(), b._version)) for b in biases)
-        if key != self._key:
+        ts = list(weights) + list(biases)
+        if key != self._key or not self._alive(ts):
             ws = [w.detach() if transform is None else transform(w.detach()) for w in weights]
             self._build(ws, biases, split, key)
+            self._remember(ts)
         return self
 
     def _build(self, ws, biases, split, key):
@@ -686,13 +703,15 @@ class FoldedConv:
     `layout` = None keeps the module's layout, 'c3d' gives the [Cin,27,Cout] pack of as_conv3d_k3."""
 
     def __init__(self, layout=None):
-        self._key, self._wb, self.layout = None, None, layout
+        self._key, self._wb, self.layout, self._refs = None, None, layout, None
 
     @torch.no_grad()
     def get(self, conv, bn=None):
         ts = [conv.weight, conv.bias] + ([] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var])
         key = tuple(None if t is None else (t.data_ptr(), t._version, t.device) for t in ts)
-        if key != self._key:
+        alive = self._refs is not None and all((r is None) == (t is None) and (r is None or r() is t) for r, t in zip(self._refs, ts))
+        if key != self._key or not alive:
+            self._refs = [None if t is None else weakref.ref(t) for t in ts]
             if bn is None:
                 w, b = conv.weight.detach().float(), None if conv.bias is None else conv.bias.detach().float().contiguous()
             else:
@@ -933,5 +952,9 @@ def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_
 
 
 def split_overflow_count(reset: bool = True) -> int:
-    """Waves in which a split-precision kernel saturated an operand that left the fp16 range (synchronises)."""
-    return int(L.load().as_liif_split_overflow(1 if reset else 0)) + int(L.load().as_lookup_split_overflow(1 if reset else 0))
+    """Split-precision range check: number of waves (since the last reset) in which a kernel met an operand with
+    |x| >= 65504 (outside fp16) or NaN.  Such operands are SATURATED to +-65504 — results stay finite but are no longer the
+    reference's; switch to `set_precision("fp32")` for such data.  Synchronises the device (diagnostics, tests, bench)."""
+    lib, r = L.load(), 1 if reset else 0
+    return sum(int(f(r)) for f in (lib.as_liif_split_overflow, lib.as_lookup_split_overflow, lib.as_conv_split_overflow,
+                                   lib.as_volumes_split_overflow))

@@ -29,6 +29,16 @@ int precision_mode();
 inline bool use_split_precision() { return precision_mode() == 1; }
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Split-precision range safety.  MODE.FP16_OVFL (hwreg MODE, bit 23): an overflowed fp16 VALU result — here: the
+// v_cvt_f16_f32 of the operand split x = hi + lo/2048 — is clamped to +-65504 instead of becoming inf, so |x| >= 65504
+// yields a SATURATED finite operand instead of hi = inf, lo = NaN.  Zero cost per element; set once at kernel entry by
+// every kernel that splits.  In-range values convert exactly as before (bit-identical results).
+__device__ __forceinline__ void fp16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+// a thread's running max |x| over the values it split -> one atomic per wave that saw an out-of-range (or NaN) operand
+__device__ __forceinline__ void note_split_overflow(float amax, unsigned* counter) {
+  if (__builtin_amdgcn_ballot_w64(!(amax < 65504.f)) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);
+}
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace as

@@ -190,6 +190,8 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
 // issued before epi_finish(i) computes and stores, so only the first memory latency is exposed per block.
 // col0: channel of accumulator row 0 relative to n0; poff: byte offset of this lane's pixel inside a channel
 // plane or the OOB sentinel; bias_s: LDS bias of the block (index = channel - n0).
+__device__ unsigned g_split_overflow_conv;  // as_conv_split_overflow
+
 struct EpiRegs {
   unsigned off[8];
   float av[8], hv[8], zv[8];
@@ -211,7 +213,8 @@ __device__ __forceinline__ void epi_load(const EpiCtx& e, int col0, int half, un
 
 template <int EPI>
 __device__ __forceinline__ void epi_finish(const ConvParams& p, const EpiCtx& e, const f32x16& v, int col0, int half, int g,
-                                           const float* bias_s, bool is_r, const EpiRegs& R, unsigned poff = 0x7FFFFFF0u) {
+                                           const float* bias_s, bool is_r, const EpiRegs& R, float& amax,
+                                           unsigned poff = 0x7FFFFFF0u) {
   float ov[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -246,6 +249,7 @@ __device__ __forceinline__ void epi_finish(const ConvParams& p, const EpiCtx& e,
         hi[k] = hk;
         lo[k] = (_Float16)((o - (float)hk) * 2048.f);
       }
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(ov[m * 4]), fabsf(ov[m * 4 + 1]))), fmaxf(fabsf(ov[m * 4 + 2]), fabsf(ov[m * 4 + 3])));
       const unsigned blk = (unsigned)(col0 >> 3) + 2u * g + m;
       const unsigned off = poff == 0x7FFFFFF0u ? poff : blk * (e.plane4 * 4u) + poff * 4u + (unsigned)half * 8u;
       const int crel = (int)blk * 8 + 4 * half;  // first of this lane's four channels, relative to the tile
@@ -272,10 +276,11 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_tile(const ConvParams& p, const EpiCtx& e, const f32x16& v, int col0, int half,
                                               unsigned poff, const float* bias_s, bool is_r) {
   EpiRegs R0, R1;
+  float amax = 0.f;  // fp32 path: no blocked split-fp16 output, nothing to track
   epi_load<EPI>(e, col0, half, poff, 0, R0);
   epi_load<EPI>(e, col0, half, poff, 1, R1);
-  epi_finish<EPI>(p, e, v, col0, half, 0, bias_s, is_r, R0);
-  epi_finish<EPI>(p, e, v, col0, half, 1, bias_s, is_r, R1);
+  epi_finish<EPI>(p, e, v, col0, half, 0, bias_s, is_r, R0, amax);
+  epi_finish<EPI>(p, e, v, col0, half, 1, bias_s, is_r, R1, amax);
 }
 
 // Block epilogue of the split-precision kernel: rounds (q, c, g) over the wave's PTW x 2 accumulator tiles,
@@ -283,7 +288,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvParams& p, const EpiCtx&
 template <int EPI, int PTW>
 __device__ __forceinline__ void epilogue_block(const ConvParams& p, const EpiCtx& e, const f32x16 (&acc_h)[2][PTW],
                                                const f32x16 (&acc_x)[2][PTW], int co_base, const unsigned (&poff)[PTW],
-                                               int half, const float* bias_s, bool is_r) {
+                                               int half, const float* bias_s, bool is_r, float& amax) {
   constexpr int NR = PTW * 4;
   // operand loads run TWO rounds ahead of the arithmetic + stores (three register sets): with one block per CU nothing else
   // hides their latency, and the epilogue is ~15 % of a 24-chunk block's life
@@ -302,7 +307,7 @@ __device__ __forceinline__ void epilogue_block(const ConvParams& p, const EpiCtx
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc_h[c][q][r] + acc_x[c][q][r] * (1.f / 2048.f);
     }
-    epi_finish<EPI>(p, e, v, co_base + c * 32, half, g, bias_s, is_r, R[i % 3], poff[q]);
+    epi_finish<EPI>(p, e, v, co_base + c * 32, half, g, bias_s, is_r, R[i % 3], amax, poff[q]);
   }
 }
 
@@ -564,8 +569,10 @@ __global__ __launch_bounds__(256) void conv7x7_c1_kernel(const float* __restrict
 // Blocked split-fp16 output (ConvParams' BS8 comment): one thread per (8-channel block, output pixel) writes the 16-B unit of
 // the hi plane set and the one of the lo plane set.  Same per-element arithmetic as the fp32 kernels (shared helpers).
 __device__ __forceinline__ void bs8_store(_Float16* __restrict__ out_bs, long long b, int c8tot, int blk, long long plane,
-                                          long long pix, const float (&v)[8]) {
+                                          long long pix, const float (&v)[8], float& amax) {
   half8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) amax = fmaxf(amax, fmaxf(fabsf(v[j]), fabsf(v[j + 1])));
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const _Float16 hj = (_Float16)v[j];
@@ -588,6 +595,8 @@ __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restr
                                                             float* __restrict__ copy_out, int copy_ctot, int copy_coff, int copy_bs,
                                                             int out_bs) {
   __shared__ float patch[22 * 22];
+  as::fp16_saturate_mode();
+  float ovf_amax = 0.f;
   const int groups = CP / CO;
   const int b = blockIdx.z / groups;
   const int c0 = (blockIdx.z - b * groups) * CO;
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restr
         float v[8];
 #pragma unroll
         for (int j = 0; j < CO; ++j) v[j] = (c0 + j < Cout) ? fmaxf(acc[j] + (bias ? bias[c0 + j] : 0.f), 0.f) : 0.f;
-        bs8_store(reinterpret_cast<_Float16*>(out), b, (out_ctot + 7) >> 3, (out_coff + c0) >> 3, plane, (long long)gy * W + gx, v);
+        bs8_store(reinterpret_cast<_Float16*>(out), b, (out_ctot + 7) >> 3, (out_coff + c0) >> 3, plane, (long long)gy * W + gx, v, ovf_amax);
       }
     } else {
       float* o = out + ((long long)b * out_ctot + out_coff + c0) * plane + (long long)gy * W + gx;
@@ -640,11 +649,13 @@ __global__ __launch_bounds__(256) void conv7x7_c1_tm_kernel(const float* __restr
         const _Float16 hk = (_Float16)v;
         rec[0] = hk;
         rec[(long long)c8 * plane * 8] = (_Float16)((v - (float)hk) * 2048.f);
+        ovf_amax = fmaxf(ovf_amax, fabsf(v));
       } else {
         copy_out[((long long)b * copy_ctot + copy_coff) * plane + (long long)gy * W + gx] = v;
       }
     }
   }
+  as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
 }
 
 // 3x3, Cin -> 1, + bias (DispHead.conv2, update.py:19,24).  64 pixels of a row x 4 channel slices.
@@ -748,6 +759,8 @@ __global__ __launch_bounds__(256) void pool2x_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void pool2x_bs_kernel(const float* __restrict__ x, _Float16* __restrict__ out_bs, int C, int H, int W,
                                                         int Ho, int Wo, long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  as::fp16_saturate_mode();
+  float ovf_amax = 0.f;
   if (idx >= total) return;
   const int c8 = (C + 7) >> 3;
   const int xo = (int)(idx % Wo);
@@ -781,7 +794,8 @@ __global__ __launch_bounds__(256) void pool2x_bs_kernel(const float* __restrict_
     for (int k = 0; k < 9; ++k) sacc += raw[j][k];
     v[j] = sacc / 9.f;
   }
-  bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v);
+  bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v, ovf_amax);
+  as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
 }
 
 // interp: bilinear, align_corners=True (update.py:100-102)
@@ -809,6 +823,8 @@ __global__ __launch_bounds__(256) void interp_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void interp_bs_kernel(const float* __restrict__ x, _Float16* __restrict__ out_bs, int C, int H, int W,
                                                         int Ho, int Wo, float sy, float sx, long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  as::fp16_saturate_mode();
+  float ovf_amax = 0.f;
   if (idx >= total) return;
   const int c8 = (C + 7) >> 3;
   const int xo = (int)(idx % Wo);
@@ -823,7 +839,8 @@ __global__ __launch_bounds__(256) void interp_bs_kernel(const float* __restrict_
     const int c = blk * 8 + j;
     v[j] = c < C ? interp_at(x + (b * C + c) * H * W, yo, xo, H, W, sy, sx) : 0.f;
   }
-  bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v);
+  bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v, ovf_amax);
+  as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
 }
 
 // ================================================================================================
@@ -883,6 +900,8 @@ __device__ unsigned long long as_conv_stamp_buf[kStampBlocks * kStampSlots];
 // on a sibling wave of the same SIMD they do.
 template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1>
 __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
+  as::fp16_saturate_mode();      // |x| >= 65504 saturates in the operand split instead of producing inf / NaN (common.h)
+  float ovf_amax = 0.f;      // max |x| this thread split (loader path) or emitted as a blocked split-fp16 result
   // Block = NSUB sub-tiles of 128 pixels (TH x TW each, consecutive tile ids of the image) x BN output channels.
   // NSUB = 2 with BN = 64 halves the weight bytes a CU pulls per MFMA (the per-CU L1 fill rate, ~45 GB/s, is what
   // the loader waves run into) while 255 tiles of a 136x240 map still pair up into exactly 2 rounds of 256 blocks.
@@ -1063,6 +1082,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
           c_hi[sc_][i][j] = hj;                                                                       \
           c_lo[sc_][i][j] = (_Float16)((v[i][j] - (float)hj) * 2048.f);                                \
         }                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 8; j += 2)                                               \
+          ovf_amax = fmaxf(ovf_amax, fmaxf(fabsf(v[i][j]), fabsf(v[i][j + 1])));                       \
       }                                                                                               \
     }                                                                                                 \
   }
@@ -1346,6 +1367,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
           hi[j] = hj;
           lo[j] = (_Float16)((ov[j] - (float)hj) * 2048.f);
         }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) ovf_amax = fmaxf(ovf_amax, fmaxf(fabsf(ov[j]), fabsf(ov[j + 1])));
         const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)(col0 >> 3) * (e.plane4 * 4u) + poff * 4u;
         if (col0 + 8 <= e.cvalid) {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), e.r_bs, (int)off, 0, 0);
@@ -1376,8 +1399,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       const int gy = (su ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = (su ? sx0[NSUB - 1] : sx0[0]) + m % TW;
       poff[q] = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
     }
-    epilogue_block<EPI, PTW>(p, e, acc_h, acc_x, co_base, poff, half, bias_s, is_r);
+    epilogue_block<EPI, PTW>(p, e, acc_h, acc_x, co_base, poff, half, bias_s, is_r, ovf_amax);
   }
+  as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
 }
 
 // weight [Cout,Cin,KS,KS] fp32 -> split pack [chunk16][tap][comp][h][Cout_pad][8] fp16 (zero padded)
@@ -1398,6 +1422,7 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16*
   const int ci = chunk * kSplitKC + 8 * h + j;
   float v = 0.f;
   if (co < Cout && ci < Cin) v = w[((long long)co * Cin + ci) * KS * KS + tap];
+  as::fp16_saturate_mode();
   const _Float16 hi = (_Float16)v;
   wp[idx] = comp == 0 ? hi : (_Float16)((v - (float)hi) * 2048.f);
 }
@@ -1455,9 +1480,11 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   }
   if (to_bs) {
     _Float16* rec = p.out_bs + (((long long)b * 2 * p.out_bs_c8tot + p.out_bs_coff8 + (cb_ >> 3)) * plane + pix) * 8 + (cb_ & 7);
+    as::fp16_saturate_mode();
     const _Float16 hk = (_Float16)o;
     rec[0] = hk;
     rec[(long long)p.out_bs_c8tot * plane * 8] = (_Float16)((o - (float)hk) * 2048.f);
+    as::note_split_overflow(fabsf(o), &g_split_overflow_conv);
   }
 }
 
@@ -1898,6 +1925,16 @@ int as_interp_bilinear_ac_bs(const float* x, void* out_bs, int B, int C, int H, 
   hipLaunchKernelGGL(interp_bs_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x,
                      reinterpret_cast<_Float16*>(out_bs), C, H, W, Ho, Wo, sy, sx, total);
   return as::check_launch("interp_bilinear_ac_bs");
+}
+
+unsigned as_conv_split_overflow(int reset) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_overflow_conv), sizeof(v)) != hipSuccess) return 0xFFFFFFFFu;
+  if (reset && v) {
+    const unsigned z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_overflow_conv), &z, sizeof(z));
+  }
+  return v;
 }
 
 }  // extern "C"

@@ -368,28 +368,28 @@ __global__ __launch_bounds__(512) void liif_lowres_cl_kernel(LowresParams p) {
     // block fills half a k-step) re-reads the other half's channels and is zeroed by a select — a `cond ? load : 0` form
     // compiles to a branch and a full wait per load.  Two k-steps of loads are in flight ahead of the MFMAs; the scheduling
     // barriers keep the compiler from hoisting all 96 address computations to the top (which spills).
-    F8 r0 = lowres_issue(p, src0, src1, src2, c01, 0, half, b, pp);
-    F8 r1 = KS > 1 ? lowres_issue(p, src0, src1, src2, c01, 1, half, b, pp) : r0;
-    F8 r2 = r0;
+    // DEPTH k-steps of loads in flight ahead of the MFMAs (a ring of register sets with compile-time indices): the kernel is
+    // latency-bound (a tile is 36 MFMAs), so the ring covers an HBM round trip with the first k-steps' arithmetic
+    constexpr int DEPTH = KS < 6 ? KS : 6;
+    F8 ring[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) ring[d] = lowres_issue(p, src0, src1, src2, c01, d, half, b, pp);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 2 < KS) {
-        const F8 nx = lowres_issue(p, src0, src1, src2, c01, ks + 2, half, b, pp);
-        if ((ks + 2) % 3 == 0) r0 = nx; else if ((ks + 2) % 3 == 1) r1 = nx; else r2 = nx;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const F8 cur = ks % 3 == 0 ? r0 : (ks % 3 == 1 ? r1 : r2);
+      const F8 cur = ring[ks % DEPTH];
       float v[8];
       const bool ok = lowres_live(p, c01, ks, half);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = ok ? cur.v[j] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + DEPTH < KS) ring[ks % DEPTH] = lowres_issue(p, src0, src1, src2, c01, ks + DEPTH, half, b, pp);
+      __builtin_amdgcn_sched_barrier(0);
       half8 ah, al;
       split8(v, ah, al, amax);
       const half8 bh = W[((ks * 2 + ntl) * 2) * 64 + lane], bl = W[((ks * 2 + ntl) * 2 + 1) * 64 + lane];
       acc_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_h, 0, 0, 0);
       acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_x, 0, 0, 0);
       acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_x, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
     // C[row = pixel][col = output channel]: one register = 32 consecutive channels of one pixel (128 B per half wave)
 #pragma unroll

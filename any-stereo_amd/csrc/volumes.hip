@@ -181,7 +181,13 @@ __global__ __launch_bounds__(256) void corr_build_kernel(CorrParams p) {
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int kKS16 = 6;  // 16-channel k-steps per pass (96 channels)
 
-__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo) {
+__device__ unsigned g_split_overflow_vol;  // as_volumes_split_overflow
+
+// x = hi + lo/2048; with fp16_saturate_mode() (common.h) an operand outside fp16's range saturates instead of becoming
+// inf / NaN; `amax` collects max |x| for the out-of-range count
+__device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo, float& amax) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) amax = fmaxf(amax, fmaxf(fabsf(v[j]), fabsf(v[j + 1])));
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const _Float16 h = (_Float16)v[j];
@@ -192,6 +198,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], half8& hi, half8& lo
 
 template <bool A_RESIDENT>
 __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) {
+  as::fp16_saturate_mode();
+  float ovf_amax = 0.f;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l31 = lane & 31;
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) 
 #pragma unroll
       for (int j = 0; j < 8; ++j)
         v[j] = bload(r1, a_off == kOOB ? kOOB : a_off + (unsigned)((ps * kKS16 + s) * 16 + j) * cstr1);
-      split8(v, ahi[s], alo[s]);
+      split8(v, ahi[s], alo[s], ovf_amax);
     }
   };
   if (A_RESIDENT) load_a(0);
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) 
         for (int j = 0; j < 8; ++j)
           bv[j] = bload(r2, bo == kOOB ? kOOB : bo + (unsigned)((ps * kKS16 + s) * 16 + j) * cstr2);
         half8 bhi, blo;
-        split8(bv, bhi, blo);
+        split8(bv, bhi, blo, ovf_amax);
         acc_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], bhi, acc_hh, 0, 0, 0);
         acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], blo, acc_x, 0, 0, 0);
         acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], bhi, acc_x, 0, 0, 0);
@@ -261,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) 
     for (int r = 0; r < 16; ++r) res[r] = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
     store_pyramid_tile(p, tout, res, nt, lane);
   }
+  as::note_split_overflow(ovf_amax, &g_split_overflow_vol);
 }
 
 // ---- split precision, LDS-staged (C <= 96): the default at IGEV sizes -----------------------------
@@ -275,6 +284,8 @@ __global__ __launch_bounds__(256, 2) void corr_build_f16x3_kernel(CorrParams p) 
 constexpr int kNB = 4;  // x2 tiles per block
 
 __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
+  as::fp16_saturate_mode();
+  float ovf_amax = 0.f;
   extern __shared__ __attribute__((aligned(16))) unsigned char corr_smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
   for (int i = 0; i < kKS16; ++i) {
     if (i < ksteps) {
       half8 hi, lo;
-      split8(bv[i], hi, lo);
+      split8(bv[i], hi, lo, ovf_amax);
       const int g = (tid >> 7) + 2 * i;
       const unsigned o = (unsigned)(((g >> 1) * (kNB * 32) + xx) * 32 + (g & 1) * 16);
       *reinterpret_cast<half8*>(corr_smem + o) = hi;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
   }
   half8 ahi[kKS16], alo[kKS16];
 #pragma unroll
-  for (int s = 0; s < kKS16; ++s) split8(av[s], ahi[s], alo[s]);
+  for (int s = 0; s < kKS16; ++s) split8(av[s], ahi[s], alo[s], ovf_amax);
   __syncthreads();
   if (mt >= p.MT) return;
 
@@ -360,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void corr_build_lds_kernel(CorrParams p) {
     for (int r = 0; r < 16; ++r) res[r] = acc_hh[r] + acc_x[r] * (1.f / 2048.f);
     store_pyramid_tile(p, tout, res, nt, lane);
   }
+  as::note_split_overflow(ovf_amax, &g_split_overflow_vol);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,6 +674,16 @@ int as_disparity_regression(const float* cost, float* out, int B, int D, int H, 
   const long long plane = (long long)H * W, P = plane * B;
   hipLaunchKernelGGL(softmax_dispreg_kernel, dim3((unsigned)as::cdiv64(P, 256)), dim3(256), 0, as::as_stream(stream), cost, out, D, plane, P, apply_softmax);
   return as::check_launch("disparity_regression");
+}
+
+unsigned as_volumes_split_overflow(int reset) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_split_overflow_vol), sizeof(v)) != hipSuccess) return 0xFFFFFFFFu;
+  if (reset && v) {
+    const unsigned z = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_split_overflow_vol), &z, sizeof(z));
+  }
+  return v;
 }
 
 }  // extern "C"

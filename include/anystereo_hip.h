@@ -121,6 +121,9 @@ int as_lookup_convc1_fwd(const float* const* geo, const float* const* corr, cons
                          void* out_bs, int out_bs_ctot, int out_bs_coff, float* out_f32, int relu,
                          int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
 unsigned as_lookup_split_overflow(int reset);
+/* the same counter for the convolution kernels (conv.hip) and the all-pairs correlation build (volumes.hip) */
+unsigned as_conv_split_overflow(int reset);
+unsigned as_volumes_split_overflow(int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * a4  group-wise correlation volume — replaces build_gwc_volume / groupwise_correlation

@@ -106,6 +106,48 @@ def main(only=None):
     import models.coreContinuous_IGEV.liif as rliif
     from models.coreContinuous_IGEV.continuous_IGEVstereo import continuous_IGEVStereo as RefIGEV
     from models.corePrune_RAFT.prune_raft_stereo import continuous_RaftStereo as RefRAFT
+    def gen_update():
+        # ---- G5: update block (IGEV and RAFT encoders) ------------------------------------------------
+        for tag, mod, model_name in (("igev", rupd, "continuous_IGEVStereo"), ("raft", rupd_raft, "continuous_RAFTStereo")):
+            args = default_args(model_name)
+            ub = mod.BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims).eval()
+            fill_module_deterministic(ub, base_seed=5)
+            h, w = 8, 12
+            net = [torch.tanh(det_uniform((1, 128, h >> i, w >> i), 40 + i, -2, 2)) for i in range(3)]
+            ctx = [det_uniform((1, 384, h >> i, w >> i), 50 + i) for i in range(3)]
+            inp = [list(c.split(128, dim=1)) for c in ctx]
+            cor_planes = ub.encoder.convc1.in_channels
+            corr = det_uniform((1, cor_planes, h, w), 60, -3, 3)
+            disp = det_uniform((1, 1, h, w), 61, 0, 12)
+            mf = ub.encoder(disp, corr)
+            g16 = ub.gru16(net[2], *inp[2], rupd.pool2x(net[1]))
+            net_out, delta = ub([n.clone() for n in net], inp, corr, disp)
+            net_lo = ub([n.clone() for n in net], inp, iter16=True, iter08=True, iter04=False, update=False)
+            # every flag combination the forward loops use (continuous_IGEVstereo.py:288-293: the slow-fast pre-updates and the
+            # main update) plus the remaining (iter16, iter08, iter04, update) patterns a caller can pass
+            flags = {}
+            for name, kw in (("f16", dict(iter16=True, iter08=False, iter04=False, update=False)),
+                             ("f08_04", dict(iter16=False, iter08=True, iter04=True, update=True)),
+                             ("f04", dict(iter16=False, iter08=False, iter04=True, update=True)),
+                             ("fall_noup", dict(iter16=True, iter08=True, iter04=True, update=False))):
+                res = ub([n.clone() for n in net], inp, corr if kw["iter04"] else None, disp if kw["iter04"] else None, **kw)
+                nets = res[0] if kw["update"] else res
+                for i in range(3):
+                    flags[f"{name}_net{i}"] = nets[i]
+                if kw["update"]:
+                    flags[f"{name}_delta"] = res[1]
+            if only == "update":
+                save(f"update_flags_{tag}", **flags)
+                continue
+            save(f"update_flags_{tag}", **flags)
+            save(f"update_{tag}", net0=net[0], net1=net[1], net2=net[2], ctx0=ctx[0], ctx1=ctx[1], ctx2=ctx[2], corr=corr,
+                 disp=disp, motion=mf, gru16=g16, out0=net_out[0], out1=net_out[1], out2=net_out[2], delta=delta,
+                 lo1=net_lo[1], lo2=net_lo[2], pool=rupd.pool2x(net[0]), interp=rupd.interp(net[2], net[1]),
+                 head=ub.disp_head(net[0]))
+
+
+    if only == "update":
+        return gen_update()
     if only == "train":
         import ast
         import torch.nn.functional as F
@@ -149,26 +191,7 @@ def main(only=None):
     prob = torch.softmax(cost, dim=1)
     save("gwc_dispreg", fl=fl, fr=fr, vol=vol, cost=cost, init_disp=rsub.disparity_regression(prob, 48))
 
-    # ---- G5: update block (IGEV and RAFT encoders) ------------------------------------------------
-    for tag, mod, model_name in (("igev", rupd, "continuous_IGEVStereo"), ("raft", rupd_raft, "continuous_RAFTStereo")):
-        args = default_args(model_name)
-        ub = mod.BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims).eval()
-        fill_module_deterministic(ub, base_seed=5)
-        h, w = 8, 12
-        net = [torch.tanh(det_uniform((1, 128, h >> i, w >> i), 40 + i, -2, 2)) for i in range(3)]
-        ctx = [det_uniform((1, 384, h >> i, w >> i), 50 + i) for i in range(3)]
-        inp = [list(c.split(128, dim=1)) for c in ctx]
-        cor_planes = ub.encoder.convc1.in_channels
-        corr = det_uniform((1, cor_planes, h, w), 60, -3, 3)
-        disp = det_uniform((1, 1, h, w), 61, 0, 12)
-        mf = ub.encoder(disp, corr)
-        g16 = ub.gru16(net[2], *inp[2], rupd.pool2x(net[1]))
-        net_out, delta = ub([n.clone() for n in net], inp, corr, disp)
-        net_lo = ub([n.clone() for n in net], inp, iter16=True, iter08=True, iter04=False, update=False)
-        save(f"update_{tag}", net0=net[0], net1=net[1], net2=net[2], ctx0=ctx[0], ctx1=ctx[1], ctx2=ctx[2], corr=corr,
-             disp=disp, motion=mf, gru16=g16, out0=net_out[0], out1=net_out[1], out2=net_out[2], delta=delta,
-             lo1=net_lo[1], lo2=net_lo[2], pool=rupd.pool2x(net[0]), interp=rupd.interp(net[2], net[1]),
-             head=ub.disp_head(net[0]))
+    gen_update()
 
     # ---- G6: LIIF pieces --------------------------------------------------------------------------
     feat = det_uniform((2, 20, 5, 7), 71)
@@ -282,5 +305,6 @@ def main(only=None):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["train"], default=None, help="regenerate only the G8 training-step fixtures")
+    ap.add_argument("--only", choices=["train", "update"], default=None,
+                    help="regenerate only the G8 training-step fixtures / only the G5 flag-combination fixtures")
     main(ap.parse_args().only)

@@ -439,6 +439,31 @@ def test_update_block_golden(golden, precision):
             close(lo[1], g["lo1"], 2e-5, 3e-5, "slow-fast net1")
 
 
+def test_update_block_flag_combinations_golden(golden, precision):
+    """G5: every (iter16, iter08, iter04, update) pattern of BasicMultiUpdateBlock.forward against the reference's outputs
+    (update.py:116-136; slow-fast pre-updates continuous_IGEVstereo.py:288-291)."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.models.base import default_args
+    from anystereo.nn.update import BasicMultiUpdateBlock
+    from test_oracle_golden import FLAG_COMBOS
+    for tag in ("igev", "raft"):
+        g, gf = golden(f"update_{tag}"), golden(f"update_flags_{tag}")
+        args = default_args("continuous_IGEVStereo" if tag == "igev" else "continuous_RAFTStereo")
+        ub = BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims, geo_channels=8 if tag == "igev" else 0).eval()
+        fill_module_deterministic(ub, base_seed=5)
+        ub = ub.to(DEV)
+        inp = [list(g[f"ctx{i}"].to(DEV).split(128, dim=1)) for i in range(3)]
+        for name, kw in FLAG_COMBOS:
+            net = [g["net0"].to(DEV).clone(), g["net1"].to(DEV).clone(), g["net2"].to(DEV).clone()]
+            with torch.no_grad():
+                res = ub(net, inp, g["corr"].to(DEV) if kw["iter04"] else None, g["disp"].to(DEV) if kw["iter04"] else None, **kw)
+            nets = res[0] if kw["update"] else res
+            for i in range(3):
+                close(nets[i], gf[f"{name}_net{i}"], 2e-5, 3e-5, f"{tag} {name} net{i}")
+            if kw["update"]:
+                close(res[1], gf[f"{name}_delta"], 2e-5, 3e-5, f"{tag} {name} delta")
+
+
 # ---------------------------------------------------------------------------------------------
 # a12-a17 LIIF
 # ---------------------------------------------------------------------------------------------
@@ -1165,3 +1190,68 @@ def test_lookup_convc1_fused(b, h, w, g, d, L):
     ref = O.geo_corr_lookup(geo64, [t.double().cpu() for t in corr], disp.double().cpu(), 4)
     want2 = torch.relu(torch.einsum("oc,bchw->bohw", wt[:, :, 0, 0].double().cpu(), ref) + bias.double().cpu().view(1, -1, 1, 1))
     close(out, want2, 3e-5, 3e-5, "fused lookup + convc1 vs the oracle's lookup")
+
+
+def test_split_mode_range_guard():
+    """Split precision represents an operand as fp16 hi + lo: |x| >= 65504 has no such form.  The kernels SATURATE such
+    operands (MODE.FP16_OVFL / round-toward-zero conversions: finite results, never inf / NaN) and count the waves that met
+    one (ops.split_overflow_count); exact-fp32 mode computes them correctly.  Activations of scale 1e5 through a conv, the
+    blocked split-fp16 link tensor, the all-pairs correlation and the fused lookup conv, in both modes."""
+    import torch.nn.functional as F
+    from anystereo import ops
+    prev = ops.get_precision()
+    x = (U((1, 32, 12, 20), 401) * 2e5).to(DEV)           # |x| up to 2e5 > 65504
+    xs = (U((1, 32, 12, 20), 401) * 2.0).to(DEV)            # the same pattern in range
+    w = (U((64, 32, 3, 3), 402) * 0.05).to(DEV)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    try:
+        ops.set_precision("fp32")
+        pk = ops.PackedConv().get([w], [None])
+        close(ops.conv2d([x], pk), ref, 2e-5, 1e-3, "fp32 mode, 1e5-scale activations")
+        ops.set_precision("split")
+        ops.split_overflow_count()                            # reset
+        pk = ops.PackedConv().get([w], [None])
+        y = ops.conv2d([xs], pk)
+        close(y, F.conv2d(xs.double(), w.double(), padding=1), 2e-5, 2e-5, "split mode, in range")
+        assert ops.split_overflow_count() == 0, "in-range operands must not be counted"
+        bs = ops.BS8.empty(1, 64, 12, 20, DEV)
+        y = ops.conv2d([x], pk, out_bs=bs)                   # fp32 source (loader split) + blocked result (epilogue split)
+        assert torch.isfinite(y).all() and torch.isfinite(bs.t.float()).all(), "saturation must keep everything finite"
+        assert ops.split_overflow_count() > 0, "out-of-range operands must be counted"
+        big = ops.BS8.empty(1, 32, 12, 20, DEV)
+        ops.conv2d([x], ops.PackedConv().get([torch.eye(32, device=DEV).view(32, 32, 1, 1).contiguous()], [None]), out_bs=big)
+        assert big.float().abs().max().item() <= 65504.0 * (1 + 2.0 ** -10) and torch.isfinite(big.t.float()).all()
+        ops.split_overflow_count()
+        f1 = (U((1, 96, 4, 40), 403) * 1e5).to(DEV)
+        lv = ops.corr_build_pyramid(f1, f1, 2)
+        assert all(torch.isfinite(t).all() for t in lv) and ops.split_overflow_count() > 0
+        # fused lookup + convc1: a 1e6-scale correlation volume saturates in the tile split, finite output
+        corr = [t * 0 + 3e6 for t in ops.corr_build_pyramid(xs[:, :, :4].contiguous(), xs[:, :, :4].contiguous(), 4)]
+        wt = (U((64, 36, 1, 1), 404) * 0.1).to(DEV)
+        out = ops.lookup_convc1(None, corr, torch.zeros(1, 1, 4, 20, device=DEV), 4, ops.LookupConvPack().get(wt, None), want_f32=True)
+        assert torch.isfinite(out).all() and ops.split_overflow_count() > 0
+        ops.set_precision("fp32")
+        lv32 = ops.corr_build_pyramid(f1, f1, 1)
+        close(lv32[0], O.all_pairs_corr(f1.double().cpu(), f1.double().cpu()), 2e-5, 1.0, "fp32 mode all-pairs at 1e5 scale")
+    finally:
+        ops.set_precision(prev)
+        ops.split_overflow_count()
+
+
+def test_lookup_rejects_foreign_coords():
+    """`coords` is part of the reference signature (geometry.py:34) but the kernels regenerate the pixel-column grid: the
+    model's own grid and an equal caller-made grid are accepted, anything else raises instead of being ignored."""
+    from anystereo.nn.geometry import Combined_Geo_Encoding_Volume
+    b, h, w = 1, 4, 24
+    f1, f2 = U((b, 32, h, w), 501).to(DEV), U((b, 32, h, w), 502).to(DEV)
+    gev = U((b, 8, 48, h, w), 503).to(DEV)
+    fn = Combined_Geo_Encoding_Volume(f1, f2, gev, num_levels=2, radius=4)
+    disp = U((b, 1, h, w), 504, 0.0, 10.0).to(DEV)
+    good = torch.arange(w, device=DEV).float().view(1, 1, w, 1).repeat(b, h, 1, 1)
+    ref = fn(disp, good)
+    assert torch.equal(fn(disp, None), ref)
+    bad = good + 0.5
+    with pytest.raises(RuntimeError, match="arange"):
+        fn(disp, bad)
+    with pytest.raises(RuntimeError, match="coords must be"):
+        fn(disp, good[:, :, :-1])

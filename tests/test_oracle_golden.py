@@ -102,6 +102,30 @@ def test_update_block(golden):
             close(lo[2], g["lo2"], 1e-5, 2e-5)
 
 
+FLAG_COMBOS = (("f16", dict(iter16=True, iter08=False, iter04=False, update=False)),
+               ("f08_04", dict(iter16=False, iter08=True, iter04=True, update=True)),
+               ("f04", dict(iter16=False, iter08=False, iter04=True, update=True)),
+               ("fall_noup", dict(iter16=True, iter08=True, iter04=True, update=False)))
+
+
+def test_update_block_flag_combinations(golden):
+    """G5: every (iter16, iter08, iter04, update) pattern of BasicMultiUpdateBlock.forward (update.py:116-136; the slow-fast
+    pre-updates of continuous_IGEVstereo.py:288-291 and the remaining ones) against the reference's outputs."""
+    for tag in ("igev", "raft"):
+        g, gf = golden(f"update_{tag}"), golden(f"update_flags_{tag}")
+        ub = _ub(tag)
+        inp = [list(g[f"ctx{i}"].split(128, dim=1)) for i in range(3)]
+        for name, kw in FLAG_COMBOS:
+            net = [g["net0"].clone(), g["net1"].clone(), g["net2"].clone()]
+            with torch.no_grad():
+                res = O.update_block(ub, net, inp, g["corr"] if kw["iter04"] else None, g["disp"] if kw["iter04"] else None, **kw)
+            nets = res[0] if kw["update"] else res
+            for i in range(3):
+                close(nets[i], gf[f"{name}_net{i}"], 1e-5, 2e-5)
+            if kw["update"]:
+                close(res[1], gf[f"{name}_delta"], 1e-5, 2e-5)
+
+
 def test_liif_pieces(golden):
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.nn.liif import liif_out_multi_scale_Training
