@@ -48,6 +48,8 @@ class ConvDesc(C.Structure):
 SIGNATURES = {
     "as_set_precision": (_i, [_i]),
     "as_get_precision": (_i, []),
+    "as_set_fast16": (_i, [_i]),
+    "as_get_fast16": (_i, []),
     "as_last_error_string": (C.c_char_p, []),
     "as_abi_version": (_i, []),
     "as_device_count": (_i, []),

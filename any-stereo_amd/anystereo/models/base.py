@@ -156,8 +156,19 @@ class ContinuousStereoBase(nn.Module):
         self._drop_graphs()
         return super()._apply(fn, *a, **k)
 
+    def _reduced_precision(self, image1) -> bool:
+        """`args.mixed_precision` in inference: the reference wraps the feature nets and the update block in autocast (fp16
+        operands, continuous_IGEVstereo.py:245,287).  Here it selects the one-MFMA fp16-operand mode of the HIP convolution
+        kernels (fp32 storage and accumulation stay; ops.fast_fp16) for the whole forward instead of torch.autocast — a
+        second arithmetic mode with its own tolerance, never the parity mode.  Training keeps torch.autocast + fp32 kernels."""
+        return (bool(getattr(self.args, "mixed_precision", False)) and image1.is_cuda and not torch.is_grad_enabled()
+                and not self.training and ops.get_precision() == "split")
+
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
         """Reference signature (continuous_IGEVstereo.py:239, prune_raft_stereo.py:246)."""
+        if self._reduced_precision(image1) and not ops.get_fast_fp16():
+            with ops.fast_fp16(True):
+                return self.forward(image1, image2, iters, flow_init, test_mode, hr_coord, scale, output_raw)
         if (getattr(self, "_use_graph", False) and test_mode and not torch.is_grad_enabled() and image1.is_cuda
                 and torch.is_tensor(scale) and not output_raw and not self.training):
             return self._forward_graphed(image1, image2, iters, hr_coord, scale)
@@ -166,7 +177,8 @@ class ContinuousStereoBase(nn.Module):
 
     def _forward_graphed(self, image1, image2, iters, hr_coord, scale):
         key = (tuple(image1.shape), tuple(hr_coord.shape), tuple(scale.shape), int(iters), image1.device.index,
-               ops.get_precision(), self._weights_fingerprint())
+               ops.get_precision(), ops.get_fast_fp16() or bool(getattr(self.args, "mixed_precision", False)),
+               self._weights_fingerprint())
         graphs = self.__dict__.setdefault("_graphs", {})
         ent = graphs.pop(key, None)
         if ent is None:
@@ -234,6 +246,11 @@ class ContinuousStereoBase(nn.Module):
     # (ConvGRU.pre_zr) to fill the CUs the small kernels leave idle — 0.66 vs 0.60 ms per iteration on the same box.
     split_gate_conv = os.environ.get("ANYSTEREO_SPLIT_GATE_CONV", "0") != "0"
 
+    # gru16 of iteration i+1 needs only the 1/8 and 1/16 states of iteration i (gru08(i)'s output), so it can run beside
+    # gru04(i) on a third stream instead of in front of gru08(i+1) on the main one (shorter 1/8-1/16 chain between two
+    # gru04 launches).  ANYSTEREO_EARLY_GRU16=0 keeps the in-order schedule.
+    early_gru16 = os.environ.get("ANYSTEREO_EARLY_GRU16", "1") != "0"
+
     def _iterate_pipelined(self, lookup_fn, net, inp, disp, coords, iters):
         from ..nn.update import interp, pool2x
         ub = self.update_block
@@ -245,10 +262,25 @@ class ContinuousStereoBase(nn.Module):
         enc = (lambda d: ub.encoder.forward_fused_lookup(d, lookup_fn)) if fused else (lambda d: ub.encoder(d, lookup_fn(d, coords)))
         with torch.cuda.stream(side):
             mf = enc(disp)
+        early = self.early_gru16 and iters > 1
+        s16 = ub._side_stream(dev, 1) if early else None
+        net2_next = None
         for itr in range(iters):
             pre = ub.gru04.pre_zr(net[0], *(inp[0])) if self.split_gate_conv else None
-            net[2] = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
+            if net2_next is None:
+                net[2] = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
+            else:  # computed on the third stream during the previous iteration's gru04
+                main.wait_stream(s16)
+                net[2] = net2_next
+                net[2].record_stream(main)
+                net2_next = None
             net[1] = ub.gru08(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+            if early and itr + 1 < iters:
+                s16.wait_stream(main)  # net[1], net[2] of this iteration are final
+                with torch.cuda.stream(s16):
+                    net2_next = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
+                net[1].record_stream(s16)
+                net[2].record_stream(s16)
             up = interp(net[1], net[0])
             main.wait_stream(side)  # motion features (and the disparity they were computed from) are ready
             mf.record_stream(main)

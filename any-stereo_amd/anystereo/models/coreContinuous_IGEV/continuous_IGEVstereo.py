@@ -87,7 +87,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
-        with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda):
+        with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda and not self._reduced_precision(image1)):
             fast = B.fused_ok(image1, self)
             side = None
             if fast:

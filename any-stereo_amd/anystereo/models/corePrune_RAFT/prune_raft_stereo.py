@@ -79,7 +79,7 @@ class continuous_RaftStereo(ContinuousStereoBase):
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
-        with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda):
+        with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda and not self._reduced_precision(image1)):
             side = None
             if B.fused_ok(image1, self) and self.parallel_context and image1.is_cuda:
                 # context network (+ stems) on the second stream while the feature network runs (see continuous_IGEVStereo)

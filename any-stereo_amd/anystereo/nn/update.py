@@ -241,7 +241,7 @@ class BasicMotionEncoder(nn.Module):
                 else:
                     cor = ops.conv2d([corr], self._pc1.get([self.convc1.weight], [self.convc1.bias]), act=L.ACT_RELU)
             with scope("enc_convd1"):
-                d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()),
+                d1 = ops.conv7x7_c1_relu(disp, self.convd1.weight, self.convd1.bias,
                                          out=ops.BS8.empty(b, 64, h, w, disp.device) if bs else None, copy_out=out, copy_coff=127)
             with scope("enc_convc2"):
                 second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
@@ -257,7 +257,6 @@ class BasicMotionEncoder(nn.Module):
 
     dual_branches = __import__("os").environ.get("ANYSTEREO_DUAL_BRANCHES", "1") != "0"
     fused_lookup = __import__("os").environ.get("ANYSTEREO_FUSED_LOOKUP", "1") != "0"
-
     def fused_lookup_ok(self, lookup_fn) -> bool:
         return (self.fused_lookup and self.dual_branches and _links() and not torch.is_grad_enabled()
                 and getattr(lookup_fn, "fused_convc1_ok", None) is not None and lookup_fn.fused_convc1_ok()
@@ -272,10 +271,12 @@ class BasicMotionEncoder(nn.Module):
         if not hasattr(self, "_plc1"):
             self._plc1 = ops.LookupConvPack()
         cor = ops.BS8.empty(b, 64, h, w, disp.device)
+        d1 = ops.BS8.empty(b, 64, h, w, disp.device)
+        # (Tried and removed: the 7x7 conv on a branch stream beside the fused lookup — both depend on `disp` only — forked
+        # from the loop's side stream: capturing that nested fork into the forward's hipGraph crashed the process.)
         lookup_fn.lookup_convc1(disp, self._plc1.get(self.convc1.weight, self.convc1.bias), out_bs=cor)
         with scope("enc_convd1"):
-            d1 = ops.conv7x7_c1_relu(disp, _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()),
-                                     out=ops.BS8.empty(b, 64, h, w, disp.device), copy_out=out, copy_coff=127)
+            ops.conv7x7_c1_relu(disp, self.convd1.weight, self.convd1.bias, out=d1, copy_out=out, copy_coff=127)
         with scope("enc_convc2"):
             second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
             ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out_bs=cd, out_bs_coff=0,
@@ -315,7 +316,7 @@ class BasicMotionEncoder(nn.Module):
     def disp_branch(self, disp, cd, out=None):
         """convd1 -> convd2 into cd[:, 64:]; with `out` the disparity itself is also placed in out[:, 127] (update.py:91)."""
         with scope("enc_convd1"):
-            d1 = ops.conv7x7_c1_relu(_f(disp), _f(self.convd1.weight.detach()), _f(self.convd1.bias.detach()),
+            d1 = ops.conv7x7_c1_relu(_f(disp), self.convd1.weight, self.convd1.bias,
                                      copy_out=out, copy_coff=127)
         with scope("enc_convd2"):
             if isinstance(cd, ops.BS8):

@@ -40,6 +40,31 @@ def set_precision(mode: str) -> None:
     L.check(L.load().as_set_precision({"fp32": 0, "split": 1}[mode]), "set_precision")
 
 
+def set_fast_fp16(flag: bool) -> None:
+    """Reduced-precision variant of split mode for the convolution kernels: fp16 operands, fp32 accumulate, one MFMA per
+    product (the reference's autocast path, continuous_IGEVstereo.py:287).  Not the parity mode: its own tolerance."""
+    L.check(L.load().as_set_fast16(1 if flag else 0), "set_fast16")
+
+
+def get_fast_fp16() -> bool:
+    return bool(L.load().as_get_fast16())
+
+
+class fast_fp16:
+    """with ops.fast_fp16(True): ...  (restores the previous setting)"""
+
+    def __init__(self, flag: bool):
+        self.flag = flag
+
+    def __enter__(self):
+        self.prev = get_fast_fp16()
+        set_fast_fp16(self.flag)
+
+    def __exit__(self, *exc):
+        set_fast_fp16(self.prev)
+        return False
+
+
 def get_precision() -> str:
     return "fp32" if L.load().as_get_precision() == 0 else "split"
 
@@ -529,7 +554,9 @@ _TAPMAJOR = {}  # (data_ptr, version, device) of a [Cout,1,7,7] weight -> its [4
 def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_coff=0):
     """relu(conv7x7(x [B,1,H,W]) + bias) into channels [out_coff, out_coff+Cout) of `out` (update.py:81,87);
     with `copy_out` [B,C,H,W], x is also written to its channel `copy_coff`."""
-    _req(x, "x"), _req(weight, "weight")
+    _req(x, "x")
+    if not weight.is_cuda:
+        raise RuntimeError("conv7x7_c1_relu: weight must be a CUDA (HIP) tensor")
     b, one, h, w = x.shape
     cout = weight.shape[0]
     if one != 1 or tuple(weight.shape[1:]) != (1, 7, 7):
@@ -538,6 +565,9 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
         out = torch.empty((b, cout, h, w), device=x.device, dtype=torch.float32)
     obs = isinstance(out, BS8)  # blocked split-fp16 result (feeds a split-precision convolution only)
     _req(out.t if obs else out, "out", torch.float16 if obs else torch.float32)
+    # `weight` / `bias` are the module's PARAMETERS (not detached temporaries): the tap-major copy is cached per tensor object
+    # + version (a `.detach()` made at the call site is a new object every time and would rebuild the copy — two elementwise
+    # kernels, 10 us on the GRU loop's critical stream — at every call)
     key = (weight.data_ptr(), weight._version, weight.device)
     ent = _TAPMAJOR.get(key)
     # the entry must belong to THIS tensor: a freed weight's address (and version 0) is reused by the caching allocator
@@ -546,8 +576,11 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
         if len(_TAPMAJOR) > 64:
             _TAPMAJOR.clear()
         wt = torch.zeros((49, (cout + 63) // 64 * 64), device=weight.device, dtype=torch.float32)
-        wt[:, :cout] = weight.detach().reshape(cout, 49).t()
+        wt[:, :cout] = weight.detach().float().reshape(cout, 49).t()
         _TAPMAJOR[key] = (weakref.ref(weight), wt)
+    if bias is not None:
+        bias = bias.detach()
+        bias = bias if (bias.dtype == torch.float32 and bias.is_contiguous()) else bias.float().contiguous()
     with torch.cuda.device(x.device):
         cbs = isinstance(copy_out, BS8)
         if copy_out is not None:

@@ -28,9 +28,18 @@ int precision_mode() {
   return g_precision;
 }
 
+static int g_fast16 = 0;
+int fast16_mode() { return g_fast16; }
+
 }  // namespace as
 
 extern "C" {
+
+int as_set_fast16(int on) {
+  as::g_fast16 = on ? 1 : 0;
+  return AS_OK;
+}
+int as_get_fast16(void) { return as::g_fast16; }
 
 int as_set_precision(int mode) {
   if (mode != 0 && mode != 1) return as::fail(AS_ERR_BAD_ARG, "set_precision: mode %d (0 = fp32 MFMA, 1 = 3 x fp16 split)", mode);
@@ -41,7 +50,7 @@ int as_get_precision(void) { return as::precision_mode(); }
 
 const char* as_last_error_string(void) { return as::err_buf(); }
 
-int as_abi_version(void) { return 16; }
+int as_abi_version(void) { return 17; }
 
 int as_device_count(void) {
   int n = 0;

@@ -27,6 +27,9 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // 1 = split-precision 3 x fp16 MFMA (~2^-22 relative per product, needs |x| < 65504).
 int precision_mode();
 inline bool use_split_precision() { return precision_mode() == 1; }
+// Reduced-precision variant of the split mode (as_set_fast16): plain fp16 operands (the hi parts only), fp32 accumulate —
+// ONE MFMA per product instead of three; the counterpart of the reference's autocast path (continuous_IGEVstereo.py:287).
+int fast16_mode();
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

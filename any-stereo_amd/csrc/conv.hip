@@ -72,6 +72,7 @@ struct ConvParams {
   // conv's epilogue accumulates instead of storing its own result (out = [B][n_tiles * 9][H][W])
   const float* tap_w;
   int xcd_map;  // conv_split_kernel: XCD-aware block order (channel tiles of one pixel tile on the same XCD)
+  int fast16;   // conv_split_kernel: skip the two cross-term MFMAs (fp16 operands, fp32 accumulate: as_set_fast16)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
 };
@@ -898,10 +899,13 @@ __device__ unsigned long long as_conv_stamp_buf[kStampBlocks * kStampSlots];
 // the LDS commit.  Measured on the single-role version: an LDS-DMA instruction costs the issuing wave
 // ~180 cycles, so 18 of them per chunk in front of 108 MFMAs could not overlap with them (in-order issue);
 // on a sibling wave of the same SIMD they do.
-template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1>
+template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   as::fp16_saturate_mode();      // |x| >= 65504 saturates in the operand split instead of producing inf / NaN (common.h)
   float ovf_amax = 0.f;      // max |x| this thread split (loader path) or emitted as a blocked split-fp16 result
+  // FAST: fp16 operands (the hi parts only), ONE MFMA per product (as_set_fast16).  A compile-time variant: a run-time
+  // branch around the two cross-term MFMAs costs the three-MFMA stream 25 % end to end (measured on one box: 25.8 vs 21.6 ms)
+  constexpr bool fast16 = FAST;
   // Block = NSUB sub-tiles of 128 pixels (TH x TW each, consecutive tile ids of the image) x BN output channels.
   // NSUB = 2 with BN = 64 halves the weight bytes a CU pulls per MFMA (the per-CU L1 fill rate, ~45 GB/s, is what
   // the loader waves run into) while 255 tiles of a 136x240 map still pair up into exactly 2 rounds of 256 blocks.
@@ -1206,21 +1210,23 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   {                                                                                                     \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                      \
       a_hi[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 0) * 2) * WSEG + c * 512);          \
-      a_lo[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 1) * 2) * WSEG + c * 512);          \
+      if (!fast16) a_lo[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 1) * 2) * WSEG + c * 512); \
     }                                                                                                   \
     constexpr int tapoff_ = (KS == 1) ? (TAP) * PIMG : (((TAP) / KS) * PW + ((TAP) % KS)) * 16;          \
     _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                    \
       b_hi[S][q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff_);                         \
-      b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHT * 16 + plane_off[q] + tapoff_);       \
+      if (!fast16) b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHT * 16 + plane_off[q] + tapoff_); \
     }                                                                                                   \
   }
 #define AS_SPLIT_MFMA_C(S, c)                                                                           \
   _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                      \
     acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);   \
-    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
+    if (!fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
   }                                                                                                     \
+  if (!fast16) {                                                                                        \
   _Pragma("unroll") for (int q = 0; q < PTW; ++q)  /* second cross term: not back to back with the first on the same accumulator */ \
-    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0);
+    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0); \
+  }
 #define AS_SPLIT_STEP(TAP)                                                                              \
   if constexpr ((TAP) < NTAPE) {                                                                        \
     AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
@@ -1488,8 +1494,11 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   }
 }
 
-template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1>
+template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1, bool FAST = false>
 int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
+  if constexpr (!FAST && KS == 3 && S == 1) {  // the one-MFMA variant exists for the stride-1 3x3 convolutions (the GRU loop, the context net)
+    if (p.fast16) return launch_conv_split_epi<KS, TW, BN, EPI, NSUB, S, true>(p, s);
+  }
   constexpr int TH = 128 / TW, PATCHP = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
   constexpr int NSC = (KS == 1) ? 4 : 1;
   constexpr size_t wimg = (size_t)(KS * KS * NSC * 4 * BN * 16), pimg = (size_t)NSC * (4 * NSUB * PATCHP * 16);
@@ -1497,7 +1506,7 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "conv_split: LDS budget");
   static bool configured = false;  // per instantiation; the attribute is idempotent
   if (!configured && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI, NSUB, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
   const long long groups = as::cdiv64((long long)p.tiles_x * p.tiles_y, NSUB);
@@ -1505,7 +1514,7 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   static const int xcd_mode = getenv("AS_CONV_XCD") ? atoi(getenv("AS_CONV_XCD")) : 1;
   ConvParams q = p;
   q.xcd_map = (xcd_mode && p.n_tiles > 1) ? 1 : 0;
-  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB, S>), grid, dim3(512), lds, s, q);
+  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST>), grid, dim3(512), lds, s, q);
   return as::check_launch("conv2d(split)");
 }
 
@@ -1704,6 +1713,7 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(!d->add || (d->add_coff >= 0 && d->add_coff + d->Cout <= d->add_ctot), AS_ERR_BAD_SHAPE, "conv2d: add channel window [%d,%d) outside %d", d->add_coff, d->add_coff + d->Cout, d->add_ctot);
   p.h = d->h; p.z = d->z; p.out = d->out; p.out2 = d->out2;
   p.B = d->B; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
+  p.fast16 = (d->precision == 1 && as::fast16_mode()) ? 1 : 0;
   p.Cout_pad = conv_cout_pad(d->Cout);
   const int epi = d->epilogue;
   if (epi == AS_EPI_LINEAR) {

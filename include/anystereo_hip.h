@@ -61,6 +61,11 @@ extern "C" {
  *   1 = split precision, 3 x fp16 MFMA per product (operand = hi + lo/2048, fp32 accumulation; relative
  *       error ~2^-22 per product, requires |x| < 65504).  Process-wide; initial value from the environment
  *       variable ANYSTEREO_PRECISION ("fp32" -> 0, otherwise 1). */
+/* Reduced-precision variant of mode 1 for the convolution kernels: plain fp16 operands (the hi parts of the split), fp32
+ * accumulate, ONE MFMA per product — the counterpart of the reference's autocast path (`autocast(enabled=args.mixed_precision)`,
+ * continuous_IGEVstereo.py:287; evaluation.py:558,644).  Process-wide; own, looser tolerance. */
+int as_set_fast16(int on);
+int as_get_fast16(void);
 int as_set_precision(int mode);
 int as_get_precision(void);
 

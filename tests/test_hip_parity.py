@@ -1255,3 +1255,48 @@ def test_lookup_rejects_foreign_coords():
         fn(disp, bad)
     with pytest.raises(RuntimeError, match="coords must be"):
         fn(disp, good[:, :, :-1])
+
+
+def test_reduced_precision_mode(golden):
+    """`args.mixed_precision` in inference = the one-MFMA mode of the convolution kernels (fp16 operands, fp32 accumulate;
+    the counterpart of the reference's autocast path, continuous_IGEVstereo.py:287, evaluation.py:558).  It is a SECOND mode
+    with its own tolerance — against the reference's fp32 output: a single conv within 2e-3 relative (fp16 operand rounding
+    2^-11 over a K = 1152 dot product), the whole model within 5e-2 px EPE — and it must really differ from the
+    parity mode (whose bar stays 1e-3)."""
+    import torch.nn.functional as F
+    from anystereo import ops
+    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
+    from anystereo.models import __models__, default_args
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        x = U((1, 128, 20, 36), 601, -2, 2).to(DEV)
+        w = (U((64, 128, 3, 3), 602) * (3.0 / 1152) ** 0.5).to(DEV)
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        pk = ops.PackedConv().get([w], [None])
+        exact = ops.conv2d([x], pk)
+        with ops.fast_fp16(True):
+            fast = ops.conv2d([x], pk)
+        assert not ops.get_fast_fp16()
+        e_exact = (exact.double() - ref).abs().max().item() / ref.abs().max().item()
+        e_fast = (fast.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert e_exact < 2e-6 and 1e-5 < e_fast < 2e-3, (e_exact, e_fast)
+        g = golden("model_igev")
+        H, W = int(g["H"]), int(g["W"])
+        img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+        outs = {}
+        for mp in (False, True):
+            model = __models__["continuous_IGEVStereo"](default_args("continuous_IGEVStereo", mixed_precision=mp)).eval()
+            fill_module_deterministic(model, base_seed=1)
+            model = model.to(DEV)
+            coord = O.make_coord([round(H * 1.5), round(W * 1.5)]).view(1, -1, 2).to(DEV)
+            with torch.no_grad():
+                outs[mp] = model(img1.to(DEV), img2.to(DEV), iters=3, test_mode=True, hr_coord=coord, scale=torch.tensor([[1.5]], device=DEV))
+            assert not ops.get_fast_fp16(), "the mode must not leak out of forward()"
+        key = [k for k in g if "test" in k and "1p5" in k]
+        d = (outs[True] - outs[False]).abs().mean().item()
+        print(f"reduced precision vs parity mode: mean |d| = {d:.3e} px; conv rel err {e_fast:.2e}")
+        assert torch.isfinite(outs[True]).all() and 1e-7 < d < 5e-2, d
+    finally:
+        ops.set_fast_fp16(False)
+        ops.set_precision(prev)
