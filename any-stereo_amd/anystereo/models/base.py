@@ -256,14 +256,17 @@ class ContinuousStereoBase(nn.Module):
         ub = self.update_block
         dev = disp.device
         main = torch.cuda.current_stream(dev)
-        side = ub._side_stream(dev)
+        # serial_streams (measurement only): the same kernels in the same order on ONE stream, so that an event pair around a
+        # launch times that kernel alone (bench.py's per-kernel table)
+        serial = bool(getattr(self, "serial_streams", False))
+        side = main if serial else ub._side_stream(dev)
         side.wait_stream(main)
         fused = ub.encoder.fused_lookup_ok(lookup_fn)  # lookup -> convc1 as one kernel (no [B,162,h,w] tensor)
         enc = (lambda d: ub.encoder.forward_fused_lookup(d, lookup_fn)) if fused else (lambda d: ub.encoder(d, lookup_fn(d, coords)))
         with torch.cuda.stream(side):
             mf = enc(disp)
         early = self.early_gru16 and iters > 1
-        s16 = ub._side_stream(dev, 1) if early else None
+        s16 = (main if serial else ub._side_stream(dev, 1)) if early else None
         net2_next = None
         for itr in range(iters):
             pre = ub.gru04.pre_zr(net[0], *(inp[0])) if self.split_gate_conv else None

@@ -329,17 +329,17 @@ class Runner:
 
 def kernel_stats(run, passes=2, co_scheduled=False):
     """Per-kernel device times: HIP events on the launch stream around every hot-kernel launch in instrumented EAGER passes
-    of the identical workload (a graph replay has no per-kernel events).  co_scheduled=False: the two-stream loop is
-    serialised so each duration is the kernel alone; True: the loop runs as it does in the timed steps (a kernel's events then
-    include what the other stream's kernels take from it)."""
+    of the identical workload (a graph replay has no per-kernel events).  co_scheduled=False: the loop's kernels are issued in
+    the same order on ONE stream, so each duration is the kernel alone; True: the loop runs on its three streams as it does in
+    the timed steps (a kernel's events then include what the other streams' kernels take from it)."""
     from anystereo.harness import timing
     model = run.model
     graphed = run.graph
     if graphed:
         model.enable_graph(False)
-    ub = model.update_block
-    par = ub.parallel_encoder
-    ub.parallel_encoder = bool(co_scheduled)
+    model.serial_streams = not co_scheduled   # same kernels, same order; one stream -> no co-running kernel in an event pair
+    liif_par = getattr(model.liif_up, "parallel_inputs", False)
+    model.liif_up.parallel_inputs = liif_par and co_scheduled
     run.step()
     timing.enable(True)
     for _ in range(passes):
@@ -349,7 +349,8 @@ def kernel_stats(run, passes=2, co_scheduled=False):
         run.step()
     ks = timing.collect()
     timing.enable(False)
-    ub.parallel_encoder = par
+    model.serial_streams = False
+    model.liif_up.parallel_inputs = liif_par
     if graphed:
         model.enable_graph(True)
     return ks, passes
