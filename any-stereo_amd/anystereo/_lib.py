@@ -62,6 +62,8 @@ SIGNATURES = {
     "as_lookup_convc1_pack_bytes": (C.c_int64, [_i]),
     "as_lookup_convc1_pack": (_i, [_vp, _i, _vp, _vp]),
     "as_lookup_convc1_fwd": (_i, [_pp, _pp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_loop_front_fwd": (_i, [_pp, _pp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i,
+                                _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_lookup_split_overflow": (C.c_uint, [_i]),
     "as_conv_split_overflow": (C.c_uint, [_i]),
     "as_volumes_split_overflow": (C.c_uint, [_i]),

@@ -265,6 +265,7 @@ class ContinuousStereoBase(nn.Module):
         enc = (lambda d: ub.encoder.forward_fused_lookup(d, lookup_fn)) if fused else (lambda d: ub.encoder(d, lookup_fn(d, coords)))
         with torch.cuda.stream(side):
             mf = enc(disp)
+        front = fused and ub.encoder.fused_front and ub.disp_head.taps_ok(net[0])
         early = self.early_gru16 and iters > 1
         s16 = (main if serial else ub._side_stream(dev, 1)) if early else None
         net2_next = None
@@ -294,9 +295,13 @@ class ContinuousStereoBase(nn.Module):
                 twin[0].record_stream(side)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                disp = ub.disp_head(net[0], addend=disp)
-                if itr + 1 < iters:
-                    mf = enc(disp)
+                if front and itr + 1 < iters:
+                    # head conv1 -> ONE launch: disp += delta, lookup + convc1, 7x7 conv -> the encoder's remaining two convs
+                    mf, disp = ub.encoder.forward_front(ub.disp_head.taps(net[0]), ub.disp_head, disp, lookup_fn)
+                else:
+                    disp = ub.disp_head(net[0], addend=disp)
+                    if itr + 1 < iters:
+                        mf = enc(disp)
         main.wait_stream(side)
         disp.record_stream(main)
         return disp

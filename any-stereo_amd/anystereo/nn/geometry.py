@@ -83,6 +83,12 @@ class Combined_Geo_Encoding_Volume:
             return ops.lookup_convc1(self.geo_volume_pyramid, self.init_corr_pyramid, disp.float().contiguous(), self.radius, pack,
                                      out_bs=out_bs, want_f32=want_f32)
 
+    def loop_front(self, taps, head_bias, disp_old, pack, w7, b7, copy_out, copy_coff):
+        """disp += delta (from the head's tap planes), lookup + convc1 and the encoder's 7x7 conv in one launch (ops.loop_front)."""
+        with scope("loop_front"):
+            return ops.loop_front(self.geo_volume_pyramid, self.init_corr_pyramid, taps, head_bias, disp_old.float().contiguous(),
+                                  self.radius, pack, w7, b7, copy_out=copy_out, copy_coff=copy_coff)
+
     @staticmethod
     def corr(fmap1, fmap2):
         """All-pairs correlation only -> [B,h,w1,1,w2] (geometry.py:63-72)."""

@@ -102,6 +102,20 @@ class DispHead(nn.Module):
 
     fused_head = __import__("os").environ.get("ANYSTEREO_FUSED_HEAD", "1") != "0"
 
+    def taps_ok(self, x) -> bool:
+        return (self.fused_head and self.conv2.out_channels == 1 and ops.get_precision() == "split" and not _train(x, self.conv1.weight))
+
+    def taps(self, x):
+        """First half of forward(): the per-tap channel reductions of conv2 over relu(conv1(x)) ([B, 4*9, H, W]); finish with
+        `finish(taps, addend)` or hand them to the fused loop front (BasicMotionEncoder.forward_front)."""
+        with scope("disp_head_conv1"):
+            return ops.conv2d([_twin(_f(x))], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU,
+                              epilogue=L.EPI_RELU_TAPS, tap_w=self._tap_weights())
+
+    def finish(self, taps, addend=None):
+        with scope("disp_head_conv2"):
+            return ops.tap_shift_sum(taps, _f(self.conv2.bias.detach()), None if addend is None else _f(addend))
+
     def _tap_weights(self):
         """conv2.weight [1, C, 3, 3] as [C, 9] (tap = ky*3+kx), cached per weight version."""
         w = self.conv2.weight
@@ -261,6 +275,26 @@ class BasicMotionEncoder(nn.Module):
         return (self.fused_lookup and self.dual_branches and _links() and not torch.is_grad_enabled()
                 and getattr(lookup_fn, "fused_convc1_ok", None) is not None and lookup_fn.fused_convc1_ok()
                 and self.convc1.out_channels == 64 and self.convc1.kernel_size == (1, 1))
+
+    # opt-in: measured on cfg 2 the one launch takes 28.3 us against 27.9 us for the three staged launches it replaces (the lookup
+    # blocks alone fill the chip for 16 us, so the 7x7 blocks run as a second wave rather than beside them) -- no end-to-end gain
+    fused_front = __import__("os").environ.get("ANYSTEREO_FUSED_FRONT", "0") != "0"
+
+    def forward_front(self, taps, head, disp_old, lookup_fn):
+        """The head's finish (disp_old + delta), the fused lookup + convc1 and the 7x7 conv of the disparity branch as ONE launch,
+        then convc2 || convd2 and the merge conv: -> (motion features, new disparity).  Same arithmetic as
+        head.finish -> forward_fused_lookup (the new disparity is bit-identical)."""
+        disp_old = _f(disp_old)
+        cd, out = self.new_buffer(disp_old), self.new_output(disp_old)
+        if not hasattr(self, "_plc1"):
+            self._plc1 = ops.LookupConvPack()
+        disp, cor, d1 = lookup_fn.loop_front(taps, head.conv2.bias, disp_old, self._plc1.get(self.convc1.weight, self.convc1.bias),
+                                             self.convd1.weight, self.convd1.bias, out, 127)
+        with scope("enc_convc2"):
+            second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
+            ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out_bs=cd, out_bs_coff=0,
+                       bs_only=True, dual=second)
+        return self.merge(cd, disp, out), disp
 
     def forward_fused_lookup(self, disp, lookup_fn):
         """forward(disp, lookup_fn(disp)) with the lookup fused into convc1 (one kernel, blocked split-fp16 result): the

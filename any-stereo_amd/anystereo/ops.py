@@ -206,6 +206,49 @@ def lookup_convc1(geo: Optional[Sequence[torch.Tensor]], corr: Sequence[torch.Te
     return out
 
 
+def loop_front(geo, corr, taps: torch.Tensor, head_bias, disp_old: torch.Tensor, radius: int, pack: LookupConvPack,
+               w7: torch.Tensor, b7, copy_out: Optional["BS8"] = None, copy_coff: int = 0):
+    """The front of a GRU iteration in one launch (as_loop_front_fwd): disp_new = disp_old + tap_shift_sum(taps) + head_bias,
+    cor = relu(convc1(lookup(disp_new))), d1 = relu(conv7x7(disp_new) + b7) -> (disp_new [B,1,H,W], cor BS8, d1 BS8); with
+    `copy_out` (BS8) disp_new is also written to its channel `copy_coff`."""
+    _req(taps, "taps"), _req(disp_old, "disp")
+    b, one, h, w = disp_old.shape
+    if taps.shape[0] != b or tuple(taps.shape[2:]) != (h, w) or taps.shape[1] % 9:
+        raise RuntimeError("loop_front: taps must be [B, groups*9, H, W]")
+    nl = len(corr)
+    w2 = corr[0].shape[3]
+    for i, t in enumerate(corr):
+        _req(t, f"corr[{i}]")
+        if tuple(t.shape) != (b, h, w, w2 >> i):
+            raise RuntimeError(f"loop_front: corr[{i}] has shape {tuple(t.shape)}")
+    g = d = 0
+    if geo:
+        d, g = geo[0].shape[3], geo[0].shape[4]
+        for i, t in enumerate(geo):
+            _req(t, f"geo[{i}]")
+            if tuple(t.shape) != (b, h, w, d >> i, g):
+                raise RuntimeError(f"loop_front: geo[{i}] has shape {tuple(t.shape)}")
+    if nl * (2 * radius + 1) * (g + 1) != pack.cin or tuple(w7.shape) != (64, 1, 7, 7):
+        raise RuntimeError("loop_front: convc1 / convd1 shapes do not match the lookup")
+    wt = tapmajor_7x7(w7)
+    f = lambda t: None if t is None else (t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous())  # noqa: E731
+    hb, bb7 = f(head_bias), f(b7)
+    disp_new = torch.empty_like(disp_old)
+    cor, d1 = BS8.empty(b, 64, h, w, disp_old.device), BS8.empty(b, 64, h, w, disp_old.device)
+    if copy_out is not None:
+        _req(copy_out.t, "copy_out", torch.float16)
+        if copy_out.shape[0] != b or tuple(copy_out.shape[2:]) != (h, w):
+            raise RuntimeError("loop_front: copy_out shape mismatch")
+    gp, k1 = L.ptr_array([t.data_ptr() for t in geo]) if geo else (None, None)
+    cp, k2 = L.ptr_array([t.data_ptr() for t in corr])
+    with torch.cuda.device(disp_old.device):
+        L.check(L.load().as_loop_front_fwd(gp, cp, _p(taps), taps.shape[1] // 9, _p(hb), _p(disp_old), _p(disp_new), _p(pack.image),
+                                           _p(pack.bias), _p(cor.t), _p(wt), wt.shape[1], _p(bb7), _p(d1.t),
+                                           _p(None if copy_out is None else copy_out.t), 0 if copy_out is None else copy_out.c, copy_coff,
+                                           b, h, w, w2, d, g, nl, radius, _stream()), "loop_front_fwd")
+    return disp_new, cor, d1
+
+
 def geo_corr_lookup_backward(disp, d_out, geo_shapes, corr_shapes, radius):
     """Gradients w.r.t. the pyramid levels (transpose of the lookup)."""
     _req(disp, "disp"), _req(d_out, "d_out")
@@ -551,6 +594,24 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
 _TAPMAJOR = {}  # (data_ptr, version, device) of a [Cout,1,7,7] weight -> its [49,Cout] transpose
 
 
+def tapmajor_7x7(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout,1,7,7] -> tap-major [49, Cout padded to 64] fp32, cached per PARAMETER object + version.  (Pass the module's
+    parameter, not a `.detach()` made at the call site: that is a new object every time and would rebuild the copy — two
+    elementwise kernels, 10 us on the GRU loop's critical stream — at every call.)"""
+    cout = weight.shape[0]
+    key = (weight.data_ptr(), weight._version, weight.device)
+    ent = _TAPMAJOR.get(key)
+    # the entry must belong to THIS tensor: a freed weight's address (and version 0) is reused by the caching allocator
+    wt = ent[1] if (ent is not None and ent[0]() is weight) else None
+    if wt is None:
+        if len(_TAPMAJOR) > 64:
+            _TAPMAJOR.clear()
+        wt = torch.zeros((49, (cout + 63) // 64 * 64), device=weight.device, dtype=torch.float32)
+        wt[:, :cout] = weight.detach().float().reshape(cout, 49).t()
+        _TAPMAJOR[key] = (weakref.ref(weight), wt)
+    return wt
+
+
 def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_coff=0):
     """relu(conv7x7(x [B,1,H,W]) + bias) into channels [out_coff, out_coff+Cout) of `out` (update.py:81,87);
     with `copy_out` [B,C,H,W], x is also written to its channel `copy_coff`."""
@@ -565,19 +626,7 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
         out = torch.empty((b, cout, h, w), device=x.device, dtype=torch.float32)
     obs = isinstance(out, BS8)  # blocked split-fp16 result (feeds a split-precision convolution only)
     _req(out.t if obs else out, "out", torch.float16 if obs else torch.float32)
-    # `weight` / `bias` are the module's PARAMETERS (not detached temporaries): the tap-major copy is cached per tensor object
-    # + version (a `.detach()` made at the call site is a new object every time and would rebuild the copy — two elementwise
-    # kernels, 10 us on the GRU loop's critical stream — at every call)
-    key = (weight.data_ptr(), weight._version, weight.device)
-    ent = _TAPMAJOR.get(key)
-    # the entry must belong to THIS tensor: a freed weight's address (and version 0) is reused by the caching allocator
-    wt = ent[1] if (ent is not None and ent[0]() is weight) else None
-    if wt is None:  # tap-major copy, rebuilt when the weight changes (one entry per live weight tensor)
-        if len(_TAPMAJOR) > 64:
-            _TAPMAJOR.clear()
-        wt = torch.zeros((49, (cout + 63) // 64 * 64), device=weight.device, dtype=torch.float32)
-        wt[:, :cout] = weight.detach().float().reshape(cout, 49).t()
-        _TAPMAJOR[key] = (weakref.ref(weight), wt)
+    wt = tapmajor_7x7(weight)
     if bias is not None:
         bias = bias.detach()
         bias = bias if (bias.dtype == torch.float32 and bias.is_contiguous()) else bias.float().contiguous()

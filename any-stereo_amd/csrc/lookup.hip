@@ -254,18 +254,18 @@ __global__ __launch_bounds__(256) void lookup_fwd_coop_kernel(LookupParams p) {
 // eight LDS reads in flight per lane.  Interpolation arithmetic is identical to the kernels above.
 // gather + interpolation of a block's 64 pixels into the LDS tile [CH][65] (shared by the plain and the fused kernel)
 template <int G>
-__device__ __forceinline__ void quad_fill_tile(const LookupParams& p, float* tile) {
+__device__ __forceinline__ void quad_fill_tile(const LookupParams& p, float* tile, int bid, bool have_d = false, float d_in = 0.f) {
   constexpr int R = 4, K = 9, NW = 10;
   constexpr int PX = 64, TS = PX + 1;
   const int tid = threadIdx.x;
   const int px = tid >> 2, sub = tid & 3;
-  const long long pix0 = (long long)blockIdx.x * PX;
+  const long long pix0 = (long long)bid * PX;
   const long long pix = pix0 + px;
   const bool live = pix < p.P;
   const int level = G ? (sub >> 1) : sub;
   const int q = G ? (sub & 1) : 0;
   const unsigned kOOB = 0x7FFFFFF0u;
-  const float d0 = pix < p.P ? p.disp[pix] : 0.f;
+  const float d0 = have_d ? d_in : (pix < p.P ? p.disp[pix] : 0.f);
   const float ds = ldexpf(d0, -level);  // disp / 2**level (exact)
   f32x4 gw[NW];
   float cw[NW];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void lookup_fwd_quad_kernel(LookupParams p) {
   extern __shared__ float tile[];  // [CH][TS]
   const int tid = threadIdx.x;
   const long long pix0 = (long long)blockIdx.x * PX;
-  quad_fill_tile<G>(p, tile);
+  quad_fill_tile<G>(p, tile, blockIdx.x);
   __syncthreads();
   // coalesced NCHW rows: lane = pixel, wave w takes channels w, w+4, ...; 8 LDS reads in flight per lane
   const int lx = tid & 63;
@@ -382,11 +382,10 @@ struct FusedParams {
 __device__ unsigned g_split_overflow_lookup;
 
 template <int G>
-__global__ __launch_bounds__(256, 2) void lookup_convc1_kernel(LookupParams p, FusedParams f) {
+__device__ __forceinline__ void lookup_convc1_body(const LookupParams& p, const FusedParams& f, float* tile, int bid, bool have_d, float d_in) {
   constexpr int PX = 64, TS = PX + 1;
   constexpr int CH = (G ? 2 : 4) * 9 * (G + 1);
   constexpr int KS = (CH + 15) / 16;
-  extern __shared__ float tile[];  // [KS*16][TS]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void lookup_convc1_kernel(LookupParams p, F
     }
   }
   for (int i = tid; i < (KS * 16 - CH) * TS; i += 256) tile[CH * TS + i] = 0.f;  // padded channels of the last k-step
-  quad_fill_tile<G>(p, tile);
+  quad_fill_tile<G>(p, tile, bid, have_d, d_in);
   __syncthreads();
   f32x16 acc_h, acc_x;
 #pragma unroll
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void lookup_convc1_kernel(LookupParams p, F
     acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc_x, 0, 0, 0);
     acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc_x, 0, 0, 0);
   }
-  const long long pix = (long long)blockIdx.x * PX + 32 * nt + c;
+  const long long pix = (long long)bid * PX + 32 * nt + c;
   if (pix < p.P) {
     const int b = (int)(pix / p.HW);
     const int rem = (int)(pix - (long long)b * p.HW);
@@ -468,6 +467,162 @@ __global__ __launch_bounds__(256, 2) void lookup_convc1_kernel(LookupParams p, F
     }
   }
   if (__builtin_amdgcn_ballot_w64(!(amax < 65504.f)) != 0ull && lane == 0) atomicAdd(&g_split_overflow_lookup, 1u);
+}
+
+
+template <int G>
+__global__ __launch_bounds__(256, 2) void lookup_convc1_kernel(LookupParams p, FusedParams f) {
+  extern __shared__ float tile[];  // [KS*16][65]
+  lookup_convc1_body<G>(p, f, tile, blockIdx.x, false, 0.f);
+}
+
+// ---- the front of a GRU iteration in ONE launch -------------------------------------------------------------------------------
+// After the disparity head's first conv (as_conv2d, AS_EPI_RELU_TAPS) three small dependent launches sat on the loop's critical
+// chain: as_tap_shift_sum (disp += delta), the fused lookup + convc1, and the 7x7 conv of the disparity branch (update.py:87).
+// Both consumers need only the new disparity, so they run side by side here, each block computing the disparity of the pixels
+// it needs straight from the tap planes (same summation order as tap_shift_sum_kernel: bit-identical disparity):
+//   blocks [0, n_lookup):  64 pixels each: disp -> (stored for the next iteration) -> lookup -> convc1 + ReLU -> blocked result
+//   blocks [n_lookup, ..): 16x16 pixels x 32 channels: disp on the 22x22 halo patch -> relu(conv7x7 + bias) -> blocked result,
+//                          plus the disparity pass-through channel of the motion features (update.py:91)
+struct FrontParams {
+  const float* taps;      // [B][groups*9][H][W] per-tap channel reductions of the head's conv2 (AS_EPI_RELU_TAPS)
+  int groups;
+  const float* head_bias; // [1] or null
+  const float* disp_old;  // [B][1][H][W]
+  float* disp_new;        // [B][1][H][W]
+  const float* w7;        // tap-major [49][CP7] weights of the 7x7 conv (zero padded columns)
+  const float* b7;        // [64] or null
+  int CP7;
+  _Float16* d1_bs;        // blocked split-fp16 result of the 7x7 conv [B][2][8][H][W][8]
+  _Float16* copy_bs;      // blocked tensor that receives the new disparity in channel copy_coff (or null)
+  int copy_ctot, copy_coff;
+  int n_lookup, n_conv7, tiles_x, tiles_y;
+};
+
+// disp_old + (sum over groups and taps of the shifted tap planes + bias): tap_shift_sum_kernel's arithmetic for one pixel
+__device__ __forceinline__ float front_disp(const FrontParams& q, __amdgpu_buffer_rsrc_t rs, unsigned boff, long long plane, int H, int W,
+                                            int y, int x, float addend) {
+  // rs covers the WHOLE tap tensor (wave-uniform descriptor: a per-lane one makes hipcc wrap every load in a waterfall
+  // loop); boff = this pixel's batch offset in bytes
+  float acc = 0.f;
+  unsigned toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    toff[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? boff + (unsigned)(((long long)t * plane + (long long)yy * W + xx) * 4) : 0x7FFFFFF0u;
+  }
+  const unsigned gstep = (unsigned)(9 * plane * 4);
+  for (int g0 = 0; g0 < q.groups; g0 += 4) {
+    float v[4][9];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        v[g][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+            rs, (int)((toff[t] == 0x7FFFFFF0u || g0 + g >= q.groups) ? 0x7FFFFFF0u : toff[t] + (unsigned)(g0 + g) * gstep), 0, 0));
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc += v[g][t];
+  }
+  const float delta = acc + (q.head_bias ? q.head_bias[0] : 0.f);
+  return addend + delta;
+}
+
+template <int G>
+__global__ __launch_bounds__(256, 2) void loop_front_kernel(LookupParams p, FusedParams f, FrontParams q, const float* __restrict__ w7,
+                                                                 const float* __restrict__ b7) {
+  extern __shared__ float tile[];
+  const long long plane = p.HW;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)q.taps, 0, (int)((long long)p.B * q.groups * 9 * plane * 4), 0x00020000);
+  if ((int)blockIdx.x < q.n_lookup) {
+    // ---- role 1: disparity of this block's 64 pixels (the four lanes of a pixel compute the same value), lookup + convc1 ----
+    const int px = threadIdx.x >> 2;
+    const int lb = (int)blockIdx.x;   // the (longer) lookup blocks come first: 510 + 270 blocks on 768 slots (3 per CU) leave a
+                                      // dozen of the SHORT 7x7 blocks for the second round instead of a dozen long ones
+    const long long pix = (long long)lb * 64 + px;
+    float d = 0.f;
+    if (pix < p.P) {
+      const int b = (int)(pix / plane);
+      const int rem = (int)(pix - (long long)b * plane);
+      d = front_disp(q, rs, (unsigned)((long long)b * q.groups * 9 * plane * 4), plane, p.H, p.W, rem / p.W, rem % p.W, q.disp_old[pix]);
+      if ((threadIdx.x & 3) == 0) q.disp_new[pix] = d;
+    }
+    lookup_convc1_body<G>(p, f, tile, lb, true, d);
+    return;
+  }
+  // ---- role 2: 7x7 conv of the new disparity, 16x16 pixels x 16 output channels per block ----
+  constexpr int CO = 32;
+  float* patch = tile;  // 22 x 22
+  // w7 / b7 are separate noalias kernel arguments: as members of q the compiler cannot prove the stores of this kernel leave them
+  // alone and fetches them with per-lane vector loads (1568 per thread) instead of scalar loads
+  as::fp16_saturate_mode();
+  const int bid = blockIdx.x - q.n_lookup;
+  const int groups = 64 / CO;
+  const int cg = bid % groups;
+  const int t_ = bid / groups;
+  const int tx = t_ % q.tiles_x, ty = (t_ / q.tiles_x) % q.tiles_y, b = t_ / (q.tiles_x * q.tiles_y);
+  const int c0 = cg * CO;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const unsigned boff = (unsigned)((long long)b * q.groups * 9 * plane * 4);
+  for (int idx = threadIdx.x; idx < 22 * 22; idx += 256) {
+    const int py = idx / 22, pxx = idx - py * 22;
+    const int gy = y0 - 3 + py, gx = x0 - 3 + pxx;
+    float v = 0.f;  // zero padding of the convolution outside the image
+    if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = front_disp(q, rs, boff, plane, p.H, p.W, gy, gx, q.disp_old[(long long)b * plane + (long long)gy * p.W + gx]);
+    patch[idx] = v;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
+  const int gy = y0 + ly, gx = x0 + lx;
+  const bool inside = gy < p.H && gx < p.W;
+  const long long pixo = (long long)gy * p.W + gx;
+  float amax = 0.f;
+  // 8 output channels (one blocked 16-B unit) per pass: one kernel row's 7 x 8 weights are 56 scalar registers, loaded by
+  // seven s_load_dwordx8 (a wider channel group would exceed the scalar file and reload weights inside the tap loop)
+#pragma unroll 1
+  for (int k = 0; k < CO / 8; ++k) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+      const float* pr = patch + (ly + ky) * 22 + lx;
+      const float* __restrict__ wr = w7 + (ky * 7) * q.CP7 + c0 + 8 * k;  // wave-uniform (scalar loads)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const float v = pr[kx];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[kx * q.CP7 + j], acc[j]);
+      }
+    }
+    if (inside) {
+      half8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = fmaxf(acc[j] + (b7 ? b7[c0 + 8 * k + j] : 0.f), 0.f);
+        amax = fmaxf(amax, v);
+        const _Float16 hj = (_Float16)v;
+        hi[j] = hj;
+        lo[j] = (_Float16)((v - (float)hj) * 2048.f);
+      }
+      _Float16* rec = q.d1_bs + (((long long)b * 2 * 8 + (c0 >> 3) + k) * plane + pixo) * 8;
+      *reinterpret_cast<half8*>(rec) = hi;
+      *reinterpret_cast<half8*>(rec + 8ll * plane * 8) = lo;
+    }
+  }
+  if (inside) {
+    if (q.copy_bs && cg == 0) {  // the new disparity as channel copy_coff of the motion features (update.py:91)
+      const float v = patch[(ly + 3) * 22 + lx + 3];
+      const int c8 = (q.copy_ctot + 7) >> 3;
+      _Float16* rec = q.copy_bs + (((long long)b * 2 * c8 + (q.copy_coff >> 3)) * plane + pixo) * 8 + (q.copy_coff & 7);
+      const _Float16 hk = (_Float16)v;
+      rec[0] = hk;
+      rec[(long long)c8 * plane * 8] = (_Float16)((v - (float)hk) * 2048.f);
+      amax = fmaxf(amax, fabsf(v));
+    }
+  }
+  as::note_split_overflow(amax, &g_split_overflow_lookup);
 }
 
 // [Cout][ldw] fp32 weight columns [koff, koff+K) -> split-fp16 MFMA fragments [ks][tile of 32 rows][hi|lo][lane][8]:
@@ -800,6 +955,44 @@ int as_lookup_convc1_fwd(const float* const* geo, const float* const* corr, cons
   if (G == 8) hipLaunchKernelGGL((lookup_convc1_kernel<8>), grid, dim3(256), lds, as::as_stream(stream), p, f);
   else hipLaunchKernelGGL((lookup_convc1_kernel<0>), grid, dim3(256), lds, as::as_stream(stream), p, f);
   return as::check_launch("lookup_convc1_fwd");
+}
+
+int as_loop_front_fwd(const float* const* geo, const float* const* corr, const float* taps, int groups, const float* head_bias,
+                      const float* disp_old, float* disp_new, const void* wimage, const float* bias_c1, void* cor_bs,
+                      const float* w7, int cp7, const float* b7, void* d1_bs, void* copy_bs, int copy_ctot, int copy_coff,
+                      int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream) {
+  LookupParams p{};
+  int rc = fill_common(p, B, H, W, W2, D, G, L, radius);
+  if (rc != AS_OK) return rc;
+  AS_REQUIRE(corr && taps && disp_old && disp_new && wimage && cor_bs && w7 && d1_bs && (G == 0 || geo), AS_ERR_BAD_ARG, "loop_front: null pointer");
+  AS_REQUIRE(radius == 4 && ((G == 8 && L == 2) || (G == 0 && L == 4)), AS_ERR_BAD_ARG,
+             "loop_front: built for radius 4 with (G, L) = (8, 2) or (0, 4); got r=%d G=%d L=%d", radius, G, L);
+  AS_REQUIRE(groups >= 1 && groups <= 64 && cp7 >= 64 && (long long)B * groups * 9 * H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "loop_front: groups=%d cp7=%d", groups, cp7);
+  AS_REQUIRE(!copy_bs || (copy_coff >= 0 && copy_coff < (copy_ctot + 7) / 8 * 8), AS_ERR_BAD_SHAPE, "loop_front: copy channel %d outside %d", copy_coff, copy_ctot);
+  for (int i = 0; i < L; ++i) {
+    AS_REQUIRE(corr[i] && (G == 0 || geo[i]), AS_ERR_BAD_ARG, "loop_front: null level %d", i);
+    p.corr[i] = corr[i];
+    p.geo[i] = G ? geo[i] : nullptr;
+    AS_REQUIRE(G == 0 || (reinterpret_cast<uintptr_t>(geo[i]) & 15) == 0, AS_ERR_BAD_ARG, "loop_front: geo[%d] not 16-B aligned", i);
+    const long long cb = p.P * (W2 >> i) * 4, gb = p.P * (long long)(D >> i) * G * 4;
+    AS_REQUIRE(cb < 0x7FFFFFF0ll && gb < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "loop_front: pyramid level %d exceeds 2 GiB", i);
+    p.corr_bytes[i] = (int)cb;
+    p.geo_bytes[i] = (int)gb;
+  }
+  p.disp = disp_new;  // unused by the kernel's lookup role (the disparity comes from registers)
+  FusedParams f{(const _Float16*)wimage, bias_c1, (_Float16*)cor_bs, 8, 0, nullptr, 1};
+  FrontParams q{};
+  q.taps = taps; q.groups = groups; q.head_bias = head_bias; q.disp_old = disp_old; q.disp_new = disp_new;
+  q.w7 = w7; q.b7 = b7; q.CP7 = cp7; q.d1_bs = (_Float16*)d1_bs; q.copy_bs = (_Float16*)copy_bs; q.copy_ctot = copy_ctot; q.copy_coff = copy_coff;
+  q.n_lookup = (int)as::cdiv64(p.P, 64);
+  q.tiles_x = as::cdiv(W, 16); q.tiles_y = as::cdiv(H, 16);
+  const long long n7 = (long long)B * q.tiles_x * q.tiles_y * 2;  // 32 of the 64 output channels per block
+  q.n_conv7 = (int)n7;
+  const size_t lds = (size_t)((p.CH + 15) / 16 * 16 * 65) * sizeof(float);
+  const dim3 grid((unsigned)(q.n_lookup + n7));
+  if (G == 8) hipLaunchKernelGGL((loop_front_kernel<8>), grid, dim3(256), lds, as::as_stream(stream), p, f, q, q.w7, q.b7);
+  else hipLaunchKernelGGL((loop_front_kernel<0>), grid, dim3(256), lds, as::as_stream(stream), p, f, q, q.w7, q.b7);
+  return as::check_launch("loop_front_fwd");
 }
 
 unsigned as_lookup_split_overflow(int reset) {

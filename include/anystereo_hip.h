@@ -125,6 +125,19 @@ int as_lookup_convc1_pack(const float* w, int cin, void* image, void* stream);
 int as_lookup_convc1_fwd(const float* const* geo, const float* const* corr, const float* disp, const void* wimage, const float* bias,
                          void* out_bs, int out_bs_ctot, int out_bs_coff, float* out_f32, int relu,
                          int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
+/* The front of a GRU iteration in ONE launch (inference): what followed the disparity head's first conv as three dependent
+ *   launches — as_tap_shift_sum (`disp = disp + delta_disp`, continuous_IGEVstereo.py:295 with update.py:24 folded),
+ *   as_lookup_convc1_fwd (geometry.py:34-60 + update.py:84-85) and as_conv7x7_c1_relu (update.py:87, with the disparity
+ *   pass-through of update.py:91) — runs side by side; every block derives the new disparity of the pixels it needs from
+ *   the tap planes with as_tap_shift_sum's own arithmetic (bit-identical).
+ *   taps [B][groups*9][H][W] (as_conv2d AS_EPI_RELU_TAPS), head_bias [1]|NULL, disp_old -> disp_new [B,1,H,W];
+ *   wimage / bias_c1: as_lookup_convc1_pack; cor_bs: blocked split-fp16 [B][2][8][H][W][8] = relu(convc1(lookup(disp_new)));
+ *   w7: 7x7 weights tap-major [49][cp7 >= 64] (zero padded), b7 [64]|NULL; d1_bs: blocked relu(conv7x7(disp_new) + b7);
+ *   copy_bs (optional): blocked tensor of copy_ctot channels that receives disp_new in channel copy_coff. */
+int as_loop_front_fwd(const float* const* geo, const float* const* corr, const float* taps, int groups, const float* head_bias,
+                      const float* disp_old, float* disp_new, const void* wimage, const float* bias_c1, void* cor_bs,
+                      const float* w7, int cp7, const float* b7, void* d1_bs, void* copy_bs, int copy_ctot, int copy_coff,
+                      int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
 unsigned as_lookup_split_overflow(int reset);
 /* the same counter for the convolution kernels (conv.hip) and the all-pairs correlation build (volumes.hip) */
 unsigned as_conv_split_overflow(int reset);

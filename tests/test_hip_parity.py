@@ -1300,3 +1300,43 @@ def test_reduced_precision_mode(golden):
     finally:
         ops.set_fast_fp16(False)
         ops.set_precision(prev)
+
+
+@pytest.mark.parametrize("tag,h,w", [("igev", 8, 12), ("igev", 23, 37), ("raft", 9, 21)])
+def test_loop_front_fused_equals_staged(golden, tag, h, w):
+    """The front of a GRU iteration as ONE launch (disp += delta from the head's tap planes, lookup + convc1, 7x7 conv of the
+    disparity branch; as_loop_front_fwd) against the staged launches it replaces (as_tap_shift_sum -> as_lookup_convc1_fwd ->
+    as_conv7x7_c1_relu): the new disparity and the motion features are bit-identical, for both model geometries and map
+    sizes that do not fill the 64-pixel / 16x16 blocks."""
+    from anystereo import ops
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.models.base import default_args
+    from anystereo.nn.geometry import Combined_Geo_Encoding_Volume, CorrBlock1D
+    from anystereo.nn.update import BasicMultiUpdateBlock
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        args = default_args("continuous_IGEVStereo" if tag == "igev" else "continuous_RAFTStereo")
+        ub = BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims, geo_channels=8 if tag == "igev" else 0).eval()
+        fill_module_deterministic(ub, base_seed=5)
+        ub = ub.to(DEV)
+        b = 2
+        f1, f2 = U((b, 32, h, w), 701).to(DEV), U((b, 32, h, w), 702).to(DEV)
+        if tag == "igev":
+            fn = Combined_Geo_Encoding_Volume(f1, f2, U((b, 8, 48, h, w), 703).to(DEV), num_levels=2, radius=4)
+        else:
+            fn = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+        net0 = torch.tanh(U((b, 128, h, w), 704, -2, 2)).to(DEV)
+        disp = U((b, 1, h, w), 705, 0.0, float(w)).to(DEV)
+        with torch.no_grad():
+            assert ub.encoder.fused_lookup_ok(fn) and ub.disp_head.taps_ok(net0)
+            taps = ub.disp_head.taps(net0)
+            d_ref = ub.disp_head.finish(taps, addend=disp)
+            mf_ref = ub.encoder.forward_fused_lookup(d_ref, fn)
+            mf, d_new = ub.encoder.forward_front(taps, ub.disp_head, disp, fn)
+            d_full = ub.disp_head(net0, addend=disp)
+        assert torch.equal(d_new, d_ref) and torch.equal(d_full, d_ref), "new disparity"
+        assert torch.equal(mf.t, mf_ref.t), "motion features (blocked split-fp16)"
+        assert (mf.float()[:, 127:128] - d_ref).abs().max().item() <= 2e-6 * max(1.0, d_ref.abs().max().item()), "disparity pass-through"
+    finally:
+        ops.set_precision(prev)
