@@ -8,6 +8,8 @@ to these when gradients are required; under `torch.no_grad()` they call `ops` di
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -197,17 +199,96 @@ class LiifGatherMlp1(torch.autograd.Function):
         return d_u0, d_u1, None, d_wrel, d_bias
 
 
+# ---- weight gradients of layers that run once per GRU iteration: one batched reduction per step ----------------------
+# A layer of the update block / the LIIF MLP is applied `iters` times per training step (train_continuous_IGEV.py:214-239), so
+# autograd would run `iters` small wgrad reductions per weight and add them up one by one.  Instead every call's backward only
+# stashes its (input, output gradient) pair, and the WeightAnchor node — an identity the weight passes through once per step,
+# which autograd therefore reaches after ALL of the weight's uses — reduces the whole stack in one launch and hands the weight
+# its gradient once (one AccumulateGrad, hence one DDP hook, per parameter and step).
+_DEFER = os.environ.get("ANYSTEREO_DEFER_WGRAD", "1") != "0"
+
+
+class _Stash:
+    __slots__ = ("key", "kind", "xs", "ds", "done", "w_tok", "b_tok")
+
+    def __init__(self, key, kind):
+        self.key, self.kind, self.xs, self.ds, self.done = key, kind, [], [], False
+
+
+def _stack(ts):
+    return ts[0] if len(ts) == 1 else torch.cat(ts, 0)
+
+
+def _wgrad_conv(d, x, weight, bias_sizes, want_w, want_b):
+    k = weight.shape[2]
+    _, d_w, d_b = torch.ops.aten.convolution_backward(d, x, weight, bias_sizes, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                                      [False, want_w, want_b])
+    return d_w, d_b
+
+
+def _wgrad_linear(d, x, want_w, want_b):
+    return (torch.bmm(d, x.transpose(1, 2)).sum(0) if want_w else None), (d.sum((0, 2)) if want_b else None)
+
+
+class WeightAnchor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stash, weight, bias):
+        ctx.stash, ctx.bias_sizes = stash, None if bias is None else list(bias.shape)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(weight)
+        return weight.view_as(weight), None if bias is None else bias.view_as(bias)
+
+    @staticmethod
+    def backward(ctx, g_w, g_b):
+        st = ctx.stash
+        (weight,) = ctx.saved_tensors
+        st.done = True
+        xs, ds, st.xs, st.ds = st.xs, st.ds, [], []
+        want_w, want_b = ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]
+        groups = {}
+        for x, d in zip(xs, ds):  # calls of one layer share a shape; group anyway
+            groups.setdefault((tuple(x.shape), tuple(d.shape)), ([], []))
+            groups[(tuple(x.shape), tuple(d.shape))][0].append(x)
+            groups[(tuple(x.shape), tuple(d.shape))][1].append(d)
+        for gx, gd in groups.values():
+            x, d = _stack(gx), _stack(gd)
+            d_w, d_b = _wgrad_conv(d, x, weight, ctx.bias_sizes, want_w, want_b) if st.kind == "conv" else _wgrad_linear(d, x, want_w, want_b)
+            if want_w:
+                g_w = d_w if g_w is None else g_w + d_w
+            if want_b:
+                g_b = d_b if g_b is None else g_b + d_b
+        return None, g_w, g_b
+
+
+def anchored(mod, name, kind, weights, biases):
+    """(weight, bias, stash) of layer `name` of `mod` for this training forward: `weights` / `biases` are tuples of parameters
+    (concatenated along dim 0 when there are several: convz|convr).  stash None = gradients are not deferred."""
+    def build():
+        w = weights[0] if len(weights) == 1 else torch.cat(list(weights))
+        b = None if biases[0] is None else (biases[0] if len(biases) == 1 else torch.cat(list(biases)))
+        return w, b
+    if not (_DEFER and torch.is_grad_enabled() and any(p.requires_grad for p in weights)):
+        return (*build(), None)
+    slot = mod.__dict__.setdefault("_wgrad_anchors", {})
+    key = tuple((id(p), p._version) for p in (*weights, *biases) if p is not None)
+    st = slot.get(name)
+    if st is None or st.done or st.key != key:
+        st = slot[name] = _Stash(key, kind)
+        st.w_tok, st.b_tok = WeightAnchor.apply(st, *build())
+    return st.w_tok, st.b_tok, st
+
+
 # ---- remaining Linear/ReLU layers of a15 over channel-major activations (liif.py:9-25) ---------------------------
 class PointwiseLinear(torch.autograd.Function):
     """y[b,:,q] = act(W x[b,:,q] + bias), x [B,C,Q].  Forward and dgrad run on the implicit-GEMM conv kernel (1x1, the
     dgrad with W^T); wgrad and the bias gradient are library reductions over the queries."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, pack_f, pack_b):
+    def forward(ctx, x, weight, bias, relu, pack_f, pack_b, stash=None):
         b, c, q = x.shape
         y = ops.conv2d([x.view(b, c, 1, q)], pack_f.get([weight], [bias]), act=L.ACT_RELU if relu else L.ACT_NONE).view(b, -1, q)
         ctx.save_for_backward(x, weight, y if relu else None)
-        ctx.pack_b, ctx.has_bias = pack_b, bias is not None
+        ctx.pack_b, ctx.has_bias, ctx.stash = pack_b, bias is not None, stash
         return y
 
     @staticmethod
@@ -222,11 +303,13 @@ class PointwiseLinear(torch.autograd.Function):
                 d_x = ops.conv2d([d.view(b, -1, 1, q)], pk).view(b, c, q)
             else:  # a handful of output channels (the 9 mask logits): not worth a K-padded MFMA launch
                 d_x = torch.matmul(weight.t(), d)
-        if ctx.needs_input_grad[1]:
-            d_w = torch.matmul(d, x.transpose(1, 2)).sum(0)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            d_b = d.sum((0, 2))
-        return d_x, d_w, d_b, None, None, None
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.stash is not None:
+            if want_w or want_b:
+                ctx.stash.xs.append(x), ctx.stash.ds.append(d)
+        else:
+            d_w, d_b = _wgrad_linear(d, x, want_w, want_b)
+        return d_x, d_w, d_b, None, None, None, None
 
 
 # ---- a6/a7/a9: stride-1 "same" convolutions of the update block (update.py:16-92) -------------------------------
@@ -235,10 +318,10 @@ class Conv2dSame(torch.autograd.Function):
     kernel (dgrad = the same kernel on W transposed and flipped); wgrad / bias gradient on the library (MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, pack_f, pack_b):
+    def forward(ctx, x, weight, bias, relu, pack_f, pack_b, stash=None):
         y = ops.conv2d([x], pack_f.get([weight], [bias]), act=L.ACT_RELU if relu else L.ACT_NONE)
         ctx.save_for_backward(x, weight, y if relu else None)
-        ctx.pack_b, ctx.bias_sizes = pack_b, None if bias is None else list(bias.shape)
+        ctx.pack_b, ctx.bias_sizes, ctx.stash = pack_b, None if bias is None else list(bias.shape), stash
         return y
 
     @staticmethod
@@ -252,9 +335,11 @@ class Conv2dSame(torch.autograd.Function):
             d_x = ops.conv2d([d], pk)
         want_w, want_b = ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]
         if want_w or want_b:
-            _, d_w, d_b = torch.ops.aten.convolution_backward(d, x, weight, ctx.bias_sizes, [1, 1], [k // 2, k // 2], [1, 1], False,
-                                                              [0, 0], 1, [False, want_w, want_b])
-        return d_x, d_w, d_b, None, None, None
+            if ctx.stash is not None:
+                ctx.stash.xs.append(x), ctx.stash.ds.append(d)
+            else:
+                d_w, d_b = _wgrad_conv(d, x, weight, ctx.bias_sizes, want_w, want_b)
+        return d_x, d_w, d_b, None, None, None, None
 
 
 # ---- a7: ConvGRU gate math as two fused stages (update.py:36-41) ---------------------------------------------------
@@ -311,10 +396,58 @@ class GruGatesQ(torch.autograd.Function):
 
 
 def conv2d_same(mod, name, x, weight, bias, relu=False):
-    """Conv2dSame with the forward / dgrad weight packs cached on `mod` under `name`."""
+    """Conv2dSame with the forward / dgrad weight packs cached on `mod` under `name`.  `weight` / `bias`: a parameter, or a tuple
+    of parameters that are concatenated along the output channels (convz | convr as one convolution)."""
     packs = mod.__dict__.setdefault("_train_packs", {})
     pf, pb = packs.setdefault(name, (ops.PackedConv(), ops.PackedConv()))
-    return Conv2dSame.apply(_c(x), weight, bias, relu, pf, pb)
+    ws = weight if isinstance(weight, tuple) else (weight,)
+    bs = bias if isinstance(bias, tuple) else (bias,)
+    w, b, stash = anchored(mod, name, "conv", ws, bs)
+    return Conv2dSame.apply(_c(x), w, b, relu, pf, pb, stash)
+
+
+def pointwise_linear(mod, key, x, lin, relu):
+    """PointwiseLinear of the nn.Linear `lin` with packs and the step's weight anchor cached on `mod` under `key`."""
+    packs = mod.__dict__.setdefault("_train_packs", {})
+    pf, pb = packs.setdefault(key, (ops.PackedConv(), ops.PackedConv()))
+    w, b, stash = anchored(mod, key, "linear", (lin.weight,), (lin.bias,))
+    return PointwiseLinear.apply(x.contiguous(), w, b, relu, pf, pb, stash)
+
+
+# ---- a8: the update block's resamplers (update.py:94-102) -----------------------------------------------------------
+class Pool2x(torch.autograd.Function):
+    """avg_pool2d(x, 3, stride=2, padding=1); backward = as_pool2x_bwd (gather form)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return ops.pool2x(_c(x))
+
+    @staticmethod
+    def backward(ctx, d_out):
+        b, c, h, w = ctx.shape
+        d_x = torch.empty(ctx.shape, device=d_out.device, dtype=torch.float32)
+        with torch.cuda.device(d_out.device):
+            L.check(L.load().as_pool2x_bwd(_p(_c(d_out)), _p(d_x), b, c, h, w, _stream()), "pool2x_bwd")
+        return d_x
+
+
+class InterpBilinear(torch.autograd.Function):
+    """F.interpolate(x, (ho, wo), mode="bilinear", align_corners=True); backward = as_interp_bilinear_ac_bwd (gather form)."""
+
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        ctx.shape, ctx.dest = tuple(x.shape), (int(ho), int(wo))
+        return ops.interp(_c(x), int(ho), int(wo))
+
+    @staticmethod
+    def backward(ctx, d_out):
+        b, c, h, w = ctx.shape
+        d_x = torch.empty(ctx.shape, device=d_out.device, dtype=torch.float32)
+        with torch.cuda.device(d_out.device):
+            L.check(L.load().as_interp_bilinear_ac_bwd(_p(_c(d_out)), _p(d_x), b, c, h, w, ctx.dest[0], ctx.dest[1], _stream()),
+                    "interp_bilinear_ac_bwd")
+        return d_x, None, None
 
 
 # ---- a16/a17: (softmax +) convex 3x3 upsampling at the queries (submodule.py:357-372) ---------------------------

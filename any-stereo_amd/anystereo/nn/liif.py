@@ -258,10 +258,8 @@ class liif_out_multi_scale_Training(nn.Module):
             lin = lin[1:]
         else:
             x = torch.cat([G.LiifGather.apply(s, coord) for s in sfs], dim=1)
-        packs = self.__dict__.setdefault("_train_packs", {})
         for i, m in enumerate(lin):
-            pf, pb = packs.setdefault(id(m), (ops.PackedConv(), ops.PackedConv()))
-            x = G.PointwiseLinear.apply(x.contiguous(), m.weight, m.bias, i + 1 < len(lin), pf, pb)
+            x = G.pointwise_linear(self, id(m), x, m, i + 1 < len(lin))
         return x
 
     def _mask_logits(self, sfs, coord, ctot, pre=None):

@@ -167,7 +167,7 @@ class ConvGRU(nn.Module):
         if _train(h, cz, cr, cq, self.convz.weight, *x_list):  # update.py:33-41
             x = torch.cat(x_list, dim=1)
             hx = torch.cat([h, x], dim=1)
-            zr = _cs(self, "zr", hx, torch.cat([self.convz.weight, self.convr.weight]), torch.cat([self.convz.bias, self.convr.bias]))
+            zr = _cs(self, "zr", hx, (self.convz.weight, self.convr.weight), (self.convz.bias, self.convr.bias))
             hid = h.shape[1]
             if zr.is_cuda and self.fused_gates:
                 base, coff = _context_window(cz, cr, cq)
@@ -377,6 +377,8 @@ class BasicMotionEncoder(nn.Module):
 
 def pool2x(x):
     if _train(x):
+        if x.is_cuda and x.dtype == torch.float32:
+            return G.Pool2x.apply(x)
         return F.avg_pool2d(x, 3, stride=2, padding=1)  # update.py:94-95
     with scope("pool2x"):
         return ops.pool2x_bs(_f(x)) if _links() else ops.pool2x(_f(x))  # the pooled / resized maps only feed GRU convs
@@ -384,7 +386,8 @@ def pool2x(x):
 
 def interp(x, dest):
     if _train(x):
-        # (a HIP forward + aten.upsample_bilinear2d_backward pair measured SLOWER than this on the same box: 124 vs 116 ms/step)
+        if x.is_cuda and x.dtype == torch.float32:
+            return G.InterpBilinear.apply(x, dest.shape[2], dest.shape[3])
         return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)  # update.py:100-102
     with scope("interp"):
         if _links():

@@ -325,9 +325,87 @@ __global__ __launch_bounds__(256) void gru_gates_q_bwd_kernel(GateBwdParams p) {
   p.d_h[t] = g * (1.f - z);
 }
 
+// ---- a8^T: pool2x / interp of BasicMultiUpdateBlock (update.py:94-102) ------------------------------------------------
+// Gather form (one thread per INPUT element, no atomics, fixed summation order).
+// pool2x: output (yo, xo) averages rows 2yo-1 .. 2yo+1, divisor 9: an even input row feeds yo = y/2, an odd one (y-1)/2 and (y+1)/2.
+__global__ __launch_bounds__(256) void pool2x_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int H, int W, int Ho,
+                                                         int Wo, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  long long t = idx / W;
+  const int y = (int)(t % H);
+  const float* gp = g + (t / H) * Ho * Wo;
+  const int ya = y >> 1, yb = (y & 1) ? ya + 1 : ya, xa = x >> 1, xb = (x & 1) ? xa + 1 : xa;
+  float s = 0.f;
+  for (int yo = ya; yo <= yb; ++yo) {
+    if (yo >= Ho) continue;
+    for (int xo = xa; xo <= xb; ++xo)
+      if (xo < Wo) s += gp[(long long)yo * Wo + xo];
+  }
+  dx[idx] = s / 9.f;
+}
+
+// interp (bilinear, align_corners): the weight of output o on input i along one axis, with the forward kernel's arithmetic
+__device__ __forceinline__ float interp_axis_weight(int o, int i, int n_in, float sc) {
+  const float f = sc * (float)o;
+  const int i0 = min((int)f, n_in - 1), i1 = min(i0 + 1, n_in - 1);
+  const float t = f - (float)i0;
+  return (i == i0 ? 1.f - t : 0.f) + (i == i1 ? t : 0.f);
+}
+// candidate outputs of input i: sc * o in (i - 1, i + 1), widened by one on both sides (the weight test above is the exact filter)
+__device__ __forceinline__ void interp_axis_range(int i, int n_out, float sc, int& lo, int& hi) {
+  if (sc <= 0.f) { lo = 0; hi = n_out - 1; return; }
+  lo = max(0, (int)floorf((float)(i - 1) / sc) - 1);
+  hi = min(n_out - 1, (int)ceilf((float)(i + 1) / sc) + 1);
+}
+__global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int H, int W, int Ho,
+                                                         int Wo, float sy, float sx, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  long long t = idx / W;
+  const int y = (int)(t % H);
+  const float* gp = g + (t / H) * Ho * Wo;
+  int ylo, yhi, xlo, xhi;
+  interp_axis_range(y, Ho, sy, ylo, yhi);
+  interp_axis_range(x, Wo, sx, xlo, xhi);
+  float s = 0.f;
+  for (int yo = ylo; yo <= yhi; ++yo) {
+    const float wy = interp_axis_weight(yo, y, H, sy);
+    if (wy == 0.f) continue;
+    float r = 0.f;
+    for (int xo = xlo; xo <= xhi; ++xo) {
+      const float wx = interp_axis_weight(xo, x, W, sx);
+      if (wx != 0.f) r += wx * gp[(long long)yo * Wo + xo];
+    }
+    s += wy * r;
+  }
+  dx[idx] = s;
+}
+
 }  // namespace
 
 extern "C" {
+
+int as_pool2x_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(d_out && d_x, AS_ERR_BAD_ARG, "pool2x_bwd: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "pool2x_bwd: non-positive size");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(pool2x_bwd_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), d_out, d_x, H, W, Ho, Wo, total);
+  return as::check_launch("pool2x_bwd");
+}
+
+int as_interp_bilinear_ac_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, int Ho, int Wo, void* stream) {
+  AS_REQUIRE(d_out && d_x, AS_ERR_BAD_ARG, "interp_bwd: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, AS_ERR_BAD_ARG, "interp_bwd: non-positive size");
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+  const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  const long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), d_out, d_x, H, W, Ho, Wo, sy, sx, total);
+  return as::check_launch("interp_bilinear_ac_bwd");
+}
 
 int as_gru_gates_zr(const float* lin, const float* ctx, int ctx_ctot, int ctx_coff, const float* h, float* z, float* r, float* rh,
                     int B, int C, int H, int W, void* stream) {

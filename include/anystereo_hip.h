@@ -359,6 +359,11 @@ unsigned as_liif_split_overflow(int reset);
  *   a16/a17^T as_convex_upsample_bwd: d_out [B,1,Q] -> d_mask [B,9,Q] (w.r.t. the logits when mask_is_logits) and
  *         d_disp [B,1,H,W] (may be NULL) w.r.t. the UNscaled disparity when scale != NULL.
  * ------------------------------------------------------------------------------------------- */
+/*   a8^T  as_pool2x_bwd / as_interp_bilinear_ac_bwd: d_out [B,C,Ho,Wo] -> d_x [B,C,H,W], the transposes of as_pool2x /
+ *         as_interp_bilinear_ac (what autograd derives for F.avg_pool2d / F.interpolate at update.py:94-102); gather form, one
+ *         thread per input element, fixed summation order. */
+int as_pool2x_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, void* stream);
+int as_interp_bilinear_ac_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, int Ho, int Wo, void* stream);
 int as_corr_pyramid_bwd(const float* const* d_levels, float* d_corr0, long long rows, int W2, int L, void* stream);
 int as_geo_pyramid_bwd(const float* const* d_levels, float* d_gev, int B, int G, int D, int H, int W, int L, void* stream);
 int as_gwc_volume_bwd(const float* fl, const float* fr, const float* d_vol, float* d_fl, float* d_fr,

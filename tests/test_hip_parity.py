@@ -635,6 +635,34 @@ def test_disparity_regression_backward():
         close(a.grad, r.grad, 2e-5, 1e-6, f"d cost (softmax={softmax})")
 
 
+@pytest.mark.parametrize("b,c,h,w", [(2, 5, 7, 10), (1, 3, 8, 9), (2, 4, 1, 6), (1, 2, 40, 80)])
+def test_pool2x_interp_backward(b, c, h, w):
+    """a8^T: the update block's resamplers under autograd (as_pool2x_bwd, as_interp_bilinear_ac_bwd) against autograd of the
+    fp64 oracle (avg_pool2d / bilinear align_corners, update.py:94-102), odd sizes, a one-row map, and the same-size / 2x / odd
+    destination sizes the update block meets."""
+    from anystereo import grad as G
+    x = U((b, c, h, w), 460)
+    a = _leaf(x, DEV)
+    y = G.Pool2x.apply(a)
+    g = U(tuple(y.shape), 461)
+    y.backward(g.to(DEV))
+    r = _leaf(x, dt=torch.float64)
+    yr = O.pool2x(r)
+    yr.backward(g.double())
+    close(y.detach(), yr.detach(), 1e-6, 1e-7, "pool2x forward")
+    close(a.grad, r.grad, 1e-6, 1e-7, "pool2x backward")
+    for ho, wo in ((2 * h, 2 * w), (2 * h - 1, 2 * w - 1), (h, w), (2 * h + 1, 2 * w - 3 if w > 2 else 3), (1, 1), (max(1, h // 2), max(1, w // 2))):
+        a = _leaf(x, DEV)
+        y = G.InterpBilinear.apply(a, ho, wo)
+        g = U((b, c, ho, wo), 462 + ho)
+        y.backward(g.to(DEV))
+        r = _leaf(x, dt=torch.float64)
+        yr = O.interp_to(r, ho, wo)
+        yr.backward(g.double())
+        close(y.detach(), yr.detach(), 1e-5, 2e-6, f"interp forward -> {ho}x{wo}")  # fp32 source positions
+        close(a.grad, r.grad, 2e-5, 2e-6, f"interp backward -> {ho}x{wo}")
+
+
 @pytest.mark.parametrize("scale", [1.0, 1.5, 2.95])
 def test_liif_gather_and_convex_backward(scale):
     """Scatter-add transposes (float atomics: summation order varies, tolerance covers it)."""
@@ -787,6 +815,67 @@ def test_conv2d_same_backward(cin, cout, k, relu, precision):
     close(a[1].grad, r[1].grad, 2e-4, 1e-5, "d w")
     close(a[2].grad, r[2].grad, 2e-4, 1e-5, "d b")
 
+
+@pytest.mark.parametrize("kind", ["conv3", "conv1_cat", "linear"])
+def test_deferred_weight_gradients(kind):
+    """A layer applied once per GRU iteration: its weight / bias gradients as ONE batched reduction per step (grad.WeightAnchor)
+    against fp64 autograd of the same recurrence — three chained uses, one use whose output never reaches the loss, two
+    steps in a row with a weight update in between (the anchor is renewed), and convz|convr as one concatenated weight."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from anystereo import grad as G
+    torch.manual_seed(0)
+    b, c, h, w = 2, 32, 7, 11
+    mod = nn.Module()
+    if kind == "linear":
+        lin = nn.Linear(c, c)
+        ref = nn.Linear(c, c).double()
+        ref.load_state_dict(lin.state_dict())
+        lin = lin.to(DEV)
+        params, rparams = [lin.weight, lin.bias], [ref.weight, ref.bias]
+    else:
+        k = 3 if kind == "conv3" else 1
+        convs = [nn.Conv2d(c, c // 2 if kind == "conv1_cat" else c, k, padding=k // 2) for _ in range(2 if kind == "conv1_cat" else 1)]
+        refs = [nn.Conv2d(c, m.out_channels, k, padding=k // 2).double() for m in convs]
+        for m, r in zip(convs, refs):
+            r.load_state_dict(m.state_dict())
+            m.to(DEV)
+        params = [p for m in convs for p in (m.weight, m.bias)]
+        rparams = [p for m in refs for p in (m.weight, m.bias)]
+    for step in range(2):
+        x0 = U((b, c, h * w) if kind == "linear" else (b, c, h, w), 520 + step)
+
+        def run(x, dev_side):
+            outs = []
+            for i in range(4):
+                if kind == "linear":
+                    y = G.pointwise_linear(mod, "l", x, lin, True) if dev_side else torch.relu(torch.einsum("oc,bcq->boq", ref.weight, x) + ref.bias[None, :, None])
+                elif dev_side:
+                    y = G.conv2d_same(mod, "c", x, tuple(m.weight for m in convs) if len(convs) > 1 else convs[0].weight,
+                                      tuple(m.bias for m in convs) if len(convs) > 1 else convs[0].bias, relu=True)
+                else:
+                    y = torch.relu(F.conv2d(x, torch.cat([m.weight for m in refs]), torch.cat([m.bias for m in refs]), padding=k // 2))
+                outs.append(y)
+                x = 0.5 * x + 0.25 * y
+            return sum((i + 1) * o.sum() for i, o in enumerate(outs[:3]))  # the fourth use gets no gradient
+
+        a = x0.to(DEV).requires_grad_(True)
+        for p in params:
+            p.grad = None
+        run(a, True).backward()
+        r = x0.double().requires_grad_(True)
+        for p in rparams:
+            p.grad = None
+        run(r, False).backward()
+        close(a.grad, r.grad, 1e-4, 1e-4, f"step {step}: d x")
+        for i, (p, q) in enumerate(zip(params, rparams)):
+            close(p.grad, q.grad, 2e-4, 1e-4, f"step {step}: d param {i}")
+        with torch.no_grad():  # "optimizer step": the next forward must see the new weights and build a new anchor
+            for p, q in zip(params, rparams):
+                p.mul_(0.9)
+                q.mul_(0.9)
+    st = mod.__dict__["_wgrad_anchors"]["l" if kind == "linear" else "c"]
+    assert st.done and not st.xs and not st.ds, "the stash is emptied by the anchor's backward"
 
 
 def test_conv_gru_training_fused_gates():
