@@ -14,7 +14,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .ops import _p, _req, _stream
+from .ops import _guard, _p, _req, _stream
 
 
 def needs_grad(*ts) -> bool:
@@ -42,7 +42,7 @@ class CorrBuildPyramid(torch.autograd.Function):
               for i, g in enumerate(d_levels)]
         d0 = torch.empty((b, h, w1, w2), device=f1.device, dtype=torch.float32)
         pp, keep = L.ptr_array([t.data_ptr() for t in lv])
-        with torch.cuda.device(f1.device):
+        with _guard(f1.device):
             L.check(L.load().as_corr_pyramid_bwd(pp, _p(d0), b * h * w1, w2, len(lv), _stream()), "corr_pyramid_bwd")
         # corr[b,y,i,j] = sum_c f1[b,c,y,i] f2[b,c,y,j]:  d f1[b,:,y,:] = f2[b,:,y,:] @ d0[b,y]^T,  d f2[b,:,y,:] = f1[b,:,y,:] @ d0[b,y]
         f1r, f2r = f1.permute(0, 2, 1, 3), f2.permute(0, 2, 1, 3)  # [B,H,C,W]
@@ -66,7 +66,7 @@ class GeoPyramid(torch.autograd.Function):
               for i, t in enumerate(d_levels)]
         out = torch.empty(ctx.shape, device=dev, dtype=torch.float32)
         pp, keep = L.ptr_array([t.data_ptr() for t in lv])
-        with torch.cuda.device(dev):
+        with _guard(dev):
             L.check(L.load().as_geo_pyramid_bwd(pp, _p(out), b, g, d, h, w, len(lv), _stream()), "geo_pyramid_bwd")
         return out, None
 
@@ -103,7 +103,7 @@ class GwcVolume(torch.autograd.Function):
         b, c, h, w = fl.shape
         d_vol = _c(d_vol)
         dfl, dfr = torch.empty_like(fl), torch.empty_like(fr)
-        with torch.cuda.device(fl.device):
+        with _guard(fl.device):
             L.check(L.load().as_gwc_volume_bwd(_p(fl), _p(fr), _p(d_vol), _p(dfl), _p(dfr), b, c, h, w, ctx.maxdisp, ctx.groups,
                                                _stream()), "gwc_volume_bwd")
         return dfl, dfr, None, None
@@ -123,7 +123,7 @@ class DisparityRegression(torch.autograd.Function):
         b, d, h, w = cost.shape
         d_out = _c(d_out)
         d_cost = torch.empty_like(cost)
-        with torch.cuda.device(cost.device):
+        with _guard(cost.device):
             L.check(L.load().as_disparity_regression_bwd(_p(cost), _p(d_out), _p(d_cost), b, d, h, w, 1 if ctx.apply_softmax else 0,
                                                          _stream()), "disparity_regression_bwd")
         return d_cost, None
@@ -219,8 +219,18 @@ def _stack(ts):
     return ts[0] if len(ts) == 1 else torch.cat(ts, 0)
 
 
+# "hip": as_conv2d_wgrad (bf16 hi/lo split MFMA, ~2^-16 relative per product) for the layers it wins on — 3x3, >= 96 channels on
+# both sides, maps of >= 400 pixels (tools/kbench_wgrad.py: 1.1-1.9x the library's fp32 wgrad there, slower on the 64-channel
+# and 1/16-resolution layers, whose 128 x 32 tiles are mostly padding); "all": every 1x1 / 3x3 layer; "library": MIOpen only
+_WGRAD = os.environ.get("ANYSTEREO_WGRAD", "hip")
+
+
 def _wgrad_conv(d, x, weight, bias_sizes, want_w, want_b):
     k = weight.shape[2]
+    big = k == 3 and weight.shape[0] >= 96 and weight.shape[1] >= 96 and x.shape[2] * x.shape[3] >= 400
+    if want_w and x.is_cuda and ((_WGRAD == "hip" and big) or (_WGRAD == "all" and k in (1, 3))):
+        d_w, d_b = ops.conv2d_wgrad(_c(x), _c(d), k, want_bias=want_b)
+        return d_w, d_b
     _, d_w, d_b = torch.ops.aten.convolution_backward(d, x, weight, bias_sizes, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
                                                       [False, want_w, want_b])
     return d_w, d_b
@@ -351,7 +361,7 @@ class GruGatesZR(torch.autograd.Function):
     def forward(ctx, lin, cz, cr, h, base, coff):
         b, c, hh, ww = h.shape
         z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _guard(h.device):
             L.check(L.load().as_gru_gates_zr(_p(lin), _p(base), base.shape[1], coff, _p(h), _p(z), _p(r), _p(rh), b, c, hh, ww,
                                              _stream()), "gru_gates_zr")
         ctx.save_for_backward(z, r, h)
@@ -365,7 +375,7 @@ class GruGatesZR(torch.autograd.Function):
         d_rh = None if d_rh is None else _c(d_rh)
         d_lin = torch.empty((b, 2 * c, hh, ww), device=h.device, dtype=torch.float32)
         d_h = torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _guard(h.device):
             L.check(L.load().as_gru_gates_zr_bwd(_p(d_z), _p(d_rh), _p(z), _p(r), _p(h), _p(d_lin), _p(d_h), b, c, hh, ww, _stream()),
                     "gru_gates_zr_bwd")
         return d_lin, d_lin[:, :c], d_lin[:, c:], d_h, None, None
@@ -378,7 +388,7 @@ class GruGatesQ(torch.autograd.Function):
     def forward(ctx, lin, cq, z, h, base, coff):
         b, c, hh, ww = h.shape
         out, t = torch.empty_like(h), torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _guard(h.device):
             L.check(L.load().as_gru_gates_q(_p(lin), _p(base), base.shape[1], coff, _p(z), _p(h), _p(out), _p(t), b, c, hh, ww,
                                             _stream()), "gru_gates_q")
         ctx.save_for_backward(z, t, h)
@@ -389,7 +399,7 @@ class GruGatesQ(torch.autograd.Function):
         z, t, h = ctx.saved_tensors
         b, c, hh, ww = h.shape
         d_lin, d_z, d_h = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _guard(h.device):
             L.check(L.load().as_gru_gates_q_bwd(_p(_c(d_out)), _p(z), _p(t), _p(h), _p(d_lin), _p(d_z), _p(d_h), b, c, hh, ww,
                                                 _stream()), "gru_gates_q_bwd")
         return d_lin, d_lin, d_z, d_h, None, None
@@ -427,7 +437,7 @@ class Pool2x(torch.autograd.Function):
     def backward(ctx, d_out):
         b, c, h, w = ctx.shape
         d_x = torch.empty(ctx.shape, device=d_out.device, dtype=torch.float32)
-        with torch.cuda.device(d_out.device):
+        with _guard(d_out.device):
             L.check(L.load().as_pool2x_bwd(_p(_c(d_out)), _p(d_x), b, c, h, w, _stream()), "pool2x_bwd")
         return d_x
 
@@ -444,7 +454,7 @@ class InterpBilinear(torch.autograd.Function):
     def backward(ctx, d_out):
         b, c, h, w = ctx.shape
         d_x = torch.empty(ctx.shape, device=d_out.device, dtype=torch.float32)
-        with torch.cuda.device(d_out.device):
+        with _guard(d_out.device):
             L.check(L.load().as_interp_bilinear_ac_bwd(_p(_c(d_out)), _p(d_x), b, c, h, w, ctx.dest[0], ctx.dest[1], _stream()),
                     "interp_bilinear_ac_bwd")
         return d_x, None, None
@@ -468,7 +478,7 @@ class ConvexUpsample(torch.autograd.Function):
         d_out = _c(d_out)
         d_mask = torch.empty_like(mask)
         d_disp = torch.empty_like(disp) if ctx.needs_input_grad[0] else None
-        with torch.cuda.device(disp.device):
+        with _guard(disp.device):
             L.check(L.load().as_convex_upsample_bwd(_p(disp), _p(scale), _p(mask), _p(coord), _p(d_out), _p(d_mask), _p(d_disp),
                                                     b, h, w, q, 1 if ctx.logits else 0, _stream()), "convex_upsample_bwd")
         return d_disp, d_mask, None, None, None

@@ -80,7 +80,7 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
         scaler.unscale_(optimizer)
     else:
         loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+    torch.nn.utils.clip_grad_norm_([p for g in optimizer.param_groups for p in g["params"]], clip)  # = model.parameters(), without the module walk
     if scaler is not None:
         scaler.step(optimizer)
     else:

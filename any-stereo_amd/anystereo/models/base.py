@@ -66,9 +66,11 @@ class ContinuousStereoBase(nn.Module):
             require_grad=args.require_grad, number_input=len(chanels), chanels=chanels)
 
     def freeze_bn(self):
-        for m in self.modules():
-            if isinstance(m, nn.BatchNorm2d):
-                m.eval()
+        bns = self.__dict__.get("_bn2d_modules")
+        if bns is None:  # the module tree is fixed after construction; the training step calls this every step
+            bns = self.__dict__["_bn2d_modules"] = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        for m in bns:
+            m.eval()
 
     # ---- hot-path hooks (HIP) ------------------------------------------------------------------
     def _hot_update(self, net_list, inp_list, corr, disp, **flags):

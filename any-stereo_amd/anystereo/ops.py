@@ -15,8 +15,34 @@ import torch
 from . import _lib as L
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_CUR_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> C.c_void_p:
+    """The current stream of the current device as a raw hipStream_t (the dispatcher-free lookup: ~0.3 us instead of ~10 us for
+    torch.cuda.current_stream() — the training step issues ~1500 of these per step and is host-bound)."""
+    if _RAW_STREAM is not None and _CUR_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_CUR_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def _guard(dev):
+    """Device guard for a launch: free when `dev` already is the current device (the normal case: one process per GPU)."""
+    if _CUR_DEVICE is not None and dev.index is not None and _CUR_DEVICE() == dev.index:
+        return _NOGUARD
+    return torch.cuda.device(dev)
 
 
 def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
@@ -83,7 +109,7 @@ def corr_build_pyramid(f1: torch.Tensor, f2: torch.Tensor, num_levels: int) -> L
     w2 = f2.shape[3]
     lv = [torch.empty((b, h, w1, w2 >> i), device=f1.device, dtype=torch.float32) for i in range(num_levels)]
     pp, keep = L.ptr_array([t.data_ptr() for t in lv])
-    with torch.cuda.device(f1.device):
+    with _guard(f1.device):
         L.check(L.load().as_corr_build_pyramid(_p(f1), _p(f2), pp, b, c, h, w1, w2, num_levels, _stream()),
                 "corr_build_pyramid")
     return lv
@@ -97,7 +123,7 @@ def geo_pyramid(gev: torch.Tensor, num_levels: int) -> List[torch.Tensor]:
     b, g, d, h, w = gev.shape
     lv = [torch.empty((b, h, w, d >> i, g), device=gev.device, dtype=torch.float32) for i in range(num_levels)]
     pp, keep = L.ptr_array([t.data_ptr() for t in lv])
-    with torch.cuda.device(gev.device):
+    with _guard(gev.device):
         L.check(L.load().as_geo_pyramid(_p(gev), pp, b, g, d, h, w, num_levels, _stream()), "geo_pyramid")
     return lv
 
@@ -134,7 +160,7 @@ def geo_corr_lookup(geo: Optional[Sequence[torch.Tensor]], corr: Sequence[torch.
             raise RuntimeError("geo_corr_lookup: bad out shape")
     gp, k1 = L.ptr_array([t.data_ptr() for t in geo]) if geo else (None, None)
     cp, k2 = L.ptr_array([t.data_ptr() for t in corr])
-    with torch.cuda.device(disp.device):
+    with _guard(disp.device):
         L.check(L.load().as_geo_corr_lookup_fwd(gp, cp, _p(disp), _p(out), b, h, w, w2, d, g, nl, radius, _stream()),
                 "geo_corr_lookup_fwd")
     return out
@@ -156,7 +182,7 @@ class LookupConvPack:
             if w.shape[0] != 64:
                 raise RuntimeError("LookupConvPack: convc1 must have 64 output channels")
             image = torch.empty(L.load().as_lookup_convc1_pack_bytes(w.shape[1]), device=w.device, dtype=torch.uint8)
-            with torch.cuda.device(w.device):
+            with _guard(w.device):
                 L.check(L.load().as_lookup_convc1_pack(_p(w), w.shape[1], _p(image), _stream()), "lookup_convc1_pack")
             self.image, self.cin = image, w.shape[1]
             self.bias = None if bias is None else bias.detach().float().contiguous()
@@ -199,7 +225,7 @@ def lookup_convc1(geo: Optional[Sequence[torch.Tensor]], corr: Sequence[torch.Te
             raise RuntimeError("lookup_convc1: out_bs shape mismatch")
     gp, k1 = L.ptr_array([t.data_ptr() for t in geo]) if geo else (None, None)
     cp, k2 = L.ptr_array([t.data_ptr() for t in corr])
-    with torch.cuda.device(disp.device):
+    with _guard(disp.device):
         L.check(L.load().as_lookup_convc1_fwd(gp, cp, _p(disp), _p(pack.image), _p(pack.bias), _p(None if out_bs is None else out_bs.t),
                                               0 if out_bs is None else out_bs.c, out_bs_coff, _p(out), 1 if relu else 0,
                                               b, h, w, w2, d, g, nl, radius, _stream()), "lookup_convc1_fwd")
@@ -241,7 +267,7 @@ def loop_front(geo, corr, taps: torch.Tensor, head_bias, disp_old: torch.Tensor,
             raise RuntimeError("loop_front: copy_out shape mismatch")
     gp, k1 = L.ptr_array([t.data_ptr() for t in geo]) if geo else (None, None)
     cp, k2 = L.ptr_array([t.data_ptr() for t in corr])
-    with torch.cuda.device(disp_old.device):
+    with _guard(disp_old.device):
         L.check(L.load().as_loop_front_fwd(gp, cp, _p(taps), taps.shape[1] // 9, _p(hb), _p(disp_old), _p(disp_new), _p(pack.image),
                                            _p(pack.bias), _p(cor.t), _p(wt), wt.shape[1], _p(bb7), _p(d1.t),
                                            _p(None if copy_out is None else copy_out.t), 0 if copy_out is None else copy_out.c, copy_coff,
@@ -262,7 +288,7 @@ def geo_corr_lookup_backward(disp, d_out, geo_shapes, corr_shapes, radius):
     w2 = corr_shapes[0][3]
     gp, k1 = L.ptr_array([t.data_ptr() for t in d_geo]) if d_geo else (None, None)
     cp, k2 = L.ptr_array([t.data_ptr() for t in d_corr])
-    with torch.cuda.device(disp.device):
+    with _guard(disp.device):
         L.check(L.load().as_geo_corr_lookup_bwd(_p(disp), _p(d_out), gp, cp, b, h, w, w2, d, g, nl, radius, _stream()),
                 "geo_corr_lookup_bwd")
     return d_geo, d_corr
@@ -282,7 +308,7 @@ def corr_sampler_forward(volume: torch.Tensor, coords: torch.Tensor, radius: int
     if (coords.shape[0], coords.shape[2], coords.shape[3]) != (n, h1, w1):
         raise RuntimeError("corr_sampler: coords shape does not match volume")
     out = torch.empty((n, 2 * radius + 1, h1, w1), device=volume.device, dtype=volume.dtype)
-    with torch.cuda.device(volume.device):
+    with _guard(volume.device):
         L.check(L.load().as_corr_sampler_fwd(_p(volume), _p(coords), _p(out), n, h1, w1, w2, radius,
                                              coords.shape[1], _DT[volume.dtype], _stream()), "corr_sampler_fwd")
     return out
@@ -297,7 +323,7 @@ def corr_sampler_backward(volume: torch.Tensor, coords: torch.Tensor, corr_grad:
     if tuple(corr_grad.shape) != (n, 2 * radius + 1, h1, w1):
         raise RuntimeError("corr_sampler: corr_grad shape mismatch")
     grad = torch.empty_like(volume)
-    with torch.cuda.device(volume.device):
+    with _guard(volume.device):
         L.check(L.load().as_corr_sampler_bwd(_p(coords), _p(corr_grad), _p(grad), n, h1, w1, w2, radius,
                                              coords.shape[1], _DT[volume.dtype], _stream()), "corr_sampler_bwd")
     return grad
@@ -310,7 +336,7 @@ def gwc_volume(fl: torch.Tensor, fr: torch.Tensor, maxdisp: int, groups: int) ->
         raise RuntimeError("gwc_volume: feature maps must share a [B,C,H,W] shape")
     b, c, h, w = fl.shape
     out = torch.empty((b, groups, maxdisp, h, w), device=fl.device, dtype=torch.float32)
-    with torch.cuda.device(fl.device):
+    with _guard(fl.device):
         L.check(L.load().as_gwc_volume_fwd(_p(fl), _p(fr), _p(out), b, c, h, w, maxdisp, groups, _stream()), "gwc_volume_fwd")
     return out
 
@@ -320,7 +346,7 @@ def disparity_regression(cost: torch.Tensor, apply_softmax: bool) -> torch.Tenso
     _req(cost, "cost")
     b, d, h, w = cost.shape
     out = torch.empty((b, 1, h, w), device=cost.device, dtype=torch.float32)
-    with torch.cuda.device(cost.device):
+    with _guard(cost.device):
         L.check(L.load().as_disparity_regression(_p(cost), _p(out), b, d, h, w, 1 if apply_softmax else 0, _stream()),
                 "disparity_regression")
     return out
@@ -393,7 +419,7 @@ class PackedConv:
         if n <= 0:
             raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}")
         wp = torch.empty(n, device=w.device, dtype=torch.float16 if split else torch.float32)
-        with torch.cuda.device(w.device):
+        with _guard(w.device):
             if split:
                 L.check(L.load().as_conv_pack_weights_split(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights_split")
             else:
@@ -586,7 +612,7 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
         if n_ws > 0:  # small feature map: give the kernel split-K scratch (caching allocator: no sync)
             ws = torch.empty(n_ws, device=dev, dtype=torch.float32)
             d.ws, d.ws_elems = ws.data_ptr(), n_ws
-    with torch.cuda.device(dev):
+    with _guard(dev):
         L.check(L.load().as_conv2d(C.byref(d), _stream()), "conv2d")
     return (out, out2) if epilogue == L.EPI_GRU_ZR else out
 
@@ -630,7 +656,7 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
     if bias is not None:
         bias = bias.detach()
         bias = bias if (bias.dtype == torch.float32 and bias.is_contiguous()) else bias.float().contiguous()
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         cbs = isinstance(copy_out, BS8)
         if copy_out is not None:
             _req(copy_out.t if cbs else copy_out, "copy_out", torch.float16 if cbs else torch.float32)
@@ -650,7 +676,7 @@ def conv3x3_to1(x, weight, bias):
     if tuple(weight.shape) != (1, cin, 3, 3):
         raise RuntimeError("conv3x3_to1: weight must be [1,Cin,3,3]")
     out = torch.empty((b, 1, h, w), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_conv3x3_to1(_p(x), _p(weight), _p(bias), _p(out), b, cin, h, w, _stream()), "conv3x3_to1")
     return out
 
@@ -666,7 +692,7 @@ def tap_shift_sum(s, bias, addend=None):
     if planes % 9:
         raise RuntimeError("tap_shift_sum: expects [B, groups*9, H, W]")
     out = torch.empty((b, 1, h, w), device=s.device, dtype=torch.float32)
-    with torch.cuda.device(s.device):
+    with _guard(s.device):
         L.check(L.load().as_tap_shift_sum(_p(s), _p(bias), _p(addend), _p(out), b, h, w, planes // 9, _stream()), "tap_shift_sum")
     return out
 
@@ -676,7 +702,7 @@ def pool2x(x):
     _req(x, "x")
     b, c, h, w = x.shape
     out = torch.empty((b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_pool2x(_p(x), _p(out), b, c, h, w, _stream()), "pool2x")
     return out
 
@@ -686,7 +712,7 @@ def pool2x_bs(x) -> "BS8":
     _req(x, "x")
     b, c, h, w = x.shape
     out = BS8.empty(b, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_pool2x_bs(_p(x), _p(out.t), b, c, h, w, _stream()), "pool2x_bs")
     return out
 
@@ -696,7 +722,7 @@ def interp_bs(x, ho: int, wo: int) -> "BS8":
     _req(x, "x")
     b, c, h, w = x.shape
     out = BS8.empty(b, c, ho, wo, x.device)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_interp_bilinear_ac_bs(_p(x), _p(out.t), b, c, h, w, ho, wo, _stream()), "interp_bs")
     return out
 
@@ -714,7 +740,7 @@ def dwconv3x3(x, weight, bias=None, stride: int = 1, act: int = L.ACT_NONE, resi
             raise RuntimeError("dwconv3x3: residual shape mismatch")
     if bias is not None:
         _req(bias, "bias")
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_dwconv3x3(_p(x), _p(weight), _p(bias), _p(residual), _p(out), b, c, h, w, stride, act, _stream()),
                 "dwconv3x3")
     return out
@@ -731,7 +757,7 @@ def conv3d_k3(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
         _req(bias, "bias")
     out = torch.empty((b, cout, (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1), device=x.device,
                       dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_conv3d_k3(_p(x), _p(wpack), _p(bias), _p(out), b, cin, cout, d, h, w, stride, act, _stream()),
                 "conv3d_k3")
     return out
@@ -747,7 +773,7 @@ def deconv3d_k4s2(x, wpack, bias=None, act: int = L.ACT_NONE):
     if bias is not None:
         _req(bias, "bias")
     out = torch.empty((b, cout, 2 * d, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_deconv3d_k4s2(_p(x), _p(wpack), _p(bias), _p(out), b, cin, cout, d, h, w, act, _stream()),
                 "deconv3d_k4s2")
     return out
@@ -765,7 +791,7 @@ def instance_norm_act(x, eps: float = 1e-5, act: int = L.ACT_NONE, residual=None
     hw = x[0, 0].numel()
     out = torch.empty_like(x)
     ws = torch.empty(L.load().as_instance_norm_ws_bytes(b * c) // 8, device=x.device, dtype=torch.float64)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_instance_norm_act(_p(x), _p(residual), _p(out), _p(ws), b * c, hw, eps, act, _stream()), "instance_norm_act")
     return out
 
@@ -775,7 +801,7 @@ def layernorm2d_act(x, weight, bias, eps: float = 1e-6, act: int = L.ACT_NONE):
     _req(x, "x"), _req(weight, "weight"), _req(bias, "bias")
     b, c, h, w = x.shape
     out = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_layernorm2d_act(_p(x), _p(weight), _p(bias), _p(out), b, c, h, w, eps, act, _stream()), "layernorm2d_act")
     return out
 
@@ -811,9 +837,30 @@ def interp(x, ho: int, wo: int):
     _req(x, "x")
     b, c, h, w = x.shape
     out = torch.empty((b, c, ho, wo), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_interp_bilinear_ac(_p(x), _p(out), b, c, h, w, ho, wo, _stream()), "interp_bilinear_ac")
     return out
+
+
+def conv2d_wgrad(x, dy, ks: int, want_bias: bool = True):
+    """(dW [Cout,Cin,ks,ks], db [Cout] | None) of a stride-1 "same" convolution from its input x [B,Cin,H,W] and output gradient
+    dy [B,Cout,H,W] (as_conv2d_wgrad: bf16 hi/lo split MFMA, deterministic split-K) — update.py:16-92 under autograd."""
+    _req(x, "x"), _req(dy, "dy")
+    b, cin, h, w = x.shape
+    cout = dy.shape[1]
+    if dy.shape[0] != b or tuple(dy.shape[2:]) != (h, w):
+        raise RuntimeError(f"conv2d_wgrad: x {tuple(x.shape)} and dy {tuple(dy.shape)} do not match")
+    lib = L.load()
+    nbytes = int(lib.as_conv2d_wgrad_ws_bytes(b, cin, cout, h, w, ks))
+    if nbytes < 0:
+        raise RuntimeError(f"conv2d_wgrad: unsupported problem (ks={ks}, x {tuple(x.shape)})")
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty((cout, cin, ks, ks), device=x.device, dtype=torch.float32)
+    db = torch.empty((cout,), device=x.device, dtype=torch.float32) if want_bias else None
+    with _guard(x.device):
+        L.check(lib.as_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db) if db is not None else None, b, cin, cout, h, w, ks, _p(ws), nbytes,
+                                    _stream()), "conv2d_wgrad")
+    return dw, db
 
 
 # ------------------------------------------------------------------------------------------------
@@ -827,7 +874,7 @@ def structure_feature(x: torch.Tensor) -> torch.Tensor:
     b, c, h, w = x.shape
     out = torch.empty((b, c + 8, h, w), device=x.device, dtype=torch.float32)
     ws = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
-    with torch.cuda.device(x.device):
+    with _guard(x.device):
         L.check(L.load().as_structure_feature(_p(x), _p(out), _p(ws), b, c, h, w, _stream()), "structure_feature")
     return out
 
@@ -840,7 +887,7 @@ def liif_gather(feat: torch.Tensor, coord: torch.Tensor, latent: torch.Tensor, l
     q = coord.shape[1]
     if tuple(coord.shape) != (b, q, 2) or latent.shape[0] != b or latent.shape[2] != q:
         raise RuntimeError("liif_gather: coord must be [B,Q,2] and latent [B,Ctot,Q]")
-    with torch.cuda.device(feat.device):
+    with _guard(feat.device):
         L.check(L.load().as_liif_gather(_p(feat), _p(coord), _p(latent), b, c, h, w, q, latent.shape[1], lat_coff, _stream()),
                 "liif_gather")
 
@@ -861,7 +908,7 @@ def liif_gather_mlp1(u0, u1, coord, wrel, bias):
     if bias is not None:
         _req(bias, "bias")
     out = torch.empty((b, c, q), device=u0.device, dtype=torch.float32)
-    with torch.cuda.device(u0.device):
+    with _guard(u0.device):
         L.check(L.load().as_liif_gather_mlp1(_p(u0), _p(u1), _p(coord), _p(wrel), _p(bias), _p(out), b, c, h0, w0, h1, w1, q,
                                              _stream()), "liif_gather_mlp1")
     return out
@@ -878,7 +925,7 @@ def liif_rel_key(coord, sizes, want_rel=True, want_key=False):
     rel = torch.empty((b, 2 * n, q), device=coord.device, dtype=torch.float32) if want_rel else None
     key = torch.empty((b, q), device=coord.device, dtype=torch.int32) if want_key else None
     (h0, w0), (h1, w1) = sizes[0], (sizes[1] if n > 1 else (0, 0))
-    with torch.cuda.device(coord.device):
+    with _guard(coord.device):
         L.check(L.load().as_liif_rel_key(_p(coord), _p(rel), _p(key), b, q, n, h0, w0, h1, w1, _stream()), "liif_rel_key")
     return rel, key
 
@@ -888,7 +935,7 @@ def liif_scatter_add(d_rows, coord, c, h, w, coff=0):
     _req(d_rows, "d_rows"), _req(coord, "coord")
     b, ctot, q = d_rows.shape
     out = torch.empty((b, c, h, w), device=d_rows.device, dtype=torch.float32)
-    with torch.cuda.device(d_rows.device):
+    with _guard(d_rows.device):
         L.check(L.load().as_liif_gather_bwd(_p(d_rows), _p(coord), _p(out), b, c, h, w, q, ctot, coff, _stream()), "liif_gather_bwd")
     return out
 
@@ -907,7 +954,7 @@ def convex_upsample(disp, mask, coord, scale=None, mask_is_logits=False):
         if scale.numel() != b:
             raise RuntimeError("convex_upsample: scale must hold one value per batch element")
     out = torch.empty((b, 1, q), device=disp.device, dtype=torch.float32)
-    with torch.cuda.device(disp.device):
+    with _guard(disp.device):
         L.check(L.load().as_convex_upsample(_p(disp), _p(scale), _p(mask), _p(coord), _p(out), b, h, w, q,
                                             1 if mask_is_logits else 0, _stream()), "convex_upsample")
     return out
@@ -935,7 +982,7 @@ def liif_affinity(srcs: Sequence[torch.Tensor]) -> torch.Tensor:
     ctot = sum(int(t.shape[1]) for t in srcs)
     ws = torch.empty(L.load().as_liif_affinity_ws_bytes(b, h, w, (ctot + 7) // 8) // 4, device=srcs[0].device, dtype=torch.float32)
     ptrs, ch, keep = _src_arrays(srcs)
-    with torch.cuda.device(aff.device):
+    with _guard(aff.device):
         L.check(L.load().as_liif_affinity(ptrs, ch, len(srcs), _p(aff), _p(ws), b, h, w, _stream()), "liif_affinity")
     return aff
 
@@ -955,7 +1002,7 @@ class LiifLowresPack:
             if w.dim() != 2 or w.shape[0] != 128:
                 raise RuntimeError("LiifLowresPack: weight must be [128, in_dim]")
             image = torch.empty(L.load().as_liif_lowres_pack_bytes(k), device=w.device, dtype=torch.uint8)
-            with torch.cuda.device(w.device):
+            with _guard(w.device):
                 L.check(L.load().as_liif_lowres_pack(_p(w), w.shape[1], koff, k, _p(image), _stream()), "liif_lowres_pack")
             self.image, self._key, self._ref = image, key, weakref.ref(weight)
         return self
@@ -971,7 +1018,7 @@ def liif_lowres_cl(srcs: Sequence[torch.Tensor], pack: LiifLowresPack) -> torch.
         raise RuntimeError("liif_lowres_cl: sources do not hold the packed column count")
     out = torch.empty((b, h * w, 128), device=srcs[0].device, dtype=torch.float32)
     ptrs, ch, keep = _src_arrays(srcs)
-    with torch.cuda.device(out.device):
+    with _guard(out.device):
         L.check(L.load().as_liif_lowres_cl(ptrs, ch, len(srcs), _p(pack.image), _p(out), b, h, w, _stream()), "liif_lowres_cl")
     return out
 
@@ -1000,7 +1047,7 @@ class LiifTailPack:
                 raise RuntimeError("LiifTailPack: the fused tail is built for the default MLP 128-64-64-9")
             b1, b2, b3, b4 = f(lin[0].bias), f(lin[1].bias), f(lin[2].bias), f(lin[3].bias)
             image = torch.empty(L.load().as_liif_tail_image_bytes(), device=w1.device, dtype=torch.uint8)
-            with torch.cuda.device(w1.device):
+            with _guard(w1.device):
                 L.check(L.load().as_liif_tail_pack(_p(wrel), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(w4), _p(b4),
                                                    len(rel_cols), _p(image), _stream()), "liif_tail_pack")
             self.image, self.wrel, self._key = image, wrel, key
@@ -1026,7 +1073,7 @@ def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_
             raise RuntimeError("liif_tail: scale must hold one value per batch element")
     out = torch.empty((b, 1, q), device=coord.device, dtype=torch.float32)
     logits = torch.empty((b, 9, q), device=coord.device, dtype=torch.float32) if want_logits else None
-    with torch.cuda.device(coord.device):
+    with _guard(coord.device):
         L.check(L.load().as_liif_tail(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(disp), _p(scale), _p(out), _p(logits), b, q,
                                       h0, w0, h1, w1, disp.shape[2], disp.shape[3], 1 if clamp_inplace else 0, _stream()),
                 "liif_tail")

@@ -359,6 +359,15 @@ unsigned as_liif_split_overflow(int reset);
  *   a16/a17^T as_convex_upsample_bwd: d_out [B,1,Q] -> d_mask [B,9,Q] (w.r.t. the logits when mask_is_logits) and
  *         d_disp [B,1,H,W] (may be NULL) w.r.t. the UNscaled disparity when scale != NULL.
  * ------------------------------------------------------------------------------------------- */
+/*   a6/a7/a9 weight gradient  as_conv2d_wgrad: x [B,Cin,H,W], dy [B,Cout,H,W] -> dw [Cout,Cin,KS,KS] (+ db [Cout] when db != NULL) of a
+ *         stride-1 "same" convolution, KS = 1 | 3 — what autograd derives for the nn.Conv2d layers of update.py:16-92
+ *         (train_continuous_IGEV.py:214-239 applies each `iters` times per step; the binding stacks all iterations along B and
+ *         reduces them in one launch).  bf16 hi/lo operand split (hi*hi + hi*lo + lo*hi, one fp32 accumulator: ~2^-16 relative
+ *         per product, fp32 exponent range), split-K over a workspace of as_conv2d_wgrad_ws_bytes() bytes, summed in a fixed
+ *         order (deterministic).  dw / db are overwritten. */
+int64_t as_conv2d_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int KS);
+int as_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int KS,
+                    void* ws, int64_t ws_bytes, void* stream);
 /*   a8^T  as_pool2x_bwd / as_interp_bilinear_ac_bwd: d_out [B,C,Ho,Wo] -> d_x [B,C,H,W], the transposes of as_pool2x /
  *         as_interp_bilinear_ac (what autograd derives for F.avg_pool2d / F.interpolate at update.py:94-102); gather form, one
  *         thread per input element, fixed summation order. */

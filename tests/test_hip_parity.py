@@ -816,6 +816,33 @@ def test_conv2d_same_backward(cin, cout, k, relu, precision):
     close(a[2].grad, r[2].grad, 2e-4, 1e-5, "d b")
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w,k", [(3, 40, 70, 6, 16, 3), (2, 162, 64, 5, 24, 1), (4, 33, 130, 7, 21, 3), (2, 7, 5, 3, 5, 1),
+                                              (2, 64, 128, 4, 104, 3), (16, 128, 127, 10, 20, 3)])
+def test_conv2d_wgrad(b, cin, cout, h, w, k):
+    """as_conv2d_wgrad (bf16 hi/lo split MFMA, split-K, bias gradient as a tile of ones) against fp64 autograd of F.conv2d:
+    channel counts that do not fill the 128 x 32 tiles, widths with and without the 16-byte fetch path, rows longer than one
+    96-pixel segment, tiny gradients (1e-7 scale: fp32 exponent range, no scaling pass), repeatable bit for bit."""
+    import torch.nn.functional as F
+    from anystereo import ops
+    x, dy = U((b, cin, h, w), 530), U((b, cout, h, w), 531)
+    for scale in (1.0, 1e-7):
+        g = (dy * scale).contiguous()
+        dw, db = ops.conv2d_wgrad(x.to(DEV), g.to(DEV), k)
+        wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+        bias = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), wt, bias, padding=k // 2).backward(g.double())
+        # error model: 3 bf16 products = 2^-16 relative per term, random over K = b*h*w terms of size <= |x||dy|
+        lim = 4e-5 * scale * (b * h * w) ** 0.5
+        assert (dw.double().cpu() - wt.grad).abs().max().item() <= lim, ((dw.double().cpu() - wt.grad).abs().max().item(), lim)
+        assert (db.double().cpu() - bias.grad).abs().max().item() <= lim
+        rel = (dw.double().cpu() - wt.grad).norm() / wt.grad.norm()
+        assert rel < 2e-5, rel
+        dw2, db2 = ops.conv2d_wgrad(x.to(DEV), g.to(DEV), k)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2), "deterministic"
+    dw3, none = ops.conv2d_wgrad(x.to(DEV), dy.to(DEV), k, want_bias=False)
+    assert none is None and torch.isfinite(dw3).all()
+
+
 @pytest.mark.parametrize("kind", ["conv3", "conv1_cat", "linear"])
 def test_deferred_weight_gradients(kind):
     """A layer applied once per GRU iteration: its weight / bias gradients as ONE batched reduction per step (grad.WeightAnchor)

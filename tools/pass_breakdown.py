@@ -1,8 +1,8 @@
 """Steady-state per-kernel breakdown of ONE forward pass from a rocprofv3 --kernel-trace CSV.
 
     python tools/pass_breakdown.py <dir with *kernel_trace.csv> <out.json>
-A pass = the dispatches between the ends of two consecutive softmax_convex_kernel launches (the last kernel of
-a forward); the LAST complete window is used, so MIOpen's first-call solver search is excluded.  Phases:
+A pass = the dispatches between the ends of two consecutive liif_tail_kernel (or softmax_convex_kernel) launches (the last
+kernel of a forward); the LAST complete window is used, so MIOpen's first-call solver search is excluded.  Phases:
 pre (before the first lookup), loop (first lookup .. last GRU-iteration kernel), post.
 """
 import csv
@@ -21,10 +21,11 @@ def main():
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    ends = [i for i, r in enumerate(rows) if "softmax_convex_kernel" in r[2]]
+    last = "liif_tail_kernel" if any("liif_tail_kernel" in r[2] for r in rows) else "softmax_convex_kernel"
+    ends = [i for i, r in enumerate(rows) if last in r[2]]
     assert len(ends) >= 2, "need two complete passes"
     win = rows[ends[-2] + 1: ends[-1] + 1]
-    look = [i for i, r in enumerate(win) if "lookup_fwd" in r[2]]
+    look = [i for i, r in enumerate(win) if "lookup_fwd" in r[2] or "lookup_convc1_kernel" in r[2] or "loop_front_kernel" in r[2]]
     last_loop = max(i for i, r in enumerate(win) if "tap_shift_sum" in r[2] or "conv3x3_to1" in r[2])
     phases = {"pre": win[:look[0]], "loop": win[look[0]:last_loop + 1], "post": win[last_loop + 1:]}
     res = {"wall_ms": (win[-1][1] - win[0][0]) / 1e6, "n_lookups": len(look)}
