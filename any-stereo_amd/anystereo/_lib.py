@@ -59,6 +59,7 @@ SIGNATURES = {
     "as_geo_pyramid": (_i, [_vp, _pp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_geo_corr_lookup_fwd": (_i, [_pp, _pp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_geo_corr_lookup_bwd": (_i, [_vp, _vp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_geo_corr_lookup_bwd_accum": (_i, [_vp, _vp, _pp, _pp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_lookup_convc1_pack_bytes": (C.c_int64, [_i]),
     "as_lookup_convc1_pack": (_i, [_vp, _i, _vp, _vp]),
     "as_lookup_convc1_fwd": (_i, [_pp, _pp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -72,11 +72,31 @@ class GeoPyramid(torch.autograd.Function):
 
 
 # ---- a3: lookup (gradients to the volumes only; disp arrives detached, continuous_IGEVstereo.py:285) -----------
+class LookupAnchor(torch.autograd.Function):
+    """Identity on the pyramid levels that all lookups of one forward hang off: the lookups' backward passes add their windows to
+    ONE zero-filled gradient per level (`holder`), and this node — reached after the last of them — hands those to the levels,
+    instead of `iters` zero-filled full-size volumes that autograd sums pairwise."""
+
+    @staticmethod
+    def forward(ctx, holder, *levels):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for t in levels)
+
+    @staticmethod
+    def backward(ctx, *g):
+        acc, ctx.holder["acc"] = ctx.holder.get("acc"), None
+        if acc is None:
+            return (None, *g)
+        out = [*acc[0], *acc[1]]
+        return (None, *[o if gi is None else o + gi for o, gi in zip(out, g)])
+
+
 class Lookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, disp, radius, n_geo, *levels):
+    def forward(ctx, disp, radius, n_geo, holder, *levels):
         geo, corr = list(levels[:n_geo]), list(levels[n_geo:])
-        ctx.radius, ctx.n_geo = radius, n_geo
+        ctx.radius, ctx.n_geo, ctx.holder = radius, n_geo, holder
         ctx.geo_shapes = [tuple(t.shape) for t in geo]
         ctx.corr_shapes = [tuple(t.shape) for t in corr]
         ctx.save_for_backward(disp)
@@ -85,8 +105,12 @@ class Lookup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         (disp,) = ctx.saved_tensors
+        if ctx.holder is not None:  # levels came through a LookupAnchor: accumulate, it returns the sums
+            ctx.holder["acc"] = ops.geo_corr_lookup_backward(disp, _c(d_out), ctx.geo_shapes, ctx.corr_shapes, ctx.radius,
+                                                             into=ctx.holder.get("acc"))
+            return (None,) * (4 + len(ctx.geo_shapes) + len(ctx.corr_shapes))
         d_geo, d_corr = ops.geo_corr_lookup_backward(disp, _c(d_out), ctx.geo_shapes, ctx.corr_shapes, ctx.radius)
-        return (None, None, None, *d_geo, *d_corr)
+        return (None, None, None, None, *d_geo, *d_corr)
 
 
 # ---- a4: group-wise correlation volume (submodule.py:253-271) ---------------------------------------------------

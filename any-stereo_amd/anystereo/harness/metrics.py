@@ -63,11 +63,14 @@ def thres_metric(d_est, d_gt, mask, thres):
     return _per_image(lambda e, g, m: ((g[m] - e[m]).abs() > thres).float().mean(), d_est, d_gt, mask)
 
 
-def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0):
+def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0, loss_scale=1.0):
     """One optimisation step with the reference's ordering (train_continuous_IGEV.py:214-239, multi_training branch):
     zero_grad -> forward(train mode) -> sequence_loss_multiscale with valid = (gt < 512) & (gt > 0) -> scaled backward ->
     unscale -> clip_grad_norm_(1.0) -> optimizer step -> scheduler step (unless fixed lr) -> scaler update.
     `batch` = (image1, image2, hr_coord, hr_disp_gt, scale); `scaler` may be None (no mixed precision).
+    `loss_scale` (a power of two, no GradScaler): the backward pass runs on loss * loss_scale and the gradients are divided by it
+    before clipping — exact in fp32, it only moves the 1e-6 .. 1e-9 activation gradients of this loss away from the fp16
+    subnormal range of the split-precision dgrad kernels (x = hi + lo/2048 keeps 22 bits only above |x| ~ 6e-5).
     Model-agnostic host logic (any module with the reference's forward signature)."""
     image1, image2, hr_coord, hr_disp_gt, scale = batch
     optimizer.zero_grad()
@@ -78,6 +81,10 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
     if scaler is not None:
         scaler.scale(loss).backward()
         scaler.unscale_(optimizer)
+    elif loss_scale != 1.0:
+        (loss * loss_scale).backward()
+        grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+        torch._foreach_mul_(grads, 1.0 / loss_scale)
     else:
         loss.backward()
     torch.nn.utils.clip_grad_norm_([p for g in optimizer.param_groups for p in g["params"]], clip)  # = model.parameters(), without the module walk

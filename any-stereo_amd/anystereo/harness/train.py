@@ -63,7 +63,7 @@ class Trainer:
 
     def __init__(self, model, lr: float = 2e-4, wdecay: float = 1e-5, num_steps: int = 100000, train_iters: int = 16,
                  max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int = 25,
-                 force_ddp: bool = False):
+                 force_ddp: bool = False, loss_scale: float | None = None):
         model.train()
         model.freeze_bn()  # train_continuous_IGEV.py:203
         self.model = model
@@ -75,6 +75,11 @@ class Trainer:
         self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed)
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
         self.train_iters, self.max_disp = train_iters, max_disp
+        # static power-of-two loss scale (exact in fp32): keeps the activation gradients (1e-6 .. 1e-9 at cfg-4 scale) out of the
+        # fp16 subnormal range of the split-precision dgrad; the split's range guard (ops.split_overflow_count) watches the other end
+        if loss_scale is None:
+            loss_scale = float(os.environ.get("ANYSTEREO_LOSS_SCALE", "4096"))
+        self.loss_scale = 1.0 if mixed_precision else loss_scale
 
     def _wrap_ddp(self, batch):
         """Probe pass on the bare module -> freeze gradient-less parameters -> wrap (see the class docstring)."""
@@ -113,6 +118,6 @@ class Trainer:
         if not sync_grads and self.module is not self.model:
             with self.module.no_sync():
                 return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
-                                  max_disp=self.max_disp)
+                                  max_disp=self.max_disp, loss_scale=self.loss_scale)
         return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
-                          max_disp=self.max_disp)
+                          max_disp=self.max_disp, loss_scale=self.loss_scale)

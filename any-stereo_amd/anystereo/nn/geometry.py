@@ -67,7 +67,10 @@ class Combined_Geo_Encoding_Volume:
             self._check_coords(coords, disp)
         levels = list(self.geo_volume_pyramid) + list(self.init_corr_pyramid)
         if _needs_grad(*levels):
-            return G.Lookup.apply(disp, self.radius, len(self.geo_volume_pyramid), *levels)
+            if getattr(self, "_anchored", None) is None:  # once per forward: every iteration's lookup hangs off these views
+                self._holder = {}
+                self._anchored = G.LookupAnchor.apply(self._holder, *levels) if G._DEFER else tuple(levels)
+            return G.Lookup.apply(disp, self.radius, len(self.geo_volume_pyramid), self._holder if G._DEFER else None, *self._anchored)
         with scope("lookup"):
             return ops.geo_corr_lookup(self.geo_volume_pyramid, self.init_corr_pyramid, disp, self.radius)
 

@@ -275,13 +275,17 @@ def loop_front(geo, corr, taps: torch.Tensor, head_bias, disp_old: torch.Tensor,
     return disp_new, cor, d1
 
 
-def geo_corr_lookup_backward(disp, d_out, geo_shapes, corr_shapes, radius):
-    """Gradients w.r.t. the pyramid levels (transpose of the lookup)."""
+def geo_corr_lookup_backward(disp, d_out, geo_shapes, corr_shapes, radius, into=None):
+    """Gradients w.r.t. the pyramid levels (transpose of the lookup).  `into` = (d_geo, d_corr) of an earlier call: the windows
+    are ADDED to those buffers (one gradient per level for all GRU iterations of a step) instead of filling fresh ones."""
     _req(disp, "disp"), _req(d_out, "d_out")
     b, _, h, w = disp.shape
     nl = len(corr_shapes)
-    d_corr = [torch.zeros(s, device=disp.device, dtype=torch.float32) for s in corr_shapes]
-    d_geo = [torch.zeros(s, device=disp.device, dtype=torch.float32) for s in geo_shapes] if geo_shapes else []
+    if into is not None:
+        d_geo, d_corr = into
+    else:
+        d_corr = [torch.zeros(s, device=disp.device, dtype=torch.float32) for s in corr_shapes]
+        d_geo = [torch.zeros(s, device=disp.device, dtype=torch.float32) for s in geo_shapes] if geo_shapes else []
     g = d = 0
     if d_geo:
         d, g = geo_shapes[0][3], geo_shapes[0][4]
@@ -289,8 +293,8 @@ def geo_corr_lookup_backward(disp, d_out, geo_shapes, corr_shapes, radius):
     gp, k1 = L.ptr_array([t.data_ptr() for t in d_geo]) if d_geo else (None, None)
     cp, k2 = L.ptr_array([t.data_ptr() for t in d_corr])
     with _guard(disp.device):
-        L.check(L.load().as_geo_corr_lookup_bwd(_p(disp), _p(d_out), gp, cp, b, h, w, w2, d, g, nl, radius, _stream()),
-                "geo_corr_lookup_bwd")
+        fn = L.load().as_geo_corr_lookup_bwd_accum if into is not None else L.load().as_geo_corr_lookup_bwd
+        L.check(fn(_p(disp), _p(d_out), gp, cp, b, h, w, w2, d, g, nl, radius, _stream()), "geo_corr_lookup_bwd")
     return d_geo, d_corr
 
 

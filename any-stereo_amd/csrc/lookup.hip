@@ -21,6 +21,7 @@ struct LookupParams {
   float* out;
   int B, H, W, W2, D, G, L, radius;
   int HW, CH;
+  int accum;  // lookup_bwd_kernel: add the windows to the gradients instead of storing them (one buffer for all GRU iterations)
   long long P;
   int geo_bytes[AS_MAX_LEVELS];
   int corr_bytes[AS_MAX_LEVELS];
@@ -682,7 +683,13 @@ __global__ __launch_bounds__(256) void lookup_bwd_kernel(LookupParams p) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int dd = i0 - R + j;
-      if (dd >= 0 && dd < Dl) row[(long long)dd * gstride] = w[j];
+      if (dd >= 0 && dd < Dl) {
+        if (p.accum) {
+          const float4 o = row[(long long)dd * gstride];
+          w[j].x += o.x; w[j].y += o.y; w[j].z += o.z; w[j].w += o.w;
+        }
+        row[(long long)dd * gstride] = w[j];
+      }
     }
   } else {
     const int Wl = p.W2 >> level;
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(256) void lookup_bwd_kernel(LookupParams p) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int dd = i0 - R + j;
-      if (dd >= 0 && dd < Wl) row[dd] = w[j];
+      if (dd >= 0 && dd < Wl) row[dd] = p.accum ? row[dd] + w[j] : w[j];
     }
   }
 }
@@ -855,9 +862,20 @@ int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, co
   return as::check_launch("geo_corr_lookup_fwd");
 }
 
+static int lookup_bwd_impl(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr, int B, int H, int W, int W2,
+                           int D, int G, int L, int radius, int accum, void* stream);
 int as_geo_corr_lookup_bwd(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr,
                            int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream) {
+  return lookup_bwd_impl(disp, d_out, d_geo, d_corr, B, H, W, W2, D, G, L, radius, 0, stream);
+}
+int as_geo_corr_lookup_bwd_accum(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr,
+                                 int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream) {
+  return lookup_bwd_impl(disp, d_out, d_geo, d_corr, B, H, W, W2, D, G, L, radius, 1, stream);
+}
+static int lookup_bwd_impl(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr, int B, int H, int W, int W2,
+                           int D, int G, int L, int radius, int accum, void* stream) {
   LookupParams p{};
+  p.accum = accum;
   int rc = fill_common(p, B, H, W, W2, D, G, L, radius);
   if (rc != AS_OK) return rc;
   AS_REQUIRE(d_corr && disp && d_out && (G == 0 || d_geo), AS_ERR_BAD_ARG, "lookup_bwd: null pointer");

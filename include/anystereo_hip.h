@@ -111,6 +111,11 @@ int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, co
  * d_geo[i], d_corr[i] must be ZERO-FILLED by the caller; rows are pixel-private so no atomics are used. */
 int as_geo_corr_lookup_bwd(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr,
                            int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
+/* the same, ADDING each pixel's windows to d_geo / d_corr: the lookup runs once per GRU iteration on the same pyramid
+ * (continuous_IGEVstereo.py:286), so one zero-filled gradient per level collects all iterations of a training step instead of
+ * `iters` zero-filled volumes that autograd then sums.  Calls on one stream are ordered; within a call every window is private. */
+int as_geo_corr_lookup_bwd_accum(const float* disp, const float* d_out, float* const* d_geo, float* const* d_corr,
+                                 int B, int H, int W, int W2, int D, int G, int L, int radius, void* stream);
 
 /* a3 + the first conv of a6 fused (csrc/lookup.hip): out = act(convc1(lookup(disp))) — replaces
  *   `corr = geo_fn(disp, coords)` (continuous_IGEVstereo.py:286 -> geometry.py:34-60) followed by

@@ -162,6 +162,33 @@ def test_lookup_backward_is_transpose():
         close(dg[i].permute(0, 1, 2, 4, 3), gr[i].grad, 2e-5, 1e-6, f"d_geo{i}")
 
 
+@pytest.mark.parametrize("tag", ["igev", "raft"])
+def test_lookup_backward_accumulates_over_iterations(tag):
+    """Several lookups on one pyramid (one per GRU iteration) under autograd: their backward passes add into ONE gradient per
+    level (as_geo_corr_lookup_bwd_accum behind grad.LookupAnchor); gradients w.r.t. the feature maps / the geometry volume
+    against fp64 autograd of the oracle lookups, including a lookup whose output never reaches the loss and overlapping windows."""
+    from anystereo.nn.geometry import Combined_Geo_Encoding_Volume, CorrBlock1D
+    b, c, h, w, r = 2, 16, 3, 24, 4
+    f1, f2, gev = U((b, c, h, w), 80), U((b, c, h, w), 81), U((b, 8, 48, h, w), 82)
+    disps = [U((b, 1, h, w), 83 + i, -3.0, w + 3.0) for i in range(4)]
+    disps[2] = disps[0] + 0.25  # windows overlapping those of the first lookup
+    L = 2 if tag == "igev" else 4
+    a1, a2, ag = _leaf(f1, DEV), _leaf(f2, DEV), _leaf(gev, DEV)
+    fn = Combined_Geo_Encoding_Volume(a1, a2, ag, num_levels=L, radius=r) if tag == "igev" else CorrBlock1D(a1, a2, num_levels=L, radius=r)
+    outs = [fn(d.to(DEV)) for d in disps]
+    gs = [U(tuple(outs[0].shape), 90 + i) for i in range(3)]
+    sum((o * g.to(DEV)).sum() for o, g in zip(outs[:3], gs)).backward()
+    r1, r2, rg = _leaf(f1, dt=torch.float64), _leaf(f2, dt=torch.float64), _leaf(gev, dt=torch.float64)
+    corr = O.corr_pyramid(O.all_pairs_corr(r1, r2), L)
+    geo = O.geo_pyramid(rg, L) if tag == "igev" else []
+    sum((O.geo_corr_lookup(geo, corr, d.double(), r) * g.double()).sum() for d, g in zip(disps[:3], gs)).backward()
+    close(a1.grad, r1.grad, 5e-5, 1e-5, "d f1")
+    close(a2.grad, r2.grad, 5e-5, 1e-5, "d f2")
+    if tag == "igev":
+        close(ag.grad, rg.grad, 2e-5, 1e-6, "d gev")
+    assert fn._holder.get("acc") is None, "the shared gradient is released by the anchor's backward"
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12), (torch.float16, 8e-3)])
 def test_corr_sampler_module(dtype, tol):
     """`corr_sampler.forward/backward` (sampler/sampler.cpp:48-51) incl. zero-pad edges, ragged W2, r != 4."""
