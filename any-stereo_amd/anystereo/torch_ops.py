@@ -76,7 +76,7 @@ def _geo_corr_lookup(geo_levels, corr_levels, disp, radius):
     disp = _f(disp)
     levels = list(geo_levels) + list(corr_levels)
     if G.needs_grad(*levels):
-        return G.Lookup.apply(disp, radius, len(geo_levels), *levels)
+        return G.Lookup.apply(disp, radius, len(geo_levels), None, *levels)
     return ops.geo_corr_lookup(list(geo_levels), list(corr_levels), disp, radius)
 
 

@@ -271,6 +271,11 @@ def train_main(a, rank, world, local):
         overlap = {"ms_per_step_with_allreduce": round(ms_sync, 2), "ms_per_step_no_sync": round(ms_nosync, 2),
                    "exposed_allreduce_ms": round(ms_sync - ms_nosync, 2), "gradient_bytes": nbytes,
                    "ddp": tr.ddp_mode}
+    roof = cpu = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        roof = train_roofline(a, batch, dev)
+        if not a.no_cpu_baseline:
+            cpu = train_cpu_baseline(a, args, model, batch)
     if rank == 0:
         nparam = sum(p.numel() for p in model.parameters())
         print(json.dumps({
@@ -283,11 +288,66 @@ def train_main(a, rank, world, local):
             "per_rank_samples_per_s": [round(a.batch_per_gpu * a.steps / v, 3) for v in per_rank],
             "allreduce_overlap": overlap,
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
-            "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample transposes and the update-block/MLP dgrad; wgrad and backbone convs on MIOpen/rocBLAS",
-            "roofline": None, "cpu_baseline": None}))
+            "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample/pool/interp transposes, the update-block/MLP dgrad and "
+                        "the weight gradients of the >= 96-channel 3x3 layers (one batched launch per layer and step); small layers' "
+                        "wgrad and the backbone convs on MIOpen/rocBLAS",
+            "loss_scale": tr.loss_scale, "roofline": roof, "cpu_baseline": cpu}))
     if dist:
         td.barrier()
         td.destroy_process_group()
+
+
+def train_roofline(a, batch, dev):
+    """The largest single launch of a training step: the weight gradient of the 1/4-resolution GRU's z|r convolution over all
+    `train_iters` iterations (as_conv2d_wgrad, 3 bf16 MFMAs per product), timed here with HIP events on its own stream."""
+    from anystereo import ops
+    b, h4, w4 = batch[0].shape[0], batch[0].shape[2] // 4, batch[0].shape[3] // 4
+    n, cin, cout = a.train_iters * b, 384, 256
+    x = torch.randn(n, cin, h4, w4, device=dev)
+    dy = torch.randn(n, cout, h4, w4, device=dev) * 1e-4
+    for _ in range(2):
+        ops.conv2d_wgrad(x, dy, 3)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ops.conv2d_wgrad(x, dy, 3)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    flop = 2.0 * n * h4 * w4 * cin * 9 * cout
+    peak = 2500.0 / 3.0
+    ach = flop / (us * 1e-6) / 1e12
+    return {"kernel": "wgrad_kernel<3,1> + wgrad_finish_kernel (gru04 convz|convr, all iterations of a step in one launch)",
+            "bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 3),
+            "peak_note": "2.5 PF dense bf16 / 3 MFMAs per product (bf16 hi/lo operand split)", "us_per_launch": round(us, 1),
+            "algorithmic_gflop_per_launch": round(flop / 1e9, 1), "traffic": None, "timing": "HIP events around 5 launches"}
+
+
+def train_cpu_baseline(a, args, model, batch):
+    """One full optimisation step (forward + backward + clip + AdamW) of the CPU oracle model on ONE sample of the batch, same
+    weights — the oracle's operators are explicit-index torch code, so autograd differentiates them as it does the reference."""
+    try:
+        from anystereo.harness.metrics import fetch_optimizer, train_step
+        from oracle.model import OracleIGEV
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        torch.set_num_threads(threads)
+        ref = OracleIGEV(args)
+        ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        ref.train()
+        ref.freeze_bn()
+        opt, sched = fetch_optimizer(2e-4, 1e-5, 1000, ref.parameters())
+        one = tuple(t[:1].cpu().contiguous() for t in batch)
+        t0 = time.perf_counter()
+        loss, _ = train_step(ref, opt, sched, None, one, a.train_iters, max_disp=args.max_disp)
+        dt = time.perf_counter() - t0
+        return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": threads, "kind": "port", "s_per_sample": round(dt, 2),
+                "sample": f"one full step (forward + backward + clip + AdamW) on 1 of the {batch[0].shape[0]} samples, "
+                          f"{a.train_iters} GRU iters, Q={batch[2].shape[1]}, fp32, {threads} threads, no warm-up",
+                "loss": round(float(loss), 4)}
+    except Exception as e:  # the baseline is a report, never a reason to lose the line
+        return {"value": None, "unit": "samples/s", "kind": "port", "error": f"{type(e).__name__}: {e}"[:200]}
 
 
 # ------------------------------------------------------------------------------------------------------------------
