@@ -320,7 +320,7 @@ class PointwiseLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu, pack_f, pack_b, stash=None):
         b, c, q = x.shape
-        y = ops.conv2d([x.view(b, c, 1, q)], pack_f.get([weight], [bias]), act=L.ACT_RELU if relu else L.ACT_NONE).view(b, -1, q)
+        y = ops.conv2d_plain(x.view(b, c, 1, q), pack_f.get([weight], [bias]), L.ACT_RELU if relu else L.ACT_NONE).view(b, -1, q)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.pack_b, ctx.has_bias, ctx.stash = pack_b, bias is not None, stash
         return y
@@ -334,7 +334,7 @@ class PointwiseLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if weight.shape[0] >= 16:
                 pk = ctx.pack_b.get([weight], [None], transform=lambda w: w.t().contiguous())
-                d_x = ops.conv2d([d.view(b, -1, 1, q)], pk).view(b, c, q)
+                d_x = ops.conv2d_plain(d.view(b, -1, 1, q), pk).view(b, c, q)
             else:  # a handful of output channels (the 9 mask logits): not worth a K-padded MFMA launch
                 d_x = torch.matmul(weight.t(), d)
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
@@ -353,7 +353,7 @@ class Conv2dSame(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, pack_f, pack_b, stash=None):
-        y = ops.conv2d([x], pack_f.get([weight], [bias]), act=L.ACT_RELU if relu else L.ACT_NONE)
+        y = ops.conv2d_plain(x, pack_f.get([weight], [bias]), L.ACT_RELU if relu else L.ACT_NONE)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.pack_b, ctx.bias_sizes, ctx.stash = pack_b, None if bias is None else list(bias.shape), stash
         return y
@@ -366,7 +366,7 @@ class Conv2dSame(torch.autograd.Function):
         d_x = d_w = d_b = None
         if ctx.needs_input_grad[0]:
             pk = ctx.pack_b.get([weight], [None], transform=lambda w: w.transpose(0, 1).flip(2, 3).contiguous())
-            d_x = ops.conv2d([d], pk)
+            d_x = ops.conv2d_plain(d, pk)
         want_w, want_b = ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]
         if want_w or want_b:
             if ctx.stash is not None:

@@ -621,6 +621,34 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     return (out, out2) if epilogue == L.EPI_GRU_ZR else out
 
 
+def conv2d_plain(x: torch.Tensor, pack: "PackedConv", act: int = L.ACT_NONE) -> torch.Tensor:
+    """conv2d([x], pack, act) for the plain case — one fp32 source, LINEAR epilogue, stride 1, fresh output — with the host
+    work cut to the descriptor fields that case needs (the training step issues ~450 of these per step and is host-bound)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()) or x.shape[1] != pack.cin:
+        return conv2d([x], pack, act=act)  # full checks and error messages
+    b, cin, hh, ww = x.shape
+    cout = pack.cout
+    lib = L.load()
+    out = torch.empty((b, cout, hh, ww), device=x.device, dtype=torch.float32)
+    d = L.ConvDesc()
+    d.src[0], d.src_c[0], d.n_src = x.data_ptr(), cin, 1
+    d.wpack = pack.wpack.data_ptr()
+    if pack.bias is not None:
+        d.bias = pack.bias.data_ptr()
+    d.out, d.out_ctot = out.data_ptr(), cout
+    d.B, d.H, d.W, d.Cin, d.Cout, d.KS = b, hh, ww, cin, cout, pack.ks
+    d.stride, d.act, d.epilogue, d.precision = 1, act, L.EPI_LINEAR, 1 if pack.split else 0
+    ws = None
+    if pack.split:
+        n_ws = lib.as_conv_ws_elems(b, cout, hh, ww)
+        if n_ws > 0:
+            ws = torch.empty(n_ws, device=x.device, dtype=torch.float32)
+            d.ws, d.ws_elems = ws.data_ptr(), n_ws
+    with _guard(x.device):
+        L.check(lib.as_conv2d(C.byref(d), _stream()), "conv2d")
+    return out
+
+
 _TAPMAJOR = {}  # (data_ptr, version, device) of a [Cout,1,7,7] weight -> its [49,Cout] transpose
 
 

@@ -1,0 +1,49 @@
+"""One hipGraph replay of the forward as a timeline: rocprofv3 --kernel-trace CSV -> the kernels of the LAST complete pass
+(the FASTEST window between two liif_tail_kernel ends = a graph replay) with start / end relative to the pass start, duration and queue; phase totals.
+    python tools/pass_timeline.py <dir with *kernel_trace.csv> <out.json>"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    f = glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = []
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
+    rows.sort()
+    ends = [i for i, r in enumerate(rows) if "liif_tail_kernel" in r[2]]
+    # the fastest complete pass = a hipGraph replay (bench.py also runs eager passes for its per-kernel event timing)
+    j = min(range(1, len(ends)), key=lambda i: rows[ends[i]][1] - rows[ends[i - 1]][1])
+    win = rows[ends[j - 1] + 1: ends[j] + 1]
+    t0 = win[0][0]
+    first_lookup = next(i for i, r in enumerate(win) if "lookup_convc1_kernel" in r[2] or "lookup_fwd" in r[2])
+    pre = win[:first_lookup]
+    res = {"pass_ms": (win[-1][1] - t0) / 1e6, "pre_loop_wall_ms": (win[first_lookup][0] - t0) / 1e6,
+           "pre_loop_kernel_ms": sum(e - s for s, e, _, _ in pre) / 1e6, "pre_loop_launches": len(pre),
+           "pre_loop": [{"kernel": k[:70], "start_us": round((s - t0) / 1e3, 1), "dur_us": round((e - s) / 1e3, 1), "queue": q} for s, e, k, q in pre]}
+    json.dump(res, open(out, "w"), indent=0)
+    print({k: v for k, v in res.items() if k != "pre_loop"})
+    # busy time per queue and the gaps on the timeline
+    last = t0
+    idle = 0
+    for s, e, k, q in pre:
+        if s > last:
+            idle += s - last
+        last = max(last, e)
+    print("pre-loop: no kernel running for %.1f us" % (idle / 1e3))
+    agg = {}
+    for s, e, k, q in pre:
+        a = agg.setdefault(k[:60], [0, 0])
+        a[0] += e - s
+        a[1] += 1
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
+        print("%8.1f us n=%3d %s" % (v[0] / 1e3, v[1], k))
+
+
+if __name__ == "__main__":
+    main()
