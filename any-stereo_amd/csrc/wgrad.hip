@@ -9,15 +9,19 @@
 // per product, fp32 range — gradients of 1e-9 need no scaling, unlike the fp16 split of the forward kernels).
 //
 // Block = 512 threads: waves 0-3 CONSUMERS (wave w owns output-gradient rows co0+32w.. and all TAPS*NT column tiles: 144 fp32
-// accumulators for 3x3), waves 4-7 LOADERS.  K-chunk = one image row segment of XS = 16*KST pixels:
-//   * the dy operand of a wave is private to it (no reuse across waves), so it never touches LDS: each lane fetches its 8
-//     consecutive pixels straight from global memory two k-steps ahead (three rotating register sets) and splits them in
-//     registers;
-//   * the x operand (32*NT channels x KS rows x XS+2 pixels) is shared by all four consumers: the loaders fetch it, split it
-//     and park hi / lo in a double-buffered LDS image, one barrier per chunk.  The three kx taps of a row are the same eight
-//     pixels shifted by one element: one aligned 16-byte read + the two neighbouring dwords, and five v_alignbit build the
-//     kx = 0 and kx = 2 fragments (16-byte reads at 2-byte-aligned addresses ran the loop 6x below the matrix-core rate).
-//     Row pitch = 8 * odd elements: the 16 lanes of a read phase hit 16 distinct 16-byte bank groups.
+// accumulators for 3x3; nothing but ds_read + MFMA in their loop), waves 4-7 LOADERS.  K-chunk = one image row segment of
+// XS = 16*KST <= 80 pixels, chunks ordered (image, segment, row) so that consecutive chunks of a block share two x rows:
+//   * dy (128 rows x XS): fetched by the loaders as coalesced 16-B groups (every load of a chunk in flight before the first
+//     conversion), split, parked hi / lo in a double-buffered LDS image [co][pitch];
+//   * x (32*NT channels x KS rows x XS+halo): a ring of KS+1 row slots in LDS — a chunk stages only its ONE new row
+//     (y+1) while the consumers read rows y-2 .. y of the previous chunk; a new (image, segment) column restages all KS rows
+//     behind one extra barrier.  Rows outside the image are staged as zeros, columns outside it too, so the flat k index needs
+//     no masks.  The three kx taps of a row are the same eight pixels shifted by one element: one aligned 16-byte read + the two
+//     neighbouring dwords, and five v_alignbit build the kx = 0 and kx = 2 fragments.  Row pitches = 8 * odd elements: the 16
+//     lanes of a read phase hit 16 distinct 16-byte bank groups.
+//   First version (dy fragments fetched per lane straight from global memory, all KS x rows restaged per chunk): 1.76 ms for
+//   the gru04 z|r layer — the per-lane 32-B fetches touch 64 cache lines per wave-load and ~150 KB per chunk went through the
+//   CU's L1 fill path (~21 B/clk) against 4640 clk of MFMA work; this form moves 51 KB per chunk.
 // Split-K: the grid is (K ranges) x (output tiles); each block writes its partial tile to a workspace and
 // wgrad_finish_kernel sums the ranges in a fixed order (deterministic, no atomics).  The bias gradient rides along as one
 // extra column tile of ones in the blocks of the first channel tile.
@@ -35,15 +39,16 @@ struct WgradParams {
   float* ws;        // [nsplit][T][Cout][Cin] partial weight gradients, T = KS*KS
   float* wsb;       // [nsplit][Cout] partial bias gradients (null: none)
   int B, Cin, Cout, H, W;
-  int nseg, XS, KST;  // segments per image row, segment width = 16*KST
-  int pitch;          // LDS row pitch of the x image (bf16 elements)
-  int n_co, n_ci;     // output tiles: 128 rows x 32*NT channels
+  int nseg, XS, KST;   // segments per image row, segment width = 16*KST
+  int pitch_x, pitch_g;  // LDS row pitches (bf16 elements, 8 * odd)
+  int n_co, n_ci;      // output tiles: 128 rows x 32*NT channels
   int nsplit;
-  long long chunks;  // B*H*nseg
+  long long chunks;  // B*nseg*H, ordered (image, segment, row)
+  int dbg;           // timing ablations (AS_WGRAD_DBG): 1 = loaders only meet the barriers, 2 = consumers only meet the barriers
 };
 
-struct G8 { float v[8]; };
 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u2;
 struct B3 { bf8 k[3]; };  // the fragments of the taps kx = 0, 1, 2 of one row
 
 // D = elements e0..e7 (aligned), L = (e-2, e-1), R = (e8, e9): kx = 1 is D, kx = 0 / 2 are D shifted by one element
@@ -59,79 +64,75 @@ __device__ __forceinline__ B3 tap_shifts(u4 D, unsigned L, unsigned R) {
   return o;
 }
 
-// x = hi + lo, both bf16 (round to nearest even): pairs -> packed dwords
+// x = hi + lo, both bf16 (round to nearest even): pairs -> packed dwords.  One packed conversion per pair and part (written
+// element by element the compiler emits a v_cvt_pk_bf16_f32 per ELEMENT).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-  bf2 h;
-  h[0] = (__bf16)a;
-  h[1] = (__bf16)b;
-  __builtin_memcpy(&hi, &h, 4);
-  const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xFFFF0000u);
-  bf2 l;
-  l[0] = (__bf16)ra;
-  l[1] = (__bf16)rb;
-  __builtin_memcpy(&lo, &l, 4);
+  hi = cvt_pk_bf16(a, b);
+  lo = cvt_pk_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xFFFF0000u));
 }
 
-__device__ __forceinline__ void split8(const G8& g, bf8& hi, bf8& lo) {
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) split_pair(g.v[2 * j], g.v[2 * j + 1], h[j], l[j]);
-  __builtin_memcpy(&hi, h, 16);
-  __builtin_memcpy(&lo, l, 16);
-}
-
-struct Pos { int b, y, seg; };  // a K-chunk: image b, row y, row segment seg
+struct Pos { int b, seg, y; };  // a K-chunk: image b, row segment seg, row y (y innermost: consecutive chunks share two x rows)
 __device__ __forceinline__ Pos pos_of(const WgradParams& p, long long c) {  // one division per block, then pos_next
   Pos q;
-  const long long ru = c / p.nseg;
-  q.seg = (int)(c - ru * p.nseg);
-  q.b = (int)(ru / p.H);
-  q.y = (int)(ru - (long long)q.b * p.H);
+  const long long bs = c / p.H;
+  q.y = (int)(c - bs * p.H);
+  q.b = (int)(bs / p.nseg);
+  q.seg = (int)(bs - (long long)q.b * p.nseg);
   return q;
 }
 __device__ __forceinline__ void pos_next(const WgradParams& p, Pos& q) {
-  if (++q.seg == p.nseg) {
-    q.seg = 0;
-    if (++q.y == p.H) { q.y = 0; ++q.b; }
+  if (++q.y == p.H) {
+    q.y = 0;
+    if (++q.seg == p.nseg) { q.seg = 0; ++q.b; }
   }
 }
 
-// the dy fragment of k-step ks of chunk q for this lane: 8 consecutive pixels of row `co` (zeros outside the row / tile / range)
+// Four consecutive pixels of one row: fetch (zeros outside [0, W) / for invalid rows) ...
 template <bool VEC>
-__device__ __forceinline__ G8 dy_load(const WgradParams& p, const float* __restrict__ dy, const Pos& q, int ks, bool live, int co, int h) {
-  G8 g;
-  const int col0 = q.seg * p.XS + ks * 16 + 8 * h;
-  const long long row = live ? (((long long)q.b * p.Cout + co) * p.H + q.y) * p.W : 0;
-  if (VEC) {
-    const bool ok = live && col0 < p.W;  // W % 8 == 0: the group is inside the row or outside it as a whole
-    const f4* src = reinterpret_cast<const f4*>(dy + (ok ? row + col0 : 0));
-    const f4 a = src[0], b = src[1];
+__device__ __forceinline__ f4 load4(const float* __restrict__ src, long long row, int col, int W, bool row_ok) {
+  f4 v;
+  if (VEC) {  // W % 4 == 0 and col % 4 == 0: the group lies inside the row or outside it as a whole
+    const bool ok = row_ok && col >= 0 && col < W;
+    const f4 t = *reinterpret_cast<const f4*>(src + (ok ? row + col : 0));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      g.v[j] = ok ? a[j] : 0.f;
-      g.v[4 + j] = ok ? b[j] : 0.f;
-    }
+    for (int j = 0; j < 4; ++j) v[j] = ok ? t[j] : 0.f;
   } else {
-    float t[8];
+    float t[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = dy[(live && col0 + j < p.W) ? row + col0 + j : 0];
+    for (int j = 0; j < 4; ++j) t[j] = src[(row_ok && col + j >= 0 && col + j < W) ? row + col + j : 0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) g.v[j] = (live && col0 + j < p.W) ? t[j] : 0.f;
+    for (int j = 0; j < 4; ++j) v[j] = (row_ok && col + j >= 0 && col + j < W) ? t[j] : 0.f;
   }
-  return g;
+  return v;
+}
+// ... and park as bf16 hi / lo pairs (8-byte aligned destinations)
+__device__ __forceinline__ void store4(f4 v, unsigned short* dst_hi, unsigned short* dst_lo) {
+  unsigned h0, l0, h1, l1;
+  split_pair(v[0], v[1], h0, l0);
+  split_pair(v[2], v[3], h1, l1);
+  const u2 hi = {h0, h1}, lo = {l0, l1};
+  *reinterpret_cast<u2*>(dst_hi) = hi;
+  *reinterpret_cast<u2*>(dst_lo) = lo;
 }
 
 template <int KS, int NT, bool VEC>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
   constexpr int TAPS = KS * KS, PAD = KS / 2, NB = TAPS * NT, CIB = 32 * NT;
+  constexpr int NS = KS + 1;                     // ring slots of the x image: rows y-PAD .. y+PAD in use, row y+PAD+1 being staged
+  constexpr int PADL = KS == 3 ? 8 : 0;          // stored element s = col - x0 + PADL: the centre tap's 8-pixel groups are 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const float* __restrict__ xg = p.x;
   const float* __restrict__ dyg = p.dy;
-  constexpr int PADL = KS == 3 ? 8 : 0;          // stored element s = col - x0 + PADL: the centre tap's 8-pixel groups are 16-byte aligned
-  const int pitch = p.pitch;                     // 8 * odd >= XS + PADL + 2
-  const int img = CIB * KS * pitch;              // bf16 elements of one (hi or lo) image
-  unsigned short* const lds = reinterpret_cast<unsigned short*>(smem);  // [buf 2][hi, lo][CIB][KS][pitch]
+  const int px = p.pitch_x, pg = p.pitch_g;
+  const int ximg = CIB * NS * px;                // bf16 elements of the hi (or lo) x ring   [slot][ci][px]: consecutive channels one (odd) pitch apart
+  const int gimg = 128 * pg;                     // bf16 elements of one hi (or lo) dy image [co][pg]
+  unsigned short* const ldx = reinterpret_cast<unsigned short*>(smem);  // [hi, lo][NS][CIB][px]
+  unsigned short* const ldg = ldx + 2 * ximg;                           // [buf 2][hi, lo][128][pg]
   const int tid = threadIdx.x;
   const int tiles = p.n_co * p.n_ci;
   const int split = blockIdx.x / tiles, tile = blockIdx.x - split * tiles;
@@ -140,58 +141,150 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
   const long long c_lo = p.chunks * split / p.nsplit, c_hi = p.chunks * (split + 1) / p.nsplit;
 
   if (tid >= 256) {
-    // ---------------- loaders: the x image of chunk c -> LDS buffer ----------------
-    const int lt = tid - 256, cl = lt >> 3, qd = lt & 7;
-    const int npair = KS == 3 ? p.XS / 2 + 2 : p.XS / 2;  // element pairs s = PADL - 2 + 2m + {0,1} (KS = 3), 2m + {0,1} (KS = 1)
-    constexpr int C0 = KS == 3 ? -2 : 0, S0 = KS == 3 ? PADL - 2 : 0;
-    constexpr int NIT = 7;  // pair columns per thread: npair <= 8 * NIT (XS <= 96)
-    Pos q = pos_of(p, c_lo);
-    for (long long cn = c_lo; cn <= c_hi; ++cn) {  // stage chunk cn (the prologue stages c_lo), then meet the consumers
-      if (cn < c_hi) {
-        const int x0 = q.seg * p.XS;
-        unsigned short* const dst = lds + (int)((cn - c_lo) & 1) * 2 * img;
+    // ---------------- loaders ----------------
+    // Global loads run TWO chunks ahead of the LDS images in two register sets (A, B): the fetches of chunk c+2 are issued
+    // when chunk c is parked, so a load has a whole chunk period to land (one chunk ahead left one exposed round trip per chunk:
+    // 6.3 us per chunk against 2.2 us of MFMA work).
+    const int lt = tid - 256;
+    const int g4 = p.XS >> 2;                                  // 4-pixel groups of a dy row segment
+    const int xg4 = KS == 3 ? g4 + 2 : g4;                     // ... of an x row: cols x0-4 .. x0+XS+3 (KS = 3), s = 4g' + (KS == 3 ? 4 : 0)
+    constexpr int NG = 10;                                     // dy groups per loader thread: 128 rows x XS/4 <= 256 * NG (XS <= 80)
+    constexpr int NX = (CIB * 22 + 255) / 256;                 // x groups per loader thread and row: CIB x (XS/4 + 2) <= 256 * NX
+    const int n_g = 128 * g4, n_x = CIB * xg4;
+    struct Regs { f4 g[NG]; f4 x[NX]; };
+    // Everything about a thread's work items that does not change from chunk to chunk is computed ONCE: the loaders share
+    // their SIMDs' vector issue with the consumers' MFMAs (6 slots per MFMA), and a division + 64-bit row arithmetic per item
+    // and chunk (~100 VALU instructions) made the LOADERS' instruction stream the bound of the kernel (1.5 ms for gru04 z|r).
+    const int plane_hw = p.H * p.W;
+    constexpr unsigned OOB = 0x80000000u;  // a byte offset no image reaches (images < 2 GiB): the range check returns zeros
+    // VEC: byte offsets from the image's first element, OOB for items that do not exist; !VEC: element offsets + flags
+    unsigned g_off[NG], x_off[NX];
+    int g_col[NG], g_lds[NG], x_col[NX], x_lds[NX];
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-          const int cil = ct * 32 + cl, ci = ci0 + cil;
-          const bool ci_ok = ci < p.Cin;
-#pragma unroll
-          for (int ky = 0; ky < KS; ++ky) {
-            const int yy = q.y + ky - PAD;
-            const bool row_ok = ci_ok && yy >= 0 && yy < p.H;
-            const long long row = row_ok ? (((long long)q.b * p.Cin + ci) * p.H + yy) * p.W : 0;
-            float va[NIT], vb[NIT];
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {  // every load in flight before the first conversion
-              const int ca = x0 + 2 * (qd + 8 * i) + C0, cb = ca + 1;
-              va[i] = xg[(row_ok && ca >= 0 && ca < p.W) ? row + ca : 0];
-              vb[i] = xg[(row_ok && cb >= 0 && cb < p.W) ? row + cb : 0];
-            }
-#pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-              const int m = qd + 8 * i;
-              const int ca = x0 + 2 * m + C0, cb = ca + 1;
-              const bool oa = row_ok && ca >= 0 && ca < p.W, ob = row_ok && cb >= 0 && cb < p.W;
-              if (m < npair) {
-                unsigned hi, lo;
-                split_pair(oa ? va[i] : 0.f, ob ? vb[i] : 0.f, hi, lo);
-                const int e = (cil * KS + ky) * pitch + S0 + 2 * m;
-                *reinterpret_cast<unsigned*>(dst + e) = hi;
-                *reinterpret_cast<unsigned*>(dst + img + e) = lo;
-              }
-            }
-          }
-        }
-        pos_next(p, q);
-      }
-      __syncthreads();
+    for (int j = 0; j < NG; ++j) {
+      const int it = lt + 256 * j, rr = it / g4, g = it - rr * g4;
+      const bool ok = it < n_g && co0 + rr < p.Cout;
+      g_off[j] = ok ? (unsigned)((co0 + rr) * plane_hw + 4 * g) * (VEC ? 4u : 1u) : OOB;
+      g_col[j] = 4 * g;
+      g_lds[j] = rr * pg + 4 * g;
     }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int it = lt + 256 * j, cl = it / xg4, g = it - cl * xg4;
+      const bool ok = it < n_x && ci0 + cl < p.Cin;
+      x_col[j] = 4 * g - (KS == 3 ? 4 : 0);
+      x_off[j] = ok ? (unsigned)((ci0 + cl) * plane_hw + 4 * g) * (VEC ? 4u : 1u) : OOB;  // + (row * W + x0 - 4) per chunk
+      x_lds[j] = cl * px + 4 * g + (KS == 3 ? PADL - 4 : 0);
+    }
+    const int img_g = (int)((long long)p.Cout * plane_hw * 4), img_x = (int)((long long)p.Cin * plane_hw * 4);  // bytes per image
+
+#define WG_LOAD_G(SET, Q)                                                                                   \
+  {                                                                                                         \
+    const int x0 = (Q).seg * p.XS;                                                                          \
+    if (VEC) { /* range-checked 16-B buffer loads: items outside the tensor / the row read zeros, no selects */ \
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dyg + (long long)(Q).b * p.Cout * plane_hw), 0, img_g, 0x00020000); \
+      const unsigned add = (unsigned)((Q).y * p.W + x0) * 4u;                                               \
+      _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                      \
+        const unsigned off = (x0 + g_col[j] < p.W) ? g_off[j] + add : OOB;                                  \
+        (SET).g[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));     \
+      }                                                                                                     \
+    } else {                                                                                                \
+      const float* gb = dyg + (long long)(Q).b * p.Cout * plane_hw;                                         \
+      _Pragma("unroll") for (int j = 0; j < NG; ++j)                                                        \
+        (SET).g[j] = load4<false>(gb, (long long)(g_off[j] & ~OOB) - g_col[j] + (Q).y * p.W, x0 + g_col[j], p.W, g_off[j] != OOB); \
+    }                                                                                                       \
+  }
+#define WG_STORE_G(SET, CN)                                                                                 \
+  {                                                                                                         \
+    unsigned short* const gdst = ldg + (int)(((CN) - c_lo) & 1) * 2 * gimg;                                 \
+    _Pragma("unroll") for (int j = 0; j < NG; ++j)                                                          \
+      if (lt + 256 * j < n_g) store4((SET).g[j], gdst + g_lds[j], gdst + gimg + g_lds[j]);                  \
+  }
+#define WG_LOAD_X(SET, Q, YY)                                                                               \
+  {                                                                                                         \
+    const int x0 = (Q).seg * p.XS;                                                                          \
+    const bool row_in = (YY) >= 0 && (YY) < p.H;                                                            \
+    if (VEC) {                                                                                              \
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (long long)(Q).b * p.Cin * plane_hw), 0, row_in ? img_x : 0, 0x00020000); \
+      const unsigned add = (unsigned)((YY) * p.W + x0 - (KS == 3 ? 4 : 0)) * 4u;                            \
+      _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                      \
+        const int col = x0 + x_col[j];                                                                      \
+        const unsigned off = (col >= 0 && col < p.W) ? x_off[j] + add : OOB;                                \
+        (SET).x[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));     \
+      }                                                                                                     \
+    } else {                                                                                                \
+      const float* xb = xg + (long long)(Q).b * p.Cin * plane_hw;                                           \
+      _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                        \
+        (SET).x[j] = load4<false>(xb, (long long)(x_off[j] & ~OOB) - (x_col[j] + (KS == 3 ? 4 : 0)) + (row_in ? (YY) : 0) * p.W, x0 + x_col[j], p.W, \
+                                  x_off[j] != OOB && row_in);                                               \
+    }                                                                                                       \
+  }
+#define WG_STORE_X(SET, YY)                                                                                 \
+  {                                                                                                         \
+    unsigned short* const xdst = ldx + (((YY) + NS) % NS) * (CIB * px);                                     \
+    _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                          \
+      if (lt + 256 * j < n_x) store4((SET).x[j], xdst + x_lds[j], xdst + ximg + x_lds[j]);                  \
+  }
+// all KS rows of chunk Q (a new column): fetched and parked row by row (once per image column, not worth registers)
+#define WG_STAGE_COLUMN(SET, Q)                                                                             \
+  for (int yy = (Q).y - PAD; yy <= (Q).y + PAD; ++yy) {                                                     \
+    WG_LOAD_X(SET, Q, yy)                                                                                   \
+    WG_STORE_X(SET, yy)                                                                                     \
+  }
+// park chunk CN (position Q, fetched into SET two iterations ago), then fetch chunk CN + 2 into SET, then meet the consumers
+#define WG_ITER(SET, CN, Q)                                                                                 \
+  {                                                                                                         \
+    const bool live = (CN) < c_hi, fresh = live && (Q).y == 0;                                              \
+    if (live && p.dbg != 1) WG_STORE_G(SET, CN)                                                             \
+    if (fresh) {                                                                                            \
+      __syncthreads(); /* the consumers are done with the previous column's rows: any slot may be rewritten */ \
+      WG_STAGE_COLUMN(SET, Q)                                                                               \
+    } else if (live && p.dbg != 1) {                                                                        \
+      WG_STORE_X(SET, (Q).y + PAD)                                                                          \
+    }                                                                                                       \
+    pos_next(p, Q);                                                                                         \
+    pos_next(p, Q);                                                                                         \
+    if ((CN) + 2 < c_hi && p.dbg != 1) {                                                                    \
+      WG_LOAD_G(SET, Q)                                                                                     \
+      if ((Q).y != 0) WG_LOAD_X(SET, Q, (Q).y + PAD)                                                        \
+    }                                                                                                       \
+    __syncthreads();                                                                                        \
+  }
+
+    Regs A, B;
+    Pos qa = pos_of(p, c_lo), qb;
+    if (c_lo < c_hi) {  // prologue: chunk c_lo in full
+      WG_LOAD_G(A, qa)
+      WG_STORE_G(A, c_lo)
+      WG_STAGE_COLUMN(A, qa)
+    }
+    pos_next(p, qa);  // qa = chunk c_lo + 1 (set A), qb = chunk c_lo + 2 (set B)
+    qb = qa;
+    pos_next(p, qb);
+    if (c_lo + 1 < c_hi) {
+      WG_LOAD_G(A, qa)
+      if (qa.y != 0) WG_LOAD_X(A, qa, qa.y + PAD)
+    }
+    if (c_lo + 2 < c_hi) {
+      WG_LOAD_G(B, qb)
+      if (qb.y != 0) WG_LOAD_X(B, qb, qb.y + PAD)
+    }
+    __syncthreads();  // chunk c_lo staged
+    for (long long cn = c_lo + 1; cn <= c_hi; cn += 2) {
+      WG_ITER(A, cn, qa)
+      if (cn + 1 <= c_hi) WG_ITER(B, cn + 1, qb)
+    }
+#undef WG_ITER
+#undef WG_STAGE_COLUMN
+#undef WG_STORE_X
+#undef WG_LOAD_X
+#undef WG_STORE_G
+#undef WG_LOAD_G
     return;
   }
 
   // ---------------- consumers ----------------
   const int lane = tid & 63, r = lane & 31, h = lane >> 5, w = tid >> 6;
-  const int co = co0 + 32 * w + r;
-  const bool co_ok = co < p.Cout;
   const bool do_bias = p.wsb != nullptr && tci == 0;
   acc16 acc[NB];
 #pragma unroll
@@ -201,69 +294,92 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
   acc16 accb;
 #pragma unroll
   for (int i = 0; i < 16; ++i) accb[i] = 0.f;
-  bf8 ones;
-  {
-    unsigned o[4] = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-    __builtin_memcpy(&ones, o, 16);
-  }
-  const long long steps = (c_hi - c_lo) * p.KST;
-  // (chunk, k-step) of the step being computed and of the step whose dy is fetched (two ahead)
-  long long cc = c_lo, cf = c_lo;
-  int ks = 0, kf = 0;
-  Pos qf = pos_of(p, c_lo);
-#define WG_FETCH(TGT)                                                  \
-  TGT = dy_load<VEC>(p, dyg, qf, kf, co_ok && cf < c_hi, co, h);       \
-  if (++kf == p.KST) { kf = 0; ++cf; pos_next(p, qf); }
-  G8 R0, R1, R2;
-  WG_FETCH(R0)
-  WG_FETCH(R1)
+  const u4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf8 ones = __builtin_bit_cast(bf8, ones_u);
+  const int a_e = (32 * w + r) * pg + 8 * h;       // this lane's dy element (k-step 0)
+  const int b_e = r * px + PADL + 8 * h;           // this lane's x element inside a column tile (slot 0, k-step 0, centre tap)
+  Pos q = pos_of(p, c_lo);
   __syncthreads();  // chunk c_lo staged
-  const int lane_e = (r * KS) * pitch + PADL + 8 * h;  // this lane's element inside a column tile's image (tap row 0, k-step 0, centre tap)
-
-#define WG_STEP(CUR, TGT)                                                                                              \
-  {                                                                                                                    \
-    WG_FETCH(TGT)                                                                                                      \
-    bf8 a_hi, a_lo;                                                                                                    \
-    split8(CUR, a_hi, a_lo);                                                                                           \
-    const unsigned short* xb = lds + (int)((cc - c_lo) & 1) * 2 * img + lane_e + ks * 16;                              \
-    _Pragma("unroll") for (int ct = 0; ct < NT; ++ct) {                                                                \
-      _Pragma("unroll") for (int ky = 0; ky < KS; ++ky) {                                                              \
-        const unsigned short* xe = xb + (ct * 32 * KS + ky) * pitch;                                                   \
-        const u4 dh = *reinterpret_cast<const u4*>(xe), dl = *reinterpret_cast<const u4*>(xe + img);                    \
-        if (KS == 3) {                                                                                                 \
-          const unsigned lh = *reinterpret_cast<const unsigned*>(xe - 2), rh = *reinterpret_cast<const unsigned*>(xe + 8);           \
-          const unsigned ll = *reinterpret_cast<const unsigned*>(xe + img - 2), rl = *reinterpret_cast<const unsigned*>(xe + img + 8); \
-          const B3 bh = tap_shifts(dh, lh, rh), bl = tap_shifts(dl, ll, rl);                                           \
-          const int t = ct * TAPS + ky * KS;                                                                           \
-          _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[t + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bh.k[kx], acc[t + kx], 0, 0, 0); \
-          _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[t + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bl.k[kx], acc[t + kx], 0, 0, 0); \
-          _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[t + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bh.k[kx], acc[t + kx], 0, 0, 0); \
-        } else {                                                                                                       \
-          const bf8 b_hi = __builtin_bit_cast(bf8, dh), b_lo = __builtin_bit_cast(bf8, dl);                            \
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[ct], 0, 0, 0);                             \
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[ct], 0, 0, 0);                             \
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[ct], 0, 0, 0);                             \
-        }                                                                                                              \
-      }                                                                                                                \
-    }                                                                                                                  \
-    if (do_bias) {                                                                                                     \
-      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, ones, accb, 0, 0, 0);                                       \
-      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, ones, accb, 0, 0, 0);                                       \
-    }                                                                                                                  \
-    if (++ks == p.KST) {                                                                                               \
-      ks = 0;                                                                                                          \
-      ++cc;                                                                                                            \
-      __syncthreads();                                                                                                 \
-    }                                                                                                                  \
+  struct Raw { u4 dh, dl; unsigned lh, rh, ll, rl; };  // one x row of a k-step as read from LDS: hi / lo groups + their neighbour dwords
+  for (long long cc = c_lo; cc < c_hi; ++cc) {
+    const unsigned short* ga = ldg + (int)((cc - c_lo) & 1) * 2 * gimg + a_e;
+    if (p.dbg == 2) {
+    } else if (KS == 3) {
+      // The LDS reads of row (k-step, ky) + 1 are issued BEFORE the nine MFMAs of row (k-step, ky): with one consumer wave per
+      // SIMD nothing else hides the ~150-cycle read latency (reads after the MFMAs: 1.54 ms for gru04 z|r, 35 % of the MFMA rate).
+      const unsigned short* xr[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) xr[ky] = ldx + b_e + ((q.y + ky - PAD + NS) % NS) * (CIB * px);
+#define WG_READ(R, KY, KS_)                                                                      \
+  {                                                                                              \
+    const unsigned short* xe = xr[KY] + (KS_) * 16;                                              \
+    (R).dh = *reinterpret_cast<const u4*>(xe);                                                   \
+    (R).dl = *reinterpret_cast<const u4*>(xe + ximg);                                            \
+    (R).lh = *reinterpret_cast<const unsigned*>(xe - 2);                                         \
+    (R).rh = *reinterpret_cast<const unsigned*>(xe + 8);                                         \
+    (R).ll = *reinterpret_cast<const unsigned*>(xe + ximg - 2);                                  \
+    (R).rl = *reinterpret_cast<const unsigned*>(xe + ximg + 8);                                  \
   }
-
-  for (long long n = 0; n < steps; n += 3) {
-    WG_STEP(R0, R2)
-    if (n + 1 < steps) WG_STEP(R1, R0)
-    if (n + 2 < steps) WG_STEP(R2, R1)
+#define WG_MMA(R, KY)                                                                            \
+  {                                                                                              \
+    const B3 bh = tap_shifts((R).dh, (R).lh, (R).rh), bl = tap_shifts((R).dl, (R).ll, (R).rl);   \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[(KY) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bh.k[kx], acc[(KY) * 3 + kx], 0, 0, 0); \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[(KY) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bl.k[kx], acc[(KY) * 3 + kx], 0, 0, 0); \
+    _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[(KY) * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bh.k[kx], acc[(KY) * 3 + kx], 0, 0, 0); \
   }
-#undef WG_STEP
-#undef WG_FETCH
+      Raw R0, R1, R2;
+      u4 ah_n = *reinterpret_cast<const u4*>(ga), al_n = *reinterpret_cast<const u4*>(ga + gimg);
+      WG_READ(R0, 0, 0)
+      for (int ks = 0; ks < p.KST; ++ks) {
+        const bf8 a_hi = __builtin_bit_cast(bf8, ah_n), a_lo = __builtin_bit_cast(bf8, al_n);
+        const bool more = ks + 1 < p.KST;
+        WG_READ(R1, 1, ks)
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads AHEAD of the MFMAs that do not need them (the scheduler sinks them
+        WG_MMA(R0, 0)                        // next to their first use and waits on them at once: 61 instead of 32 cycles per MFMA)
+        __builtin_amdgcn_sched_barrier(0);
+        WG_READ(R2, 2, ks)
+        __builtin_amdgcn_sched_barrier(0);
+        WG_MMA(R1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          WG_READ(R0, 0, ks + 1)
+          ah_n = *reinterpret_cast<const u4*>(ga + (ks + 1) * 16);
+          al_n = *reinterpret_cast<const u4*>(ga + gimg + (ks + 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        WG_MMA(R2, 2)
+        if (do_bias) {
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, ones, accb, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, ones, accb, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef WG_MMA
+#undef WG_READ
+    } else {
+      const unsigned short* xr0 = ldx + b_e + ((q.y + NS) % NS) * (CIB * px);
+      for (int ks = 0; ks < p.KST; ++ks) {
+        const bf8 a_hi = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(ga + ks * 16));
+        const bf8 a_lo = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(ga + gimg + ks * 16));
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+          const unsigned short* xe = xr0 + (ct * 32) * px + ks * 16;
+          const bf8 b_hi = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(xe));
+          const bf8 b_lo = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(xe + ximg));
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_lo, acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b_hi, acc[ct], 0, 0, 0);
+        }
+        if (do_bias) {
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, ones, accb, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, ones, accb, 0, 0, 0);
+        }
+      }
+    }
+    pos_next(p, q);
+    __syncthreads();  // this chunk's images are free; the next chunk's dy and its new x row are staged
+    if (cc + 1 < c_hi && q.y == 0) __syncthreads();  // new column: the loaders restage all KS rows after the barrier above
+  }
 
   // ---------------- partial tile -> workspace [split][tap][Cout][Cin] ----------------
   const long long plane = (long long)p.Cout * p.Cin;
@@ -309,7 +425,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 }
 
 struct WgradPlan {
-  int nseg, XS, KST, pitch, n_co, n_ci, nsplit, NT;
+  int nseg, XS, KST, pitch_x, pitch_g, n_co, n_ci, nsplit, NT;
   long long chunks;
   size_t lds;
   long long ws_floats;
@@ -317,10 +433,17 @@ struct WgradPlan {
 
 bool wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, WgradPlan& q) {
   if (!(KS == 1 || KS == 3) || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
-  q.NT = KS == 1 ? 4 : 1;
-  q.nseg = as::cdiv(W, 96);
+  q.NT = KS == 1 ? 2 : 1;
+  q.nseg = as::cdiv(W, 80);  // row segments of <= 80 pixels: both LDS images (x ring + double-buffered dy) fit 160 KB
   q.XS = as::cdiv(as::cdiv(W, q.nseg), 16) * 16;
   q.KST = q.XS / 16;
+  auto pitch = [](int need) {  // multiple of 8 elements (16-B rows) with an odd number of 16-B units: conflict-free b128 reads
+    int v = (need + 7) / 8 * 8;
+    if ((v / 8) % 2 == 0) v += 8;
+    return v;
+  };
+  q.pitch_x = pitch(q.XS + (KS == 3 ? 12 : 0));
+  q.pitch_g = pitch(q.XS);
   q.n_co = as::cdiv(Cout, 128);
   q.n_ci = as::cdiv(Cin, 32 * q.NT);
   q.chunks = (long long)B * H * q.nseg;
@@ -330,10 +453,7 @@ bool wgrad_plan(int B, int Cin, int Cout, int H, int W, int KS, WgradPlan& q) {
   if (ns < 1) ns = 1;
   if (ns > 256) ns = 256;
   q.nsplit = (int)ns;
-  q.pitch = q.XS + (KS == 3 ? 10 : 0);  // >= XS + PADL + 2, rounded up to 8 * odd
-  q.pitch = (q.pitch + 7) / 8 * 8;
-  if ((q.pitch / 8) % 2 == 0) q.pitch += 8;
-  q.lds = (size_t)2 * 2 * (32 * q.NT) * KS * q.pitch * sizeof(unsigned short);
+  q.lds = ((size_t)2 * (32 * q.NT) * (KS + 1) * q.pitch_x + (size_t)2 * 2 * 128 * q.pitch_g) * sizeof(unsigned short);
   q.ws_floats = (long long)q.nsplit * (KS * KS) * Cout * Cin + (long long)q.nsplit * Cout;
   return true;
 }
@@ -368,16 +488,18 @@ int as_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int B
   AS_REQUIRE(wgrad_plan(B, Cin, Cout, H, W, KS, q), AS_ERR_BAD_ARG, "conv2d_wgrad: KS=%d (1 or 3), B=%d Cin=%d Cout=%d H=%d W=%d", KS, B, Cin, Cout, H, W);
   AS_REQUIRE(ws_bytes >= q.ws_floats * 4, AS_ERR_BAD_ARG, "conv2d_wgrad: workspace of %lld bytes, need %lld", (long long)ws_bytes, (long long)q.ws_floats * 4);
   AS_REQUIRE((long long)B * Cin * H * W < (1ll << 40) && (long long)B * Cout * H * W < (1ll << 40), AS_ERR_BAD_SHAPE, "conv2d_wgrad: tensor too large");
-  AS_REQUIRE(q.XS <= 96 && q.lds <= 160 * 1024, AS_ERR_BAD_SHAPE, "conv2d_wgrad: row segment of %d pixels", q.XS);
+  AS_REQUIRE(q.XS <= 80 && q.lds <= 160 * 1024, AS_ERR_BAD_SHAPE, "conv2d_wgrad: row segment of %d pixels", q.XS);
   WgradParams p;
   p.x = x; p.dy = dy;
   p.ws = (float*)ws;
   p.wsb = db ? (float*)ws + (long long)q.nsplit * (KS * KS) * Cout * Cin : nullptr;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
-  p.nseg = q.nseg; p.XS = q.XS; p.KST = q.KST; p.pitch = q.pitch; p.n_co = q.n_co; p.n_ci = q.n_ci; p.nsplit = q.nsplit; p.chunks = q.chunks;
+  static const int dbg = getenv("AS_WGRAD_DBG") ? atoi(getenv("AS_WGRAD_DBG")) : 0;
+  p.dbg = dbg;
+  p.nseg = q.nseg; p.XS = q.XS; p.KST = q.KST; p.pitch_x = q.pitch_x; p.pitch_g = q.pitch_g; p.n_co = q.n_co; p.n_ci = q.n_ci; p.nsplit = q.nsplit; p.chunks = q.chunks;
   hipStream_t s = as::as_stream(stream);
-  const bool vec = (W % 8) == 0 && (reinterpret_cast<uintptr_t>(dy) % 16) == 0;
-  const int rc = KS == 3 ? wgrad_launch<3, 1>(p, q, vec, s) : wgrad_launch<1, 4>(p, q, vec, s);
+  const bool vec = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) % 16) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0;
+  const int rc = KS == 3 ? wgrad_launch<3, 1>(p, q, vec, s) : wgrad_launch<1, 2>(p, q, vec, s);
   if (rc != AS_OK) return rc;
   const long long plane = (long long)Cout * Cin;
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)as::cdiv64(plane > Cout ? plane : Cout, 256)), dim3(256), 0, s, p.ws, p.wsb, dw, db, Cout,

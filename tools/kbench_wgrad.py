@@ -36,5 +36,5 @@ for name, b, cin, cout, h, w, k in SHAPES:
     dw, db = ops.conv2d_wgrad(x, dy, k)
     _, rw, rb = torch.ops.aten.convolution_backward(dy, x, wt, [cout], [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, True, True])
     gf = 2.0 * b * h * w * cin * k * k * cout / 1e9
-    print(f"{name:11s} hip {t_hip:8.1f} us ({gf / t_hip * 1e-3:6.1f} TFLOP/s algorithmic)  library {t_lib:8.1f} us   rel diff {float((dw - rw).norm() / rw.norm()):.2e}  "
+    print(f"{name:11s} hip {t_hip:8.1f} us ({gf / t_hip * 1e3:6.1f} TFLOP/s algorithmic)  library {t_lib:8.1f} us   rel diff {float((dw - rw).norm() / rw.norm()):.2e}  "
           f"bias {float((db - rb).norm() / rb.norm()):.2e}", flush=True)
