@@ -243,17 +243,14 @@ def _stack(ts):
     return ts[0] if len(ts) == 1 else torch.cat(ts, 0)
 
 
-# "hip": as_conv2d_wgrad (bf16 hi/lo split MFMA, ~2^-16 relative per product) for the layers it wins on — Cin * Cout >= 96 * 96
-# (tools/kbench_wgrad.py at the cfg-4 shapes: 1.1-2.7x the library's fp32 wgrad there; the 64 -> 64 layers, whose 128 x 32 tiles
-# are half padding and whose split-K workspace outweighs the tile, take 2.7x longer); "all": every 1x1 / 3x3 layer;
-# "library": MIOpen only
+# "hip": as_conv2d_wgrad (bf16 hi/lo split MFMA, ~2^-16 relative per product) for every 1x1 / 3x3 layer (tools/kbench_wgrad.py at
+# the cfg-4 shapes: 1.9-3.2x the library's fp32 wgrad, 64 -> 64 and 1/16-resolution layers included); "library": MIOpen only
 _WGRAD = os.environ.get("ANYSTEREO_WGRAD", "hip")
 
 
 def _wgrad_conv(d, x, weight, bias_sizes, want_w, want_b):
     k = weight.shape[2]
-    big = k in (1, 3) and weight.shape[0] * weight.shape[1] >= 96 * 96
-    if want_w and x.is_cuda and ((_WGRAD == "hip" and big) or (_WGRAD == "all" and k in (1, 3))):
+    if want_w and x.is_cuda and _WGRAD != "library" and k in (1, 3):
         d_w, d_b = ops.conv2d_wgrad(_c(x), _c(d), k, want_bias=want_b)
         return d_w, d_b
     _, d_w, d_b = torch.ops.aten.convolution_backward(d, x, weight, bias_sizes, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
