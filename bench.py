@@ -289,8 +289,8 @@ def train_main(a, rank, world, local):
             "allreduce_overlap": overlap,
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
             "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample/pool/interp transposes, the update-block/MLP dgrad and "
-                        "the weight gradients of the >= 96-channel 3x3 layers (one batched launch per layer and step); small layers' "
-                        "wgrad and the backbone convs on MIOpen/rocBLAS",
+                        "the weight gradients of every 1x1 / 3x3 update-block layer (one batched launch per layer and step); the backbone "
+                        "convs and the MLP's linear-layer wgrad on MIOpen/rocBLAS",
             "loss_scale": tr.loss_scale, "roofline": roof, "cpu_baseline": cpu}))
     if dist:
         td.barrier()
