@@ -315,6 +315,10 @@ class ContinuousStereoBase(nn.Module):
         disp_up = None
         ub = self.update_block
         self.__dict__.pop("_qorder", None)
+        if getattr(self, "liif_up", None) is not None:
+            # reuse of the iteration-invariant upsampler branch (stem_2x) across this forward's iterations; a fresh cache per
+            # forward, so no entry outlives the autograd graph it belongs to
+            self.liif_up.__dict__["_train_static"] = {}
         if (test_mode and iters > 0 and a.n_gru_layers == 3 and not a.slow_fast_gru and disp.is_cuda
                 and not torch.is_grad_enabled() and getattr(ub, "parallel_encoder", False)
                 and type(self)._hot_update is ContinuousStereoBase._hot_update and self.pipelined_loop):
@@ -336,4 +340,6 @@ class ContinuousStereoBase(nn.Module):
                 continue
             disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, None, hr_coord=hr_coord, scale=scale)
             disp_preds.append(disp_up)
+        if getattr(self, "liif_up", None) is not None:
+            self.liif_up.__dict__.pop("_train_static", None)
         return disp, disp_up, disp_preds

@@ -140,10 +140,10 @@ class liif_out_multi_scale_Training(nn.Module):
         """feats: list of [B,C_i,H_i,W_i]; coord [B,Q,2] (row, col) -> mask logits [B,9,Q] (liif.py:644-678)."""
         coord = coord.float().contiguous()
         b, q = coord.shape[:2]
+        if G.needs_grad(*feats, *self.imnet.parameters()):
+            return self._mask_logits_train(feats, coord)
         with scope("structure_feature"):
             sfs = [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
-        if G.needs_grad(*sfs, *self.imnet.parameters()):
-            return self._mask_logits_train(sfs, coord)
         ctot = sum(s.shape[1] + 2 for s in sfs)
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
         pre = self._first_layer_lowres(sfs, lin[0]) if (self.fused_first_layer and len(sfs) <= 2 and len(lin) > 1) else None
@@ -240,19 +240,33 @@ class liif_out_multi_scale_Training(nn.Module):
             return ops.liif_tail(us[0], us[1] if len(us) > 1 else None, sizes, coord, pack, disp, scale_vec,
                                  clamp_inplace=True, want_logits=want_logits)
 
-    def _mask_logits_train(self, sfs, coord):
+    def _mask_logits_train(self, feats, coord):
         """Differentiable form (liif.py:652-678).  With <= 2 sources the first Linear layer is applied at LOW resolution
         (two library 1x1 convs under autograd) and the per-query stage is the fused HIP gather + add + ReLU with its HIP
         scatter-add backward (grad.LiifGatherMlp1); otherwise the latent [B,228,Q] is gathered per source.  The remaining
-        layers run forward and dgrad as 1x1 convs on the implicit-GEMM kernel (grad.PointwiseLinear)."""
+        layers run forward and dgrad as 1x1 convs on the implicit-GEMM kernel (grad.PointwiseLinear).
+        The training loop upsamples EVERY iteration's disparity (train_continuous_IGEV.py:219 needs all predictions); of the
+        feature maps only the first (stem_4x | hidden state) changes between iterations, so the structure feature and the
+        low-resolution first layer of the others (stem_2x) are computed once per forward and reused — same values, the
+        gradients of the reuses are summed by autograd."""
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
-        if self.fused_first_layer and len(sfs) <= 2 and len(lin) > 1:
-            w1, off, us, rel_cols = lin[0].weight, 0, [], []
-            for s in sfs:
-                c = s.shape[1]
-                us.append(F.conv2d(s, w1[:, off:off + c, None, None]))
-                rel_cols.append(w1[:, off + c:off + c + 2])
-                off += c + 2
+        lowres = self.fused_first_layer and len(feats) <= 2 and len(lin) > 1
+        cache = self.__dict__.get("_train_static")  # installed per forward by the model's GRU loop; None = no reuse
+        w1, off, sfs, us, rel_cols = lin[0].weight, 0, [], [], []
+        for i, (sf, f) in enumerate(zip(self.to_sf_l2, feats)):
+            ent = cache.get(i) if (cache is not None and i > 0) else None
+            if ent is not None and ent[0] is f and ent[1] == (f._version, w1._version, torch.is_grad_enabled()):
+                s, u = ent[2], ent[3]
+            else:
+                s = sf(f)
+                u = F.conv2d(s, w1[:, off:off + s.shape[1], None, None]) if lowres else None
+                if cache is not None and i > 0:
+                    cache[i] = (f, (f._version, w1._version, torch.is_grad_enabled()), s, u)
+            sfs.append(s)
+            us.append(u)
+            rel_cols.append(w1[:, off + s.shape[1]:off + s.shape[1] + 2])
+            off += s.shape[1] + 2
+        if lowres:
             x = G.LiifGatherMlp1.apply(us[0].contiguous(), us[1].contiguous() if len(us) > 1 else None, coord,
                                        torch.cat(rel_cols, dim=1).contiguous(), lin[0].bias)
             lin = lin[1:]
