@@ -114,6 +114,16 @@ def test_c_oracle_matches_python_oracle():
     assert np.abs(vg - O.corr_sampler_backward(vol, coords, gr, r).numpy()).max() < 1e-6
 
 
+def test_c_oracle_under_sanitizers():
+    """The plain-C oracle of sampler_kernel.cu under AddressSanitizer + UBSan on its edge cases (windows outside the row, W2 = 1,
+    radius > row, huge coordinates) — GPU sanitizers are unavailable on the pool, the CPU build is what can be checked."""
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_build", "corr_sampler_asan")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sanitizer run clean" in r.stdout
+
+
 def test_query_grid_harness(golden):
     """§8(f1): pad_for_multi_train semantics (evaluation.py:67-89) pinned by reference outputs."""
     import json
