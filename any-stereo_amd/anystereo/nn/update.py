@@ -276,9 +276,13 @@ class BasicMotionEncoder(nn.Module):
                 and getattr(lookup_fn, "fused_convc1_ok", None) is not None and lookup_fn.fused_convc1_ok()
                 and self.convc1.out_channels == 64 and self.convc1.kernel_size == (1, 1))
 
-    # opt-in: measured on cfg 2 the one launch takes 28.3 us against 27.9 us for the three staged launches it replaces (the lookup
-    # blocks alone fill the chip for 16 us, so the 7x7 blocks run as a second wave rather than beside them) -- no end-to-end gain
-    fused_front = __import__("os").environ.get("ANYSTEREO_FUSED_FRONT", "0") != "0"
+    # Opt-in fusions of the front of an iteration (ANYSTEREO_FUSED_FRONT), both bit-identical to the staged launches and both
+    # measured NOT faster on cfg 2, so the default stays staged ("0"):
+    #   "lite": the head's finish rides in the lookup + convc1 launch (the lookup blocks derive the new disparity from the 36
+    #           tap planes themselves), the 7x7 conv stays its own launch — 48.4-48.6 vs 49.4 pairs/s staged on the same box;
+    #   "full": the 7x7 conv's blocks in the same grid as well — 28.3 us against 27.9 us for the three staged launches (the
+    #           lookup blocks alone fill the chip for 16 us, so the 7x7 blocks run as a second wave rather than beside them).
+    fused_front = {"0": False, "1": "full", "lite": "lite", "full": "full"}[__import__("os").environ.get("ANYSTEREO_FUSED_FRONT", "0")]
 
     def forward_front(self, taps, head, disp_old, lookup_fn):
         """The head's finish (disp_old + delta), the fused lookup + convc1 and the 7x7 conv of the disparity branch as ONE launch,
@@ -288,8 +292,13 @@ class BasicMotionEncoder(nn.Module):
         cd, out = self.new_buffer(disp_old), self.new_output(disp_old)
         if not hasattr(self, "_plc1"):
             self._plc1 = ops.LookupConvPack()
+        full = self.fused_front == "full"
         disp, cor, d1 = lookup_fn.loop_front(taps, head.conv2.bias, disp_old, self._plc1.get(self.convc1.weight, self.convc1.bias),
-                                             self.convd1.weight, self.convd1.bias, out, 127)
+                                             self.convd1.weight if full else None, self.convd1.bias if full else None, out, 127)
+        if not full:
+            d1 = ops.BS8.empty(disp.shape[0], 64, disp.shape[2], disp.shape[3], disp.device)
+            with scope("enc_convd1"):
+                ops.conv7x7_c1_relu(disp, self.convd1.weight, self.convd1.bias, out=d1, copy_out=out, copy_coff=127)
         with scope("enc_convc2"):
             second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
             ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out_bs=cd, out_bs_coff=0,

@@ -254,13 +254,14 @@ def loop_front(geo, corr, taps: torch.Tensor, head_bias, disp_old: torch.Tensor,
             _req(t, f"geo[{i}]")
             if tuple(t.shape) != (b, h, w, d >> i, g):
                 raise RuntimeError(f"loop_front: geo[{i}] has shape {tuple(t.shape)}")
-    if nl * (2 * radius + 1) * (g + 1) != pack.cin or tuple(w7.shape) != (64, 1, 7, 7):
+    if nl * (2 * radius + 1) * (g + 1) != pack.cin or (w7 is not None and tuple(w7.shape) != (64, 1, 7, 7)):
         raise RuntimeError("loop_front: convc1 / convd1 shapes do not match the lookup")
-    wt = tapmajor_7x7(w7)
+    wt = tapmajor_7x7(w7) if w7 is not None else None  # None: finish + lookup + convc1 only (the caller runs the 7x7 conv)
     f = lambda t: None if t is None else (t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous())  # noqa: E731
     hb, bb7 = f(head_bias), f(b7)
     disp_new = torch.empty_like(disp_old)
-    cor, d1 = BS8.empty(b, 64, h, w, disp_old.device), BS8.empty(b, 64, h, w, disp_old.device)
+    cor = BS8.empty(b, 64, h, w, disp_old.device)
+    d1 = BS8.empty(b, 64, h, w, disp_old.device) if wt is not None else None
     if copy_out is not None:
         _req(copy_out.t, "copy_out", torch.float16)
         if copy_out.shape[0] != b or tuple(copy_out.shape[2:]) != (h, w):
@@ -269,7 +270,8 @@ def loop_front(geo, corr, taps: torch.Tensor, head_bias, disp_old: torch.Tensor,
     cp, k2 = L.ptr_array([t.data_ptr() for t in corr])
     with _guard(disp_old.device):
         L.check(L.load().as_loop_front_fwd(gp, cp, _p(taps), taps.shape[1] // 9, _p(hb), _p(disp_old), _p(disp_new), _p(pack.image),
-                                           _p(pack.bias), _p(cor.t), _p(wt), wt.shape[1], _p(bb7), _p(d1.t),
+                                           _p(pack.bias), _p(cor.t), _p(wt), 0 if wt is None else wt.shape[1], _p(bb7),
+                                           _p(None if d1 is None else d1.t),
                                            _p(None if copy_out is None else copy_out.t), 0 if copy_out is None else copy_out.c, copy_coff,
                                            b, h, w, w2, d, g, nl, radius, _stream()), "loop_front_fwd")
     return disp_new, cor, d1

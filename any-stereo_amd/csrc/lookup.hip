@@ -982,10 +982,10 @@ int as_loop_front_fwd(const float* const* geo, const float* const* corr, const f
   LookupParams p{};
   int rc = fill_common(p, B, H, W, W2, D, G, L, radius);
   if (rc != AS_OK) return rc;
-  AS_REQUIRE(corr && taps && disp_old && disp_new && wimage && cor_bs && w7 && d1_bs && (G == 0 || geo), AS_ERR_BAD_ARG, "loop_front: null pointer");
+  AS_REQUIRE(corr && taps && disp_old && disp_new && wimage && cor_bs && (!w7 || d1_bs) && (G == 0 || geo), AS_ERR_BAD_ARG, "loop_front: null pointer");
   AS_REQUIRE(radius == 4 && ((G == 8 && L == 2) || (G == 0 && L == 4)), AS_ERR_BAD_ARG,
              "loop_front: built for radius 4 with (G, L) = (8, 2) or (0, 4); got r=%d G=%d L=%d", radius, G, L);
-  AS_REQUIRE(groups >= 1 && groups <= 64 && cp7 >= 64 && (long long)B * groups * 9 * H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "loop_front: groups=%d cp7=%d", groups, cp7);
+  AS_REQUIRE(groups >= 1 && groups <= 64 && (!w7 || cp7 >= 64) && (long long)B * groups * 9 * H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "loop_front: groups=%d cp7=%d", groups, cp7);
   AS_REQUIRE(!copy_bs || (copy_coff >= 0 && copy_coff < (copy_ctot + 7) / 8 * 8), AS_ERR_BAD_SHAPE, "loop_front: copy channel %d outside %d", copy_coff, copy_ctot);
   for (int i = 0; i < L; ++i) {
     AS_REQUIRE(corr[i] && (G == 0 || geo[i]), AS_ERR_BAD_ARG, "loop_front: null level %d", i);
@@ -1004,7 +1004,8 @@ int as_loop_front_fwd(const float* const* geo, const float* const* corr, const f
   q.w7 = w7; q.b7 = b7; q.CP7 = cp7; q.d1_bs = (_Float16*)d1_bs; q.copy_bs = (_Float16*)copy_bs; q.copy_ctot = copy_ctot; q.copy_coff = copy_coff;
   q.n_lookup = (int)as::cdiv64(p.P, 64);
   q.tiles_x = as::cdiv(W, 16); q.tiles_y = as::cdiv(H, 16);
-  const long long n7 = (long long)B * q.tiles_x * q.tiles_y * 2;  // 32 of the 64 output channels per block
+  // w7 == NULL: the head's finish + lookup + convc1 only (the 7x7 conv is launched by the caller from disp_new)
+  const long long n7 = w7 ? (long long)B * q.tiles_x * q.tiles_y * 2 : 0;  // 32 of the 64 output channels per block
   q.n_conv7 = (int)n7;
   const size_t lds = (size_t)((p.CH + 15) / 16 * 16 * 65) * sizeof(float);
   const dim3 grid((unsigned)(q.n_lookup + n7));

@@ -138,7 +138,9 @@ int as_lookup_convc1_fwd(const float* const* geo, const float* const* corr, cons
  *   taps [B][groups*9][H][W] (as_conv2d AS_EPI_RELU_TAPS), head_bias [1]|NULL, disp_old -> disp_new [B,1,H,W];
  *   wimage / bias_c1: as_lookup_convc1_pack; cor_bs: blocked split-fp16 [B][2][8][H][W][8] = relu(convc1(lookup(disp_new)));
  *   w7: 7x7 weights tap-major [49][cp7 >= 64] (zero padded), b7 [64]|NULL; d1_bs: blocked relu(conv7x7(disp_new) + b7);
- *   copy_bs (optional): blocked tensor of copy_ctot channels that receives disp_new in channel copy_coff. */
+ *   copy_bs (optional): blocked tensor of copy_ctot channels that receives disp_new in channel copy_coff.
+ *   w7 == NULL: the head's finish + lookup + convc1 only (d1_bs / copy_bs untouched); the caller launches as_conv7x7_c1_relu on
+ *   disp_new itself — two launches instead of three on the loop's critical chain. */
 int as_loop_front_fwd(const float* const* geo, const float* const* corr, const float* taps, int groups, const float* head_bias,
                       const float* disp_old, float* disp_new, const void* wimage, const float* bias_c1, void* cor_bs,
                       const float* w7, int cp7, const float* b7, void* d1_bs, void* copy_bs, int copy_ctot, int copy_coff,

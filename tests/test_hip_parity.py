@@ -1476,10 +1476,12 @@ def test_loop_front_fused_equals_staged(golden, tag, h, w):
             taps = ub.disp_head.taps(net0)
             d_ref = ub.disp_head.finish(taps, addend=disp)
             mf_ref = ub.encoder.forward_fused_lookup(d_ref, fn)
-            mf, d_new = ub.encoder.forward_front(taps, ub.disp_head, disp, fn)
             d_full = ub.disp_head(net0, addend=disp)
-        assert torch.equal(d_new, d_ref) and torch.equal(d_full, d_ref), "new disparity"
-        assert torch.equal(mf.t, mf_ref.t), "motion features (blocked split-fp16)"
-        assert (mf.float()[:, 127:128] - d_ref).abs().max().item() <= 2e-6 * max(1.0, d_ref.abs().max().item()), "disparity pass-through"
+            for mode in ("lite", "full"):  # lite: finish + lookup + convc1 in one launch, 7x7 staged; full: all three in one grid
+                ub.encoder.fused_front = mode
+                mf, d_new = ub.encoder.forward_front(taps, ub.disp_head, disp, fn)
+                assert torch.equal(d_new, d_ref) and torch.equal(d_full, d_ref), f"new disparity ({mode})"
+                assert torch.equal(mf.t, mf_ref.t), f"motion features (blocked split-fp16, {mode})"
+                assert (mf.float()[:, 127:128] - d_ref).abs().max().item() <= 2e-6 * max(1.0, d_ref.abs().max().item()), "disparity pass-through"
     finally:
         ops.set_precision(prev)
