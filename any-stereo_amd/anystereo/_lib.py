@@ -52,6 +52,7 @@ SIGNATURES = {
     "as_get_fast16": (_i, []),
     "as_last_error_string": (C.c_char_p, []),
     "as_abi_version": (_i, []),
+    "as_source_hash": (C.c_char_p, []),
     "as_device_count": (_i, []),
     "as_corr_sampler_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_corr_sampler_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -136,8 +137,22 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    from ._srchash import source_hash
+    want, have = source_hash(), lib.as_source_hash().decode()
+    if want is not None and want != have and os.environ.get("ANYSTEREO_ALLOW_STALE_LIB", "0") != "1":
+        raise RuntimeError(f"{LIB_PATH} was built from other sources (library {have}, tree {want}): run `python any-stereo_amd/build.py` "
+                           "(ANYSTEREO_ALLOW_STALE_LIB=1 overrides)")
     _lib = lib
     return lib
+
+
+def library_info() -> dict:
+    """What is loaded: path, ABI version, the source hash compiled into it and whether it matches the tree."""
+    from ._srchash import source_hash
+    lib = load()
+    have, want = lib.as_source_hash().decode(), source_hash()
+    return {"path": os.path.relpath(LIB_PATH), "abi": int(lib.as_abi_version()), "src_hash": have,
+            "matches_sources": None if want is None else have == want}
 
 
 def check(rc: int, what: str) -> None:

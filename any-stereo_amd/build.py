@@ -36,10 +36,23 @@ def _newer(src_list, target) -> bool:
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
+def _source_hash() -> str:
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("anystereo_srchash", os.path.join(HERE, "anystereo", "_srchash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    # the hash of every native source, compiled into the library (as_source_hash): _lib.load() refuses a stale binary
+    stamp_src = os.path.join(OBJ, "stamp.cpp")
+    stamp = 'extern "C" const char* as_source_hash(void) { return "%s"; }\n' % _source_hash()
+    if not os.path.exists(stamp_src) or open(stamp_src).read() != stamp:
+        open(stamp_src, "w").write(stamp)
     deps = [os.path.join(CSRC, "common.h"), HEADER]
     hipcc = _hipcc()
     jobs = []
@@ -65,8 +78,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if verbose:
                     print(f"[build] compiled {os.path.basename(src)}")
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
-    if force or jobs or _newer(objs, LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or _newer(objs + [stamp_src], LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [stamp_src]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr)

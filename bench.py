@@ -291,7 +291,7 @@ def train_main(a, rank, world, local):
             "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample/pool/interp transposes, the update-block/MLP dgrad and "
                         "the weight gradients of every 1x1 / 3x3 update-block layer (one batched launch per layer and step); the backbone "
                         "convs and the MLP's linear-layer wgrad on MIOpen/rocBLAS",
-            "loss_scale": tr.loss_scale, "roofline": roof, "cpu_baseline": cpu}))
+            "loss_scale": tr.loss_scale, "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu}))
     if dist:
         td.barrier()
         td.destroy_process_group()
@@ -677,6 +677,7 @@ def infer_main(a, rank, world, local):
                                    f"{nb} pair(s) per GPU, random-init weights", "name": wl.name, "pairs_per_gpu": nb,
                        "parallelism": f"replicas x{world}", "gru_loop": "hipGraph" if run.graph else "eager"},
             "per_rank_pairs_per_s": [round(nb * a.steps / v, 4) for v in per_rank],
+            "library": _lib.library_info(),
             "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "roofline_source": ("HIP events on the launch stream around each hot-kernel launch, " +

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/anystereo_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     bound = _lib.load()
-    assert bound.as_abi_version() == 21
+    assert bound.as_abi_version() == 22
     assert bound.as_last_error_string() is not None
 
 
@@ -112,6 +112,20 @@ def test_c_oracle_matches_python_oracle():
     lib.ref_corr_sampler_backward_f32(coords.numpy().ctypes.data_as(fp), gr.numpy().ctypes.data_as(fp),
                                       vg.ctypes.data_as(fp), n, h1, w1, w2, r)
     assert np.abs(vg - O.corr_sampler_backward(vol, coords, gr, r).numpy()).max() < 1e-6
+
+
+def test_library_carries_its_source_hash(monkeypatch):
+    """build.py compiles the hash of the native sources into the library; the binding refuses a library built from other sources
+    (the .so is git-ignored but travels with the snapshot: a stale binary must not run silently on the GPU box)."""
+    from anystereo import _lib, _srchash
+    info = _lib.library_info()
+    assert info["matches_sources"] is True and len(info["src_hash"]) == 16 and info["abi"] == _lib.load().as_abi_version()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_srchash, "source_hash", lambda: "0" * 16)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.setenv("ANYSTEREO_ALLOW_STALE_LIB", "1")
+    _lib.load()
 
 
 def test_c_oracle_under_sanitizers():
