@@ -71,7 +71,7 @@ int as_get_precision(void);
 
 const char* as_last_error_string(void);
 int as_abi_version(void);        /* bumped on any signature change */
-/* 16 hex digits: sha256 over csrc/*.hip, csrc/*.h and this header at build time (any-stereo_amd/build.py); the Python binding
+/* 16 hex digits: sha256 over the .hip / .h files of csrc and this header at build time (any-stereo_amd/build.py); the Python binding
  * recomputes it from the tree and refuses a library built from other sources */
 const char* as_source_hash(void);
 int as_device_count(void);       /* hipGetDeviceCount; 0 on a CPU-only host */

@@ -13,6 +13,8 @@ for f in $tmp/any-stereo_amd/csrc/*.hip; do
   objs="$objs ${f%.hip}.o"
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o any-stereo_amd/anystereo/lib/$name.so
+# the loader checks as_source_hash() against the tree: a variant carries its revision instead (run with ANYSTEREO_ALLOW_STALE_LIB=1)
+echo "extern \"C\" const char* as_source_hash(void) { return \"variant:$rev\"; }" > $tmp/stamp.cpp
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs $tmp/stamp.cpp -o any-stereo_amd/anystereo/lib/$name.so
 rm -rf $tmp
 echo built any-stereo_amd/anystereo/lib/$name.so

@@ -82,6 +82,23 @@ def main():
             m = used[:, i].mean().item()
             print(f"  {names[i]:45s} {m / chunks:9.0f} ticks/chunk  {100 * m / tot:5.1f} %   (min {used[:, i].min().item() / chunks:.0f}, max {used[:, i].max().item() / chunks:.0f})")
         print(f"  {role} total {tot / chunks:.0f} ticks/chunk")
+    # block lifetime (thread 0 of each block): entry -> first unit staged -> chunk loop done -> tile parked -> end
+    life = getattr(lib, "as_debug_conv_life", None)
+    if life is not None:
+        life.restype, life.argtypes = C.c_int, [C.c_void_p, C.c_int]
+        lb = (C.c_ulonglong * (1024 * 8))()
+        assert life(lb, 1024 * 8) == 0
+        lt = torch.tensor(list(lb), dtype=torch.float64).view(1024, 8)
+        ok = lt[(lt[:, 4] > lt[:, 0]) & (lt[:, 0] > 0)]
+        if ok.shape[0]:
+            seg = [("prologue (entry -> first unit staged)", 0, 1), ("chunk loop", 1, 2), ("bias + park + barriers", 2, 3), ("finish (operands, math, stores)", 3, 4)]
+            tot = (ok[:, 4] - ok[:, 0]).mean().item()
+            print(f"  block lifetime over {ok.shape[0]} blocks: {tot:.0f} ticks")
+            for name, a, b in seg:
+                d = (ok[:, b] - ok[:, a])
+                print(f"    {name:42s} {d.mean().item():9.0f} ticks {100 * d.mean().item() / tot:5.1f} %  (min {d.min().item():.0f}, max {d.max().item():.0f})")
+            first = ok[:, 0].min().item()
+            print(f"    block starts span {ok[:, 0].max().item() - first:.0f} ticks, ends span {ok[:, 4].max().item() - first:.0f} ticks after the first start")
 
 
 if __name__ == "__main__":
