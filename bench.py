@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip fp32_mode / other_configs / cold-cache timing (profiling runs)")
     ap.add_argument("--no-graph", action="store_true", help="run the GRU loop eagerly instead of as a captured hipGraph")
+    ap.add_argument("--serial-loop", action="store_true",
+                    help="profiling runs: every kernel of the GRU loop on ONE stream (same kernels, same order), so that a rocprofv3 "
+                         "average is the kernel's own duration, as the HIP-event averages in kernel_times_us are; implies --no-graph")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = the headline benchmark (default); train = cfg 4: DDP training steps at 160x320, 16 GRU iterations")
     ap.add_argument("--batch-per-gpu", type=int, default=4, help="train mode: samples per rank (global batch 32 = 4 x 8)")
@@ -513,7 +516,9 @@ def infer_main(a, rank, world, local):
         wl = WL.Workload(wl.name, wl.model, wl.height, wl.width, a.scale or wl.scale, a.iters or wl.iters, wl.protocol,
                          wl.divis_by, wl.what)
     nb = max(1, a.pairs_per_gpu)
-    run = Runner(wl, dev, seed=1234 + rank, pairs=nb, graph=not a.no_graph)
+    run = Runner(wl, dev, seed=1234 + rank, pairs=nb, graph=not (a.no_graph or a.serial_loop))
+    if a.serial_loop:
+        run.model.serial_streams = True
     model = run.model
 
     for _ in range(a.warmup):
