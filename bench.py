@@ -13,7 +13,8 @@ on libanystereo_hip.so) with inputs resident in HBM.  Rank 0 prints ONE JSON lin
   parity          EPE of this run's output against the CPU oracle's output on the same input, split and fp32 mode
   fp32_mode       the same workload in exact-fp32 MFMA mode (the same-precision figure next to the split-precision headline)
   reduced_precision_mode  the same workload with fp16 operands / one MFMA per product (the reference's autocast path)
-  other_configs   cfg 3 (KITTI x2.0) and cfg 5 (Middlebury-F x1.5, 48 iterations) pairs/s, N = 1 only
+  other_configs   cfg 3 (KITTI x2.0), cfg 5 (Middlebury-F x1.5, 48 iterations) and cfg 1 (corePrune_RAFT, with its EPE vs the oracle)
+                  pairs/s, N = 1 only
   cpu_baseline    the CPU oracle (oracle/model.py) timed on this host's cores: cfg 2 (and cfg 1 under `also`)
 `--mode train` = cfg 4 (DDP training step).  Without a visible GPU the launcher protocol alone runs (gloo, "dry_run").
 """
@@ -673,6 +674,27 @@ def infer_main(a, rank, world, local):
                     model.enable_graph(run.graph)  # drop that shape's graph pool
                 except Exception as ex:
                     others[name] = {"error": repr(ex)}
+            # cfg 1: the other model family (corePrune_RAFT, 256x512, 8 iterations) — its own weights, checked against its oracle
+            try:
+                wl1 = WL.WORKLOADS["cfg1"]
+                m1, a1 = WL.build_model(wl1, device=dev)
+                m1.enable_graph(run.graph)
+                r1 = Runner(wl1, dev, seed=1234, graph=run.graph, model=m1, args=a1)
+                t_step, o1 = r1.time_steps(5)
+                rec = {"workload": f"{wl1.what}, {wl1.iters} GRU iters, padded {r1.wp}x{r1.hp}, Q={r1.Q}", "value": round(1.0 / t_step, 3),
+                       "unit": "pairs/s", "ms_per_step": round(t_step * 1e3, 2), "steps": 5, "finite": bool(torch.isfinite(o1).all())}
+                if not a.no_cpu_baseline:
+                    from oracle.model import OracleRAFT
+                    ref = OracleRAFT(a1).eval()
+                    ref.load_state_dict({k: v.cpu() for k, v in m1.state_dict().items()})
+                    i1, i2, coord, sc = r1.cpu_inputs
+                    with torch.no_grad():
+                        oo = ref(i1, i2, iters=wl1.iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
+                    rec["epe_vs_oracle"] = float((o1.float().cpu() - oo.float()).abs().mean())
+                others["cfg1"] = rec
+                del r1, m1, o1
+            except Exception as ex:
+                others["cfg1"] = {"error": repr(ex)}
         line = {
             "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",
             "value": round(world * nb * a.steps / dt, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
