@@ -26,8 +26,16 @@ def main():
     res = {"pass_ms": (win[-1][1] - t0) / 1e6, "pre_loop_wall_ms": (win[first_lookup][0] - t0) / 1e6,
            "pre_loop_kernel_ms": sum(e - s for s, e, _, _ in pre) / 1e6, "pre_loop_launches": len(pre),
            "pre_loop": [{"kernel": k[:70], "start_us": round((s - t0) / 1e3, 1), "dur_us": round((e - s) / 1e3, 1), "queue": q} for s, e, k, q in pre]}
+    # post-loop = the upsampler: from the end of the last GRU-iteration kernel (tap_shift_sum) to the end of the pass
+    last_loop = max(i for i, r in enumerate(win) if "tap_shift_sum" in r[2])
+    post = win[last_loop + 1:]
+    res["post_loop_wall_us"] = (win[-1][1] - win[last_loop][1]) / 1e3
+    res["post_loop_kernel_us"] = sum(e - s for s, e, _, _ in post) / 1e3
+    res["post_loop"] = [{"kernel": k[:70], "start_us": round((s - win[last_loop][1]) / 1e3, 1), "dur_us": round((e - s) / 1e3, 1), "queue": q} for s, e, k, q in post]
     json.dump(res, open(out, "w"), indent=0)
-    print({k: v for k, v in res.items() if k != "pre_loop"})
+    print({k: v for k, v in res.items() if k not in ("pre_loop", "post_loop")})
+    for r in res["post_loop"]:
+        print("  post", r)
     # busy time per queue and the gaps on the timeline
     last = t0
     idle = 0
