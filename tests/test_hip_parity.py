@@ -192,7 +192,9 @@ def test_lookup_backward_accumulates_over_iterations(tag):
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12), (torch.float16, 8e-3)])
 def test_corr_sampler_module(dtype, tol):
     """`corr_sampler.forward/backward` (sampler/sampler.cpp:48-51) incl. zero-pad edges, ragged W2, r != 4."""
+    import corr_sampler as top_level  # the reference's extension module name (sampler/sampler.cpp:48-51), any-stereo_amd on sys.path
     from anystereo import corr_sampler
+    assert top_level.forward is corr_sampler.forward and top_level.backward is corr_sampler.backward
     for (n, h1, w1, w2, r) in [(2, 3, 20, 20, 4), (1, 2, 33, 17, 3), (1, 1, 5, 1, 4)]:
         vol = U((n, h1, w1, w2), 70, -2, 2).to(dtype)
         coords = torch.stack([U((n, h1, w1), 71, -6.0, w2 + 6.0), torch.zeros(n, h1, w1)], dim=1)
