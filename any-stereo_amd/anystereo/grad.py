@@ -327,7 +327,7 @@ class PointwiseLinear(torch.autograd.Function):
     def backward(ctx, d_y):
         x, weight, y = ctx.saved_tensors
         b, c, q = x.shape
-        d = _c(d_y if y is None else d_y * (y > 0))
+        d = _c(d_y if y is None else torch.ops.aten.threshold_backward(d_y, y, 0.0))  # ReLU backward in one launch (was compare + multiply)
         d_x = d_w = d_b = None
         if ctx.needs_input_grad[0]:
             if weight.shape[0] >= 16:
@@ -359,7 +359,7 @@ class Conv2dSame(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_y):
         x, weight, y = ctx.saved_tensors
-        d = _c(d_y if y is None else d_y * (y > 0))
+        d = _c(d_y if y is None else torch.ops.aten.threshold_backward(d_y, y, 0.0))  # ReLU backward in one launch (was compare + multiply)
         k = weight.shape[2]
         d_x = d_w = d_b = None
         if ctx.needs_input_grad[0]:
