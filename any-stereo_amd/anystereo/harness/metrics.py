@@ -10,15 +10,35 @@ from __future__ import annotations
 import torch
 
 
-def sequence_loss_multiscale(disp_preds, disp_gt, valid, loss_gamma=0.9, max_disp=700):
-    """disp_preds: list of [B,1,Q]; disp_gt, valid [B,1,Q].  Returns (loss, {'epe','1px','3px'})."""
+def sequence_loss_multiscale(disp_preds, disp_gt, valid, loss_gamma=0.9, max_disp=700, sync_free=False):
+    """disp_preds: list of [B,1,Q]; disp_gt, valid [B,1,Q].  Returns (loss, {'epe','1px','3px'}).
+
+    sync_free=False is the reference's statement line by line (train_continuous_IGEV.py:68-94): boolean-mask indexing and
+    `.item()` — 16 + 3 host synchronisations per call, ~100 small launches.  sync_free=True evaluates the same quantities as
+    masked sums over the stacked predictions (mean over the valid set = sum(err * valid) / count; same value up to the fp32
+    summation order, pinned by the same golden numbers) in ~10 launches with NO synchronisation: the host keeps issuing the
+    backward pass while the GPU still runs the forward.  The metrics then are 0-d tensors (convert when logging)."""
     n = len(disp_preds)
     assert n >= 1
     valid = (valid >= 0.5) & (disp_gt < max_disp)
     assert valid.shape == disp_gt.shape, [valid.shape, disp_gt.shape]
+    gamma = loss_gamma ** (15 / (n - 1)) if n > 1 else loss_gamma
+    if sync_free:
+        vm = valid.to(disp_gt.dtype)
+        cnt = vm.sum()
+        preds = torch.stack(list(disp_preds))                       # [n,B,1,Q]
+        assert preds.shape[1:] == valid.shape
+        per_pred = ((preds - disp_gt).abs() * vm).flatten(1).sum(1)  # [n] masked L1 sums
+        w = torch.tensor([gamma ** (n - i - 1) for i in range(n)], dtype=per_pred.dtype, device=per_pred.device)
+        loss = (w * per_pred).sum() / cnt
+        with torch.no_grad():
+            epe = torch.sum((disp_preds[-1] - disp_gt) ** 2, dim=1).sqrt().view(-1)
+            v = vm.view(-1)
+            metrics = {"epe": (epe * v).sum() / cnt, "1px": ((epe > 1).to(v.dtype) * v).sum() / cnt,
+                       "3px": ((epe > 3).to(v.dtype) * v).sum() / cnt}
+        return loss, metrics
     loss = 0.0
     for i, pred in enumerate(disp_preds):
-        gamma = loss_gamma ** (15 / (n - 1)) if n > 1 else loss_gamma
         w = gamma ** (n - i - 1)
         err = (pred - disp_gt).abs()
         assert err.shape == valid.shape
@@ -63,7 +83,7 @@ def thres_metric(d_est, d_gt, mask, thres):
     return _per_image(lambda e, g, m: ((g[m] - e[m]).abs() > thres).float().mean(), d_est, d_gt, mask)
 
 
-def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0, loss_scale=1.0):
+def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0, loss_scale=1.0, sync_free_loss=False):
     """One optimisation step with the reference's ordering (train_continuous_IGEV.py:214-239, multi_training branch):
     zero_grad -> forward(train mode) -> sequence_loss_multiscale with valid = (gt < 512) & (gt > 0) -> scaled backward ->
     unscale -> clip_grad_norm_(1.0) -> optimizer step -> scheduler step (unless fixed lr) -> scaler update.
@@ -77,7 +97,8 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
     assert model.training
     res = model(image1, image2, iters=train_iters, hr_coord=hr_coord, scale=scale)
     disp_preds = res[1] if isinstance(res, tuple) else res  # IGEV: (init_disp, preds); RAFT: preds (prune_raft_stereo.py:297)
-    loss, metrics = sequence_loss_multiscale(disp_preds, hr_disp_gt, (hr_disp_gt < 512) & (hr_disp_gt > 0.0), max_disp=max_disp)
+    loss, metrics = sequence_loss_multiscale(disp_preds, hr_disp_gt, (hr_disp_gt < 512) & (hr_disp_gt > 0.0), max_disp=max_disp,
+                                             sync_free=sync_free_loss)
     if scaler is not None:
         scaler.scale(loss).backward()
         scaler.unscale_(optimizer)

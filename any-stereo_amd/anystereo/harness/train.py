@@ -80,6 +80,9 @@ class Trainer:
         if loss_scale is None:
             loss_scale = float(os.environ.get("ANYSTEREO_LOSS_SCALE", "4096"))
         self.loss_scale = 1.0 if mixed_precision else loss_scale
+        # the loss as masked sums without host synchronisation (harness/metrics.py); ANYSTEREO_SYNC_FREE_LOSS=0 = the reference's
+        # boolean-mask statement (16 + 3 synchronisations per step)
+        self.sync_free_loss = os.environ.get("ANYSTEREO_SYNC_FREE_LOSS", "1") != "0"
 
     def _wrap_ddp(self, batch):
         """Probe pass on the bare module -> freeze gradient-less parameters -> wrap (see the class docstring)."""
@@ -118,6 +121,6 @@ class Trainer:
         if not sync_grads and self.module is not self.model:
             with self.module.no_sync():
                 return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
-                                  max_disp=self.max_disp, loss_scale=self.loss_scale)
+                                  max_disp=self.max_disp, loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss)
         return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
-                          max_disp=self.max_disp, loss_scale=self.loss_scale)
+                          max_disp=self.max_disp, loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss)

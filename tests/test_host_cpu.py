@@ -165,6 +165,18 @@ def test_loss_and_metrics_match_reference(golden):
     assert abs(loss.item() - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
     for k, gk in (("epe", "epe_m"), ("1px", "px1"), ("3px", "px3")):
         assert abs(met[k] - float(g[gk])) <= 1e-6
+    # the synchronisation-free form (masked sums over the stacked predictions) against the same reference numbers, and its gradient
+    # against the reference statement's
+    loss2, met2 = M.sequence_loss_multiscale(preds, gt, valid, max_disp=700, sync_free=True)
+    assert abs(loss2.item() - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    for k, gk in (("epe", "epe_m"), ("1px", "px1"), ("3px", "px3")):
+        assert abs(float(met2[k]) - float(g[gk])) <= 2e-6
+    pa = [p.clone().requires_grad_(True) for p in preds]
+    pb = [p.clone().requires_grad_(True) for p in preds]
+    M.sequence_loss_multiscale(pa, gt, valid, max_disp=700)[0].backward()
+    M.sequence_loss_multiscale(pb, gt, valid, max_disp=700, sync_free=True)[0].backward()
+    for a, b in zip(pa, pb):
+        assert (a.grad - b.grad).abs().max().item() <= 1e-7 * max(1e-30, a.grad.abs().max().item()) + 1e-12
     est, g3 = preds[-1][:, 0].reshape(2, 20, 25), gt[:, 0].reshape(2, 20, 25)
     m3 = (g3 > 0) & (g3 < 192)
     assert abs(M.epe_metric(est, g3, m3).item() - float(g["EPE"])) <= 1e-6
