@@ -248,9 +248,13 @@ def _stack(ts):
 _WGRAD = os.environ.get("ANYSTEREO_WGRAD", "hip")
 
 
+def _hip_wgrad(weight) -> bool:
+    return _WGRAD != "library" and weight.dim() == 4 and weight.shape[2] in (1, 3)
+
+
 def _wgrad_conv(d, x, weight, bias_sizes, want_w, want_b):
     k = weight.shape[2]
-    if want_w and x.is_cuda and _WGRAD != "library" and k in (1, 3):
+    if want_w and x.is_cuda and _hip_wgrad(weight):
         d_w, d_b = ops.conv2d_wgrad(_c(x), _c(d), k, want_bias=want_b)
         return d_w, d_b
     _, d_w, d_b = torch.ops.aten.convolution_backward(d, x, weight, bias_sizes, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
@@ -283,8 +287,12 @@ class WeightAnchor(torch.autograd.Function):
             groups[(tuple(x.shape), tuple(d.shape))][0].append(x)
             groups[(tuple(x.shape), tuple(d.shape))][1].append(d)
         for gx, gd in groups.values():
-            x, d = _stack(gx), _stack(gd)
-            d_w, d_b = _wgrad_conv(d, x, weight, ctx.bias_sizes, want_w, want_b) if st.kind == "conv" else _wgrad_linear(d, x, want_w, want_b)
+            if st.kind == "conv" and _hip_wgrad(weight) and want_w and gx[0].is_cuda:
+                # all iterations of the step in one launch, straight from the per-iteration tensors (no stacking copy)
+                d_w, d_b = ops.conv2d_wgrad([_c(t) for t in gx], [_c(t) for t in gd], weight.shape[2], want_bias=want_b)
+            else:
+                x, d = _stack(gx), _stack(gd)
+                d_w, d_b = _wgrad_conv(d, x, weight, ctx.bias_sizes, want_w, want_b) if st.kind == "conv" else _wgrad_linear(d, x, want_w, want_b)
             if want_w:
                 g_w = d_w if g_w is None else g_w + d_w
             if want_b:

@@ -878,22 +878,33 @@ def interp(x, ho: int, wo: int):
 
 def conv2d_wgrad(x, dy, ks: int, want_bias: bool = True):
     """(dW [Cout,Cin,ks,ks], db [Cout] | None) of a stride-1 "same" convolution from its input x [B,Cin,H,W] and output gradient
-    dy [B,Cout,H,W] (as_conv2d_wgrad: bf16 hi/lo split MFMA, deterministic split-K) — update.py:16-92 under autograd."""
-    _req(x, "x"), _req(dy, "dy")
-    b, cin, h, w = x.shape
-    cout = dy.shape[1]
-    if dy.shape[0] != b or tuple(dy.shape[2:]) != (h, w):
-        raise RuntimeError(f"conv2d_wgrad: x {tuple(x.shape)} and dy {tuple(dy.shape)} do not match")
+    dy [B,Cout,H,W] (as_conv2d_wgrad: bf16 hi/lo split MFMA, deterministic split-K) — update.py:16-92 under autograd.
+    x / dy may be equally long LISTS of such tensors (one pair per GRU iteration, same shapes): reduced in one launch without a
+    stacking copy (as_conv2d_wgrad_multi, up to 32 pairs)."""
+    xs, dys = (list(x), list(dy)) if isinstance(x, (list, tuple)) else ([x], [dy])
+    if len(xs) != len(dys) or not xs:
+        raise RuntimeError("conv2d_wgrad: x and dy must be lists of the same length")
+    if len(xs) > 32:
+        xs, dys = [torch.cat(xs, 0)], [torch.cat(dys, 0)]
+    for t in xs + dys:
+        _req(t, "x / dy")
+    per, cin, h, w = xs[0].shape
+    cout = dys[0].shape[1]
+    if any(tuple(t.shape) != (per, cin, h, w) for t in xs) or any(tuple(t.shape) != (per, cout, h, w) for t in dys):
+        raise RuntimeError(f"conv2d_wgrad: x {[tuple(t.shape) for t in xs][:2]} and dy {[tuple(t.shape) for t in dys][:2]} do not match")
     lib = L.load()
-    nbytes = int(lib.as_conv2d_wgrad_ws_bytes(b, cin, cout, h, w, ks))
+    dev = xs[0].device
+    nbytes = int(lib.as_conv2d_wgrad_ws_bytes(per * len(xs), cin, cout, h, w, ks))
     if nbytes < 0:
-        raise RuntimeError(f"conv2d_wgrad: unsupported problem (ks={ks}, x {tuple(x.shape)})")
-    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
-    dw = torch.empty((cout, cin, ks, ks), device=x.device, dtype=torch.float32)
-    db = torch.empty((cout,), device=x.device, dtype=torch.float32) if want_bias else None
-    with _guard(x.device):
-        L.check(lib.as_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db) if db is not None else None, b, cin, cout, h, w, ks, _p(ws), nbytes,
-                                    _stream()), "conv2d_wgrad")
+        raise RuntimeError(f"conv2d_wgrad: unsupported problem (ks={ks}, x {tuple(xs[0].shape)})")
+    ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+    dw = torch.empty((cout, cin, ks, ks), device=dev, dtype=torch.float32)
+    db = torch.empty((cout,), device=dev, dtype=torch.float32) if want_bias else None
+    xp, k1 = L.ptr_array([t.data_ptr() for t in xs])
+    dp, k2 = L.ptr_array([t.data_ptr() for t in dys])
+    with _guard(dev):
+        L.check(lib.as_conv2d_wgrad_multi(xp, dp, len(xs), per, _p(dw), _p(db) if db is not None else None, cin, cout, h, w, ks, _p(ws),
+                                          nbytes, _stream()), "conv2d_wgrad")
     return dw, db
 
 

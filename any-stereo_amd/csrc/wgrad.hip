@@ -33,9 +33,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((ext_vector_type(16))) float acc16;
 typedef __attribute__((ext_vector_type(4))) float f4;
 
+constexpr int kWgradMaxTensors = 32;
 struct WgradParams {
-  const float* x;   // [B][Cin][H][W]
-  const float* dy;  // [B][Cout][H][W]
+  // the B images may be spread over up to 32 tensors of `per` images each (the GRU iterations of a training step: no stacking copy)
+  const float* xs[kWgradMaxTensors];   // each [per][Cin][H][W]
+  const float* dys[kWgradMaxTensors];  // each [per][Cout][H][W]
+  int per;
   float* ws;        // [nsplit][T][Cout][Cin] partial weight gradients, T = KS*KS
   float* wsb;       // [nsplit][Cout] partial bias gradients (null: none)
   int B, Cin, Cout, H, W;
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
   constexpr int NS = KS + 1;                     // ring slots of the x image: rows y-PAD .. y+PAD in use, row y+PAD+1 being staged
   constexpr int PADL = KS == 3 ? 8 : 0;          // stored element s = col - x0 + PADL: the centre tap's 8-pixel groups are 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const float* __restrict__ xg = p.x;
-  const float* __restrict__ dyg = p.dy;
+  // image b -> (tensor b / per, image b % per): wave-uniform, read from the kernel arguments
+#define WG_IMG(ARR, B_, C_) ((ARR)[(B_) / p.per] + (long long)((B_) % p.per) * (C_) * plane_hw)
   const int px = p.pitch_x, pg = p.pitch_g;
   const int ximg = CIB * NS * px;                // bf16 elements of the hi (or lo) x ring   [slot][ci][px]: consecutive channels one (odd) pitch apart
   const int gimg = 128 * pg;                     // bf16 elements of one hi (or lo) dy image [co][pg]
@@ -182,14 +185,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
   {                                                                                                         \
     const int x0 = (Q).seg * p.XS;                                                                          \
     if (VEC) { /* range-checked 16-B buffer loads: items outside the tensor / the row read zeros, no selects */ \
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dyg + (long long)(Q).b * p.Cout * plane_hw), 0, img_g, 0x00020000); \
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)WG_IMG(p.dys, (Q).b, p.Cout), 0, img_g, 0x00020000); \
       const unsigned add = (unsigned)((Q).y * p.W + x0) * 4u;                                               \
       _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                      \
         const unsigned off = (x0 + g_col[j] < p.W) ? g_off[j] + add : OOB;                                  \
         (SET).g[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));     \
       }                                                                                                     \
     } else {                                                                                                \
-      const float* gb = dyg + (long long)(Q).b * p.Cout * plane_hw;                                         \
+      const float* gb = WG_IMG(p.dys, (Q).b, p.Cout);                                         \
       _Pragma("unroll") for (int j = 0; j < NG; ++j)                                                        \
         (SET).g[j] = load4<false>(gb, (long long)(g_off[j] & ~OOB) - g_col[j] + (Q).y * p.W, x0 + g_col[j], p.W, g_off[j] != OOB); \
     }                                                                                                       \
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
     const int x0 = (Q).seg * p.XS;                                                                          \
     const bool row_in = (YY) >= 0 && (YY) < p.H;                                                            \
     if (VEC) {                                                                                              \
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (long long)(Q).b * p.Cin * plane_hw), 0, row_in ? img_x : 0, 0x00020000); \
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)WG_IMG(p.xs, (Q).b, p.Cin), 0, row_in ? img_x : 0, 0x00020000); \
       const unsigned add = (unsigned)((YY) * p.W + x0 - (KS == 3 ? 4 : 0)) * 4u;                            \
       _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                      \
         const int col = x0 + x_col[j];                                                                      \
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
         (SET).x[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));     \
       }                                                                                                     \
     } else {                                                                                                \
-      const float* xb = xg + (long long)(Q).b * p.Cin * plane_hw;                                           \
+      const float* xb = WG_IMG(p.xs, (Q).b, p.Cin);                                           \
       _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                        \
         (SET).x[j] = load4<false>(xb, (long long)(x_off[j] & ~OOB) - (x_col[j] + (KS == 3 ? 4 : 0)) + (row_in ? (YY) : 0) * p.W, x0 + x_col[j], p.W, \
                                   x_off[j] != OOB && row_in);                                               \
@@ -490,16 +493,24 @@ int64_t as_conv2d_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int KS)
   return q.ws_floats * 4;
 }
 
-int as_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int KS, void* ws,
-                    int64_t ws_bytes, void* stream) {
-  AS_REQUIRE(x && dy && dw && ws, AS_ERR_BAD_ARG, "conv2d_wgrad: null pointer");
+static int wgrad_run(const float* const* xs, const float* const* dys, int n, int per, float* dw, float* db, int Cin, int Cout, int H, int W,
+                     int KS, void* ws, int64_t ws_bytes, void* stream) {
+  AS_REQUIRE(xs && dys && dw && ws && n >= 1 && n <= kWgradMaxTensors && per >= 1, AS_ERR_BAD_ARG, "conv2d_wgrad: null pointer / %d tensors (1..%d)", n, kWgradMaxTensors);
+  const int B = n * per;
   WgradPlan q;
   AS_REQUIRE(wgrad_plan(B, Cin, Cout, H, W, KS, q), AS_ERR_BAD_ARG, "conv2d_wgrad: KS=%d (1 or 3), B=%d Cin=%d Cout=%d H=%d W=%d", KS, B, Cin, Cout, H, W);
   AS_REQUIRE(ws_bytes >= q.ws_floats * 4, AS_ERR_BAD_ARG, "conv2d_wgrad: workspace of %lld bytes, need %lld", (long long)ws_bytes, (long long)q.ws_floats * 4);
-  AS_REQUIRE((long long)B * Cin * H * W < (1ll << 40) && (long long)B * Cout * H * W < (1ll << 40), AS_ERR_BAD_SHAPE, "conv2d_wgrad: tensor too large");
+  AS_REQUIRE((long long)Cin * H * W * 4 < 0x7FFFFFF0ll && (long long)Cout * H * W * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "conv2d_wgrad: an image exceeds 2 GiB");
   AS_REQUIRE(q.XS <= 80 && q.lds <= 160 * 1024, AS_ERR_BAD_SHAPE, "conv2d_wgrad: row segment of %d pixels", q.XS);
   WgradParams p;
-  p.x = x; p.dy = dy;
+  bool vec = (W % 4) == 0;
+  for (int i = 0; i < kWgradMaxTensors; ++i) {
+    p.xs[i] = xs[i < n ? i : 0];
+    p.dys[i] = dys[i < n ? i : 0];
+    AS_REQUIRE(p.xs[i] && p.dys[i], AS_ERR_BAD_ARG, "conv2d_wgrad: null tensor %d", i);
+    vec = vec && (reinterpret_cast<uintptr_t>(p.xs[i]) % 16) == 0 && (reinterpret_cast<uintptr_t>(p.dys[i]) % 16) == 0;
+  }
+  p.per = per;
   p.ws = (float*)ws;
   p.wsb = db ? (float*)ws + (long long)q.nsplit * (KS * KS) * Cout * Cin : nullptr;
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W;
@@ -507,13 +518,22 @@ int as_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int B
   p.dbg = dbg;
   p.nseg = q.nseg; p.XS = q.XS; p.KST = q.KST; p.pitch_x = q.pitch_x; p.pitch_g = q.pitch_g; p.n_co = q.n_co; p.n_ci = q.n_ci; p.nsplit = q.nsplit; p.chunks = q.chunks;
   hipStream_t s = as::as_stream(stream);
-  const bool vec = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(dy) % 16) == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0;
   const int rc = KS == 3 ? wgrad_launch<3, 1>(p, q, vec, s) : wgrad_launch<1, 2>(p, q, vec, s);
   if (rc != AS_OK) return rc;
   const long long n_out = (long long)Cout * Cin * KS * KS;
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)as::cdiv64(n_out > Cout ? n_out : Cout, 256)), dim3(256), 0, s, p.ws, p.wsb, dw, db, Cout,
                      Cin, KS * KS, q.nsplit);
   return as::check_launch("conv2d_wgrad_finish");
+}
+
+int as_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int KS, void* ws,
+                    int64_t ws_bytes, void* stream) {
+  return wgrad_run(&x, &dy, 1, B, dw, db, Cin, Cout, H, W, KS, ws, ws_bytes, stream);
+}
+
+int as_conv2d_wgrad_multi(const float* const* xs, const float* const* dys, int n, int per, float* dw, float* db, int Cin, int Cout, int H,
+                          int W, int KS, void* ws, int64_t ws_bytes, void* stream) {
+  return wgrad_run(xs, dys, n, per, dw, db, Cin, Cout, H, W, KS, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

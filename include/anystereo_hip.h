@@ -378,6 +378,10 @@ unsigned as_liif_split_overflow(int reset);
 int64_t as_conv2d_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int KS);
 int as_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int Cout, int H, int W, int KS,
                     void* ws, int64_t ws_bytes, void* stream);
+/* the same over n <= 32 (x, dy) tensor pairs of `per` images each — the GRU iterations of one training step, reduced in ONE launch
+ * without stacking them into one tensor first (the stacking copies were 3-4 ms of a step); workspace as for B = n * per */
+int as_conv2d_wgrad_multi(const float* const* xs, const float* const* dys, int n, int per, float* dw, float* db, int Cin, int Cout,
+                          int H, int W, int KS, void* ws, int64_t ws_bytes, void* stream);
 /*   a8^T  as_pool2x_bwd / as_interp_bilinear_ac_bwd: d_out [B,C,Ho,Wo] -> d_x [B,C,H,W], the transposes of as_pool2x /
  *         as_interp_bilinear_ac (what autograd derives for F.avg_pool2d / F.interpolate at update.py:94-102); gather form, one
  *         thread per input element, fixed summation order. */

@@ -870,6 +870,12 @@ def test_conv2d_wgrad(b, cin, cout, h, w, k):
         assert torch.equal(dw, dw2) and torch.equal(db, db2), "deterministic"
     dw3, none = ops.conv2d_wgrad(x.to(DEV), dy.to(DEV), k, want_bias=False)
     assert none is None and torch.isfinite(dw3).all()
+    # the same reduction over a LIST of (x, dy) pairs (one per GRU iteration, no stacking copy): bit-identical to the stacked call
+    xs = [t.contiguous().to(DEV) for t in x.split(1)]
+    gs = [t.contiguous().to(DEV) for t in dy.split(1)]
+    dw4, db4 = ops.conv2d_wgrad(xs, gs, k)
+    dw5, db5 = ops.conv2d_wgrad(x.to(DEV), dy.to(DEV), k)
+    assert torch.equal(dw4, dw5) and torch.equal(db4, db5)
 
 
 @pytest.mark.parametrize("kind", ["conv3", "conv1_cat", "linear"])
