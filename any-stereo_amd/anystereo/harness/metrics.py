@@ -29,7 +29,9 @@ def sequence_loss_multiscale(disp_preds, disp_gt, valid, loss_gamma=0.9, max_dis
         preds = torch.stack(list(disp_preds))                       # [n,B,1,Q]
         assert preds.shape[1:] == valid.shape
         per_pred = ((preds - disp_gt).abs() * vm).flatten(1).sum(1)  # [n] masked L1 sums
-        w = torch.tensor([gamma ** (n - i - 1) for i in range(n)], dtype=per_pred.dtype, device=per_pred.device)
+        # gamma^(n-1-i), built on the device (a torch.tensor(list, device=...) is a blocking host-to-device copy)
+        w = torch.pow(torch.full((), gamma, dtype=torch.float64, device=per_pred.device),
+                      torch.arange(n - 1, -1, -1, dtype=torch.float64, device=per_pred.device)).to(per_pred.dtype)
         loss = (w * per_pred).sum() / cnt
         with torch.no_grad():
             epe = torch.sum((disp_preds[-1] - disp_gt) ** 2, dim=1).sqrt().view(-1)
