@@ -290,6 +290,10 @@ class WeightAnchor(torch.autograd.Function):
             if st.kind == "conv" and _hip_wgrad(weight) and want_w and gx[0].is_cuda:
                 # all iterations of the step in one launch, straight from the per-iteration tensors (no stacking copy)
                 d_w, d_b = ops.conv2d_wgrad([_c(t) for t in gx], [_c(t) for t in gd], weight.shape[2], want_bias=want_b)
+            elif st.kind == "linear" and _WGRAD != "library" and want_w and gx[0].is_cuda:
+                # a Linear layer over [B,C,Q] activations = a 1x1 convolution over a one-row image of Q pixels
+                d_w, d_b = ops.conv2d_wgrad([_c(t).unsqueeze(2) for t in gx], [_c(t).unsqueeze(2) for t in gd], 1, want_bias=want_b)
+                d_w = d_w.view(weight.shape)
             else:
                 x, d = _stack(gx), _stack(gd)
                 d_w, d_b = _wgrad_conv(d, x, weight, ctx.bias_sizes, want_w, want_b) if st.kind == "conv" else _wgrad_linear(d, x, want_w, want_b)
@@ -444,6 +448,20 @@ def conv2d_same(mod, name, x, weight, bias, relu=False):
     bs = bias if isinstance(bias, tuple) else (bias,)
     w, b, stash = anchored(mod, name, "conv", ws, bs)
     return Conv2dSame.apply(_c(x), w, b, relu, pf, pb, stash)
+
+
+_TRAIN_BACKBONE = os.environ.get("ANYSTEREO_TRAIN_BACKBONE_CONVS", "1") != "0"
+
+
+def module_conv2d(mod, name, conv, x):
+    """`conv(x)` of an nn.Conv2d under autograd.  Stride-1 "same" 1x1 / 3x3 convolutions (no dilation, no groups) of CUDA fp32
+    tensors run forward, dgrad and wgrad on this library's kernels (Conv2dSame); anything else is the module itself."""
+    if (_TRAIN_BACKBONE and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and isinstance(conv, torch.nn.Conv2d)
+            and conv.kernel_size in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding == (conv.kernel_size[0] // 2,) * 2 and conv.padding_mode == "zeros" and x.shape[1] >= 16
+            and (x.requires_grad or conv.weight.requires_grad)):
+        return conv2d_same(mod, name, x, conv.weight, conv.bias)
+    return conv(x)
 
 
 def pointwise_linear(mod, key, x, lin, relu):

@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import _lib as L
+from .. import grad as G
 from .. import ops
 
 
@@ -141,7 +142,7 @@ class _ConvNormAct(nn.Module):
         if fused_ok(x, self) and x.dim() == 4 and _plain_instance_norm(norm):
             # conv (library kernel where it applies, else MIOpen) -> fused InstanceNorm + LeakyReLU
             return ops.instance_norm_act(conv2d_plain(self, self.conv, x), norm.eps, L.ACT_LEAKY if self.relu else L.ACT_NONE)
-        x = conv3d_train(self.conv, x) if x.dim() == 5 else self.conv(x)
+        x = conv3d_train(self.conv, x) if x.dim() == 5 else G.module_conv2d(self, "t", self.conv, x)
         if self.use_norm:
             x = norm(x)
         return F.leaky_relu(x, 0.01) if self.relu else x

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import grad as G
 from .. import ops
 from .blocks import BasicConv_IN, Conv2x_IN, conv2d_hip_ok as _conv_hip_ok, conv2d_plain, fused_ok as _fused_ok
 
@@ -62,8 +63,8 @@ class ResidualBlock(nn.Module):
             return self._forward_fused(x)
         if _fused_ok(x, self) and _plain_in(self.norm1) and _plain_in(self.norm2):
             return self._forward_fused_in(x)
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
+        y = self.relu(self.norm1(G.module_conv2d(self, "t1", self.conv1, x)))  # training: own kernels where the shape allows
+        y = self.relu(self.norm2(G.module_conv2d(self, "t2", self.conv2, y)))
         if self.downsample is not None:
             x = self.downsample(x)
         return self.relu(x + y)

@@ -127,6 +127,7 @@ template <int KS, int NT, bool VEC>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
   constexpr int TAPS = KS * KS, PAD = KS / 2, NB = TAPS * NT, CIB = 32 * NT;
   constexpr int NS = KS + 1;                     // ring slots of the x image: rows y-PAD .. y+PAD in use, row y+PAD+1 being staged
+  constexpr bool RING = KS == 3;                 // 1x1: no row is shared between chunks — two slots alternating by chunk parity
   constexpr int PADL = KS == 3 ? 8 : 0;          // stored element s = col - x0 + PADL: the centre tap's 8-pixel groups are 16-byte aligned
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // image b -> (tensor b / per, image b % per): wave-uniform, read from the kernel arguments
@@ -222,9 +223,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
                                   x_off[j] != OOB && row_in);                                               \
     }                                                                                                       \
   }
-#define WG_STORE_X(SET, YY)                                                                                 \
+#define WG_STORE_X(SET, SLOT)                                                                               \
   {                                                                                                         \
-    unsigned short* const xdst = ldx + (((YY) + NS) % NS) * (CIB * px);                                     \
+    unsigned short* const xdst = ldx + (SLOT) * (CIB * px);                                                 \
     _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                          \
       if (lt + 256 * j < n_x) store4((SET).x[j], xdst + x_lds[j], xdst + ximg + x_lds[j]);                  \
   }
@@ -232,24 +233,24 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
 #define WG_STAGE_COLUMN(SET, Q)                                                                             \
   for (int yy = (Q).y - PAD; yy <= (Q).y + PAD; ++yy) {                                                     \
     WG_LOAD_X(SET, Q, yy)                                                                                   \
-    WG_STORE_X(SET, yy)                                                                                     \
+    WG_STORE_X(SET, (yy + NS) % NS)                                                                         \
   }
 // park chunk CN (position Q, fetched into SET two iterations ago), then fetch chunk CN + 2 into SET, then meet the consumers
 #define WG_ITER(SET, CN, Q)                                                                                 \
   {                                                                                                         \
-    const bool live = (CN) < c_hi, fresh = live && (Q).y == 0;                                              \
+    const bool live = (CN) < c_hi, fresh = RING && live && (Q).y == 0;                                      \
     if (live && p.dbg != 1) WG_STORE_G(SET, CN)                                                             \
     if (fresh) {                                                                                            \
       __syncthreads(); /* the consumers are done with the previous column's rows: any slot may be rewritten */ \
       WG_STAGE_COLUMN(SET, Q)                                                                               \
     } else if (live && p.dbg != 1) {                                                                        \
-      WG_STORE_X(SET, (Q).y + PAD)                                                                          \
+      WG_STORE_X(SET, RING ? ((Q).y + PAD + NS) % NS : (int)(((CN) - c_lo) & 1))                            \
     }                                                                                                       \
     pos_next(p, Q);                                                                                         \
     pos_next(p, Q);                                                                                         \
     if ((CN) + 2 < c_hi && p.dbg != 1) {                                                                    \
       WG_LOAD_G(SET, Q)                                                                                     \
-      if ((Q).y != 0) WG_LOAD_X(SET, Q, (Q).y + PAD)                                                        \
+      if (!RING || (Q).y != 0) WG_LOAD_X(SET, Q, (Q).y + PAD)                                               \
     }                                                                                                       \
     __syncthreads();                                                                                        \
   }
@@ -259,18 +260,23 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
     if (c_lo < c_hi) {  // prologue: chunk c_lo in full
       WG_LOAD_G(A, qa)
       WG_STORE_G(A, c_lo)
-      WG_STAGE_COLUMN(A, qa)
+      if (RING) {
+        WG_STAGE_COLUMN(A, qa)
+      } else {  // 1x1: no rows shared between chunks, the x image simply alternates between two slots
+        WG_LOAD_X(A, qa, qa.y)
+        WG_STORE_X(A, 0)
+      }
     }
     pos_next(p, qa);  // qa = chunk c_lo + 1 (set A), qb = chunk c_lo + 2 (set B)
     qb = qa;
     pos_next(p, qb);
     if (c_lo + 1 < c_hi) {
       WG_LOAD_G(A, qa)
-      if (qa.y != 0) WG_LOAD_X(A, qa, qa.y + PAD)
+      if (!RING || qa.y != 0) WG_LOAD_X(A, qa, qa.y + PAD)
     }
     if (c_lo + 2 < c_hi) {
       WG_LOAD_G(B, qb)
-      if (qb.y != 0) WG_LOAD_X(B, qb, qb.y + PAD)
+      if (!RING || qb.y != 0) WG_LOAD_X(B, qb, qb.y + PAD)
     }
     __syncthreads();  // chunk c_lo staged
     for (long long cn = c_lo + 1; cn <= c_hi; cn += 2) {
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
 #undef WG_MMA
 #undef WG_READ
     } else {
-      const unsigned short* xr0 = ldx + b_e + ((q.y + NS) % NS) * (CIB * px);
+      const unsigned short* xr0 = ldx + b_e + (int)((cc - c_lo) & 1) * (CIB * px);
       for (int ks = 0; ks < p.KST; ++ks) {
         const bf8 a_hi = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(ga + ks * 16));
         const bf8 a_lo = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(ga + gimg + ks * 16));
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
     }
     pos_next(p, q);
     __syncthreads();  // this chunk's images are free; the next chunk's dy and its new x row are staged
-    if (cc + 1 < c_hi && q.y == 0) __syncthreads();  // new column: the loaders restage all KS rows after the barrier above
+    if (RING && cc + 1 < c_hi && q.y == 0) __syncthreads();  // new column: the loaders restage all KS rows after the barrier above
   }
 
   // ---------------- partial tile -> workspace [split][tap][Cout][Cin] ----------------

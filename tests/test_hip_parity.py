@@ -846,7 +846,7 @@ def test_conv2d_same_backward(cin, cout, k, relu, precision):
 
 
 @pytest.mark.parametrize("b,cin,cout,h,w,k", [(3, 40, 70, 6, 16, 3), (2, 162, 64, 5, 24, 1), (4, 33, 130, 7, 21, 3), (2, 7, 5, 3, 5, 1),
-                                              (2, 64, 128, 4, 104, 3), (16, 128, 127, 10, 20, 3)])
+                                              (2, 64, 128, 4, 104, 3), (16, 128, 127, 10, 20, 3), (3, 64, 9, 1, 1000, 1), (2, 128, 64, 1, 333, 1)])
 def test_conv2d_wgrad(b, cin, cout, h, w, k):
     """as_conv2d_wgrad (bf16 hi/lo split MFMA, split-K, bias gradient as a tile of ones) against fp64 autograd of F.conv2d:
     channel counts that do not fill the 128 x 32 tiles, widths with and without the 16-byte fetch path, rows longer than one
