@@ -198,13 +198,18 @@ __global__ __launch_bounds__(256) void liif_rel_key_kernel(RelParams p) {
 }
 
 // ---- a16/a17ᵀ: (softmax +) convex 3x3 combination at the nearest low-res pixel (submodule.py:357-372) -----------
+// d_disp is a scatter-add of nine taps per query onto a map ~16x smaller than the query set: lanes whose queries share the
+// nearest pixel (consecutive lanes once the training path has sorted the queries) are summed inside the wave first and only the
+// head of each run issues the atomics — same scheme as liif_gather_bwd_kernel (9 atomics per RUN instead of per query:
+// 140 -> ~45 us per call at cfg 4).
 __global__ __launch_bounds__(256) void convex_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ scale,
                                                         const float* __restrict__ mask, const float* __restrict__ coord,
                                                         const float* __restrict__ dout, float* __restrict__ dmask,
                                                         float* __restrict__ ddisp, int B, int H, int W, int Q, int logits,
                                                         float lo, float hi) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long long)B * Q) return;
+  const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = t0 < (long long)B * Q;  // no early return: every lane takes part in the shuffles
+  const long long t = valid ? t0 : 0;
   const long long b = t / Q, q = t - b * Q;
   const float* mp = mask + b * 9 * Q + q;
   float l[9], dk[9];
@@ -228,16 +233,37 @@ __global__ __launch_bounds__(256) void convex_bwd_kernel(const float* __restrict
   const int ix = nearest_idx_b(fminf(fmaxf(coord[t * 2 + 1], lo), hi), W);
   const float* dp = disp + b * H * W;
   const float mul = scale ? __fmul_rn(4.f, scale[b]) : 1.f;
-  const float g = dout[t];
+  const float g = valid ? dout[t] : 0.f;
+  // runs of consecutive lanes with the same (batch, nearest pixel): see liif_gather_bwd_kernel
+  const int lane = threadIdx.x & 63;
+  const int key = valid ? (int)(b * H * W + (long long)iy * W + ix) : -1;
+  const int prev = __shfl_up(key, 1);
+  const bool starts = lane == 0 || prev != key;
+  const unsigned long long heads = __ballot(starts);
+  const unsigned long long after = (heads >> lane) >> 1;
+  unsigned same = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (lane + (1 << k) < 64 && (after & ((1ull << (1 << k)) - 1ull)) == 0ull) same |= 1u << k;
+  const bool head = valid && starts;
   float out = 0.f;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const int yy = iy + k / 3 - 1, xx = ix + k % 3 - 1;
-    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;  // the same for every lane of a run
     dk[k] = in ? dp[(long long)yy * W + xx] * mul : 0.f;
     out += dk[k] * l[k];
-    if (in && ddisp) atomicAdd(ddisp + b * H * W + (long long)yy * W + xx, g * l[k] * mul);
+    if (ddisp) {
+      float v = in ? g * l[k] * mul : 0.f;
+#pragma unroll
+      for (int s_ = 0; s_ < 6; ++s_) {
+        const float o = __shfl_down(v, 1 << s_);
+        v += ((same >> s_) & 1u) ? o : 0.f;
+      }
+      if (head && in) atomicAdd(ddisp + b * H * W + (long long)yy * W + xx, v);
+    }
   }
+  if (!valid) return;
   float* gm = dmask + b * 9 * Q + q;
 #pragma unroll
   for (int k = 0; k < 9; ++k) gm[(long long)k * Q] = logits ? g * l[k] * (dk[k] - out) : g * dk[k];
@@ -534,6 +560,7 @@ int as_convex_upsample_bwd(const float* disp, const float* scale, const float* m
                            float* d_mask, float* d_disp, int B, int H, int W, int Q, int mask_is_logits, void* stream) {
   AS_REQUIRE(disp && mask && coord && d_out && d_mask, AS_ERR_BAD_ARG, "convex_upsample_bwd: null pointer");
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && Q > 0, AS_ERR_BAD_ARG, "convex_upsample_bwd: non-positive size");
+  AS_REQUIRE((long long)B * H * W < 2147483647ll, AS_ERR_BAD_SHAPE, "convex_upsample_bwd: B*H*W too large for a 32-bit run key");
   if (d_disp) {
     hipError_t e = hipMemsetAsync(d_disp, 0, sizeof(float) * (size_t)B * H * W, as::as_stream(stream));
     if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "convex_upsample_bwd: memset: %s", hipGetErrorString(e));
