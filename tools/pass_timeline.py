@@ -32,10 +32,20 @@ def main():
     res["post_loop_wall_us"] = (win[-1][1] - win[last_loop][1]) / 1e3
     res["post_loop_kernel_us"] = sum(e - s for s, e, _, _ in post) / 1e3
     res["post_loop"] = [{"kernel": k[:70], "start_us": round((s - win[last_loop][1]) / 1e3, 1), "dur_us": round((e - s) / 1e3, 1), "queue": q} for s, e, k, q in post]
+    # one GRU iteration from the middle of the loop: kernels between two consecutive gru04 z|r convolutions
+    zr = [i for i, r in enumerate(win) if "conv_split_kernel<3, 16, 64, 1, 2, 1" in r[2]]
+    if len(zr) >= 4:
+        a, b = zr[len(zr) // 2], zr[len(zr) // 2 + 1]
+        t1 = win[a][0]
+        res["iteration_period_us"] = (win[b][0] - t1) / 1e3
+        res["iteration"] = [{"kernel": k[:60], "start_us": round((s - t1) / 1e3, 1), "end_us": round((e - t1) / 1e3, 1), "queue": q}
+                            for s, e, k, q in win[a:b]]
     json.dump(res, open(out, "w"), indent=0)
-    print({k: v for k, v in res.items() if k not in ("pre_loop", "post_loop")})
+    print({k: v for k, v in res.items() if k not in ("pre_loop", "post_loop", "iteration")})
     for r in res["post_loop"]:
         print("  post", r)
+    for r in res.get("iteration", []):
+        print("  iter", r["start_us"], r["end_us"], r["queue"], r["kernel"])
     # busy time per queue and the gaps on the timeline
     last = t0
     idle = 0
