@@ -117,6 +117,8 @@ SIGNATURES = {
     "as_gru_gates_zr_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_gru_gates_q": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_gru_gates_q_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_gru_gates_zr_bwd_ctx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_gru_gates_q_bwd_ctx": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_liif_rel_key": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_convex_upsample_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }

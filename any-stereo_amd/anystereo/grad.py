@@ -387,18 +387,57 @@ class Conv2dSame(torch.autograd.Function):
 
 
 # ---- a7: ConvGRU gate math as two fused stages (update.py:36-41) ---------------------------------------------------
-class GruGatesZR(torch.autograd.Function):
-    """(z, r*h) from the convz‖convr output; cz, cr are passed for the autograd graph, the kernel reads them in place from
-    the context tensor they are views of (`base`, channel offset `coff`)."""
+class ContextAnchor(torch.autograd.Function):
+    """Identity on the GRU context tensor (cz | cr | cq of one level, continuous_IGEVstereo.py:273) that every iteration's gate
+    stages hang off: their backward passes add the context-window gradients into ONE accumulator (`holder`), handed to the
+    context once — instead of 3 x iters sliced gradients that autograd sums one by one."""
 
     @staticmethod
-    def forward(ctx, lin, cz, cr, h, base, coff):
+    def forward(ctx, holder, base):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return base.view_as(base)
+
+    @staticmethod
+    def backward(ctx, g):
+        acc, ctx.holder["acc"] = ctx.holder.get("acc"), None
+        ctx.holder["done"] = True
+        if acc is None:
+            return None, g
+        return None, acc if g is None else acc + g
+
+
+def context_anchor(mod, base):
+    """(anchored view of `base`, holder) for this forward, cached on `mod` per context tensor; (base, None) without deferral."""
+    if not (_DEFER and torch.is_grad_enabled() and base.requires_grad and base.is_cuda):
+        return base, None
+    ent = mod.__dict__.get("_ctx_anchor")
+    if ent is None or ent[0] is not base or ent[1] != base._version or ent[3].get("done"):
+        holder = {}
+        ent = mod.__dict__["_ctx_anchor"] = (base, base._version, ContextAnchor.apply(holder, base), holder)
+    return ent[2], ent[3]
+
+
+def _ctx_acc(holder, base):
+    if holder.get("acc") is None:
+        holder["acc"] = torch.zeros_like(base)
+    return holder["acc"]
+
+
+class GruGatesZR(torch.autograd.Function):
+    """(z, r*h) from the convz‖convr output; cz, cr are passed for the autograd graph, the kernel reads them in place from
+    the context tensor they are views of (`base`, channel offset `coff`).  With `holder` (grad.context_anchor) `base` is the
+    anchored context and its gradient is accumulated by the backward kernel instead of returned through cz / cr."""
+
+    @staticmethod
+    def forward(ctx, lin, cz, cr, h, base, coff, holder=None):
         b, c, hh, ww = h.shape
         z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
         with _guard(h.device):
             L.check(L.load().as_gru_gates_zr(_p(lin), _p(base), base.shape[1], coff, _p(h), _p(z), _p(r), _p(rh), b, c, hh, ww,
                                              _stream()), "gru_gates_zr")
         ctx.save_for_backward(z, r, h)
+        ctx.holder, ctx.coff, ctx.base_like = holder, coff, (base if holder is not None else None)
         return z, rh
 
     @staticmethod
@@ -410,22 +449,28 @@ class GruGatesZR(torch.autograd.Function):
         d_lin = torch.empty((b, 2 * c, hh, ww), device=h.device, dtype=torch.float32)
         d_h = torch.empty_like(h)
         with _guard(h.device):
+            if ctx.holder is not None:
+                acc = _ctx_acc(ctx.holder, ctx.base_like)
+                L.check(L.load().as_gru_gates_zr_bwd_ctx(_p(d_z), _p(d_rh), _p(z), _p(r), _p(h), _p(d_lin), _p(d_h), _p(acc), acc.shape[1],
+                                                         ctx.coff, b, c, hh, ww, _stream()), "gru_gates_zr_bwd")
+                return d_lin, None, None, d_h, None, None, None
             L.check(L.load().as_gru_gates_zr_bwd(_p(d_z), _p(d_rh), _p(z), _p(r), _p(h), _p(d_lin), _p(d_h), b, c, hh, ww, _stream()),
                     "gru_gates_zr_bwd")
-        return d_lin, d_lin[:, :c], d_lin[:, c:], d_h, None, None
+        return d_lin, d_lin[:, :c], d_lin[:, c:], d_h, None, None, None
 
 
 class GruGatesQ(torch.autograd.Function):
     """h' = (1 - z) h + z tanh(lin + cq)."""
 
     @staticmethod
-    def forward(ctx, lin, cq, z, h, base, coff):
+    def forward(ctx, lin, cq, z, h, base, coff, holder=None):
         b, c, hh, ww = h.shape
         out, t = torch.empty_like(h), torch.empty_like(h)
         with _guard(h.device):
             L.check(L.load().as_gru_gates_q(_p(lin), _p(base), base.shape[1], coff, _p(z), _p(h), _p(out), _p(t), b, c, hh, ww,
                                             _stream()), "gru_gates_q")
         ctx.save_for_backward(z, t, h)
+        ctx.holder, ctx.coff, ctx.base_like = holder, coff, (base if holder is not None else None)
         return out
 
     @staticmethod
@@ -434,9 +479,14 @@ class GruGatesQ(torch.autograd.Function):
         b, c, hh, ww = h.shape
         d_lin, d_z, d_h = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
         with _guard(h.device):
-            L.check(L.load().as_gru_gates_q_bwd(_p(_c(d_out)), _p(z), _p(t), _p(h), _p(d_lin), _p(d_z), _p(d_h), b, c, hh, ww,
-                                                _stream()), "gru_gates_q_bwd")
-        return d_lin, d_lin, d_z, d_h, None, None
+            if ctx.holder is not None:
+                acc = _ctx_acc(ctx.holder, ctx.base_like)
+                L.check(L.load().as_gru_gates_q_bwd_ctx(_p(_c(d_out)), _p(z), _p(t), _p(h), _p(d_lin), _p(d_z), _p(d_h), _p(acc), acc.shape[1],
+                                                        ctx.coff, b, c, hh, ww, _stream()), "gru_gates_q_bwd")
+                return d_lin, None, d_z, d_h, None, None, None
+            L.check(L.load().as_gru_gates_q_bwd(_p(_c(d_out)), _p(z), _p(t), _p(h), _p(d_lin), _p(d_z), _p(d_h), b, c, hh, ww, _stream()),
+                    "gru_gates_q_bwd")
+        return d_lin, d_lin, d_z, d_h, None, None, None
 
 
 def conv2d_same(mod, name, x, weight, bias, relu=False):

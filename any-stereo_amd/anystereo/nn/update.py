@@ -172,9 +172,12 @@ class ConvGRU(nn.Module):
             if zr.is_cuda and self.fused_gates:
                 base, coff = _context_window(cz, cr, cq)
                 hc = _f(h)
-                z, rh = G.GruGatesZR.apply(zr, cz, cr, hc, base, coff)
+                # the context is the same tensor in every iteration: its gradient is accumulated by the gate stages' backward kernels
+                # (grad.ContextAnchor) when it is the tensor cz / cr / cq are views of; the views stay inputs for the graph otherwise
+                tok, holder = G.context_anchor(self, base) if base is cz._base else (base, None)
+                z, rh = G.GruGatesZR.apply(zr, cz, cr, hc, tok, coff, holder)
                 ql = _cs(self, "q", torch.cat([rh, x], dim=1), self.convq.weight, self.convq.bias)
-                return G.GruGatesQ.apply(ql, cq, z, hc, base, coff + 2 * hid)
+                return G.GruGatesQ.apply(ql, cq, z, hc, tok, coff + 2 * hid, holder)
             z = torch.sigmoid(zr[:, :hid] + cz)
             r = torch.sigmoid(zr[:, hid:] + cr)
             q = torch.tanh(_cs(self, "q", torch.cat([r * h, x], dim=1), self.convq.weight, self.convq.bias) + cq)

@@ -310,8 +310,9 @@ struct GateBwdParams {
   float* d_lin;      // ZR: [B,2C,H,W]  Q: [B,C,H,W]     (also the gradient of the context window)
   float* d_h;        // partial d h of this stage
   float* d_z;        // Q only
+  float* d_ctx;      // optional accumulator of the context gradient [B, ctx_ctot, H, W]: window [ctx_coff, ..) += d_lin
   long long plane, total;
-  int C;
+  int C, ctx_ctot, ctx_coff;
 };
 
 __global__ __launch_bounds__(256) void gru_gates_zr_bwd_kernel(GateBwdParams p) {
@@ -324,9 +325,15 @@ __global__ __launch_bounds__(256) void gru_gates_zr_bwd_kernel(GateBwdParams p) 
   const float z = p.z[t], r = p.r[t], h = p.h[t];
   const float dz = p.g0 ? p.g0[t] : 0.f, drh = p.g1 ? p.g1[t] : 0.f;
   float* dl = p.d_lin + (b * 2 * p.C) * p.plane + pix;
-  dl[(long long)c * p.plane] = dz * z * (1.f - z);
-  dl[(long long)(p.C + c) * p.plane] = drh * h * r * (1.f - r);
+  const float gz = dz * z * (1.f - z), gr = drh * h * r * (1.f - r);
+  dl[(long long)c * p.plane] = gz;
+  dl[(long long)(p.C + c) * p.plane] = gr;
   p.d_h[t] = drh * r;
+  if (p.d_ctx) {  // the context is the same tensor in every GRU iteration: its gradient is summed here, one element per thread
+    float* dc = p.d_ctx + (b * p.ctx_ctot + p.ctx_coff) * p.plane + pix;
+    dc[(long long)c * p.plane] += gz;
+    dc[(long long)(p.C + c) * p.plane] += gr;
+  }
 }
 
 __global__ __launch_bounds__(256) void gru_gates_q_kernel(GateParams p) {
@@ -346,9 +353,16 @@ __global__ __launch_bounds__(256) void gru_gates_q_bwd_kernel(GateBwdParams p) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= p.total) return;
   const float g = p.g0[t], z = p.z[t], q = p.r[t], h = p.h[t];
-  p.d_lin[t] = g * z * (1.f - q * q);
+  const float gl = g * z * (1.f - q * q);
+  p.d_lin[t] = gl;
   p.d_z[t] = g * (q - h);
   p.d_h[t] = g * (1.f - z);
+  if (p.d_ctx) {
+    const long long pix = t % p.plane, bc = t / p.plane;
+    const int c = (int)(bc % p.C);
+    const long long b = bc / p.C;
+    p.d_ctx[(b * p.ctx_ctot + p.ctx_coff + c) * p.plane + pix] += gl;
+  }
 }
 
 // ---- a8^T: pool2x / interp of BasicMultiUpdateBlock (update.py:94-102) ------------------------------------------------
@@ -445,11 +459,23 @@ int as_gru_gates_zr(const float* lin, const float* ctx, int ctx_ctot, int ctx_co
   return as::check_launch("gru_gates_zr");
 }
 
+static int gates_zr_bwd(const float* d_z, const float* d_rh, const float* z, const float* r, const float* h, float* d_lin, float* d_h,
+                        float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream);
 int as_gru_gates_zr_bwd(const float* d_z, const float* d_rh, const float* z, const float* r, const float* h, float* d_lin,
                         float* d_h, int B, int C, int H, int W, void* stream) {
+  return gates_zr_bwd(d_z, d_rh, z, r, h, d_lin, d_h, nullptr, 0, 0, B, C, H, W, stream);
+}
+int as_gru_gates_zr_bwd_ctx(const float* d_z, const float* d_rh, const float* z, const float* r, const float* h, float* d_lin,
+                            float* d_h, float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(d_ctx && ctx_coff >= 0 && ctx_coff + 2 * C <= ctx_ctot, AS_ERR_BAD_ARG, "gru_gates_zr_bwd_ctx: context window [%d,%d) outside %d", ctx_coff, ctx_coff + 2 * C, ctx_ctot);
+  return gates_zr_bwd(d_z, d_rh, z, r, h, d_lin, d_h, d_ctx, ctx_ctot, ctx_coff, B, C, H, W, stream);
+}
+static int gates_zr_bwd(const float* d_z, const float* d_rh, const float* z, const float* r, const float* h, float* d_lin, float* d_h,
+                        float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream) {
   AS_REQUIRE(z && r && h && d_lin && d_h, AS_ERR_BAD_ARG, "gru_gates_zr_bwd: null pointer");
   AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "gru_gates_zr_bwd: non-positive size");
   GateBwdParams p{};
+  p.d_ctx = d_ctx; p.ctx_ctot = ctx_ctot; p.ctx_coff = ctx_coff;
   p.g0 = d_z; p.g1 = d_rh; p.z = z; p.r = r; p.h = h; p.d_lin = d_lin; p.d_h = d_h;
   p.plane = (long long)H * W; p.total = p.plane * B * C; p.C = C;
   hipLaunchKernelGGL(gru_gates_zr_bwd_kernel, dim3((unsigned)as::cdiv64(p.total, 256)), dim3(256), 0, as::as_stream(stream), p);
@@ -468,11 +494,23 @@ int as_gru_gates_q(const float* lin, const float* ctx, int ctx_ctot, int ctx_cof
   return as::check_launch("gru_gates_q");
 }
 
+static int gates_q_bwd(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
+                       float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream);
 int as_gru_gates_q_bwd(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
                        int B, int C, int H, int W, void* stream) {
+  return gates_q_bwd(d_out, z, t, h, d_lin, d_z, d_h, nullptr, 0, 0, B, C, H, W, stream);
+}
+int as_gru_gates_q_bwd_ctx(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
+                           float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(d_ctx && ctx_coff >= 0 && ctx_coff + C <= ctx_ctot, AS_ERR_BAD_ARG, "gru_gates_q_bwd_ctx: context window [%d,%d) outside %d", ctx_coff, ctx_coff + C, ctx_ctot);
+  return gates_q_bwd(d_out, z, t, h, d_lin, d_z, d_h, d_ctx, ctx_ctot, ctx_coff, B, C, H, W, stream);
+}
+static int gates_q_bwd(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
+                       float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream) {
   AS_REQUIRE(d_out && z && t && h && d_lin && d_z && d_h, AS_ERR_BAD_ARG, "gru_gates_q_bwd: null pointer");
   AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "gru_gates_q_bwd: non-positive size");
   GateBwdParams p{};
+  p.d_ctx = d_ctx; p.ctx_ctot = ctx_ctot; p.ctx_coff = ctx_coff;
   p.g0 = d_out; p.z = z; p.r = t; p.h = h; p.d_lin = d_lin; p.d_z = d_z; p.d_h = d_h;
   p.plane = (long long)H * W; p.total = p.plane * B * C; p.C = C;
   hipLaunchKernelGGL(gru_gates_q_bwd_kernel, dim3((unsigned)as::cdiv64(p.total, 256)), dim3(256), 0, as::as_stream(stream), p);

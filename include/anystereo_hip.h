@@ -410,6 +410,13 @@ int as_gru_gates_q(const float* lin, const float* ctx, int ctx_ctot, int ctx_cof
                    float* t, int B, int C, int H, int W, void* stream);
 int as_gru_gates_q_bwd(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
                        int B, int C, int H, int W, void* stream);
+/* the same transposes, also ADDING the context-window gradient (= d_lin) into d_ctx [B,ctx_ctot,H,W] at channel ctx_coff: the
+ *   context tensor is the same in every GRU iteration (continuous_IGEVstereo.py:273), so one zero-filled accumulator collects all
+ *   iterations of a training step instead of 3 x iters sliced gradients that autograd sums one by one */
+int as_gru_gates_zr_bwd_ctx(const float* d_z, const float* d_rh, const float* z, const float* r, const float* h, float* d_lin,
+                            float* d_h, float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream);
+int as_gru_gates_q_bwd_ctx(const float* d_out, const float* z, const float* t, const float* h, float* d_lin, float* d_z, float* d_h,
+                           float* d_ctx, int ctx_ctot, int ctx_coff, int B, int C, int H, int W, void* stream);
 /* relative coordinates of a14 alone and the query sort key of the training path: rel [B, 2*n_src, Q] (rows
  *   rel_row_s, rel_col_s as in as_liif_gather; may be NULL), key [B,Q] int32 = (nearest pixel of source 0) * 4 + parity of
  *   the nearest pixel of source 1 (may be NULL).  Sorting the queries by key makes the scatter of as_liif_gather_bwd
