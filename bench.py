@@ -292,9 +292,10 @@ def train_main(a, rank, world, local):
             "per_rank_samples_per_s": [round(a.batch_per_gpu * a.steps / v, 3) for v in per_rank],
             "allreduce_overlap": overlap,
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
-            "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample/pool/interp transposes, the update-block/MLP dgrad and "
-                        "the weight gradients of every 1x1 / 3x3 update-block layer (one batched launch per layer and step); the backbone "
-                        "convs and the MLP's linear-layer wgrad on MIOpen/rocBLAS",
+            "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample/pool/interp/gate transposes, forward + dgrad + wgrad of "
+                        "every stride-1 1x1 / 3x3 convolution (update block, MLP Linear layers, backbone layers with >= 16 input "
+                        "channels; one batched wgrad launch per layer and step); strided / 3-channel / 3-D backbone convs, BatchNorm "
+                        "and elementwise glue on MIOpen / ATen",
             "loss_scale": tr.loss_scale, "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu}))
     if dist:
         td.barrier()
