@@ -205,7 +205,7 @@ class LiifGatherMlp1(torch.autograd.Function):
     def backward(ctx, d_h1):
         (h1,) = ctx.saved_tensors
         coord = ctx.coord
-        d_pre = (d_h1 * (h1 > 0)).contiguous()
+        d_pre = torch.ops.aten.threshold_backward(_c(d_h1), h1, 0.0)  # ReLU backward, one launch
         b, c, h0, w0 = ctx.s0
         d_u0 = ops.liif_scatter_add(d_pre, coord, c, h0, w0) if ctx.needs_input_grad[0] else None
         d_u1 = None
