@@ -94,6 +94,11 @@ SIGNATURES = {
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_liif_gather_mlp1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_convex_upsample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_latent": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 10 + [_vp]),
+    "as_liif_latent_bwd": (_i, [_vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "as_convex_upsample_quater": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_convex_upsample_quater_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_affinity_bwd": (_i, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_liif_affinity": (_i, [_pp, C.POINTER(C.c_int), _i, _vp, _vp, _i, _i, _i, _vp]),
     "as_liif_affinity_ws_bytes": (C.c_int64, [_i, _i, _i, _i]),
     "as_liif_lowres_pack_bytes": (C.c_int64, [_i]),

@@ -559,6 +559,85 @@ class InterpBilinear(torch.autograd.Function):
 
 
 # ---- a16/a17: (softmax +) convex 3x3 upsampling at the queries (submodule.py:357-372) ---------------------------
+# ---- §8 f4: off-by-default upsampler options (csrc/liif_variants.hip) ---------------------------------------------------
+class StructureFeatureLive(torch.autograd.Function):
+    """cat(x, affinity(x)) / affinity(x) with the affinity of the LIVE map ('with_ISU', 'with_1_4ISU', 'only_ISU',
+    liif.py:493-495,501-503,534-535): the gradient reaches x through F.normalize and the eight dot products."""
+
+    @staticmethod
+    def forward(ctx, x, with_x):
+        out = ops.structure_feature(x)
+        if not with_x:
+            out = out[:, x.shape[1]:].contiguous()
+        ctx.save_for_backward(x, out)
+        ctx.with_x = bool(with_x)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, out = ctx.saved_tensors
+        return ops.affinity_backward(x, out, _c(d_out), ctx.with_x), None
+
+
+class LiifLatent(torch.autograd.Function):
+    """One source's block of the MLP input (ops.liif_latent).  Backward: the feature channels are scattered back into the
+    map (HIP); a learned frequency table gets d_emb = sum_q (d_sin cos - d_cos sin) rel from the block itself (it holds
+    rel, sin and cos), a [n,Q] x [Q,2] reduction."""
+
+    @staticmethod
+    def forward(ctx, feat, coord, emb, cell, unfold9, n_samp):
+        b, c, h, w = feat.shape
+        q = coord.shape[1]
+        n_enc = 0 if emb is None else emb.shape[0]
+        lat = torch.empty((b, ops.liif_latent_width(c, unfold9, n_samp, n_enc, cell is not None), q), device=feat.device,
+                          dtype=torch.float32)
+        ops.liif_latent(feat, coord, lat, 0, unfold9=unfold9, n_samp=n_samp, emb=emb, cell=cell)
+        ctx.coord = coord  # see LiifGather
+        ctx.shape, ctx.opts, ctx.n_enc = (b, c, h, w), (bool(unfold9), int(n_samp)), n_enc
+        ctx.emb_grad = emb is not None and emb.requires_grad
+        if ctx.emb_grad:
+            ctx.save_for_backward(lat)
+        return lat
+
+    @staticmethod
+    def backward(ctx, d_lat):
+        b, c, h, w = ctx.shape
+        unfold9, n_samp = ctx.opts
+        d_lat = _c(d_lat)
+        d_feat = ops.liif_latent_backward(d_lat, ctx.coord, 0, c, h, w, unfold9=unfold9, n_samp=n_samp) if ctx.needs_input_grad[0] else None
+        d_emb = None
+        if ctx.emb_grad:
+            (lat,) = ctx.saved_tensors
+            o, n = (9 * c if unfold9 else c) * n_samp, ctx.n_enc
+            rel, sn, cs = lat[:, o:o + 2], lat[:, o + 2:o + 2 + n], lat[:, o + 2 + n:o + 2 + 2 * n]
+            dy = d_lat[:, o + 2:o + 2 + n] * cs - d_lat[:, o + 2 + n:o + 2 + 2 * n] * sn  # [B,n,Q]
+            d_emb = torch.einsum("bnq,bkq->nk", dy, rel)
+        return d_feat, None, d_emb, None, None, None
+
+
+class ConvexUpsampleQuater(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, mask, coord, scale, mask_is_logits):
+        ctx.save_for_backward(disp, mask, scale)
+        ctx.coord = coord
+        ctx.logits = bool(mask_is_logits)
+        return ops.convex_upsample_quater(disp, mask, coord, scale=scale, mask_is_logits=ctx.logits)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        disp, mask, scale = ctx.saved_tensors
+        coord = ctx.coord
+        b, _, h, w = disp.shape
+        q = coord.shape[1]
+        d_out = _c(d_out)
+        d_mask = torch.empty_like(mask)
+        d_disp = torch.empty_like(disp) if ctx.needs_input_grad[0] else None
+        with _guard(disp.device):
+            L.check(L.load().as_convex_upsample_quater_bwd(_p(disp), _p(scale), _p(mask), _p(coord), _p(d_out), _p(d_mask), _p(d_disp),
+                                                           b, h, w, q, 1 if ctx.logits else 0, _stream()), "convex_upsample_quater_bwd")
+        return d_disp, d_mask, None, None, None
+
+
 class ConvexUpsample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, disp, mask, coord, scale, mask_is_logits):

@@ -49,10 +49,6 @@ class ContinuousStereoBase(nn.Module):
             raise NotImplementedError(
                 "only the multi_training (arbitrary-scale LIIF) branch is built; the reference's fixed-scale branch "
                 "is dimensionally inconsistent with the default dims (SURVEY.md §0 item 8)")
-        if getattr(args, "disparity_norm", False) or getattr(args, "disparity_norm2", False):
-            raise NotImplementedError("disparity_norm options are off by default and not built")
-        if "type2" in args.agg_type:
-            raise NotImplementedError("agg_type 'type2' (three-input LIIF) is not built")
 
     def _make_update_block(self, args):
         return BasicMultiUpdateBlock(args, hidden_dims=args.hidden_dims, geo_channels=self.geo_channels)
@@ -85,6 +81,37 @@ class ContinuousStereoBase(nn.Module):
         hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)  # side effect of context_upsample_multiscale_train (submodule.py:366)
         with scope("convex_upsample"):
             return ops.convex_upsample(disp, logits, hr_coord, scale=scale_vec, mask_is_logits=True)
+
+    def _upsample_general(self, disp, feats, hr, scale_vec, scale):
+        """upsample_disp for the option sets outside the default (continuous_IGEVstereo.py:192-237): three inputs (agg_type
+        'type2'), the non-default `liif_up` options, quarter-nearest convex sum (submodule.py:375-399), disparity_norm(2)."""
+        a = self.args
+        w = disp.shape[-1]
+        d = disp.float()
+        norm = getattr(a, "disparity_norm", False)
+        norm2 = getattr(a, "disparity_norm2", False) and self.geo_channels > 0  # prune_raft_stereo.py has no disparity_norm2
+        if norm:
+            d, sv = d / w, None
+        elif norm2:
+            d, sv = d / w * 1024, None
+        else:
+            sv = scale_vec  # disp * 4 * scale is applied inside the convex kernel
+        d = d.contiguous()
+        logits = self.liif_up(feats, hr, scale if torch.is_tensor(scale) else scale_vec.view(-1, 1)).contiguous()
+        train = G.needs_grad(d, logits)
+        with scope("convex_upsample"):
+            if a.quater_nearest is not None:
+                up = (G.ConvexUpsampleQuater.apply(d, logits, hr, sv, True) if train
+                      else ops.convex_upsample_quater(d, logits, hr, scale=sv, mask_is_logits=True))
+            else:
+                hr.clamp_(-1 + 1e-6, 1 - 1e-6)  # side effect of context_upsample_multiscale_train (submodule.py:366)
+                up = (G.ConvexUpsample.apply(d, logits, hr, sv, True) if train
+                      else ops.convex_upsample(d, logits, hr, scale=sv, mask_is_logits=True))
+        if norm:
+            up = up * torch.round(w * 4.0 * scale_vec.view(-1, 1, 1))
+        elif norm2:
+            up = up / 1024 * torch.round(w * 4.0 * scale_vec.view(-1, 1, 1))
+        return up
 
     # Training: the queries are random samples of the HR grid (stereo_datasets.py:190-193), ~16 per 1/4-res pixel.  The whole
     # per-query stage (gather, MLP, softmax, convex combination) is order-independent, so it runs on the queries SORTED by
@@ -213,8 +240,6 @@ class ContinuousStereoBase(nn.Module):
     def upsample_disp(self, disp, hidden_layer, stem_4x, stem_2x, stem_1x, hr_coord=None, scale=1):
         """[B,1,h,w] disparity at 1/4 res -> [B,1,Q] at the query coordinates
         (continuous_IGEVstereo.py:192-237, prune_raft_stereo.py:200-242)."""
-        if stem_1x is not None:
-            raise NotImplementedError("stem_1x (agg_type 'type2') is not built")
         b = disp.shape[0]
         if torch.is_tensor(scale):
             scale_vec = scale.reshape(-1).float().to(disp.device)
@@ -224,6 +249,12 @@ class ContinuousStereoBase(nn.Module):
         else:
             scale_vec = torch.full((b,), float(scale), device=disp.device, dtype=torch.float32)
         hr = hr_coord if (hr_coord.dtype == torch.float32 and hr_coord.is_contiguous()) else hr_coord.float().contiguous()
+        a = self.args
+        if (stem_1x is not None or not self.liif_up._default_variant or getattr(a, "disparity_norm", False)
+                or (getattr(a, "disparity_norm2", False) and self.geo_channels > 0)):
+            x = torch.cat((stem_4x.float(), hidden_layer.float()), 1) if stem_4x is not None else hidden_layer.float()
+            feats = [x.contiguous(), stem_2x] if stem_1x is None else [stem_1x, stem_2x, x.contiguous()]  # :207-210
+            return self._upsample_general(disp, [f for f in feats if f is not None], hr, scale_vec, scale)
         parts = [[stem_4x, hidden_layer] if stem_4x is not None else [hidden_layer]] + ([[stem_2x]] if stem_2x is not None else [])
         if (type(self)._hot_upsample is ContinuousStereoBase._hot_upsample
                 and not G.needs_grad(disp, hidden_layer, *self.liif_up.parameters()) and self.liif_up.fused_ok(parts, hr)):
@@ -308,7 +339,7 @@ class ContinuousStereoBase(nn.Module):
         disp.record_stream(main)
         return disp
 
-    def _iterate(self, lookup_fn, net_list, inp_list, disp, coords, iters, test_mode, stem_4x, stem_2x, hr_coord, scale):
+    def _iterate(self, lookup_fn, net_list, inp_list, disp, coords, iters, test_mode, stem_4x, stem_2x, hr_coord, scale, stem_1x=None):
         """The GRU loop shared by both models (continuous_IGEVstereo.py:284-301, prune_raft_stereo.py:276-291)."""
         a = self.args
         disp_preds = []
@@ -323,7 +354,7 @@ class ContinuousStereoBase(nn.Module):
                 and not torch.is_grad_enabled() and getattr(ub, "parallel_encoder", False)
                 and type(self)._hot_update is ContinuousStereoBase._hot_update and self.pipelined_loop):
             disp = self._iterate_pipelined(lookup_fn, net_list, inp_list, disp, coords, iters)
-            disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, None, hr_coord=hr_coord, scale=scale)
+            disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, stem_1x, hr_coord=hr_coord, scale=scale)
             return disp, disp_up, [disp_up]
         for itr in range(iters):
             disp = disp.detach()
@@ -338,7 +369,7 @@ class ContinuousStereoBase(nn.Module):
             disp = disp + delta
             if test_mode and itr < iters - 1:
                 continue
-            disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, None, hr_coord=hr_coord, scale=scale)
+            disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, stem_1x, hr_coord=hr_coord, scale=scale)
             disp_preds.append(disp_up)
         if getattr(self, "liif_up", None) is not None:
             self.liif_up.__dict__.pop("_train_static", None)

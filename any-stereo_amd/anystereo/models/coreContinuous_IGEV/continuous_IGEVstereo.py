@@ -51,11 +51,20 @@ class continuous_IGEVStereo(ContinuousStereoBase):
             nn.Conv2d(context_dims[i], args.hidden_dims[i] * 3, 3, padding=1) for i in range(args.n_gru_layers))
         self.agg_type = args.agg_type
         self.feature = Feature()
-        self.stem_2, self.stem_4 = _stems(args.agg_type)
-        chanels = [48 + args.hidden_dims[2], 32]
+        indim = 48 + 32
+        if "type2" in args.agg_type and not any(t in args.agg_type for t in ("type1", "type3", "type4", "type5")):
+            # three upsampler inputs: a full-resolution stem in front of the two pixel-unshuffle stems (:137-158)
+            self.stem_1 = nn.Sequential(B.BasicConv_IN(3, 8, kernel_size=3, stride=1, padding=1),
+                                        nn.Conv2d(8, 8, 3, 1, 1, bias=False), nn.InstanceNorm2d(8), nn.ReLU())
+            self.stem_2, self.stem_4 = B.plain_stem(8, 32, True), B.plain_stem(32, 48, True)
+            indim = 48 + 32 + 8
+            chanels = [8, 32, 48 + args.hidden_dims[2]]
+        else:
+            self.stem_2, self.stem_4 = _stems(args.agg_type)
+            chanels = [48 + args.hidden_dims[2], 32]
         self.conv = B.BasicConv_IN(96, 96, kernel_size=3, padding=1, stride=1)
         self.desc = nn.Conv2d(96, 96, kernel_size=1, padding=0, stride=1)
-        self.liif_up = self._make_liif(args, 48 + 32 + args.hidden_dims[2], chanels)
+        self.liif_up = self._make_liif(args, indim + args.hidden_dims[2], chanels)
         self.corr_stem = B.BasicConv(8, 8, is_3d=True, kernel_size=3, stride=1, padding=1)
         self.corr_feature_att = B.FeatureAtt(8, 96)
         self.cost_agg = B.hourglass(8)
@@ -74,6 +83,12 @@ class continuous_IGEVStereo(ContinuousStereoBase):
 
     parallel_context = os.environ.get("ANYSTEREO_PARALLEL_CONTEXT", "1") != "0"
     parallel_stems = os.environ.get("ANYSTEREO_PARALLEL_STEMS", "1") != "0"
+
+    def _stems_fwd(self, image):
+        """(stem_1x | None, stem_2x, stem_4x) of one image batch (continuous_IGEVstereo.py:247-256)."""
+        s1 = self.stem_1(image) if hasattr(self, "stem_1") else None
+        s2 = self.stem_2(image if s1 is None else s1)
+        return s1, s2, self.stem_4(s2)
 
     def _context(self, image1):
         """Hidden-state initialisation and the per-level context terms (continuous_IGEVstereo.py:270-273)."""
@@ -104,8 +119,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     if self.parallel_stems:
-                        stem_2b = self.stem_2(both)
-                        stem_4b = self.stem_4(stem_2b)
+                        stem_1b, stem_2b, stem_4b = self._stems_fwd(both)
                         stems_done = torch.cuda.Event()
                         stems_done.record(side)
                     net_list, ctx_list = self._context(image1)
@@ -115,21 +129,21 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                     main.wait_event(stems_done)
                     stem_2b.record_stream(main)
                     stem_4b.record_stream(main)
+                    if stem_1b is not None:
+                        stem_1b.record_stream(main)
                 else:
-                    stem_2b = self.stem_2(both)
-                    stem_4b = self.stem_4(stem_2b)
+                    stem_1b, stem_2b, stem_4b = self._stems_fwd(both)
                 feats[0] = torch.cat((feats[0], stem_4b), 1)
                 match = self.desc(self.conv(feats[0]))
                 features_left = [f[:n] for f in feats]
                 stem_2x, stem_4x = stem_2b[:n], stem_4b[:n]
+                stem_1x = None if stem_1b is None else stem_1b[:n]
                 match_left, match_right = match[:n], match[n:]
             else:
                 features_left = self.feature(image1)
                 features_right = self.feature(image2)
-                stem_2x = self.stem_2(image1)
-                stem_2y = self.stem_2(image2)
-                stem_4x = self.stem_4(stem_2x)
-                stem_4y = self.stem_4(stem_2y)
+                stem_1x, stem_2x, stem_4x = self._stems_fwd(image1)
+                _, _, stem_4y = self._stems_fwd(image2)
                 features_left[0] = torch.cat((features_left[0], stem_4x), 1)
                 features_right[0] = torch.cat((features_right[0], stem_4y), 1)
                 match_left = self.desc(self.conv(features_left[0]))
@@ -159,7 +173,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
         coords._as_pixel_grid = True  # the kernels regenerate this grid: mark it so the lookup need not compare it
         disp, disp_up, disp_preds = self._iterate(geo_fn, net_list, inp_list, init_disp.float(), coords, iters, test_mode,
-                                                  stem_4x, stem_2x, hr_coord, scale)
+                                                  stem_4x, stem_2x, hr_coord, scale, stem_1x=stem_1x)
         if test_mode:
             return disp_up
         return init_disp.squeeze(1), disp_preds

@@ -52,9 +52,15 @@ class continuous_RaftStereo(ContinuousStereoBase):
             if "IGEV" in args.agg_type:
                 # the reference leaves `chanels` undefined on this branch (prune_raft_stereo.py:110-121)
                 chanels = [48 + args.hidden_dims[2], 32]
+        elif "type2" in args.agg_type:
+            # three upsampler inputs: a full-resolution stem in front of the two pixel-unshuffle stems (:156-177)
+            self.stem_1 = nn.Sequential(B.BasicConv_IN(3, 8, kernel_size=3, stride=1, padding=1),
+                                        nn.Conv2d(8, 8, 3, 1, 1, bias=False), nn.InstanceNorm2d(8), nn.ReLU())
+            self.stem_2, self.stem_4 = B.plain_stem(8, 32, True), B.plain_stem(32, 48, True)
+            indim, chanels = 48 + 32 + 8, [8, 32, 48 + args.hidden_dims[2]]
         else:
             indim, chanels = 0, [args.hidden_dims[2]]
-        self._has_stems = s2 is not None
+        self._has_stems = hasattr(self, "stem_2")
         self.liif_up = self._make_liif(args, indim + args.hidden_dims[2], chanels)
 
     def _hot_lookup_fn(self, match_left, match_right):
@@ -69,10 +75,12 @@ class continuous_RaftStereo(ContinuousStereoBase):
         net_list = [torch.tanh(x[0]) for x in cnet_list]
         inp_list = [torch.relu(x[1]) for x in cnet_list]
         ctx_list = [conv(i) for i, conv in zip(inp_list, self.context_zqr_convs)]
-        stem_2x = stem_4x = None
+        stem_1x = stem_2x = stem_4x = None
         if self._has_stems:
-            stem_2x = self.stem_2(image1)
+            stem_1x = self.stem_1(image1) if hasattr(self, "stem_1") else None
+            stem_2x = self.stem_2(image1 if stem_1x is None else stem_1x)
             stem_4x = self.stem_4(stem_2x)
+        self.__dict__["_stem_1x"] = stem_1x
         return net_list, ctx_list, stem_2x, stem_4x
 
     def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=False):
@@ -93,7 +101,7 @@ class continuous_RaftStereo(ContinuousStereoBase):
                 net_list, ctx_list, stem_2x, stem_4x = self._context(image1)
             else:
                 main.wait_stream(side)
-                for t in net_list + ctx_list + [t for t in (stem_2x, stem_4x) if t is not None]:
+                for t in net_list + ctx_list + [t for t in (stem_2x, stem_4x, self.__dict__.get("_stem_1x")) if t is not None]:
                     t.record_stream(main)
         net_list = [n.float() for n in net_list]
         inp_list = [list(c.float().split(split_size=c.shape[1] // 3, dim=1)) for c in ctx_list]
@@ -104,7 +112,7 @@ class continuous_RaftStereo(ContinuousStereoBase):
         coords._as_pixel_grid = True  # the kernels regenerate this grid: mark it so the lookup need not compare it
         disp0 = match_left.new_zeros((b, 1, h, w), dtype=torch.float32)
         disp, disp_up, disp_preds = self._iterate(corr_fn, net_list, inp_list, disp0, coords, iters, test_mode,
-                                                  stem_4x, stem_2x, hr_coord, scale)
+                                                  stem_4x, stem_2x, hr_coord, scale, stem_1x=self.__dict__.pop("_stem_1x", None))
         if test_mode:
             return (disp, disp_up) if output_raw else disp_up
         return disp_preds

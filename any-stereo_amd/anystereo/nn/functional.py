@@ -46,3 +46,12 @@ def context_upsample_multiscale_train(disp_low, up_weights, hr_coord):
     if G.needs_grad(d, m):
         return G.ConvexUpsample.apply(d, m, c, None, False)[:, 0]
     return ops.convex_upsample(d, m, c, scale=None, mask_is_logits=False)[:, 0]
+
+
+def context_upsample_multiscale_train_quaterp(disp_low, up_weights, hr_coord):
+    """Four-sample convex upsampling -> [B,Q] (submodule.py:375-399): disp_low [B,1,h,w] (already scaled), up_weights [B,4,Q]
+    (already softmaxed), hr_coord [B,Q,2] — NOT clamped in place by this variant."""
+    d, m, c = disp_low.float().contiguous(), up_weights.float().contiguous(), hr_coord.float().contiguous()
+    if G.needs_grad(d, m):
+        return G.ConvexUpsampleQuater.apply(d, m, c, None, False)[:, 0]
+    return ops.convex_upsample_quater(d, m, c, scale=None, mask_is_logits=False)[:, 0]

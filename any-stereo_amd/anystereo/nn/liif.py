@@ -3,9 +3,11 @@ models/*/liif.py (MLP :9-25, make_coord :32-45, liif_feat_multiscale_train :108-
 AffinityFeature :417-446, StructureFeature 'with_v2ISU' :496-499,
 liif_out_multi_scale_Training :575-678).
 
-Only the default-configuration branch is implemented (unfold_similarity='with_v2ISU', pos_dim=0,
-no positional encoding / cell decode / local ensemble / quarter-nearest); any other option raises
-at construction (SURVEY.md §2 row 5 lists them as out of scope).
+The default configuration (unfold_similarity='with_v2ISU', pos_dim=0) takes the fused kernels; every other option set the
+reference can run ('with_ISU', 'with_1_4ISU', 'with_embed_ISU', 'only_ISU', 'only_unfold', no structure feature, Fourier
+position encoding fixed or learned, cell decoding, quarter-nearest sampling, three inputs) takes the general latent builder
+(csrc/liif_variants.hip), pinned by tests/golden/liif_variants.npz.  Option sets the reference itself cannot run build the same
+parameters and fail at forward (see _DEAD).
 
 Data layout: the per-query latent is built CHANNEL-major, latent[B, 228, Q], so that
   * the gather kernel's stores are coalesced along Q,
@@ -68,51 +70,193 @@ class MLP(nn.Module):
         return y.permute(0, 2, 1).reshape(*shape, -1)
 
 
+# Option sets the REFERENCE cannot run (tests/golden/liif_variants.json records how it fails); they construct — state-dict
+# parity — and fail at forward with the reference's failure named, instead of computing something the reference never did.
+_DEAD = {
+    "dilated": "AffinityFeature with dilation > 1: the reference pads by win_w//2 = 1 whatever the dilation, its Unfold then "
+               "yields fewer than H*W windows and the reshape at liif.py:437-438 raises (all '*Dila_*', 'with_1_43*', "
+               "'with_3v2ISU' modes)",
+    "pos_enconding_new": "pos_enconding_new: PositionEncoder is built with enc_dims = 2 (liif.py:591-592 after :588), its "
+                         "frequency table is empty and the projection at liif.py:274 raises",
+}
+
+
 class AffinityFeature(nn.Module):
-    """3x3 cosine affinity (liif.py:417-446); dilation 1 only (the 'with_v2ISU' branch uses Affi1)."""
+    """3x3 cosine affinity to the 8 neighbours (liif.py:417-446).  Dilation 1 is the only window the reference can evaluate."""
 
     def __init__(self, win_h, win_w, dilation, cut):
         super().__init__()
-        if (win_h, win_w, dilation) != (3, 3, 1):
-            raise NotImplementedError("AffinityFeature: only the 3x3, dilation-1 window of the default config is built")
+        if (win_h, win_w) != (3, 3):
+            raise NotImplementedError("AffinityFeature: only the 3x3 window (lsp_width = lsp_height = 3) is built")
         self.win_w, self.win_h, self.dilation, self.cut = win_w, win_h, dilation, 0
+        self._padding = win_w // 2
 
     def forward(self, feature):
+        if self.dilation != 1:
+            raise RuntimeError(_DEAD["dilated"])
         x = feature.float().contiguous()
+        if G.needs_grad(x):
+            return G.StructureFeatureLive.apply(x, False)
         return ops.structure_feature(x)[:, x.shape[1]:]
 
 
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
+    """conv (no bias) + BatchNorm2d with the reference's layout `0` / `1` (liif.py:27-30)."""
+    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                                   padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
+                         nn.BatchNorm2d(out_planes))
+
+
 class StructureFeature(nn.Module):
-    """cat(x, Affi1(x.detach())) — the 'with_v2ISU' branch (liif.py:496-499)."""
+    """liif.py:448-572.  Modes the reference can run: 'with_ISU' / 'with_1_4ISU' cat(x, Affi1(x)); 'with_v2ISU' (default)
+    cat(x, Affi1(x.detach())); 'with_embed_ISU' sfc_embeding(cat(x, Affi1(x.detach()))); 'only_ISU' Affi1(x).  The dilated
+    modes build the reference's sub-modules (same state-dict keys) and raise at forward like the reference does."""
 
     def __init__(self, affinity_settings, unfold, input_chanels):
         super().__init__()
-        if unfold != "with_v2ISU":
-            raise NotImplementedError(f"StructureFeature: unfold_similarity={unfold!r} is not built (default: 'with_v2ISU')")
         self.win_w, self.win_h = affinity_settings["win_w"], affinity_settings["win_h"]
         self.dilation, self.unfold = affinity_settings["dilation"], unfold
-        self.Affi1 = AffinityFeature(self.win_h, self.win_w, self.dilation[0], 0)
+        in_c = self.win_w * self.win_h - 1
+        d = self.dilation
+        self.Affi1 = AffinityFeature(self.win_h, self.win_w, d[0], 0)
+        relu_bn = lambda ci, co: nn.Sequential(convbn(ci, co, 1, 1, 0, 1), nn.ReLU(inplace=True))  # noqa: E731
+        if "Dila_ISU" in unfold:
+            for i in (2, 3, 4):
+                setattr(self, f"Affi{i}", AffinityFeature(self.win_h, self.win_w, d[i - 1], 0))
+            for i in (1, 2, 3, 4):
+                setattr(self, f"sfc_conv{i}", relu_bn(in_c, in_c))
+        elif "Dila_3ISU" in unfold:
+            self.sfc_embeding = convbn(input_chanels, input_chanels // 4, 1, 1, 0, 1)
+            self.Affi2 = AffinityFeature(self.win_h, self.win_w, d[1], 0)
+            self.Affi3 = AffinityFeature(self.win_h, self.win_w, d[2], 0)
+        elif "Dila_2ISU" in unfold:
+            self.sfc_embeding = convbn(input_chanels, input_chanels // 4, 1, 1, 0, 1)
+            self.Affi2 = AffinityFeature(self.win_h, self.win_w, d[1], 0)
+        elif "with_1_43ISU" in unfold:
+            self.Affi2 = AffinityFeature(self.win_h, self.win_w, d[1], 0)
+            self.Affi3 = AffinityFeature(self.win_h, self.win_w, d[2], 0)
+            for i in (1, 2, 3):
+                setattr(self, f"sfc_conv{i}", relu_bn(in_c, in_c // 2))
+        elif "with_1_43v2ISU" in unfold or "with_3v2ISU" in unfold:
+            self.Affi2 = AffinityFeature(self.win_h, self.win_w, d[1], 0)
+            self.Affi3 = AffinityFeature(self.win_h, self.win_w, d[2], 0)
+        elif "with_embed_ISU" in unfold:
+            self.sfc_embeding = convbn(input_chanels + 8, input_chanels + 8, 1, 1, 0, 1)
 
     def forward(self, x):
+        u = self.unfold
         x = x.float().contiguous()
-        return G.StructureFeature.apply(x) if G.needs_grad(x) else ops.structure_feature(x)
+        grad = G.needs_grad(x)
+        if "with_ISU" in u or "with_1_4ISU" in u:
+            return G.StructureFeatureLive.apply(x, True) if grad else ops.structure_feature(x)
+        if "with_v2ISU" in u:
+            return G.StructureFeature.apply(x) if grad else ops.structure_feature(x)
+        if "with_embed_ISU" in u:
+            conv, bn = self.sfc_embeding[0], self.sfc_embeding[1]
+            if grad or bn.training or G.needs_grad(conv.weight):
+                return bn(G.module_conv2d(self, "embed", conv, G.StructureFeature.apply(x) if grad else ops.structure_feature(x)))
+            if not hasattr(self, "_pk_embed"):
+                self._pk_embed = ops.PackedConv()
+            return ops.conv2d([ops.structure_feature(x)], self._pk_embed.get_folded(conv, bn))
+        if "only_ISU" in u:
+            return self.Affi1(x)
+        if any(k in u for k in ("Dila_", "with_1_43", "with_3v2ISU")):
+            raise RuntimeError(_DEAD["dilated"])
+        return x  # liif.py:492-572 falls through to `return x` for any other string
+
+
+class SpatialEncoding(nn.Module):
+    """Fourier features of the relative coordinate (liif.py:339-370): x -> cat(x, sin(x emb^T), cos(x emb^T)) with
+    emb = per-axis frequencies 2^linspace(0, sigma, n); a Parameter (`emb`) when require_grad.  On the hot path the encoding is
+    evaluated inside the latent builder (ops.liif_latent); `forward` is the reference's tensor-level contract."""
+
+    def __init__(self, in_dim, out_dim, sigma=6, cat_input=True, require_grad=False):
+        super().__init__()
+        assert out_dim % (2 * in_dim) == 0, "dimension must be dividable"
+        import numpy as np
+        n = out_dim // 2 // in_dim
+        m = 2 ** np.linspace(0, sigma, n)
+        m = np.stack([m] + [np.zeros_like(m)] * (in_dim - 1), axis=-1)
+        m = np.concatenate([np.roll(m, i, axis=-1) for i in range(in_dim)], axis=0)
+        self.emb = torch.tensor(m, dtype=torch.float32)
+        if require_grad:
+            self.emb = nn.Parameter(self.emb, requires_grad=True)
+        self.in_dim, self.out_dim, self.sigma, self.cat_input, self.require_grad = in_dim, out_dim, sigma, cat_input, require_grad
+
+    def table(self, device):
+        if not self.require_grad and self.emb.device != device:
+            self.emb = self.emb.to(device)  # the reference moves the plain tensor on first use (liif.py:360-361)
+        return self.emb
+
+    def forward(self, x):
+        if self.in_dim != 2 or not self.cat_input:
+            raise NotImplementedError("SpatialEncoding: only the 2-D, cat_input form the upsampler uses is built")
+        shape = x.shape[:-1]
+        rel = x.reshape(1, -1, 2).float().contiguous()
+        q = rel.shape[1]
+        emb = self.table(x.device).contiguous()
+        dummy = torch.zeros((1, 1, 1, 1), device=x.device, dtype=torch.float32)
+        if G.needs_grad(emb):
+            raise NotImplementedError("SpatialEncoding.forward under autograd: use the upsampler (grad.LiifLatent)")
+        # the latent builder recomputes rel from coordinates; here rel is GIVEN, so feed it as the coordinate of a 1x1 map whose
+        # cell centre is 0 and whose size is 1: rel' = (x - 0) * 1
+        lat = torch.empty((1, 1 + 2 + 2 * emb.shape[0], q), device=x.device, dtype=torch.float32)
+        ops.liif_latent(dummy, rel, lat, 0, emb=emb)
+        return lat[0, 1:].t().reshape(*shape, -1)
+
+
+class PositionEncoder(nn.Module):
+    """liif.py:178-337, as the upsampler constructs it (posenc_type='sinusoid', head=8): `proj` keeps the state-dict keys; the
+    reference's forward cannot run in that construction, see _DEAD."""
+
+    def __init__(self, posenc_type=None, complex_transform=False, posenc_scale=6, gauss_scale=1, in_dims=2, enc_dims=256,
+                 hidden_dims=32, head=1, gamma=1):
+        super().__init__()
+        if posenc_type != "sinusoid":
+            raise NotImplementedError("PositionEncoder: only the 'sinusoid' construction of the upsampler is mirrored")
+        self.posenc_type, self.enc_dims, self.head = posenc_type, enc_dims, head
+        self.proj = nn.Linear(enc_dims, head)
+
+    def forward(self, positions, cells=None):
+        raise RuntimeError(_DEAD["pos_enconding_new"])
+
+
+def _cells(coords, scale):
+    """decode_cell (liif.py:111-114): ones_like(coords) with both columns set to 2/scale — the reference's own broadcasting
+    (scale [B,1] gives one value per batch element; a [B] vector only fits B = 1 or B = Q, as in the reference)."""
+    cells = torch.ones_like(coords)
+    cells[:, :, 0] = 2 / scale
+    cells[:, :, 1] = 2 / scale
+    return cells
+
+
+def _latent_block(feat, coords, unfold9=False, n_samp=1, emb=None, cell=None):
+    feat = feat.float().contiguous()
+    coords = coords.float().contiguous()
+    if G.needs_grad(feat, emb):
+        return G.LiifLatent.apply(feat, coords, emb, cell, unfold9, n_samp)
+    b, c = feat.shape[:2]
+    lat = torch.empty((b, ops.liif_latent_width(c, unfold9, n_samp, 0 if emb is None else emb.shape[0], cell is not None),
+                       coords.shape[1]), device=feat.device, dtype=torch.float32)
+    ops.liif_latent(feat, coords, lat, 0, unfold9=unfold9, n_samp=n_samp, emb=emb, cell=cell)
+    return lat
 
 
 def liif_feat_multiscale_train(feat, coords, scale=None, local=False, cell=False):
-    """(rel_coord [B,Q,2], q_feat [B,Q,C], None) — reference contract of liif.py:108-137."""
-    if local or cell:
-        raise NotImplementedError("local ensemble / cell decoding are not built (off in the default config)")
-    feat = feat.float().contiguous()
-    coords = coords.float().contiguous()
-    b, c = feat.shape[:2]
-    q = coords.shape[1]
-    if G.needs_grad(feat):
-        lat = G.LiifGather.apply(feat, coords)
-    else:
-        lat = torch.empty((b, c + 2, q), device=feat.device, dtype=torch.float32)
-        ops.liif_gather(feat, coords, lat, 0)
-    lat = lat.permute(0, 2, 1)
-    return lat[..., c:], lat[..., :c], None
+    """(rel_coord [B,Q,2], q_feat [B,Q,C], cells | None) — reference contract of liif.py:108-137."""
+    cells = _cells(coords, scale) if cell else None
+    c = feat.shape[1]
+    lat = _latent_block(feat, coords).permute(0, 2, 1)
+    assert not local  # liif.py:136-137
+    return lat[..., c:c + 2], lat[..., :c], cells
+
+
+def liif_feat_multiscale_train_quater(feat, coords, scale=None, local=False, cell=False):
+    """Four half-cell shifted nearest samples, rel to their centre (liif.py:140-176): (rel [B,Q,2], q_feat [B,Q,4C], cells)."""
+    cells = _cells(coords, scale) if cell else None
+    c4 = feat.shape[1] * 4
+    lat = _latent_block(feat, coords, n_samp=4).permute(0, 2, 1)
+    return lat[..., c4:c4 + 2], lat[..., :c4], cells
 
 
 class liif_out_multi_scale_Training(nn.Module):
@@ -120,26 +264,114 @@ class liif_out_multi_scale_Training(nn.Module):
                  pos_enconding_new=False, local_ensemble=False, decode_cell=False, unfold=False, affinity_settings=None,
                  quater_nearest=None, require_grad=True, number_input=3, chanels=0):
         super().__init__()
-        unsupported = {"pos_dim": pos_dim != 0, "pos_enconding": pos_enconding, "pos_enconding_new": pos_enconding_new,
-                       "local_ensemble": local_ensemble, "decode_cell": decode_cell,
-                       "quater_nearest": quater_nearest is not None, "unfold": unfold != "with_v2ISU"}
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
-            raise NotImplementedError(f"liif_out_multi_scale_Training: non-default options {bad} are not built")
         self.local_ensemble, self.decode_cell, self.unfold = local_ensemble, decode_cell, unfold
         self.pos_enconding, self.pos_enconding_new, self.quater_nearest = pos_enconding, pos_enconding_new, quater_nearest
         self.encoder_dim = encoder_dim
         self.pos_dim = 2
+        if pos_dim != 0:  # liif.py:587-596
+            if pos_enconding:
+                self.pos_encoding = SpatialEncoding(2, pos_dim, require_grad=require_grad)
+                self.pos_dim = pos_dim + 2
+            elif pos_enconding_new:
+                self.pos_encoding = PositionEncoder(posenc_type="sinusoid", posenc_scale=10, hidden_dims=self.pos_dim,
+                                                    enc_dims=self.pos_dim, head=8)
+                self.pos_dim = 8
+            else:
+                self.pos_encoding = SpatialEncoding(2, pos_dim, require_grad=require_grad)  # built, never applied
         self.outputdim = 9
         in_c = affinity_settings["win_h"] * affinity_settings["win_w"] - 1
-        self.to_sf_l2 = nn.ModuleList(StructureFeature(affinity_settings, unfold, input_chanels=c) for c in chanels)
-        imnet_in_dim = encoder_dim + in_c * number_input + self.pos_dim * number_input
+        imnet_in_dim = encoder_dim
+        self._single_sf = False
+        if unfold is not None:  # liif.py:599-635
+            if unfold is False or not isinstance(unfold, str):
+                raise TypeError("unfold_similarity must be a mode string or None (liif.py:600 tests `in self.unfold`)")
+            self._single_sf = any(k in unfold for k in ("with_1_4ISU", "with_1_43ISU", "with_1_43v2ISU"))
+            if self._single_sf:
+                self.to_sf_l2 = StructureFeature(affinity_settings, unfold, input_chanels=None)
+            else:
+                self.to_sf_l2 = nn.ModuleList(StructureFeature(affinity_settings, unfold, input_chanels=c) for c in chanels)
+            table = (("only_unfold", lambda d: d * 9), ("with_1_4ISU", lambda d: d + in_c), ("with_1_43ISU", lambda d: d + (in_c // 2) * 3),
+                     ("with_1_43v2ISU", lambda d: d + in_c * 3), ("with_3v2ISU", lambda d: d + in_c * 3 * number_input),
+                     ("with_ISU", lambda d: d + in_c * number_input), ("with_v2ISU", lambda d: d + in_c * number_input),
+                     ("with_embed_ISU", lambda d: d + in_c * number_input), ("only_ISU", lambda d: in_c * number_input),
+                     ("with_Dila_ISU", lambda d: d + in_c * 4 * number_input), ("only_Dila_ISU", lambda d: in_c * 4 * number_input),
+                     ("with_Dila_3ISU", lambda d: d + in_c * 3 * number_input), ("only_Dila_3ISU", lambda d: in_c * 3 * number_input),
+                     ("with_Dila_2ISU", lambda d: d + in_c * 2 * number_input), ("only_Dila_2ISU", lambda d: in_c * 2 * number_input))
+            for key, fn in table:
+                if key in unfold:
+                    imnet_in_dim = fn(imnet_in_dim)
+                    break
+            else:
+                assert False, f"unknown unfold_similarity {unfold!r}"  # liif.py:634-635
+        if quater_nearest is not None:
+            self.outputdim = 4
+            if "both" in quater_nearest:
+                imnet_in_dim = imnet_in_dim * 4
+        imnet_in_dim = imnet_in_dim + self.pos_dim * number_input
+        if decode_cell:
+            imnet_in_dim = imnet_in_dim + 2 * number_input
         self.imnet = MLP(imnet_in_dim, self.outputdim, hidden_list=mlphidden_list)
+        # the fused / low-resolution-first-layer fast paths serve the default option set; everything else takes the general
+        # latent builder (same function, csrc/liif_variants.hip)
+        self._default_variant = (unfold == "with_v2ISU" and not pos_enconding and not pos_enconding_new and not decode_cell
+                                 and not local_ensemble and quater_nearest is None)
+
+    # ---- general path: any option set the reference can run ---------------------------------------------------------------
+    def _structure(self, feats):
+        """The per-source feature maps after the `unfold_similarity` stage (liif.py:652-660)."""
+        if self.unfold is None or "only_unfold" in self.unfold:
+            return [f.float().contiguous() for f in feats]
+        if self._single_sf:
+            return [self.to_sf_l2(f) if i == 0 else f.float().contiguous() for i, f in enumerate(feats)]
+        return [sf(f) for sf, f in zip(self.to_sf_l2, feats)]
+
+    def _mask_logits_general(self, feats, coord, scale):
+        if self.local_ensemble:
+            raise AssertionError("local_ensemble: liif_feat_multiscale_train ends in `assert False` for it (liif.py:136-137)")
+        if self.pos_enconding_new and hasattr(self, "pos_encoding") and isinstance(self.pos_encoding, PositionEncoder):
+            raise RuntimeError(_DEAD["pos_enconding_new"])
+        with scope("structure_feature"):
+            sfs = self._structure(feats)
+        unfold9 = self.unfold is not None and "only_unfold" in self.unfold
+        n_samp = 4 if (self.quater_nearest is not None and "both" in self.quater_nearest) else 1
+        emb = self.pos_encoding.table(coord.device).contiguous() if (self.pos_enconding and hasattr(self, "pos_encoding")) else None
+        cell = _cells(coord, scale).contiguous() if self.decode_cell else None
+        widths = [ops.liif_latent_width(s.shape[1], unfold9, n_samp, 0 if emb is None else emb.shape[0], cell is not None) for s in sfs]
+        if sum(widths) != self.imnet.layers[0].weight.shape[1]:
+            raise RuntimeError(f"liif: inputs hold {sum(widths)} latent channels but the MLP expects {self.imnet.layers[0].weight.shape[1]}")
+        lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
+        if G.needs_grad(*sfs, emb, *self.imnet.parameters()):
+            x = torch.cat([G.LiifLatent.apply(s, coord, emb, cell, unfold9, n_samp) for s in sfs], dim=1)
+            for i, m in enumerate(lin):
+                x = G.pointwise_linear(self, id(m), x, m, i + 1 < len(lin))
+            return x
+        b, q = coord.shape[:2]
+        out = torch.empty((b, self.outputdim, q), device=coord.device, dtype=torch.float32)
+        # slabs keep the [B,ctot,Q] latent below ~1 GB whatever the option set (only_unfold: 1876 channels)
+        qmax = max(1 << 12, min(self.query_chunk, (1 << 28) // max(1, b * sum(widths))))
+        for q0 in range(0, q, qmax):
+            q1 = min(q, q0 + qmax)
+            cs = coord if (q0 == 0 and q1 == q) else coord[:, q0:q1].contiguous()
+            cl = cell if (cell is None or (q0 == 0 and q1 == q)) else cell[:, q0:q1].contiguous()
+            latent = torch.empty((b, sum(widths), q1 - q0), device=coord.device, dtype=torch.float32)
+            off = 0
+            with scope("liif_gather"):
+                for s, wd in zip(sfs, widths):
+                    ops.liif_latent(s, cs, latent, off, unfold9=unfold9, n_samp=n_samp, emb=emb, cell=cl)
+                    off += wd
+            with scope("liif_mlp"):
+                res = self.imnet.forward_cm(latent)
+            if q0 == 0 and q1 == q:
+                return res
+            out[:, :, q0:q1] = res
+        return out
 
     def forward(self, feats, coord, scale=None):
         """feats: list of [B,C_i,H_i,W_i]; coord [B,Q,2] (row, col) -> mask logits [B,9,Q] (liif.py:644-678)."""
         coord = coord.float().contiguous()
         b, q = coord.shape[:2]
+        if not self._default_variant:
+            return self._mask_logits_general(feats, coord, scale)
         if G.needs_grad(*feats, *self.imnet.parameters()):
             return self._mask_logits_train(feats, coord)
         with scope("structure_feature"):
@@ -192,7 +424,7 @@ class liif_out_multi_scale_Training(nn.Module):
         """The one-kernel tail exists for the default configuration: <= 2 inputs, MLP 128-64-64-9, split-precision mode,
         inference.  Everything else takes the staged path (same function)."""
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
-        return (self.fused_tail and coord.is_cuda and not torch.is_grad_enabled() and len(feats_parts) in (1, 2)
+        return (self.fused_tail and self._default_variant and coord.is_cuda and not torch.is_grad_enabled() and len(feats_parts) in (1, 2)
                 and [tuple(m.weight.shape) for m in lin[1:]] == [(64, 128), (64, 64), (9, 64)] and lin[0].weight.shape[0] == 128
                 and ops.get_precision() == "split" and all(len(ps) <= 2 for ps in feats_parts)
                 and all(p.shape[1] % 16 == 0 for ps in feats_parts for p in ps))

@@ -1005,6 +1005,83 @@ def convex_upsample(disp, mask, coord, scale=None, mask_is_logits=False):
     return out
 
 
+# ---- §8 f4: off-by-default upsampler options (csrc/liif_variants.hip) ---------------------------------------------------
+def liif_latent_width(c, unfold9=False, n_samp=1, n_enc=0, cell=False):
+    """Channels one source occupies in the MLP input (see as_liif_latent in the header)."""
+    return (9 * c if unfold9 else c) * n_samp + 2 + 2 * n_enc + (2 if cell else 0)
+
+
+def liif_latent(feat, coord, latent, lat_coff, unfold9=False, n_samp=1, emb=None, cell=None) -> None:
+    """One source's block [features | rel | sin/cos encoding | cell] of the MLP input, channel-major (liif.py:652-676 with the
+    options of :108-176, :339-370)."""
+    _req(feat, "feat"), _req(coord, "coord"), _req(latent, "latent")
+    b, c, h, w = feat.shape
+    q = coord.shape[1]
+    if tuple(coord.shape) != (b, q, 2) or latent.shape[0] != b or latent.shape[2] != q:
+        raise RuntimeError("liif_latent: coord must be [B,Q,2] and latent [B,Ctot,Q]")
+    n_enc = 0
+    if emb is not None:
+        _req(emb, "emb")
+        if emb.dim() != 2 or emb.shape[1] != 2:
+            raise RuntimeError("liif_latent: emb must be [n,2]")
+        n_enc = emb.shape[0]
+    if cell is not None:
+        _req(cell, "cell")
+        if tuple(cell.shape) != (b, q, 2):
+            raise RuntimeError("liif_latent: cell must be [B,Q,2]")
+    with _guard(feat.device):
+        L.check(L.load().as_liif_latent(_p(feat), _p(coord), _p(emb), _p(cell), _p(latent), b, c, h, w, q, latent.shape[1], lat_coff,
+                                        1 if unfold9 else 0, n_samp, n_enc, _stream()), "liif_latent")
+
+
+def liif_latent_backward(d_latent, coord, lat_coff, c, h, w, unfold9=False, n_samp=1):
+    """d_feat [B,C,H,W]: scatter-add of the feature channels of one source's block."""
+    _req(d_latent, "d_latent"), _req(coord, "coord")
+    b, ctot, q = d_latent.shape
+    d_feat = torch.empty((b, c, h, w), device=d_latent.device, dtype=torch.float32)
+    with _guard(d_latent.device):
+        L.check(L.load().as_liif_latent_bwd(_p(d_latent), _p(coord), _p(d_feat), b, c, h, w, q, ctot, lat_coff, 1 if unfold9 else 0,
+                                            n_samp, _stream()), "liif_latent_bwd")
+    return d_feat
+
+
+def convex_upsample_quater(disp, mask, coord, scale=None, mask_is_logits=False):
+    """Four-sample convex combination -> [B,1,Q] (context_upsample_multiscale_train_quaterp, submodule.py:375-399)."""
+    _req(disp, "disp"), _req(mask, "mask"), _req(coord, "coord")
+    b, one, h, w = disp.shape
+    q = coord.shape[1]
+    if one != 1 or tuple(mask.shape) != (b, 4, q) or tuple(coord.shape) != (b, q, 2):
+        raise RuntimeError("convex_upsample_quater: disp [B,1,h,w], mask [B,4,Q], coord [B,Q,2] expected")
+    if scale is not None:
+        _req(scale, "scale")
+        if scale.numel() != b:
+            raise RuntimeError("convex_upsample_quater: scale must hold one value per batch element")
+    out = torch.empty((b, 1, q), device=disp.device, dtype=torch.float32)
+    with _guard(disp.device):
+        L.check(L.load().as_convex_upsample_quater(_p(disp), _p(scale), _p(mask), _p(coord), _p(out), b, h, w, q,
+                                                   1 if mask_is_logits else 0, _stream()), "convex_upsample_quater")
+    return out
+
+
+def affinity_backward(x, sf_out, d_out, with_x: bool):
+    """Gradient w.r.t. x of cat(x, affinity(x)) (with_x) or of affinity(x) alone, the affinity taken on the LIVE map.
+    sf_out / d_out: the forward output and its gradient ([B,C+8,H,W] or [B,8,H,W])."""
+    _req(x, "x"), _req(sf_out, "sf_out"), _req(d_out, "d_out")
+    b, c, h, w = x.shape
+    ctot = c + 8 if with_x else 8
+    if tuple(sf_out.shape) != (b, ctot, h, w) or tuple(d_out.shape) != (b, ctot, h, w):
+        raise RuntimeError("affinity_backward: forward output / gradient shape mismatch")
+    plane = h * w
+    skip = c * plane * 4 if with_x else 0
+    dx = torch.empty_like(x)
+    ws = torch.empty((b, h, w), device=x.device, dtype=torch.float32)
+    with _guard(x.device):
+        L.check(L.load().as_affinity_bwd(_p(x), sf_out.data_ptr() + skip, ctot * plane, d_out.data_ptr() + skip, ctot * plane,
+                                         _p(d_out) if with_x else None, ctot * plane, _p(dx), _p(ws), b, c, h, w, _stream()),
+                "affinity_bwd")
+    return dx
+
+
 # ------------------------------------------------------------------------------------------------
 # LIIF upsampler, fused inference pipeline (csrc/liif_fused.hip)
 # ------------------------------------------------------------------------------------------------

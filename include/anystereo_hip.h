@@ -425,6 +425,39 @@ int as_liif_rel_key(const float* coord, float* rel, int* key, int B, int Q, int 
 int as_convex_upsample_bwd(const float* disp, const float* scale, const float* mask, const float* coord, const float* d_out,
                            float* d_mask, float* d_disp, int B, int H, int W, int Q, int mask_is_logits, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * §8 f4: the implicit upsampler's off-by-default options (csrc/liif_variants.hip)
+ *
+ * as_liif_latent   one source's block of the MLP input, CHANNEL-major, in ONE launch (liif_out_multi_scale_Training.forward,
+ *                  liif.py:652-676): latent[b, lat_coff + ..., q] = [ gathered features | rel_row, rel_col | sin/cos encoding |
+ *                  cell ].  Features: C channels of the nearest pixel (liif_feat_multiscale_train, liif.py:108-137); with
+ *                  unfold9 its zero-padded 3x3 neighbourhood, channel c*9 + ky*3 + kx (F.unfold, liif.py:655); with n_samp = 4
+ *                  the four half-cell shifted nearest samples, blocks in (vx, vy) = (-1,-1), (-1,1), (1,-1), (1,1) order, and
+ *                  rel taken to the mean of the first and last sample's cell centres (liif_feat_multiscale_train_quater,
+ *                  liif.py:140-176).  emb [n_enc,2] (NULL when n_enc = 0) are the frequency rows of SpatialEncoding: the block
+ *                  [rel, sin(rel·emb^T), cos(rel·emb^T)] replaces rel (liif.py:339-370, cat_input).  cell [B,Q,2] or NULL is
+ *                  appended as is (decode_cell, liif.py:111-114,673).  Block width = (unfold9 ? 9C : C)*n_samp + 2 + 2*n_enc +
+ *                  (cell ? 2 : 0), checked against [lat_coff, lat_ctot).
+ * as_liif_latent_bwd  d_feat [B,C,H,W] = scatter-add of the block's feature channels (zero-filled here).
+ * as_convex_upsample_quater(_bwd)  out[b,q] = sum_k w_k(q) * disp[b, nearest(coord + shift_k)] * (4*scale_b), four shifted
+ *                  samples instead of the 3x3 window, mask [B,4,Q] (context_upsample_multiscale_train_quaterp,
+ *                  submodule.py:375-399; scale / logits handling as in as_convex_upsample); the coordinates are NOT clamped
+ *                  in place by this variant.
+ * as_affinity_bwd  gradient of cat(x, AffinityFeature(x)) / AffinityFeature(x) w.r.t. x when the affinity sees the live map
+ *                  ('with_ISU', 'with_1_4ISU', 'only_ISU': liif.py:493-495,501-503,534-535 over :432-446): aff / g_aff point
+ *                  at the 8 affinity channels of the forward output and of its gradient (batch strides in floats), g_x [C
+ *                  channels] or NULL is the pass-through gradient of the concat; ws = B*H*W floats of scratch. */
+int as_liif_latent(const float* feat, const float* coord, const float* emb, const float* cell, float* latent, int B, int C, int H,
+                   int W, int Q, int lat_ctot, int lat_coff, int unfold9, int n_samp, int n_enc, void* stream);
+int as_liif_latent_bwd(const float* d_latent, const float* coord, float* d_feat, int B, int C, int H, int W, int Q, int lat_ctot,
+                       int lat_coff, int unfold9, int n_samp, void* stream);
+int as_convex_upsample_quater(const float* disp, const float* scale, const float* mask, const float* coord, float* out, int B, int H,
+                              int W, int Q, int mask_is_logits, void* stream);
+int as_convex_upsample_quater_bwd(const float* disp, const float* scale, const float* mask, const float* coord, const float* d_out,
+                                  float* d_mask, float* d_disp, int B, int H, int W, int Q, int mask_is_logits, void* stream);
+int as_affinity_bwd(const float* x, const float* aff, long long aff_batch_stride, const float* g_aff, long long g_aff_batch_stride,
+                    const float* g_x, long long g_x_batch_stride, float* dx, float* ws, int B, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

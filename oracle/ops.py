@@ -372,6 +372,110 @@ def upsample_disp(model, disp, hidden, stem_4x, stem_2x, hr_coord, scale):
 # --------------------------------------------------------------------------------------
 
 
+# ---- §8 f4: the off-by-default options of the implicit upsampler -------------------------------------------------------
+def structure_feature_mode(x: torch.Tensor, mode, embed=None) -> torch.Tensor:
+    """StructureFeature.forward for the modes the reference can run (liif.py:492-535): 'with_ISU' / 'with_1_4ISU' cat(x, aff(x)),
+    'with_v2ISU' cat(x, aff(x.detach())), 'with_embed_ISU' convbn(cat(x, aff(x.detach()))) (eval BatchNorm), 'only_ISU' aff(x)."""
+    if "with_ISU" in mode or "with_1_4ISU" in mode:
+        return torch.cat([x, affinity(x, 1)], dim=1)
+    if "with_v2ISU" in mode:
+        return structure_feature_v2isu(x)
+    if "with_embed_ISU" in mode:
+        conv, bn = embed[0], embed[1]
+        y = F.conv2d(structure_feature_v2isu(x), conv.weight.to(x.dtype))
+        s = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).to(x.dtype)
+        return (y - bn.running_mean.to(x.dtype).view(1, -1, 1, 1)) * s.view(1, -1, 1, 1) + bn.bias.to(x.dtype).view(1, -1, 1, 1)
+    if "only_ISU" in mode:
+        return affinity(x, 1)
+    return x
+
+
+def unfold3x3(feat: torch.Tensor) -> torch.Tensor:
+    """F.unfold(feat, 3, padding=1).view(B, 9C, H, W) (liif.py:655): channel c*9 + ky*3 + kx, zero padded."""
+    b, c, h, w = feat.shape
+    fp = F.pad(feat, (1, 1, 1, 1))
+    return torch.stack([fp[:, :, ky:ky + h, kx:kx + w] for ky in range(3) for kx in range(3)], dim=2).reshape(b, c * 9, h, w)
+
+
+def _gather_nearest(feat, cc):
+    b, c, lh, lw = feat.shape
+    iy = nearest_index(cc[..., 0], lh).clamp(0, lh - 1)
+    ix = nearest_index(cc[..., 1], lw).clamp(0, lw - 1)
+    idx = (iy * lw + ix).unsqueeze(1).expand(b, c, -1)
+    q_feat = torch.gather(feat.reshape(b, c, lh * lw), 2, idx).permute(0, 2, 1)
+    dt = feat.dtype
+    cy = -1 + 1.0 / lh + (2.0 / lh) * iy.to(dt)
+    cx = -1 + 1.0 / lw + (2.0 / lw) * ix.to(dt)
+    return q_feat, torch.stack([cy, cx], dim=-1)
+
+
+def liif_query_quater(feat: torch.Tensor, coords: torch.Tensor):
+    """liif_feat_multiscale_train_quater, liif.py:140-176: four nearest samples at coords + (vx/H', vy/W') + 1e-6 for
+    (vx, vy) in (-1,-1), (-1,1), (1,-1), (1,1), features concatenated; rel to the mean of the first and last cell centres."""
+    lh, lw = feat.shape[-2:]
+    qs, cs = [], []
+    for vx in (-1, 1):
+        for vy in (-1, 1):
+            sh = torch.tensor([vx * (2 / lh / 2) + 1e-6, vy * (2 / lw / 2) + 1e-6], dtype=coords.dtype, device=coords.device)
+            q, c = _gather_nearest(feat, (coords + sh).clamp(-1 + 1e-6, 1 - 1e-6))
+            qs.append(q)
+            cs.append(c)
+    centre = (cs[0] + cs[3]) / 2
+    rel = (coords - centre) * torch.tensor([lh, lw], dtype=coords.dtype, device=coords.device)
+    return rel, torch.cat(qs, dim=-1)
+
+
+def spatial_encoding(rel: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    """SpatialEncoding.forward, liif.py:359-367 (cat_input)."""
+    y = rel[..., 0:1] * emb[:, 0].to(rel.dtype) + rel[..., 1:2] * emb[:, 1].to(rel.dtype)
+    return torch.cat([rel, torch.sin(y), torch.cos(y)], dim=-1)
+
+
+def liif_up_mask_general(liif, feats, coord: torch.Tensor, scale) -> torch.Tensor:
+    """liif_out_multi_scale_Training.forward, liif.py:644-678, with every option the reference can run."""
+    u = liif.unfold
+    latent = []
+    for i, f in enumerate(feats):
+        if u is not None:
+            if "only_unfold" in u:
+                f = unfold3x3(f)
+            elif any(k in u for k in ("with_1_4ISU", "with_1_43ISU", "with_1_43v2ISU")):
+                if i == 0:
+                    f = structure_feature_mode(f, u)
+            else:
+                f = structure_feature_mode(f, u, getattr(liif.to_sf_l2[i], "sfc_embeding", None))
+        if liif.quater_nearest is not None and "both" in liif.quater_nearest:
+            rel, q = liif_query_quater(f, coord)
+        else:
+            rel, q = liif_query(f, coord)
+        if liif.pos_enconding:
+            rel = spatial_encoding(rel, liif.pos_encoding.emb.to(rel.device))
+        parts = [q, rel]
+        if liif.decode_cell:
+            cells = torch.ones_like(coord)
+            cells[:, :, 0] = 2 / scale
+            cells[:, :, 1] = 2 / scale
+            parts.append(cells)
+        latent.append(torch.cat(parts, dim=-1))
+    lat = torch.cat(latent, dim=-1)
+    b, q, _ = lat.shape
+    return mlp(liif.imnet, lat.reshape(b * q, -1)).view(b, q, -1).permute(0, 2, 1)
+
+
+def convex_upsample_quater(disp_low: torch.Tensor, mask: torch.Tensor, hr_coord: torch.Tensor) -> torch.Tensor:
+    """context_upsample_multiscale_train_quaterp, submodule.py:375-399: disp_low [B,1,h,w], mask [B,4,Q] -> [B,Q]."""
+    b, _, h, w = disp_low.shape
+    out = 0
+    k = 0
+    for vx in (-1, 1):
+        for vy in (-1, 1):
+            sh = torch.tensor([vx * (2 / h / 2) + 1e-6, vy * (2 / w / 2) + 1e-6], dtype=hr_coord.dtype, device=hr_coord.device)
+            d, _ = _gather_nearest(disp_low, (hr_coord + sh).clamp(-1 + 1e-6, 1 - 1e-6))
+            out = out + d[..., 0] * mask[:, k]
+            k += 1
+    return out
+
+
 def make_coord(shape):
     """Cell-centre coordinates in [-1,1] for a grid of `shape` -> [*shape, 2] (liif.py:32-45)."""
     seqs = []

@@ -1,0 +1,219 @@
+"""§8 f4: the implicit upsampler's off-by-default options.  tests/golden/liif_variants.npz / model_variants.npz were captured
+from the imported reference (make_golden_variants.py); liif_variants.json also records which option sets the reference
+itself cannot run.  CPU: the oracle restatement against the fixtures, constructor / state-dict parity, the dead option sets.
+GPU: the HIP path against the same fixtures, and its gradients against the oracle under autograd."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "any-stereo_amd"))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from anystereo.harness.synthetic import det_uniform, fill_module_deterministic, synthetic_pair  # noqa: E402
+from anystereo.models.base import default_args  # noqa: E402
+from anystereo.nn import liif as NL  # noqa: E402
+from oracle import ops as O  # noqa: E402
+
+META = json.load(open(os.path.join(GOLD, "liif_variants.json")))
+AFF = {"win_w": 3, "win_h": 3, "dilation": [1, 2, 4, 8]}
+LIVE = sorted(k for k, v in META["reference"].items() if v["ok"] and k in META["options"])
+DEAD = sorted(k for k, v in META["reference"].items() if not v["ok"] and k in META["options"])
+
+
+def _inputs(n_in, device="cpu", batch=1):
+    x4 = det_uniform((batch, 176, 4, 6), 81).to(device)
+    x2 = det_uniform((batch, 32, 8, 12), 82).to(device)
+    x1 = det_uniform((batch, 8, 16, 24), 84).to(device)
+    return ([x1, x2, x4], [8, 32, 176]) if n_in == 3 else ([x4, x2], [176, 32])
+
+
+def _build(name, device="cpu"):
+    opt = dict(META["options"][name])
+    n_in = opt.get("number_input", 2)
+    feats, chans = _inputs(n_in, device)
+    kw = dict(encoder_dim=sum(chans), mlphidden_list=[128, 64, 64], pos_dim=0, affinity_settings=AFF, number_input=n_in, chanels=chans)
+    kw.update(opt)
+    up = NL.liif_out_multi_scale_Training(**kw).eval()
+    fill_module_deterministic(up, base_seed=7, gain=2.0)
+    return up.to(device), feats, opt
+
+
+def _gold():
+    return np.load(os.path.join(GOLD, "liif_variants.npz"))
+
+
+@pytest.mark.parametrize("name", LIVE)
+def test_constructor_matches_reference(name):
+    up, _, _ = _build(name)
+    ref = META["reference"][name]
+    assert {k: list(v.shape) for k, v in up.state_dict().items()} == ref["state_dict"]
+    assert up.imnet.layers[0].weight.shape[1] == ref["in_dim"] and up.outputdim == ref["out_dim"]
+
+
+@pytest.mark.parametrize("name", LIVE)
+def test_oracle_matches_reference_fixture(name):
+    g = _gold()
+    up, feats, opt = _build(name)
+    coord = torch.from_numpy(g["coord"])
+    with torch.no_grad():
+        mask = O.liif_up_mask_general(up, feats, coord.clone(), torch.tensor([[1.5]]))
+        sm = torch.softmax(mask, dim=1)
+        d = torch.from_numpy(g["dlow"]) * 4.0 * 1.5
+        conv = O.convex_upsample(d, sm, coord.clone()) if opt.get("quater_nearest") is None else O.convex_upsample_quater(d, sm, coord.clone())
+    ref = g[f"{name}__mask"]
+    assert np.abs(mask.numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(conv.numpy() - g[f"{name}__convex"]).max() <= 2e-4
+
+
+@pytest.mark.parametrize("name", DEAD)
+def test_option_sets_the_reference_cannot_run_fail_loudly(name):
+    """Same constructor success as the reference (parameters exist), an error naming the reference's failure at forward."""
+    up, feats, _ = _build(name)
+    assert META["reference"][name]["error"] in ("RuntimeError", "AssertionError")
+    coord = torch.from_numpy(_gold()["coord"])
+    with pytest.raises((RuntimeError, AssertionError)) as e:
+        up(feats, coord.clone(), torch.tensor([[1.5]]))
+    assert "liif.py" in str(e.value)
+
+
+def test_model_variants_state_dict_keys():
+    keys = json.load(open(os.path.join(GOLD, "model_variants_keys.json")))
+    from anystereo.models import __models__
+    for name, (mname, _, opt) in keys["options"].items():
+        model = __models__[mname](default_args(mname, **opt))
+        got = {k: list(v.shape) for k, v in model.state_dict().items() if k.startswith(("liif_up.", "stem_"))}
+        assert got == keys["state_dict"][name], name
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", LIVE)
+def test_hip_matches_reference_fixture(name):
+    from anystereo import ops
+    g = _gold()
+    up, feats, opt = _build(name, "cuda")
+    coord = torch.from_numpy(g["coord"]).cuda()
+    scale = torch.tensor([[1.5]], device="cuda")
+    with torch.no_grad():
+        mask = up(feats, coord.clone(), scale)
+        d = torch.from_numpy(g["dlow"]).cuda()
+        sv = torch.tensor([1.5], device="cuda")
+        fn = ops.convex_upsample if opt.get("quater_nearest") is None else ops.convex_upsample_quater
+        conv = fn(d, mask.contiguous(), coord.clone(), scale=sv, mask_is_logits=True)
+    ref = g[f"{name}__mask"]
+    assert tuple(mask.shape) == ref.shape
+    assert np.abs(mask.cpu().numpy() - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    # disparities up to 120 through a softmax of logits of magnitude ~30 (gain-2 weights): 1e-5 relative
+    assert np.abs(conv[:, 0].cpu().numpy() - g[f"{name}__convex"]).max() <= 3e-3
+
+
+@pytest.mark.gpu
+def test_decode_cell_batch_broadcast():
+    g = _gold()
+    up, _, _ = _build("decode_cell", "cuda")
+    feats, _ = _inputs(2, "cuda", batch=2)
+    coord = torch.from_numpy(g["coord"]).cuda().repeat(2, 1, 1)
+    with torch.no_grad():
+        mask = up(feats, coord, torch.tensor([[1.5], [2.0]], device="cuda"))
+    ref = g["decode_cell_b2__mask"]
+    assert np.abs(mask.cpu().numpy() - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["with_ISU", "only_ISU", "with_1_4ISU", "only_unfold", "pos_enc_learned", "quater_both",
+                                  "pos_enc_cell_quater", "with_embed_ISU", "three_inputs", "unfold_none"])
+def test_hip_gradients_match_oracle(name):
+    """Loss = sum(w * upsampled disparity); gradients w.r.t. the feature maps, the low-resolution disparity, the first and last
+    MLP weights and (when learned) the frequency table — HIP autograd path vs the oracle restatement under torch autograd."""
+    from anystereo import grad as G
+    g = _gold()
+    up, feats, opt = _build(name, "cuda")
+    for p_ in up.parameters():
+        p_.requires_grad_(True)
+    coord = torch.from_numpy(g["coord"]).cuda()
+    scale = torch.tensor([[1.5]], device="cuda")
+    sv = torch.tensor([1.5], device="cuda")
+    wq = det_uniform((1, 1, coord.shape[1]), 91, -1.0, 1.0).cuda()
+    quater = opt.get("quater_nearest") is not None
+
+    def run(hip):
+        fs = [f.clone().requires_grad_(True) for f in feats]
+        d = torch.from_numpy(g["dlow"]).cuda().requires_grad_(True)
+        up.zero_grad()
+        if hip:
+            mask = up(fs, coord.clone(), scale).contiguous()
+            fn = G.ConvexUpsampleQuater if quater else G.ConvexUpsample
+            out = fn.apply(d, mask, coord.clone().clamp(-1 + 1e-6, 1 - 1e-6) if not quater else coord.clone(), sv, True)
+        else:
+            mask = O.liif_up_mask_general(up, fs, coord.clone(), scale)
+            sm = torch.softmax(mask, dim=1)
+            fn = O.convex_upsample_quater if quater else O.convex_upsample
+            out = fn(d * 4.0 * 1.5, sm, coord.clone()).unsqueeze(1)
+        (out * wq).sum().backward()
+        lin = [m for m in up.imnet.layers if isinstance(m, torch.nn.Linear)]
+        res = [f.grad for f in fs] + [d.grad, lin[0].weight.grad.clone(), lin[-1].weight.grad.clone()]
+        if isinstance(getattr(up, "pos_encoding", None), NL.SpatialEncoding) and up.pos_encoding.require_grad:
+            res.append(up.pos_encoding.emb.grad.clone())
+        emb_bn = [p_.grad.clone() for n_, p_ in up.named_parameters() if "sfc_embeding.0" in n_]
+        return out.detach(), res + emb_bn
+
+    o_hip, g_hip = run(True)
+    o_ref, g_ref = run(False)
+    assert (o_hip - o_ref).abs().max().item() <= 5e-4
+    for a, b in zip(g_hip, g_ref):
+        assert a is not None and b is not None and a.shape == b.shape
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(json.load(open(os.path.join(GOLD, "model_variants_keys.json")))["options"]))
+def test_model_variants_match_reference(name):
+    from anystereo.models import __models__
+    keys = json.load(open(os.path.join(GOLD, "model_variants_keys.json")))
+    mname, (H, W), opt = keys["options"][name]
+    model = __models__[mname](default_args(mname, **opt)).eval()
+    fill_module_deterministic(model, base_seed=1)
+    model = model.cuda()
+    img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+    coord = NL.make_coord([round(H * 1.5), round(W * 1.5)]).unsqueeze(0).cuda()
+    with torch.no_grad():
+        out = model(img1.cuda(), img2.cuda(), iters=2, test_mode=True, hr_coord=coord.clone(), scale=torch.tensor([[1.5]], device="cuda"))
+    ref = np.load(os.path.join(GOLD, "model_variants.npz"))[name]
+    assert tuple(out.shape) == ref.shape
+    err = np.abs(out.cpu().numpy() - ref)
+    assert err.mean() <= 2e-3 and err.max() <= 5e-2, (float(err.mean()), float(err.max()))
+
+
+@pytest.mark.gpu
+def test_reference_level_functions():
+    """The reference's tensor-level contracts: SpatialEncoding.forward, liif_feat_multiscale_train(_quater) with cells,
+    context_upsample_multiscale_train_quaterp — HIP vs the oracle."""
+    from anystereo.models.coreContinuous_IGEV.liif import SpatialEncoding, liif_feat_multiscale_train, liif_feat_multiscale_train_quater
+    from anystereo.models.coreContinuous_IGEV.submodule import context_upsample_multiscale_train_quaterp
+    g = _gold()
+    coord = torch.from_numpy(g["coord"]).cuda()
+    feat = det_uniform((1, 12, 5, 7), 77).cuda()
+    scale = torch.tensor([[1.5]], device="cuda")
+    rel, qf, cells = liif_feat_multiscale_train_quater(feat, coord.clone(), scale, False, True)
+    rel_o, qf_o = O.liif_query_quater(feat.cpu(), coord.cpu())
+    assert (rel.cpu() - rel_o).abs().max() <= 1e-5 and torch.equal(qf.cpu(), qf_o)
+    assert torch.allclose(cells, torch.full_like(cells, 2 / 1.5))
+    rel1, qf1, none = liif_feat_multiscale_train(feat, coord.clone(), scale)
+    rel1_o, qf1_o = O.liif_query(feat.cpu(), coord.cpu())
+    assert none is None and (rel1.cpu() - rel1_o).abs().max() <= 1e-5 and torch.equal(qf1.cpu(), qf1_o)
+    enc = SpatialEncoding(2, 24)
+    got = enc(rel1)
+    want = O.spatial_encoding(rel1.cpu(), enc.emb.cpu())
+    assert got.shape == want.shape == (1, coord.shape[1], 26) and (got.cpu() - want).abs().max() <= 2e-5
+    d = det_uniform((1, 1, 5, 7), 78, 0, 30).cuda()
+    m = torch.softmax(det_uniform((1, 4, coord.shape[1]), 79, -2, 2).cuda(), dim=1)
+    c0 = coord.clone()
+    up = context_upsample_multiscale_train_quaterp(d, m, c0)
+    assert torch.equal(c0, coord)  # no in-place clamp in this variant
+    assert (up.cpu() - O.convex_upsample_quater(d.cpu(), m.cpu(), coord.cpu())).abs().max() <= 1e-4
