@@ -71,15 +71,32 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   }
 }
 
+// value of the lane one below / one above in the wave (DPP wave shifts; lane 0 / lane 63 receive 0)
+__device__ __forceinline__ float wave_shr1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+constexpr int kC3dCols = 62;  // outputs per wave of the shift-based kernels (64 loaded columns - 2 halo lanes)
+
 // ------------------------------------------------------------------------------------------------
 // Conv3d 3x3x3, padding 1, stride S (all three dims), Cin arbitrary, CT output channels per thread
 // (Cout = groups x CT, group = blockIdx.z % groups).  wpack [Cin][27][Cout].
 // Block = 64 x-positions x 4 y-rows of one (b, z, group).
 // ------------------------------------------------------------------------------------------------
-template <int S, int CT>
+template <int S, int CT, int CO, int NR = 1>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int Cin, int Cout, int D, int H, int W, int Do, int Ho, int Wo, int act) {
+                                                        int Cin, int Cout_rt, int D, int H, int W, int Do, int Ho, int Wo, int act) {
+  // CO: Cout at compile time (0 = run time).  With a known weight row stride the 9 x CT scalar weights of a slab are
+  // loads at immediate offsets from ONE running pointer; with a run-time stride each of the nine rows costs a 64-bit
+  // scalar address computation, and the scalar unit (one instruction per SIMD every four cycles) ended up as busy as
+  // the vector FMA pipe (~40 scalar against 42 vector instructions per slab).
+  // NR (stride 1): output rows per thread.  NR = 2 reads 4 input rows for 2 x 9 x CT FMAs: the slab's weights (288 B of
+  // scalar-cache traffic per wave) and two of the rows serve both outputs.
+  static_assert(NR == 1 || S == 1, "two rows per thread: stride 1 only");
+  const int Cout = CO ? CO : Cout_rt;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int groups = Cout / CT;
@@ -88,53 +105,78 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
   id /= groups;
   const int oz = id % Do;
   const int b = id / Do;
-  const int oy = blockIdx.y * 4 + wave;
-  const int ox = blockIdx.x * 64 + lane;
+  const int oy = (blockIdx.y * 4 + wave) * NR;
+  // stride 1: a wave covers kC3dCols = 62 outputs; lane l loads input column (first output - 1 + l) ONCE per row and hands it
+  // to its neighbours with two wave shifts (DPP) — one load per row instead of three overlapping ones
+  const int ox = (S == 1) ? blockIdx.x * kC3dCols + lane - 1 : blockIdx.x * 64 + lane;
   if (oy >= Ho) return;
-  const long long plane = (long long)H * W;
-  const long long vol = (long long)D * plane;
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * Cin * vol), 0, (int)((long long)Cin * vol * 4), 0x00020000);
-  unsigned xo[3];
+  const unsigned row_b = (unsigned)W * 4u, plane_b = (unsigned)H * row_b, vol_b = (unsigned)D * plane_b;  // Cin*vol_b < kOOB (entry)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * Cin * (vol_b / 4)), 0,
+                                                                      (int)((long long)Cin * vol_b), 0x00020000);
+  // per input row: the lane's column offsets (sentinel for rows / columns outside the volume) and the row's byte offset —
+  // all loop invariant
+  constexpr int NROW = 2 + NR;
+  unsigned xo[NROW][3], rowoff[NROW];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int ix = ox * S + k - 1;
-    xo[k] = (ox < Wo && ix >= 0 && ix < W) ? (unsigned)(ix * 4) : kOOB;
+  for (int r = 0; r < NROW; ++r) {
+    const int iy = oy * S + r - 1;
+    const bool rowok = iy >= 0 && iy < H;  // wave-uniform
+    rowoff[r] = rowok ? (unsigned)iy * row_b : 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ix = (S == 1) ? ox : ox * S + k - 1;  // S == 1 uses entry [r][1] only: this lane's own column
+      const bool ok = rowok && ix >= 0 && ix < W && (S == 1 || ox < Wo);
+      xo[r][k] = ok ? (unsigned)(ix * 4) : kOOB;
+    }
   }
-  float acc[CT];
+  const bool writes = (S == 1) ? (lane >= 1 && lane <= kC3dCols && ox < Wo) : (ox < Wo);
+  float acc[NR][CT];
 #pragma unroll
-  for (int j = 0; j < CT; ++j) acc[j] = bias ? bias[g * CT + j] : 0.f;
-  const float* wg = wp + g * CT;
-  // rows outside the volume: wave-uniform sentinel scalar offset is not possible (soffset is not range checked on every
-  // generation), so invalid rows get the lane sentinel through `rowok`
-  for (int ci = 0; ci < Cin; ++ci) {
-#pragma unroll 1  // one (ci, kz) slab at a time: 9 loads in flight, then 9 x CT FMAs against 9 x CT scalar weights
-    for (int kz = 0; kz < 3; ++kz) {
+  for (int n = 0; n < NR; ++n)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) acc[n][j] = bias ? bias[g * CT + j] : 0.f;
+  const float* wt = wp + g * CT;  // running: + 9*Cout per (ci, kz) slab
+  unsigned cio = 0;                // running: ci * vol_b
+  for (int ci = 0; ci < Cin; ++ci, cio += vol_b) {
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz, wt += 9 * Cout) {
       const int iz = oz * S + kz - 1;
       if (iz < 0 || iz >= D) continue;  // block-uniform
-      float v[3][3];
+      const unsigned zo = cio + (unsigned)iz * plane_b;
+      float v[NROW][3];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * S + ky - 1;
-        const bool rowok = iy >= 0 && iy < H;  // wave-uniform
-        const unsigned so = rowok ? (unsigned)((((long long)ci * D + iz) * H + iy) * W * 4) : 0u;
+      for (int r = 0; r < NROW; ++r) {
+        if constexpr (S == 1) {
+          const float c = bload(rs, xo[r][1], zo + rowoff[r]);
+          v[r][1] = c;
+          v[r][0] = wave_shr1(c);  // column ox - 1 from lane - 1
+          v[r][2] = wave_shl1(c);  // column ox + 1 from lane + 1
+        } else {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) v[ky][kx] = bload(rs, rowok ? xo[kx] : kOOB, so);
+          for (int kx = 0; kx < 3; ++kx) v[r][kx] = bload(rs, xo[r][kx], zo + rowoff[r]);
+        }
       }
-      const float* wt = wg + (long long)(ci * 27 + kz * 9) * Cout;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-          for (int j = 0; j < CT; ++j) acc[j] = fmaf(v[ky][kx], wt[(ky * 3 + kx) * Cout + j], acc[j]);
+          for (int j = 0; j < CT; ++j) {
+            const float w = wt[(ky * 3 + kx) * Cout + j];
+#pragma unroll
+            for (int n = 0; n < NR; ++n) acc[n][j] = fmaf(v[ky + n][kx], w, acc[n][j]);
+          }
     }
   }
-  if (ox < Wo) {
+  if (writes) {
     const long long ovol = (long long)Do * Ho * Wo;
-    float* o = out + ((long long)b * Cout + g * CT) * ovol + ((long long)oz * Ho + oy) * Wo + ox;
 #pragma unroll
-    for (int j = 0; j < CT; ++j) o[j * ovol] = act_apply(acc[j], act);
+    for (int n = 0; n < NR; ++n) {
+      if (oy + n >= Ho) break;
+      float* o = out + ((long long)b * Cout + g * CT) * ovol + ((long long)oz * Ho + oy + n) * Wo + ox;
+#pragma unroll
+      for (int j = 0; j < CT; ++j) o[j * ovol] = act_apply(acc[n][j], act);
+    }
   }
 }
 
@@ -145,10 +187,11 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
 // (z, y), so the tap set is wave-uniform and the weights are SGPR operands: 3 loads feed 4*CT FMAs.
 // wpack [Cin][4][4][4][Cout] (= weight [Cin,Cout,4,4,4] with Cout moved last).
 // ------------------------------------------------------------------------------------------------
-template <int CT>
+template <int CT, int CO = 0>
 __global__ __launch_bounds__(256) void deconv3d_k4s2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                            int Cin, int Cout, int D, int H, int W, int act) {
+                                                            int Cin, int Cout_rt, int D, int H, int W, int act) {
+  const int Cout = CO ? CO : Cout_rt;  // compile-time weight row stride: see conv3d_k3_kernel
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
@@ -159,18 +202,15 @@ __global__ __launch_bounds__(256) void deconv3d_k4s2_kernel(const float* __restr
   const int oz = id % Do;
   const int b = id / Do;
   const int oy = blockIdx.y * 4 + wave;
-  const int px = blockIdx.x * 64 + lane;  // input column; outputs 2 px and 2 px + 1
+  // input column; outputs 2 px and 2 px + 1.  Like conv3d_k3_kernel<1>: 62 columns per wave, one load per row, the two
+  // neighbours by wave shifts
+  const int px = blockIdx.x * kC3dCols + lane - 1;
   if (oy >= Ho) return;
   const long long plane = (long long)H * W;
   const long long vol = (long long)D * plane;
   const __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * Cin * vol), 0, (int)((long long)Cin * vol * 4), 0x00020000);
-  unsigned xo[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int ix = px + k - 1;
-    xo[k] = (px < W && ix >= 0 && ix < W) ? (unsigned)(ix * 4) : kOOB;
-  }
+  const unsigned xc = (px >= 0 && px < W) ? (unsigned)(px * 4) : kOOB;
   float a0[CT], a1[CT];  // outputs 2 px (even) and 2 px + 1 (odd)
 #pragma unroll
   for (int j = 0; j < CT; ++j) { a0[j] = bias ? bias[g * CT + j] : 0.f; a1[j] = a0[j]; }
@@ -188,7 +228,8 @@ __global__ __launch_bounds__(256) void deconv3d_k4s2_kernel(const float* __restr
         const int iy = (oy + 1 - ky) >> 1;
         if (iy < 0 || iy >= H) continue;
         const unsigned so = (unsigned)((((long long)ci * D + iz) * H + iy) * W * 4);
-        const float vm = bload(rs, xo[0], so), v0 = bload(rs, xo[1], so), vp = bload(rs, xo[2], so);
+        const float v0 = bload(rs, xc, so);
+        const float vm = wave_shr1(v0), vp = wave_shl1(v0);
         const float* wt = wg + (long long)(((ci * 4 + kz) * 4 + ky) * 4) * Cout;  // [kx][co]
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
@@ -201,7 +242,7 @@ __global__ __launch_bounds__(256) void deconv3d_k4s2_kernel(const float* __restr
       }
     }
   }
-  if (px < W) {
+  if (lane >= 1 && lane <= kC3dCols && px < W) {
     const long long ovol = (long long)Do * Ho * Wo;
     float* o = out + ((long long)b * Cout + g * CT) * ovol + ((long long)oz * Ho + oy) * Wo + 2 * px;
 #pragma unroll
@@ -328,11 +369,20 @@ int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* o
   const int ct = (Cout % 8 == 0) ? 8 : 1;
   const long long gz = (long long)B * Do * (Cout / ct);
   AS_REQUIRE(gz <= 65535, AS_ERR_BAD_SHAPE, "conv3d_k3: B*Do*groups=%lld exceeds the grid limit", gz);
-  const dim3 grid((unsigned)as::cdiv(Wo, 64), (unsigned)as::cdiv(Ho, 4), (unsigned)gz);
+  const dim3 grid((unsigned)as::cdiv(Wo, stride == 1 ? kC3dCols : 64), (unsigned)as::cdiv(Ho, 4), (unsigned)gz);
   hipStream_t s = as::as_stream(stream);
-#define AS_C3D(S_, CT_) hipLaunchKernelGGL((conv3d_k3_kernel<S_, CT_>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, Do, Ho, Wo, act)
-  if (stride == 1) { if (ct == 8) AS_C3D(1, 8); else AS_C3D(1, 1); }
-  else { if (ct == 8) AS_C3D(2, 8); else AS_C3D(2, 1); }
+#define AS_C3D(S_, CT_, CO_, NR_) hipLaunchKernelGGL((conv3d_k3_kernel<S_, CT_, CO_, NR_>), dim3(grid.x, (unsigned)as::cdiv(Ho, 4 * NR_), grid.z), dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, Do, Ho, Wo, act)
+#define AS_C3D_CO(S_, NR_)                                     \
+  switch (ct == 8 ? Cout : -1) {                               \
+    case 8: AS_C3D(S_, 8, 8, NR_); break;                      \
+    case 16: AS_C3D(S_, 8, 16, NR_); break;                    \
+    case 32: AS_C3D(S_, 8, 32, NR_); break;                    \
+    case 48: AS_C3D(S_, 8, 48, NR_); break;                    \
+    case -1: AS_C3D(S_, 1, 0, NR_); break;                     \
+    default: AS_C3D(S_, 8, 0, NR_); break;                     \
+  }
+  if (stride == 1) { AS_C3D_CO(1, 2) } else { AS_C3D_CO(2, 1) }
+#undef AS_C3D_CO
 #undef AS_C3D
   return as::check_launch("conv3d_k3");
 }
@@ -347,10 +397,17 @@ int as_deconv3d_k4s2(const float* x, const float* wpack, const float* bias, floa
   const int ct = (Cout % 8 == 0) ? 8 : 1;
   const long long gz = (long long)B * 2 * D * (Cout / ct);
   AS_REQUIRE(gz <= 65535, AS_ERR_BAD_SHAPE, "deconv3d_k4s2: B*Do*groups=%lld exceeds the grid limit", gz);
-  const dim3 grid((unsigned)as::cdiv(W, 64), (unsigned)as::cdiv(2 * H, 4), (unsigned)gz);
+  const dim3 grid((unsigned)as::cdiv(W, kC3dCols), (unsigned)as::cdiv(2 * H, 4), (unsigned)gz);
   hipStream_t s = as::as_stream(stream);
-  if (ct == 8) hipLaunchKernelGGL((deconv3d_k4s2_kernel<8>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, act);
-  else hipLaunchKernelGGL((deconv3d_k4s2_kernel<1>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, act);
+#define AS_D3D(CT_, CO_) hipLaunchKernelGGL((deconv3d_k4s2_kernel<CT_, CO_>), grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, act)
+  switch (ct == 8 ? Cout : -1) {
+    case 8: AS_D3D(8, 8); break;
+    case 16: AS_D3D(8, 16); break;
+    case 32: AS_D3D(8, 32); break;
+    case -1: AS_D3D(1, 0); break;
+    default: AS_D3D(8, 0); break;
+  }
+#undef AS_D3D
   return as::check_launch("deconv3d_k4s2");
 }
 

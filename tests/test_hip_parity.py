@@ -343,7 +343,9 @@ def test_dwconv3x3(b, c, h, w, stride, act):
 
 
 @pytest.mark.parametrize("b,cin,cout,d,h,w,stride,act", [(1, 8, 8, 6, 9, 70, 1, 5), (2, 8, 1, 5, 6, 33, 1, 0), (1, 8, 16, 7, 9, 66, 2, 5),
-                                                         (1, 16, 16, 4, 5, 20, 1, 5), (1, 3, 5, 3, 4, 7, 2, 1)])
+                                                         (1, 16, 16, 4, 5, 20, 1, 5), (1, 3, 5, 3, 4, 7, 2, 1),
+                                                         # stride 1 covers 62 columns per wave (neighbours by wave shifts): the seams
+                                                         (1, 8, 8, 3, 5, 62, 1, 0), (1, 8, 8, 3, 5, 63, 1, 5), (1, 8, 8, 2, 6, 125, 1, 0)])
 def test_conv3d_k3(b, cin, cout, d, h, w, stride, act):
     from anystereo import ops
     x = U((b, cin, d, h, w), 180, -2, 2)
@@ -356,7 +358,8 @@ def test_conv3d_k3(b, cin, cout, d, h, w, stride, act):
     close(out, ref, 2e-6, 2e-6, "conv3d_k3")
 
 
-@pytest.mark.parametrize("b,cin,cout,d,h,w,act", [(1, 16, 8, 4, 6, 70, 0), (2, 8, 16, 3, 5, 33, 5), (1, 5, 3, 2, 3, 9, 1)])
+@pytest.mark.parametrize("b,cin,cout,d,h,w,act", [(1, 16, 8, 4, 6, 70, 0), (2, 8, 16, 3, 5, 33, 5), (1, 5, 3, 2, 3, 9, 1),
+                                                  (1, 8, 8, 2, 3, 62, 0), (1, 8, 8, 2, 3, 63, 5), (1, 8, 8, 2, 2, 125, 0)])
 def test_deconv3d_k4s2(b, cin, cout, d, h, w, act):
     from anystereo import ops
     x = U((b, cin, d, h, w), 185, -2, 2)
