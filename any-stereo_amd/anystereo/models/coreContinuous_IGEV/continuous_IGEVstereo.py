@@ -134,7 +134,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 else:
                     stem_1b, stem_2b, stem_4b = self._stems_fwd(both)
                 feats[0] = torch.cat((feats[0], stem_4b), 1)
-                match = self.desc(self.conv(feats[0]))
+                match = _plain_conv(self, self.desc, self.conv(feats[0]))
                 features_left = [f[:n] for f in feats]
                 stem_2x, stem_4x = stem_2b[:n], stem_4b[:n]
                 stem_1x = None if stem_1b is None else stem_1b[:n]

@@ -37,6 +37,13 @@ def conv2d_plain(mod: nn.Module, conv: nn.Module, x: torch.Tensor) -> torch.Tens
         packs = mod.__dict__.setdefault("_hip_packs", {})
         pk = packs.setdefault(id(conv), ops.PackedConv())
         return ops.conv2d([x.contiguous()], pk.get([conv.weight], [conv.bias]), stride=conv.stride[0])
+    if (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.stride[0] == conv.stride[1] and conv.stride[0] > 1):
+        # 1x1 with a stride = the 1x1 convolution of the subsampled map
+        packs = mod.__dict__.setdefault("_hip_packs", {})
+        pk = packs.setdefault(id(conv), ops.PackedConv())
+        st = conv.stride[0]
+        return ops.conv2d([x[:, :, ::st, ::st].contiguous()], pk.get([conv.weight], [conv.bias]))
     return conv(x)
 
 

@@ -55,7 +55,7 @@ class ResidualBlock(nn.Module):
             self.norm3 = _norm(norm_fn, planes, planes // 8)
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
 
-        self._pk1, self._pk2 = ops.PackedConv(), ops.PackedConv()
+        self._pk1, self._pk2, self._pkd = ops.PackedConv(), ops.PackedConv(), ops.PackedConv()
         self._f1, self._fd = ops.FoldedConv(), ops.FoldedConv()
 
     def forward(self, x):
@@ -94,8 +94,16 @@ class ResidualBlock(nn.Module):
             w, b = self._f1.get(self.conv1, self.norm1)
             y = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
         if self.downsample is not None:
-            w, b = self._fd.get(self.downsample[0], self.downsample[1])
-            x = nn.functional.conv2d(x, w, b, self.downsample[0].stride)
+            ds = self.downsample[0]
+            if ds.kernel_size == (1, 1) and ds.padding == (0, 0) and ds.groups == 1:
+                # 1x1 stride-s shortcut = the same 1x1 convolution on the subsampled map: library kernel instead of a GEMM through
+                # MIOpen (90 -> ~35 us for 64 -> 96 at 544x960)
+                st = ds.stride[0]
+                xs = x if st == 1 else x[:, :, ::st, ::st].contiguous()
+                x = ops.conv2d([xs], self._pkd.get_folded(ds, self.downsample[1]))
+            else:
+                w, b = self._fd.get(ds, self.downsample[1])
+                x = nn.functional.conv2d(x, w, b, ds.stride)
         # relu(x + relu(bn2(conv2 y))) in the conv epilogue
         return ops.conv2d([y], self._pk2.get_folded(self.conv2, self.norm2), act=L.ACT_RELU, h=x.contiguous())
 
