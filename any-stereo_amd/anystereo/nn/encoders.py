@@ -145,14 +145,31 @@ class _Trunk(nn.Module):
         self.in_planes = dim
         return seq
 
+    def _stem_hip_ok(self, x) -> bool:
+        c = self.conv1
+        return (ops.get_precision() == "split" and x.shape[1] == 3 and tuple(c.weight.shape) == (64, 3, 7, 7) and c.stride == (1, 1)
+                and c.padding == (3, 3) and c.dilation == (1, 1) and c.groups == 1)
+
+    def _stem_pack(self):
+        if not hasattr(self, "_pk_stem"):
+            self._pk_stem = ops.Stem7x7Pack()
+        return self._pk_stem
+
     def trunk(self, x):
         if _fused_ok(x, self) and isinstance(self.norm1, nn.BatchNorm2d):
             if not hasattr(self, "_f_stem"):
                 self._f_stem = ops.FoldedConv()
             w, b = self._f_stem.get(self.conv1, self.norm1)
-            x = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
+            if self._stem_hip_ok(x):  # 7x7, 3 -> 64, stride 1: one split-precision MFMA launch with bias + ReLU (csrc/stem7x7.hip)
+                x = ops.conv7x7_c3(x.contiguous(), self._stem_pack(), w, b, act=L.ACT_RELU)
+            else:
+                x = nn.functional.conv2d(x, w, b, self.conv1.stride, self.conv1.padding).relu_()
         elif _fused_ok(x, self) and _plain_in(self.norm1):
-            x = ops.instance_norm_act(self.conv1(x), self.norm1.eps, L.ACT_RELU)
+            if self._stem_hip_ok(x):
+                y = ops.conv7x7_c3(x.contiguous(), self._stem_pack(), self.conv1.weight, self.conv1.bias)
+            else:
+                y = self.conv1(x)
+            x = ops.instance_norm_act(y, self.norm1.eps, L.ACT_RELU)
         else:
             x = self.relu1(self.norm1(self.conv1(x)))
         return self.layer3(self.layer2(self.layer1(x)))

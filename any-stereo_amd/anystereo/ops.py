@@ -703,6 +703,43 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
     return out
 
 
+class Stem7x7Pack:
+    """MFMA fragments of a [64,3,7,7] weight (csrc/stem7x7.hip), rebuilt when the weight tensor object or its version changes."""
+
+    def __init__(self):
+        self._key = None
+        self.wpack = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        key = (id(weight), weight._version, weight.data_ptr())
+        if key != self._key:
+            if tuple(weight.shape) != (64, 3, 7, 7) or not weight.is_cuda:
+                raise RuntimeError("conv7x7_c3: weight must be a CUDA tensor [64,3,7,7]")
+            w = weight.detach().float().contiguous()
+            lib = L.load()
+            self.wpack = torch.empty((int(lib.as_conv7x7_c3_pack_bytes()),), device=weight.device, dtype=torch.uint8)
+            with _guard(weight.device):
+                L.check(lib.as_conv7x7_c3_pack(_p(w), self.wpack.data_ptr(), _stream()), "conv7x7_c3_pack")
+            self._key = key
+        return self.wpack
+
+
+def conv7x7_c3(x, pack: "Stem7x7Pack", weight, bias=None, act: int = L.ACT_NONE):
+    """act(conv7x7(x [B,3,H,W], weight [64,3,7,7], padding 3) + bias) -> [B,64,H,W] (the encoders' stem, extractor.py:127)."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    if c != 3:
+        raise RuntimeError("conv7x7_c3: x must be [B,3,H,W]")
+    wp = pack.get(weight)
+    if bias is not None:
+        bias = bias.detach()
+        bias = bias if (bias.dtype == torch.float32 and bias.is_contiguous()) else bias.float().contiguous()
+    out = torch.empty((b, 64, h, w), device=x.device, dtype=torch.float32)
+    with _guard(x.device):
+        L.check(L.load().as_conv7x7_c3(_p(x), wp.data_ptr(), _p(bias), _p(out), b, h, w, act, _stream()), "conv7x7_c3")
+    return out
+
+
 def conv3x3_to1(x, weight, bias):
     """conv3x3(x [B,Cin,H,W]) + bias -> [B,1,H,W] (DispHead.conv2, update.py:19,24)."""
     _req(x, "x"), _req(weight, "weight")

@@ -458,6 +458,14 @@ int as_convex_upsample_quater_bwd(const float* disp, const float* scale, const f
 int as_affinity_bwd(const float* x, const float* aff, long long aff_batch_stride, const float* g_aff, long long g_aff_batch_stride,
                     const float* g_x, long long g_x_batch_stride, float* dx, float* ws, int B, int C, int H, int W, void* stream);
 
+/* f4: the encoders' 7x7, 3 -> 64 channel stem (`conv1`, extractor.py:127 in BasicEncoder / MultiBasicEncoder; stride 1, padding 3)
+ *   as one split-precision MFMA launch (csrc/stem7x7.hip): out [B,64,H,W] = act(conv7x7(x [B,3,H,W]) + bias).
+ *   wpack = as_conv7x7_c3_pack_bytes() bytes written by as_conv7x7_c3_pack from the fp32 weight [64,3,7,7] (BatchNorm folded by the
+ *   caller where the norm is a frozen BatchNorm); act in {AS_ACT_NONE, AS_ACT_RELU, AS_ACT_LEAKY}.  Split-precision mode only. */
+long long as_conv7x7_c3_pack_bytes(void);
+int as_conv7x7_c3_pack(const float* weight, void* wpack, void* stream);
+int as_conv7x7_c3(const float* x, const void* wpack, const float* bias, float* out, int B, int H, int W, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,6 +371,25 @@ def test_deconv3d_k4s2(b, cin, cout, d, h, w, act):
     close(out, ref, 2e-6, 2e-6, "deconv3d_k4s2")
 
 
+@pytest.mark.parametrize("b,h,w,act,with_bias", [(1, 24, 40, 1, True), (2, 17, 33, 0, True), (1, 8, 16, 5, False), (1, 70, 130, 1, True)])
+def test_conv7x7_c3_stem(b, h, w, act, with_bias):
+    """7x7, 3 -> 64 stem on the split-precision MFMA kernel vs fp64 F.conv2d (edges, ragged tiles, several tiles per block)."""
+    from anystereo import ops
+    ops.set_precision("split")
+    x = U((b, 3, h, w), 310, -1.0, 1.0)
+    wt = U((64, 3, 7, 7), 311) * (3.0 / 147) ** 0.5
+    bias = U((64,), 312) * 0.2 if with_bias else None
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None if bias is None else bias.double(), padding=3)
+    ref = {0: ref, 1: ref.relu(), 5: torch.nn.functional.leaky_relu(ref, 0.01)}[act]
+    pk = ops.Stem7x7Pack()
+    wd = wt.to(DEV)
+    out = ops.conv7x7_c3(x.to(DEV), pk, wd, None if bias is None else bias.to(DEV), act=act)
+    close(out, ref, 3e-6, 3e-6, "conv7x7_c3")
+    wd.mul_(0.5)  # in-place weight update: the pack follows the version counter
+    out2 = ops.conv7x7_c3(x.to(DEV), pk, wd, None, act=0)
+    close(out2, torch.nn.functional.conv2d(x.double(), 0.5 * wt.double(), None, padding=3), 3e-6, 3e-6, "conv7x7_c3 repack")
+
+
 def _randomize_bn(mod, seed):
     with torch.no_grad():
         for i, m in enumerate(mm for mm in mod.modules() if isinstance(mm, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))):
