@@ -14,6 +14,10 @@ from .. import grad as G
 from .. import ops
 
 
+# ANYSTEREO_FOLD_POINTWISE=0: BasicConv (2-D BatchNorm, 1x1x1 3-D) and the FeatureAtt gate back on MIOpen + separate norm / activation
+_FOLD_POINTWISE = __import__("os").environ.get("ANYSTEREO_FOLD_POINTWISE", "1") != "0"
+
+
 def fused_ok(x: torch.Tensor, mod: nn.Module) -> bool:
     """Inference fast path: eval mode, CUDA fp32 input, nothing to differentiate."""
     return (not mod.training) and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
@@ -146,6 +150,22 @@ class _ConvNormAct(nn.Module):
                 return conv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
             if deconv3d_k4s2_ok(self.conv):
                 return deconv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE)
+        if _FOLD_POINTWISE and fused_ok(x, self) and (norm is None or isinstance(norm, (nn.BatchNorm2d, nn.BatchNorm3d))) and not isinstance(
+                self.conv, (nn.ConvTranspose2d, nn.ConvTranspose3d)):
+            # frozen BatchNorm folded into the weights, LeakyReLU in the epilogue: one library launch instead of a MIOpen
+            # GEMM / convolution + BatchNorm + activation passes
+            c, act = self.conv, (L.ACT_LEAKY if self.relu else L.ACT_NONE)
+            pk = self.__dict__.setdefault("_pk_fold", ops.PackedConv())
+            if x.dim() == 4 and conv2d_hip_ok(c):
+                pack = pk.get_folded(c, norm) if norm is not None else pk.get([c.weight], [c.bias])
+                return ops.conv2d([x.contiguous()], pack, act=act, stride=c.stride[0])
+            if (x.dim() == 5 and c.kernel_size == (1, 1, 1) and c.stride == (1, 1, 1) and c.padding == (0, 0, 0)
+                    and c.dilation == (1, 1, 1) and c.groups == 1 and x.shape[2] * x.shape[3] * x.shape[4] < 2 ** 31):
+                # 1x1x1: a pointwise map over D*H*W = the 1x1 kernel on the flattened volume
+                b_, ci, d_, h_, w_ = x.shape
+                pack = pk.get_folded(c, norm) if norm is not None else pk.get([c.weight], [c.bias])
+                y = ops.conv2d([x.contiguous().view(b_, ci, 1, d_ * h_ * w_)], pack, act=act)
+                return y.view(b_, c.out_channels, d_, h_, w_)
         if fused_ok(x, self) and x.dim() == 4 and _plain_instance_norm(norm):
             # conv (library kernel where it applies, else MIOpen) -> fused InstanceNorm + LeakyReLU
             return ops.instance_norm_act(conv2d_plain(self, self.conv, x), norm.eps, L.ACT_LEAKY if self.relu else L.ACT_NONE)
@@ -299,6 +319,11 @@ class FeatureAtt(nn.Module):
                                       nn.Conv2d(feat_chan // 2, cv_chan, 1))
 
     def forward(self, cv, feat):
+        if _FOLD_POINTWISE and fused_ok(feat, self) and conv2d_hip_ok(self.feat_att[1]):
+            c = self.feat_att[1]  # 1x1 + bias with the sigmoid in the epilogue
+            pk = self.__dict__.setdefault("_pk_gate", ops.PackedConv())
+            gate = ops.conv2d([self.feat_att[0](feat).contiguous()], pk.get([c.weight], [c.bias]), act=L.ACT_SIGMOID)
+            return gate.unsqueeze(2) * cv
         return torch.sigmoid(self.feat_att(feat).unsqueeze(2)) * cv
 
 
