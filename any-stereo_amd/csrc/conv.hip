@@ -909,8 +909,13 @@ __device__ unsigned long long as_conv_life_buf[kStampBlocks * 8];
 // the LDS commit.  Measured on the single-role version: an LDS-DMA instruction costs the issuing wave
 // ~180 cycles, so 18 of them per chunk in front of 108 MFMAs could not overlap with them (in-order issue);
 // on a sibling wave of the same SIMD they do.
-template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1, bool FAST = false>
-__global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
+template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1, bool FAST = false, bool LEAN = false>
+__global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvParams p) {
+  // LEAN: four waves that issue their own LDS-DMA and consume it (no loader waves, one weight image + one patch image:
+  // ~68 KB), so TWO blocks share a CU: while one waits for its unit to land or runs its prologue / epilogue, the other's MFMAs
+  // keep the matrix pipes busy.  All-DMA operand staging only (every source blocked split-fp16), 3x3, stride 1, 64-channel tiles.
+  constexpr int NT = LEAN ? 256 : 512;
+  static_assert(!LEAN || (KS == 3 && S == 1 && BN == 64), "lean blocks: 3x3, stride 1, 64-channel tiles");
   as::fp16_saturate_mode();      // |x| >= 65504 saturates in the operand split instead of producing inf / NaN (common.h)
   float ovf_amax = 0.f;      // max |x| this thread split (loader path) or emitted as a blocked split-fp16 result
   // FAST: fp16 operands (the hi parts only), ONE MFMA per product (as_set_fast16).  A compile-time variant: a run-time
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave >= 4;
+  const bool loader = !LEAN && wave >= 4;
   const int l31 = lane & 31, half = lane >> 5;
   AS_LIFE(0)
 
@@ -1008,7 +1013,111 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   const int co_base = (BN == 128) ? (cw >> 1) * 64 : 0;
   const int px_base = (BN == 128) ? (cw & 1) * (PTW * 32) : cw * (PTW * 32);
 
-  if (loader) {
+#define AS_SPLIT_LDOPS(TAP, S)                                                                          \
+  {                                                                                                     \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                      \
+      a_hi[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 0) * 2) * WSEG + c * 512);          \
+      if (!fast16) a_lo[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 1) * 2) * WSEG + c * 512); \
+    }                                                                                                   \
+    constexpr int tapoff_ = (KS == 1) ? (TAP) * PIMG : (((TAP) / KS) * PW + ((TAP) % KS)) * 16;          \
+    _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                    \
+      b_hi[S][q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff_);                         \
+      if (!fast16) b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHT * 16 + plane_off[q] + tapoff_); \
+    }                                                                                                   \
+  }
+#define AS_SPLIT_MFMA_C(S, c)                                                                           \
+  _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                      \
+    acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);   \
+    if (!fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
+  }                                                                                                     \
+  if (!fast16) {                                                                                        \
+  _Pragma("unroll") for (int q = 0; q < PTW; ++q)  /* second cross term: not back to back with the first on the same accumulator */ \
+    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0); \
+  }
+#define AS_SPLIT_STEP(TAP)                                                                              \
+  if constexpr ((TAP) < NTAPE) {                                                                        \
+    AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if constexpr ((TAP) + 1 < NTAPE) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+  if constexpr (LEAN) {
+    // =========================== LEAN BLOCK: every wave stages and consumes ===========================
+    constexpr int SEG_PER_STEP = 256 / BN;
+    const int ltid = tid, lwave = wave;
+    unsigned p_boff[NPI];
+    bool p_slot[NPI];
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      int idx = ltid + i * 256;
+      const bool slot = idx < 2 * PATCHT;
+      if (!slot) idx = 2 * PATCHT - 1;
+      const int hh = idx / PATCHT, ppt = idx - hh * PATCHT;
+      const int su = ppt / PATCHP, pp = ppt - su * PATCHP;
+      const int py = pp / PW, px = pp - py * PW;
+      const int gy = (NSUB > 1 && su ? sy0[NSUB - 1] : sy0[0]) - PAD + py, gx = (NSUB > 1 && su ? sx0[NSUB - 1] : sx0[0]) - PAD + px;
+      const bool in = slot && gy >= 0 && gy < p.Hi && gx >= 0 && gx < p.Wi;
+      p_boff[i] = in ? (unsigned)(((long long)hh * plane + (long long)gy * p.Wi + gx) * 16) : 0x7FFFFFF0u;
+      p_slot[i] = slot;
+    }
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wpack_sel, 0, 0x7FFFFFF0, 0x00020000);
+    const unsigned wvoff = (unsigned)((n0 + (long long)(ltid / BN) * p.Cout_pad + (ltid % BN)) * 16);
+    const long long wstep16 = (long long)SEG_PER_STEP * p.Cout_pad;
+    const long long wchunk16 = (long long)NTAPE * 4 * p.Cout_pad;
+    const int wlane = half * WSEG + (co_base + l31) * 16;
+    int plane_off[PTW];
+#pragma unroll
+    for (int q = 0; q < PTW; ++q) {
+      const int mt = px_base + q * 32 + l31;
+      const int m = mt & 127;
+      plane_off[q] = half * (PATCHT * 16) + ((mt >> 7) * PATCHP + (m / TW) * S * PW + (m % TW) * S) * 16;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < PTW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_h[c][q][r] = 0.f; acc_x[c][q][r] = 0.f; }
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+      {  // this wave's quarter of the unit: weight image -> lds[0, WCHUNK), patch image -> lds[WCHUNK, WCHUNK + PIMG)
+#pragma unroll
+        for (int g = 0; g < NWD; ++g)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (as_lds_void*)(lds + g * 4096 + lwave * 1024), 16, wvoff,
+                                                   (unsigned)(((long long)chunk * wchunk16 + (long long)g * wstep16) * 16), 0, 0);
+        const int cb = chunk * kSplitKC;
+        const float* sp = src0;
+        int sc = p.src_c[0], sb = 0;
+        if (p.n_src > 1 && cb >= p.src_end[0]) { sp = p.src[1]; sc = p.src_c[1]; sb = p.src_end[0]; }
+        if (p.n_src > 2 && cb >= p.src_end[1]) { sp = p.src[2]; sc = p.src_c[2]; sb = p.src_end[1]; }
+        if (p.n_src > 3 && cb >= p.src_end[2]) { sp = p.src[3]; sc = p.src_c[3]; sb = p.src_end[2]; }
+        const int left = sc - (cb - sb);
+        const int c8 = (sc + 7) >> 3, blk = (cb - sb) >> 3;
+        const _Float16* spb = reinterpret_cast<const _Float16*>(sp) + ((long long)b * 2 * c8 + (left > 0 ? blk : 0)) * plane * 8;
+        const int recs = left > 0 ? (int)((long long)(c8 - blk) * plane * 16) : 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)spb, 0, recs, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc((void*)(spb + (long long)c8 * plane * 8), 0, recs, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+          const int vo_ = (int)p_boff[i];
+          if (p_slot[i]) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (as_lds_void*)(lds + WCHUNK + (i * 256 + lwave * 64) * 16), 16, vo_, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsl, (as_lds_void*)(lds + WCHUNK + 2 * PATCHT * 16 + (i * 256 + lwave * 64) * 16), 16, vo_, 0, 0, 0);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // the unit has landed
+      const unsigned char* wb = lds + wlane;
+      const unsigned char* pb = lds + WCHUNK;
+      half8 a_hi[2][2], a_lo[2][2], b_hi[2][PTW], b_lo[2][PTW];
+      AS_SPLIT_LDOPS(0, 0)
+      AS_SPLIT_STEP(0) AS_SPLIT_STEP(1) AS_SPLIT_STEP(2) AS_SPLIT_STEP(3) AS_SPLIT_STEP(4)
+      AS_SPLIT_STEP(5) AS_SPLIT_STEP(6) AS_SPLIT_STEP(7) AS_SPLIT_STEP(8)
+      __syncthreads();  // every wave is done with the images before the next unit overwrites them
+    }
+  } else if (loader) {
     // =========================== LOADER WAVES ===========================
     const int ltid = tid - 256;
     const int lwave = wave - 4;
@@ -1218,42 +1327,9 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
       const unsigned char* pb = lds + 2 * WCHUNK + (dma ? ((chunk - chunk_lo) & 1) * PIMG : 0);
       // operand software pipeline: the ds_read_b128 of tap t+1 sit between the two halves of tap t's MFMAs
       half8 a_hi[2][2], a_lo[2][2], b_hi[2][PTW], b_lo[2][PTW];
-#define AS_SPLIT_LDOPS(TAP, S)                                                                          \
-  {                                                                                                     \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                      \
-      a_hi[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 0) * 2) * WSEG + c * 512);          \
-      if (!fast16) a_lo[S][c] = *reinterpret_cast<const half8*>(wb + (((TAP) * 2 + 1) * 2) * WSEG + c * 512); \
-    }                                                                                                   \
-    constexpr int tapoff_ = (KS == 1) ? (TAP) * PIMG : (((TAP) / KS) * PW + ((TAP) % KS)) * 16;          \
-    _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                    \
-      b_hi[S][q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoff_);                         \
-      if (!fast16) b_lo[S][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHT * 16 + plane_off[q] + tapoff_); \
-    }                                                                                                   \
-  }
-#define AS_SPLIT_MFMA_C(S, c)                                                                           \
-  _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                      \
-    acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);   \
-    if (!fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
-  }                                                                                                     \
-  if (!fast16) {                                                                                        \
-  _Pragma("unroll") for (int q = 0; q < PTW; ++q)  /* second cross term: not back to back with the first on the same accumulator */ \
-    acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0); \
-  }
-#define AS_SPLIT_STEP(TAP)                                                                              \
-  if constexpr ((TAP) < NTAPE) {                                                                        \
-    AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if constexpr ((TAP) + 1 < NTAPE) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-  }
       AS_SPLIT_LDOPS(0, 0)
       AS_SPLIT_STEP(0) AS_SPLIT_STEP(1) AS_SPLIT_STEP(2) AS_SPLIT_STEP(3) AS_SPLIT_STEP(4)
       AS_SPLIT_STEP(5) AS_SPLIT_STEP(6) AS_SPLIT_STEP(7) AS_SPLIT_STEP(8)
-#undef AS_SPLIT_STEP
-#undef AS_SPLIT_MFMA_C
-#undef AS_SPLIT_LDOPS
       AS_STAMP_SEG(0)  // operand reads + MFMAs of the chunk
       __syncthreads();
       AS_STAMP_SEG(1)  // waited for the loaders (next weight image stored, next patch fetched)
@@ -1276,7 +1352,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     // shifted 9-tap sum over all channel tiles is as_tap_shift_sum's.  The 256-channel hidden layer never exists in memory.
     static_assert(EPI != kEpiTaps || BN == 64, "tap reduction: one consumer wave must hold all channels of the tile");
     float* w2s = bias_s + 64;  // [64][12]
-    for (int i = tid; i < 64 * 9; i += 512) {
+    for (int i = tid; i < 64 * 9; i += NT) {
       const int c = i / 9, t = i - c * 9;
       w2s[c * 12 + t] = (n0 + c < p.Cout) ? p.tap_w[(long long)(n0 + c) * 9 + t] : 0.f;
     }
@@ -1330,7 +1406,7 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
     // gru04 z|r 149.7 -> 148.0 us, +0.6 % pairs/s)
     const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);
     const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
-    constexpr int PG = 512 / BM;           // thread groups along the channel dimension
+    constexpr int PG = NT / BM;            // thread groups along the channel dimension
     constexpr int NB8 = BN / 8 / PG;       // 8-channel blocks per thread
     const int mt = tid % BM, cg = tid / BM;
     const int su = mt >> 7, m = mt & 127;
@@ -1428,6 +1504,10 @@ __global__ __launch_bounds__(512, 2) void conv_split_kernel(ConvParams p) {
   as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
 }
 
+#undef AS_SPLIT_STEP
+#undef AS_SPLIT_MFMA_C
+#undef AS_SPLIT_LDOPS
+
 // weight [Cout,Cin,KS,KS] fp32 -> split pack [chunk16][tap][comp][h][Cout_pad][8] fp16 (zero padded)
 __global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout,
                                           int Cout_pad, int KS, long long total) {
@@ -1512,19 +1592,34 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p) {
   }
 }
 
-template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1, bool FAST = false>
+template <int KS, int TW, int BN, int EPI, int NSUB = 1, int S = 1, bool FAST = false, bool LEAN = false>
 int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   if constexpr (!FAST && KS == 3 && S == 1) {  // the one-MFMA variant exists for the stride-1 3x3 convolutions (the GRU loop, the context net)
     if (p.fast16) return launch_conv_split_epi<KS, TW, BN, EPI, NSUB, S, true>(p, s);
   }
+  if constexpr (!LEAN && !FAST && KS == 3 && S == 1 && BN == 64) {
+    // two 4-wave blocks per CU instead of one 8-wave block when every source is blocked (AS_CONV_LEAN: 0 off, 1 = the
+    // 256-pixel blocks of the big maps, 2 = every 64-channel 3x3 launch)
+    static const int lean_mode = getenv("AS_CONV_LEAN") ? atoi(getenv("AS_CONV_LEAN")) : 1;
+    // measured (cfg 2): with >= 2 blocks for every CU the pair overlaps one block's staging / prologue / epilogue with the
+    // other's MFMAs (gru04 z|r 149.3 -> 146.6 us, head conv1 58.9 -> 54.4); with fewer blocks a CU holds ONE single-buffered
+    // block and loses (gru04 q 85.5 -> 102.8, gru08 z|r 62 -> 87), as do 128-pixel lean blocks at three per CU (156.6 vs 144.4)
+    const long long nblk = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, NSUB) * p.n_tiles * p.ksplit;
+    if (p.all_bs && (lean_mode >= 2 || (lean_mode == 1 && NSUB == 2 && nblk >= 2 * kNumCU)))
+      return launch_conv_split_epi<KS, TW, BN, EPI, NSUB, S, false, true>(p, s);
+  }
   constexpr int TH = 128 / TW, PATCHP = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
   constexpr int NSC = (KS == 1) ? 4 : 1;
   constexpr size_t wimg = (size_t)(KS * KS * NSC * 4 * BN * 16), pimg = (size_t)NSC * (4 * NSUB * PATCHP * 16);
-  constexpr size_t lds = 2 * wimg + ((KS == 3 && 2 * wimg + 2 * pimg <= 160 * 1024) ? 2 : 1) * pimg;  // the kernel's PDB rule
+  // LEAN: one weight + one patch image, and room for the epilogue's staging (bias / tap weights 4 KB + the fp32 tile)
+  constexpr size_t lds_lean = (wimg + pimg > 4096 + (size_t)BN * 128 * NSUB * 4) ? wimg + pimg : 4096 + (size_t)BN * 128 * NSUB * 4;
+  constexpr size_t lds = LEAN ? lds_lean
+                              : 2 * wimg + ((KS == 3 && 2 * wimg + 2 * pimg <= 160 * 1024) ? 2 : 1) * pimg;  // the kernel's PDB rule
   static_assert(lds <= 160 * 1024, "conv_split: LDS budget");
+  static_assert(!LEAN || lds <= 80 * 1024, "conv_split (lean): two blocks per CU");
   static bool configured = false;  // per instantiation; the attribute is idempotent
   if (!configured && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
   const long long groups = as::cdiv64((long long)p.tiles_x * p.tiles_y, NSUB);
@@ -1532,7 +1627,7 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   static const int xcd_mode = getenv("AS_CONV_XCD") ? atoi(getenv("AS_CONV_XCD")) : 1;
   ConvParams q = p;
   q.xcd_map = (xcd_mode && p.n_tiles > 1) ? 1 : 0;
-  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST>), grid, dim3(512), lds, s, q);
+  hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST, LEAN>), grid, dim3(LEAN ? 256 : 512), lds, s, q);
   return as::check_launch("conv2d(split)");
 }
 
