@@ -84,6 +84,12 @@ def classify(name, grid, grids_by_epi):
     return None, False
 
 
+def blocks(r):
+    """Launch size in BLOCKS: the 8-wave and the 4-wave (lean) form of a convolution have the same block grid but 512 / 256
+    threads per block, and one pass runs both (the first iteration's sources are not blocked yet)."""
+    return int(r["Grid_Size"]) // max(1, int(r.get("Workgroup_Size", 0) or 1))
+
+
 def load(d):
     f = glob.glob(d + "/*/*counter_collection.csv")
     return list(csv.DictReader(open(f[0]))) if f else []
@@ -98,9 +104,9 @@ def main():
         for r in rows:
             a = conv_args(r["Kernel_Name"])
             if a and "conv_split_kernel" in r["Kernel_Name"]:
-                grids[a[3]].append(int(r["Grid_Size"]))
+                grids[a[3]].append(blocks(r))
         for r in rows:
-            cls, wide = classify(r["Kernel_Name"], int(r["Grid_Size"]), grids)
+            cls, wide = classify(r["Kernel_Name"], blocks(r), grids)
             if cls is None:
                 continue
             v = float(r["Counter_Value"]) * 1024.0
