@@ -217,3 +217,26 @@ def test_reference_level_functions():
     up = context_upsample_multiscale_train_quaterp(d, m, c0)
     assert torch.equal(c0, coord)  # no in-place clamp in this variant
     assert (up.cpu() - O.convex_upsample_quater(d.cpu(), m.cpu(), coord.cpu())).abs().max() <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["igev_quater_posenc_cell", "igev_type2"])
+def test_model_variants_under_graph_replay(name):
+    """The general upsampler path inside the whole-forward hipGraph: replay == eager."""
+    from anystereo.models import __models__
+    keys = json.load(open(os.path.join(GOLD, "model_variants_keys.json")))
+    mname, (H, W), opt = keys["options"][name]
+    model = __models__[mname](default_args(mname, **opt)).eval()
+    fill_module_deterministic(model, base_seed=1)
+    model = model.cuda()
+    img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+    img1, img2 = img1.cuda(), img2.cuda()
+    coord = NL.make_coord([round(H * 1.5), round(W * 1.5)]).unsqueeze(0).cuda()
+    scale = torch.tensor([[1.5]], device="cuda")
+    with torch.no_grad():
+        eager = model(img1, img2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=scale)
+        model.enable_graph(True)
+        g1 = model(img1, img2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=scale)
+        g2 = model(img1, img2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=scale)
+    assert torch.equal(g1, g2)
+    assert (g1 - eager).abs().max().item() <= 1e-4
