@@ -708,11 +708,17 @@ class Stem7x7Pack:
 
     def __init__(self):
         self._key = None
+        self._ref = None
         self.wpack = None
 
+    def invalidate(self):
+        """Force a rebuild at the next use (after edits through `.data`, which do not bump version counters)."""
+        self._key = None
+
     def get(self, weight: torch.Tensor) -> torch.Tensor:
-        key = (id(weight), weight._version, weight.data_ptr())
-        if key != self._key:
+        key = (weight._version, weight.data_ptr(), weight.device)
+        # (address, version) alone can alias a freed tensor whose storage the allocator recycled: remember the object too
+        if key != self._key or self._ref is None or self._ref() is not weight:
             if tuple(weight.shape) != (64, 3, 7, 7) or not weight.is_cuda:
                 raise RuntimeError("conv7x7_c3: weight must be a CUDA tensor [64,3,7,7]")
             w = weight.detach().float().contiguous()
@@ -720,7 +726,7 @@ class Stem7x7Pack:
             self.wpack = torch.empty((int(lib.as_conv7x7_c3_pack_bytes()),), device=weight.device, dtype=torch.uint8)
             with _guard(weight.device):
                 L.check(lib.as_conv7x7_c3_pack(_p(w), self.wpack.data_ptr(), _stream()), "conv7x7_c3_pack")
-            self._key = key
+            self._key, self._ref = key, weakref.ref(weight)
         return self.wpack
 
 
