@@ -51,6 +51,36 @@ def conv2d_plain(mod: nn.Module, conv: nn.Module, x: torch.Tensor) -> torch.Tens
     return conv(x)
 
 
+def _deconv_as_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(k=4, s=2, p=1) weight [Cin,Cout,4,4] -> the 3x3 convolution weight [4*Cout,Cin,3,3] whose output, read
+    through pixel_shuffle(2), is the transposed convolution: out[2y+py, 2x+px] takes, per dimension, exactly two taps of the
+    input's 3-neighbourhood — parity 0: offsets (0, -1) with kernel taps (1, 3); parity 1: offsets (+1, 0) with taps (0, 2)."""
+    cin, cout = w.shape[:2]
+    taps = {0: ((0, 1), (-1, 3)), 1: ((1, 0), (0, 2))}  # parity -> ((input offset, kernel tap), ...)
+    w3 = w.new_zeros((cout, 2, 2, cin, 3, 3))
+    for py in (0, 1):
+        for oy, ky in taps[py]:
+            for px in (0, 1):
+                for ox, kx in taps[px]:
+                    w3[:, py, px, :, oy + 1, ox + 1] = w[:, :, ky, kx].t()
+    return w3.reshape(cout * 4, cin, 3, 3)
+
+
+def deconv2d_k4s2_ok(conv: nn.Module) -> bool:
+    return (isinstance(conv, nn.ConvTranspose2d) and conv.kernel_size == (4, 4) and conv.stride == (2, 2) and conv.padding == (1, 1)
+            and conv.output_padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and ops.get_precision() == "split")
+
+
+def deconv2d_k4s2_plain(mod: nn.Module, conv: nn.ConvTranspose2d, x: torch.Tensor) -> torch.Tensor:
+    """conv(x) of a 4x4 / stride-2 ConvTranspose2d as ONE 3x3 library convolution to 4*Cout channels + pixel_shuffle (2.25 x
+    the FLOPs of the sparse form — these layers sit at 1/8 .. 1/32 resolution — instead of MIOpen's backward-data kernel)."""
+    packs = mod.__dict__.setdefault("_hip_packs", {})
+    pk = packs.setdefault(id(conv), ops.PackedConv())
+    y = ops.conv2d([x.contiguous()], pk.get([conv.weight], [None], transform=_deconv_as_conv3x3))
+    return F.pixel_shuffle(y, 2)
+
+
 def _plain_instance_norm(norm) -> bool:
     return isinstance(norm, nn.InstanceNorm2d) and not norm.affine and not norm.track_running_stats
 
@@ -168,7 +198,8 @@ class _ConvNormAct(nn.Module):
                 return y.view(b_, c.out_channels, d_, h_, w_)
         if fused_ok(x, self) and x.dim() == 4 and _plain_instance_norm(norm):
             # conv (library kernel where it applies, else MIOpen) -> fused InstanceNorm + LeakyReLU
-            return ops.instance_norm_act(conv2d_plain(self, self.conv, x), norm.eps, L.ACT_LEAKY if self.relu else L.ACT_NONE)
+            y = deconv2d_k4s2_plain(self, self.conv, x) if (_FOLD_POINTWISE and deconv2d_k4s2_ok(self.conv)) else conv2d_plain(self, self.conv, x)
+            return ops.instance_norm_act(y, norm.eps, L.ACT_LEAKY if self.relu else L.ACT_NONE)
         x = conv3d_train(self.conv, x) if x.dim() == 5 else G.module_conv2d(self, "t", self.conv, x)
         if self.use_norm:
             x = norm(x)
