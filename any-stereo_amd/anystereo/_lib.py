@@ -94,6 +94,7 @@ SIGNATURES = {
     "as_liif_gather": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_liif_gather_mlp1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_convex_upsample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "as_conv3x3_few": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_vp]),
     "as_conv7x7_c3_pack_bytes": (C.c_int64, []),
     "as_conv7x7_c3_pack": (_i, [_vp, _vp, _vp]),
     "as_conv7x7_c3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -348,8 +348,17 @@ class Feature(nn.Module):
         if _fused_ok(x, self) and isinstance(self.bn1, nn.BatchNorm2d):
             if not hasattr(self, "_f_stem"):
                 self._f_stem = ops.FoldedConv()
-            w, b = self._f_stem.get(self.conv_stem, self.bn1)
-            x = nn.functional.conv2d(x, w, b, self.conv_stem.stride, self.conv_stem.padding).clamp_(0.0, 6.0)
+            c = self.conv_stem
+            if (c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride in ((1, 1), (2, 2)) and c.dilation == (1, 1) and c.groups == 1
+                    and c.in_channels <= 8 and c.out_channels % 8 == 0 and isinstance(self.act1, nn.ReLU6)):
+                # 3 -> 32, stride 2 with the folded BatchNorm and ReLU6: one HBM-bound launch instead of MIOpen + bias + clamp passes
+                if not hasattr(self, "_f_stem_few"):
+                    self._f_stem_few = ops.FoldedConv("c2d")
+                wp, b = self._f_stem_few.get(c, self.bn1)
+                x = ops.conv3x3_few(x.contiguous(), wp, b, stride=c.stride[0], act=L.ACT_RELU6)
+            else:
+                w, b = self._f_stem.get(self.conv_stem, self.bn1)
+                x = nn.functional.conv2d(x, w, b, self.conv_stem.stride, self.conv_stem.padding).clamp_(0.0, 6.0)
         else:
             x = self.act1(self.bn1(self.conv_stem(x)))
         x2 = self.block0(x)

@@ -703,6 +703,22 @@ def conv7x7_c1_relu(x, weight, bias, out=None, out_coff=0, copy_out=None, copy_c
     return out
 
 
+def conv3x3_few(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
+    """act(conv3x3(x [B,Cin<=8,H,W], padding 1, stride) + bias) with wpack [Cin,9,Cout] (= weight.permute(1,2,3,0)): the
+    3-channel image stems (extractor.py:331-336)."""
+    _req(x, "x"), _req(wpack, "wpack")
+    b, cin, h, w = x.shape
+    if wpack.dim() != 3 or wpack.shape[0] != cin or wpack.shape[1] != 9:
+        raise RuntimeError("conv3x3_few: wpack must be [Cin,9,Cout]")
+    cout = wpack.shape[2]
+    if bias is not None:
+        _req(bias, "bias")
+    out = torch.empty((b, cout, (h - 1) // stride + 1, (w - 1) // stride + 1), device=x.device, dtype=torch.float32)
+    with _guard(x.device):
+        L.check(L.load().as_conv3x3_few(_p(x), _p(wpack), _p(bias), _p(out), b, cin, cout, h, w, stride, act, _stream()), "conv3x3_few")
+    return out
+
+
 class Stem7x7Pack:
     """MFMA fragments of a [64,3,7,7] weight (csrc/stem7x7.hip), rebuilt when the weight tensor object or its version changes."""
 
@@ -903,6 +919,8 @@ class FoldedConv:
                 w, b = fold_bn(conv, bn, out_dim=1 if self.layout == "d3d" else 0)
             if self.layout == "c3d":
                 w = w.permute(1, 2, 3, 4, 0).reshape(w.shape[1], 27, w.shape[0])
+            elif self.layout == "c2d":  # [Cout,Cin,3,3] -> [Cin,9,Cout] (as_conv3x3_few)
+                w = w.permute(1, 2, 3, 0).reshape(w.shape[1], 9, w.shape[0])
             elif self.layout == "d3d":  # ConvTranspose3d weight [Cin,Cout,4,4,4] -> [Cin,4,4,4,Cout]
                 w = w.permute(0, 2, 3, 4, 1)
             self._wb, self._key = (w.contiguous(), b), key

@@ -71,6 +71,64 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3, padding 1, stride S convolution of a FEW input channels (the image stems: Cin = 3) to Cout = groups x 8 channels, with
+// bias (folded BatchNorm) and activation: HBM-bound (27 MAC per output and channel), one thread per output pixel and 8 output
+// channels, the 9 x 8 weights of an input channel as scalar operands.  wpack [Cin][9][Cout].
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void conv3x3_few_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int Cin,
+                                                          int Cout, int H, int W, int Ho, int Wo, int act) {
+  constexpr int CT = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int groups = Cout / CT;
+  const int g = blockIdx.z % groups, b = blockIdx.z / groups;
+  const int oy = blockIdx.y * 4 + wave;
+  const int ox = blockIdx.x * 64 + lane;
+  if (oy >= Ho) return;
+  const unsigned row_b = (unsigned)W * 4u, plane_b = (unsigned)H * row_b;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)b * Cin * (plane_b / 4)), 0,
+                                                                      (int)((long long)Cin * plane_b), 0x00020000);
+  unsigned xo[3][3], rowoff[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * S + ky - 1;
+    const bool rowok = iy >= 0 && iy < H;  // wave-uniform
+    rowoff[ky] = rowok ? (unsigned)iy * row_b : 0u;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * S + kx - 1;
+      xo[ky][kx] = (rowok && ox < Wo && ix >= 0 && ix < W) ? (unsigned)(ix * 4) : kOOB;
+    }
+  }
+  float acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc[j] = bias ? bias[g * CT + j] : 0.f;
+  const float* wt = wp + g * CT;
+  unsigned cio = 0;
+  for (int ci = 0; ci < Cin; ++ci, cio += plane_b, wt += 9 * Cout) {
+    float v[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) v[ky][kx] = bload(rs, xo[ky][kx], cio + rowoff[ky]);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[j] = fmaf(v[ky][kx], wt[(ky * 3 + kx) * Cout + j], acc[j]);
+  }
+  if (ox < Wo) {
+    const long long oplane = (long long)Ho * Wo;
+    float* o = out + ((long long)b * Cout + g * CT) * oplane + (long long)oy * Wo + ox;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) o[j * oplane] = act_apply(acc[j], act);
+  }
+}
+
 // value of the lane one below / one above in the wave (DPP wave shifts; lane 0 / lane 63 receive 0)
 __device__ __forceinline__ float wave_shr1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
@@ -356,6 +414,24 @@ int as_dwconv3x3(const float* x, const float* weight, const float* bias, const f
   if (stride == 1) hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, residual, out, C, H, W, Ho, Wo, act);
   else hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, residual, out, C, H, W, Ho, Wo, act);
   return as::check_launch("dwconv3x3");
+}
+
+int as_conv3x3_few(const float* x, const float* wpack, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                   int stride, int act, void* stream) {
+  AS_REQUIRE(x && wpack && out, AS_ERR_BAD_ARG, "conv3x3_few: null pointer");
+  AS_REQUIRE(B > 0 && Cin > 0 && Cin <= 8 && Cout > 0 && Cout % 8 == 0 && H > 0 && W > 0, AS_ERR_BAD_ARG,
+             "conv3x3_few: Cin=%d (1..8), Cout=%d (multiple of 8)", Cin, Cout);
+  AS_REQUIRE(stride == 1 || stride == 2, AS_ERR_BAD_ARG, "conv3x3_few: stride=%d (supported: 1, 2)", stride);
+  AS_REQUIRE(act >= AS_ACT_NONE && act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "conv3x3_few: act=%d", act);
+  AS_REQUIRE((long long)Cin * H * W * 4 < (long long)kOOB, AS_ERR_BAD_SHAPE, "conv3x3_few: input too large");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long gz = (long long)B * (Cout / 8);
+  AS_REQUIRE(gz <= 65535, AS_ERR_BAD_SHAPE, "conv3x3_few: B*groups=%lld exceeds the grid limit", gz);
+  const dim3 grid((unsigned)as::cdiv(Wo, 64), (unsigned)as::cdiv(Ho, 4), (unsigned)gz);
+  hipStream_t s = as::as_stream(stream);
+  if (stride == 1) hipLaunchKernelGGL(conv3x3_few_kernel<1>, grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, H, W, Ho, Wo, act);
+  else hipLaunchKernelGGL(conv3x3_few_kernel<2>, grid, dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, H, W, Ho, Wo, act);
+  return as::check_launch("conv3x3_few");
 }
 
 int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* out,

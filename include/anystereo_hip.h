@@ -466,6 +466,12 @@ long long as_conv7x7_c3_pack_bytes(void);
 int as_conv7x7_c3_pack(const float* weight, void* wpack, void* stream);
 int as_conv7x7_c3(const float* x, const void* wpack, const float* bias, float* out, int B, int H, int W, int act, void* stream);
 
+/* f4: 3x3, padding 1, stride 1|2 convolution of an image-like input (Cin <= 8: the 3-channel stems, e.g. MobileNetV2's `conv_stem`,
+ *   extractor.py:331-336) to Cout = multiple of 8 channels, + bias (folded BatchNorm) + activation.  wpack [Cin][9][Cout] fp32
+ *   (= weight.permute(1,2,3,0)).  Plain fp32 FMA arithmetic (27 MAC per output: HBM-bound). */
+int as_conv3x3_few(const float* x, const float* wpack, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                   int stride, int act, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

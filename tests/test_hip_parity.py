@@ -390,6 +390,19 @@ def test_conv7x7_c3_stem(b, h, w, act, with_bias):
     close(out2, torch.nn.functional.conv2d(x.double(), 0.5 * wt.double(), None, padding=3), 3e-6, 3e-6, "conv7x7_c3 repack")
 
 
+@pytest.mark.parametrize("b,cin,cout,h,w,stride,act", [(2, 3, 32, 21, 70, 2, 4), (1, 3, 8, 9, 130, 1, 1), (1, 1, 16, 6, 5, 2, 0)])
+def test_conv3x3_few(b, cin, cout, h, w, stride, act):
+    from anystereo import ops
+    x = U((b, cin, h, w), 320, -1, 1)
+    wt = U((cout, cin, 3, 3), 321) * 0.5
+    bias = U((cout,), 322)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), stride=stride, padding=1)
+    ref = {0: ref, 1: ref.relu(), 4: ref.clamp(0, 6)}[act]
+    wp = wt.permute(1, 2, 3, 0).reshape(cin, 9, cout).contiguous()
+    out = ops.conv3x3_few(x.to(DEV), wp.to(DEV), bias.to(DEV), stride=stride, act=act)
+    close(out, ref, 2e-6, 2e-6, "conv3x3_few")
+
+
 def _randomize_bn(mod, seed):
     with torch.no_grad():
         for i, m in enumerate(mm for mm in mod.modules() if isinstance(mm, (torch.nn.BatchNorm2d, torch.nn.BatchNorm3d))):
