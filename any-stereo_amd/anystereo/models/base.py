@@ -283,6 +283,8 @@ class ContinuousStereoBase(nn.Module):
     # gru04(i) on a third stream instead of in front of gru08(i+1) on the main one (shorter 1/8-1/16 chain between two
     # gru04 launches).  ANYSTEREO_EARLY_GRU16=0 keeps the in-order schedule.
     early_gru16 = os.environ.get("ANYSTEREO_EARLY_GRU16", "1") != "0"
+    # ... and with it the bilinear resize of its result to 1/8 resolution (gru08's third source), instead of in front of gru08
+    early_interp16 = os.environ.get("ANYSTEREO_EARLY_INTERP16", "1") != "0"
 
     def _iterate_pipelined(self, lookup_fn, net, inp, disp, coords, iters):
         from ..nn.update import interp, pool2x
@@ -301,7 +303,7 @@ class ContinuousStereoBase(nn.Module):
         front = fused and ub.encoder.fused_front and ub.disp_head.taps_ok(net[0])
         early = self.early_gru16 and iters > 1
         s16 = (main if serial else ub._side_stream(dev, 1)) if early else None
-        net2_next = None
+        net2_next = up16_next = None
         for itr in range(iters):
             pre = ub.gru04.pre_zr(net[0], *(inp[0])) if self.split_gate_conv else None
             if net2_next is None:
@@ -311,11 +313,18 @@ class ContinuousStereoBase(nn.Module):
                 net[2] = net2_next
                 net[2].record_stream(main)
                 net2_next = None
-            net[1] = ub.gru08(net[1], *(inp[1]), pool2x(net[0]), interp(net[2], net[1]))
+            if up16_next is None:
+                up16 = interp(net[2], net[1])
+            else:  # resized on the third stream right behind the gru16 that produced it: off the 1/8-resolution chain
+                up16, up16_next = up16_next, None
+                (up16.t if isinstance(up16, ops.BS8) else up16).record_stream(main)
+            net[1] = ub.gru08(net[1], *(inp[1]), pool2x(net[0]), up16)
             if early and itr + 1 < iters:
                 s16.wait_stream(main)  # net[1], net[2] of this iteration are final
                 with torch.cuda.stream(s16):
                     net2_next = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
+                    if self.early_interp16:
+                        up16_next = interp(net2_next, net[1])  # only net[1]'s size is used
                 net[1].record_stream(s16)
                 net[2].record_stream(s16)
             up = interp(net[1], net[0])
