@@ -362,8 +362,16 @@ class ContinuousStereoBase(nn.Module):
         if (test_mode and iters > 0 and a.n_gru_layers == 3 and not a.slow_fast_gru and disp.is_cuda
                 and not torch.is_grad_enabled() and getattr(ub, "parallel_encoder", False)
                 and type(self)._hot_update is ContinuousStereoBase._hot_update and self.pipelined_loop):
+            liif = getattr(self, "liif_up", None)
+            if liif is not None and stem_2x is not None and stem_1x is None and hasattr(liif, "precompute_static"):
+                # the stem_2x input of the upsampler does not change during the loop: its affinity + low-resolution first layer
+                # run on a branch of their own beside the loop instead of in front of the tail kernel after it
+                liif.precompute_static([[stem_4x, net_list[0]] if stem_4x is not None else [net_list[0]], [stem_2x]], 1,
+                                       ub._side_stream(disp.device, 2))
             disp = self._iterate_pipelined(lookup_fn, net_list, inp_list, disp, coords, iters)
             disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, stem_1x, hr_coord=hr_coord, scale=scale)
+            if liif is not None and hasattr(liif, "clear_static"):
+                liif.clear_static()
             return disp, disp_up, [disp_up]
         for itr in range(iters):
             disp = disp.detach()

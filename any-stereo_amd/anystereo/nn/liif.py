@@ -429,6 +429,42 @@ class liif_out_multi_scale_Training(nn.Module):
                 and ops.get_precision() == "split" and all(len(ps) <= 2 for ps in feats_parts)
                 and all(p.shape[1] % 16 == 0 for ps in feats_parts for p in ps))
 
+    early_static = __import__("os").environ.get("ANYSTEREO_LIIF_EARLY_STATIC", "1") != "0"
+
+    def precompute_static(self, feats_parts, slot, stream):
+        """Affinity + first MLP layer at low resolution of input `slot`, whose maps do not change during the GRU loop (stem_2x):
+        issued on `stream` BEFORE the loop, so the post-loop upsampler only has the hidden-state input's chain in front of the
+        tail kernel.  feats_parts as in `upsample_fused` (the other inputs are read for their channel counts only).  The result
+        is picked up by the next `upsample_fused` call that sees the same tensors; `clear_static()` drops it."""
+        self.__dict__.pop("_early_static", None)
+        if not (self.early_static and self.fused_tail and self._default_variant and 0 < slot < len(feats_parts) <= 2):
+            return
+        lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
+        w1 = lin[0].weight
+        if not hasattr(self, "_lowres_packs"):
+            self._lowres_packs = [ops.LiifLowresPack() for _ in range(2)]
+        o_ = sum(sum(p_.shape[1] for p_ in ps) + 8 + 2 for ps in feats_parts[:slot])
+        src = list(feats_parts[slot])
+        parts = [p_.float().contiguous() for p_ in src]
+        c = sum(p_.shape[1] for p_ in parts) + 8
+        pk = self._lowres_packs[slot]
+        pk.get(w1, o_, c)  # built on the current stream, before the branch
+        main = torch.cuda.current_stream(parts[0].device)
+        stream.wait_stream(main)
+        with torch.cuda.stream(stream):
+            with scope("structure_feature"):
+                aff = ops.liif_affinity(parts)
+            with scope("liif_mlp_lowres"):
+                u = ops.liif_lowres_cl(parts + [aff], pk.get(w1, o_, c))
+            done = torch.cuda.Event()
+            done.record(stream)
+        for t_ in parts:
+            t_.record_stream(stream)
+        self.__dict__["_early_static"] = {"slot": slot, "src": src, "parts": parts, "u": u, "done": done, "pack": pk.get(w1, o_, c)}
+
+    def clear_static(self):
+        self.__dict__.pop("_early_static", None)
+
     def upsample_fused(self, feats_parts, coord, disp, scale_vec, want_logits=False):
         """feats_parts: per LIIF input the list of NCHW tensors whose channel concat is that input (e.g. [[stem_4x, net0],
         [stem_2x]]: the concat of continuous_IGEVstereo.py:195 is never materialised).  coord [B,Q,2] is clamped IN PLACE
@@ -453,7 +489,17 @@ class liif_out_multi_scale_Training(nn.Module):
         # ... and the branch point is HERE, before the first chain is issued (a side.wait_stream(main) issued after it made the
         # second chain wait for the first: the two ran back to back, 168 us instead of ~125)
         fork = main.record_event() if side is not None else None
+        early = self.__dict__.get("_early_static")  # the loop-invariant input's rows, computed beside the GRU loop
         for i, (parts, c, pk) in enumerate(prep):
+            if (early is not None and i == early["slot"] and len(parts) == len(early["parts"])
+                    and all(a is b_ for a, b_ in zip(early["src"], feats_parts[i])) and early["pack"] is pk):
+                main.wait_event(early["done"])
+                early["u"].record_stream(main)
+                us.append(early["u"])
+                sizes.append(tuple(parts[0].shape[2:]))
+                rel_cols.append(off + c)
+                off += c + 2
+                continue
             on_side = side is not None and i == 1
             if on_side:
                 side.wait_event(fork)
