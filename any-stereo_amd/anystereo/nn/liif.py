@@ -437,7 +437,10 @@ class liif_out_multi_scale_Training(nn.Module):
         tail kernel.  feats_parts as in `upsample_fused` (the other inputs are read for their channel counts only).  The result
         is picked up by the next `upsample_fused` call that sees the same tensors; `clear_static()` drops it."""
         self.__dict__.pop("_early_static", None)
-        if not (self.early_static and self.fused_tail and self._default_variant and 0 < slot < len(feats_parts) <= 2):
+        # only when the fused tail will pick the rows up (fused_ok's conditions that do not depend on the coordinates)
+        if not (self.early_static and self.fused_tail and self._default_variant and 0 < slot < len(feats_parts) <= 2
+                and not torch.is_grad_enabled() and ops.get_precision() == "split"
+                and all(p_.is_cuda and p_.shape[1] % 16 == 0 for ps in feats_parts for p_ in ps)):
             return
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
         w1 = lin[0].weight
@@ -463,7 +466,11 @@ class liif_out_multi_scale_Training(nn.Module):
         self.__dict__["_early_static"] = {"slot": slot, "src": src, "parts": parts, "u": u, "done": done, "pack": pk.get(w1, o_, c)}
 
     def clear_static(self):
-        self.__dict__.pop("_early_static", None)
+        """Drop the early rows; JOINS their branch into the current stream (a forked branch that nobody waited for would leave a
+        hipGraph capture with unjoined work — e.g. when the upsampler took the staged path after all)."""
+        early = self.__dict__.pop("_early_static", None)
+        if early is not None:
+            torch.cuda.current_stream(early["u"].device).wait_event(early["done"])
 
     def upsample_fused(self, feats_parts, coord, disp, scale_vec, want_logits=False):
         """feats_parts: per LIIF input the list of NCHW tensors whose channel concat is that input (e.g. [[stem_4x, net0],

@@ -240,3 +240,30 @@ def test_model_variants_under_graph_replay(name):
         g2 = model(img1, img2, iters=2, test_mode=True, hr_coord=coord.clone(), scale=scale)
     assert torch.equal(g1, g2)
     assert (g1 - eager).abs().max().item() <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_default_model_graph_capture_in_both_precisions(precision):
+    """Whole-forward hipGraph capture joins every branch it forks in both matrix-core modes (the early stem_2x branch of the
+    upsampler is only taken when the fused tail will consume it): replay == eager."""
+    from anystereo import ops
+    from anystereo.models import __models__
+    ops.set_precision(precision)
+    try:
+        model = __models__["continuous_IGEVStereo"](default_args("continuous_IGEVStereo")).eval()
+        fill_module_deterministic(model, base_seed=1)
+        model = model.cuda()
+        img1, img2 = synthetic_pair(1, 64, 128, shift=6, seed=99)
+        img1, img2 = img1.cuda(), img2.cuda()
+        coord = NL.make_coord([96, 192]).unsqueeze(0).cuda()
+        scale = torch.tensor([[1.5]], device="cuda")
+        with torch.no_grad():
+            eager = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=scale)
+            model.enable_graph(True)
+            g1 = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=scale)
+            g2 = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=scale)
+        assert torch.equal(g1, g2)
+        assert (g1 - eager).abs().max().item() <= 1e-4
+    finally:
+        ops.set_precision("split")
