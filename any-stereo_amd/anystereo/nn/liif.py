@@ -173,12 +173,14 @@ class SpatialEncoding(nn.Module):
     def __init__(self, in_dim, out_dim, sigma=6, cat_input=True, require_grad=False):
         super().__init__()
         assert out_dim % (2 * in_dim) == 0, "dimension must be dividable"
-        import numpy as np
+        # frequency table [in_dim * n, in_dim]: block d holds the n frequencies 2^linspace(0, sigma, n) in column d, zeros
+        # elsewhere — every row looks at ONE coordinate (evaluated in fp64 like the reference's numpy table, then fp32)
         n = out_dim // 2 // in_dim
-        m = 2 ** np.linspace(0, sigma, n)
-        m = np.stack([m] + [np.zeros_like(m)] * (in_dim - 1), axis=-1)
-        m = np.concatenate([np.roll(m, i, axis=-1) for i in range(in_dim)], axis=0)
-        self.emb = torch.tensor(m, dtype=torch.float32)
+        freqs = torch.pow(torch.tensor(2.0, dtype=torch.float64), torch.linspace(0, sigma, n, dtype=torch.float64))
+        table = torch.zeros((in_dim * n, in_dim), dtype=torch.float64)
+        for d in range(in_dim):
+            table[d * n:(d + 1) * n, d] = freqs
+        self.emb = table.to(torch.float32)
         if require_grad:
             self.emb = nn.Parameter(self.emb, requires_grad=True)
         self.in_dim, self.out_dim, self.sigma, self.cat_input, self.require_grad = in_dim, out_dim, sigma, cat_input, require_grad
