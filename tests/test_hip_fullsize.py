@@ -423,3 +423,44 @@ def test_gru_convs_cfg3_cfg5_sizes(hw):
         zr = torch.sigmoid(lin)
         assert (z[:, :, r0:r0 + 8].double() - zr[:, :128]).abs().max().item() < 2e-5
         assert (rh[:, :, r0:r0 + 8].double() - zr[:, 128:] * xs[0][:, :, r0:r0 + 8].double()).abs().max().item() < 4e-5
+
+
+@pytest.mark.gpu
+def test_default_bench_command_produces_its_line():
+    """`python bench.py` with its default legs (split-precision headline, fp32 mode, reduced precision, cfg 1/3/5, batched) runs to
+    the end in a fresh process and prints ONE parseable JSON line — every leg captures and replays its own hipGraph, which is
+    where a fork without a join shows up.  (One timed step per leg; the CPU baseline is skipped.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "pairs/s" and d["value"] > 0 and d["n_gpus"] == 1
+    assert d["roofline"]["frac"] > 0 and d["fp32_mode"]["value"] > 0 and d["reduced_precision_mode"]["value"] > 0
+    assert set(d["other_configs"]) >= {"cfg1", "cfg3", "cfg5"} and all(v["finite"] for v in d["other_configs"].values())
+    assert d["library"]["matches_sources"] is True
+
+
+@pytest.mark.gpu
+def test_train_bench_command_produces_its_line():
+    """`python bench.py --mode train` (one rank, no launcher) in a fresh process: one parseable line with a finite loss."""
+    import json
+    import math
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "train", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "train_samples_per_s" and d["value"] > 0 and all(math.isfinite(v) for v in d["loss_first_last"])
+    assert d["roofline"]["frac"] > 0 and d["library"]["matches_sources"] is True
