@@ -232,11 +232,25 @@ class LiifGatherMlp1(torch.autograd.Function):
 _DEFER = os.environ.get("ANYSTEREO_DEFER_WGRAD", "1") != "0"
 
 
+# The deferred-gradient anchors (WeightAnchor stashes, ContextAnchor holders) are cached on their module for the duration of ONE
+# training forward: `begin_forward()` (called at the top of every model forward) opens a new epoch and every anchor of an older epoch is
+# rebuilt on first use.  So a forward whose backward never ran (a probe pass, an exception, a validation pass with gradients enabled)
+# cannot hand its autograd nodes, its stashed activations or its context tensor to the next forward; the autograd nodes of a forward
+# hold their own stash / holder objects, so two forwards followed by their two backward() calls stay independent.
+_EPOCH = 0
+
+
+def begin_forward() -> int:
+    global _EPOCH
+    _EPOCH += 1
+    return _EPOCH
+
+
 class _Stash:
-    __slots__ = ("key", "kind", "xs", "ds", "done", "w_tok", "b_tok")
+    __slots__ = ("key", "kind", "xs", "ds", "done", "w_tok", "b_tok", "epoch")
 
     def __init__(self, key, kind):
-        self.key, self.kind, self.xs, self.ds, self.done = key, kind, [], [], False
+        self.key, self.kind, self.xs, self.ds, self.done, self.epoch = key, kind, [], [], False, _EPOCH
 
 
 def _stack(ts):
@@ -316,7 +330,7 @@ def anchored(mod, name, kind, weights, biases):
     slot = mod.__dict__.setdefault("_wgrad_anchors", {})
     key = tuple((id(p), p._version) for p in (*weights, *biases) if p is not None)
     st = slot.get(name)
-    if st is None or st.done or st.key != key:
+    if st is None or st.done or st.key != key or st.epoch != _EPOCH:
         st = slot[name] = _Stash(key, kind)
         st.w_tok, st.b_tok = WeightAnchor.apply(st, *build())
     return st.w_tok, st.b_tok, st
@@ -412,8 +426,8 @@ def context_anchor(mod, base):
     if not (_DEFER and torch.is_grad_enabled() and base.requires_grad and base.is_cuda):
         return base, None
     ent = mod.__dict__.get("_ctx_anchor")
-    if ent is None or ent[0] is not base or ent[1] != base._version or ent[3].get("done"):
-        holder = {}
+    if ent is None or ent[0] is not base or ent[1] != base._version or ent[3].get("done") or ent[3].get("epoch") != _EPOCH:
+        holder = {"epoch": _EPOCH}
         ent = mod.__dict__["_ctx_anchor"] = (base, base._version, ContextAnchor.apply(holder, base), holder)
     return ent[2], ent[3]
 

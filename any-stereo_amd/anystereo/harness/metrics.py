@@ -24,20 +24,26 @@ def sequence_loss_multiscale(disp_preds, disp_gt, valid, loss_gamma=0.9, max_dis
     assert valid.shape == disp_gt.shape, [valid.shape, disp_gt.shape]
     gamma = loss_gamma ** (15 / (n - 1)) if n > 1 else loss_gamma
     if sync_free:
-        vm = valid.to(disp_gt.dtype)
-        cnt = vm.sum()
+        # Masking is a SELECT, never a multiplication: Middlebury ground truth holds inf at invalid pixels
+        # (frame_utils.readDispMiddlebury returns the PFM raw) and inf * 0 = NaN would poison the loss, the gradients and the
+        # AdamW state.  The ground truth is sanitised first so that no inf / NaN enters the graph at all (the backward of
+        # abs() multiplies the incoming zero by sign(x)); the reference excludes those pixels by boolean indexing (:84-86).
+        zero = torch.zeros((), dtype=disp_gt.dtype, device=disp_gt.device)
+        gt = torch.where(valid, disp_gt, zero)
+        cnt = valid.sum().to(disp_gt.dtype)
         preds = torch.stack(list(disp_preds))                       # [n,B,1,Q]
         assert preds.shape[1:] == valid.shape
-        per_pred = ((preds - disp_gt).abs() * vm).flatten(1).sum(1)  # [n] masked L1 sums
+        per_pred = torch.where(valid, (preds - gt).abs(), zero).flatten(1).sum(1)  # [n] masked L1 sums
         # gamma^(n-1-i), built on the device (a torch.tensor(list, device=...) is a blocking host-to-device copy)
         w = torch.pow(torch.full((), gamma, dtype=torch.float64, device=per_pred.device),
                       torch.arange(n - 1, -1, -1, dtype=torch.float64, device=per_pred.device)).to(per_pred.dtype)
         loss = (w * per_pred).sum() / cnt
         with torch.no_grad():
-            epe = torch.sum((disp_preds[-1] - disp_gt) ** 2, dim=1).sqrt().view(-1)
-            v = vm.view(-1)
-            metrics = {"epe": (epe * v).sum() / cnt, "1px": ((epe > 1).to(v.dtype) * v).sum() / cnt,
-                       "3px": ((epe > 3).to(v.dtype) * v).sum() / cnt}
+            epe = torch.sum((disp_preds[-1] - gt) ** 2, dim=1).sqrt().view(-1)
+            v = valid.view(-1)
+            metrics = {"epe": torch.where(v, epe, zero).sum() / cnt,
+                       "1px": (v & (epe > 1)).sum().to(cnt.dtype) / cnt,
+                       "3px": (v & (epe > 3)).sum().to(cnt.dtype) / cnt}
         return loss, metrics
     loss = 0.0
     for i, pred in enumerate(disp_preds):
@@ -85,7 +91,8 @@ def thres_metric(d_est, d_gt, mask, thres):
     return _per_image(lambda e, g, m: ((g[m] - e[m]).abs() > thres).float().mean(), d_est, d_gt, mask)
 
 
-def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0, loss_scale=1.0, sync_free_loss=False):
+def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0, loss_scale=1.0, sync_free_loss=False,
+               should_step=None):
     """One optimisation step with the reference's ordering (train_continuous_IGEV.py:214-239, multi_training branch):
     zero_grad -> forward(train mode) -> sequence_loss_multiscale with valid = (gt < 512) & (gt > 0) -> scaled backward ->
     unscale -> clip_grad_norm_(1.0) -> optimizer step -> scheduler step (unless fixed lr) -> scaler update.
@@ -93,6 +100,8 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
     `loss_scale` (a power of two, no GradScaler): the backward pass runs on loss * loss_scale and the gradients are divided by it
     before clipping — exact in fp32, it only moves the 1e-6 .. 1e-9 activation gradients of this loss away from the fp16
     subnormal range of the split-precision dgrad kernels (x = hi + lo/2048 keeps 22 bits only above |x| ~ 6e-5).
+    `should_step` (optional callable, evaluated after backward): False drops this step's optimizer update (the Trainer's
+    split-precision overflow gate; the schedule still advances, as under GradScaler).
     Model-agnostic host logic (any module with the reference's forward signature)."""
     image1, image2, hr_coord, hr_disp_gt, scale = batch
     optimizer.zero_grad()
@@ -111,7 +120,9 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
     else:
         loss.backward()
     torch.nn.utils.clip_grad_norm_([p for g in optimizer.param_groups for p in g["params"]], clip)  # = model.parameters(), without the module walk
-    if scaler is not None:
+    if should_step is not None and not should_step():
+        optimizer.zero_grad()
+    elif scaler is not None:
         scaler.step(optimizer)
     else:
         optimizer.step()

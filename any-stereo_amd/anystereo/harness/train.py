@@ -75,11 +75,23 @@ class Trainer:
         self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed)
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
         self.train_iters, self.max_disp = train_iters, max_disp
-        # static power-of-two loss scale (exact in fp32): keeps the activation gradients (1e-6 .. 1e-9 at cfg-4 scale) out of the
-        # fp16 subnormal range of the split-precision dgrad; the split's range guard (ops.split_overflow_count) watches the other end
+        # Power-of-two loss scale (exact in fp32) for the split-precision dgrad kernels only: it keeps the activation gradients
+        # (1e-6 .. 1e-9 at cfg-4 scale) out of the fp16 subnormal range of x = hi + lo/2048.  It buys nothing in fp32 mode or under
+        # GradScaler, so it is 1 there.  The other end of the range is WATCHED, not assumed: the split kernels saturate |x| >= 65504
+        # and count the event (ops.split_overflow_count); `step` polls the counters every `overflow_check_every` steps (one device
+        # synchronisation, off the per-step path), halves the scale on an event and records it in `overflow_events`.
+        # overflow_policy="skip" checks EVERY step before the optimizer runs and drops a step whose gradients saw a saturated
+        # operand (GradScaler's policy; costs a synchronisation per step).
+        from .. import ops
+        split = ops.get_precision() == "split"
         if loss_scale is None:
-            loss_scale = float(os.environ.get("ANYSTEREO_LOSS_SCALE", "4096"))
-        self.loss_scale = 1.0 if mixed_precision else loss_scale
+            loss_scale = float(os.environ.get("ANYSTEREO_LOSS_SCALE", "4096")) if split else 1.0
+        self.loss_scale = 1.0 if (mixed_precision or not split) else float(loss_scale)
+        self.overflow_check_every = int(os.environ.get("ANYSTEREO_OVERFLOW_CHECK_EVERY", "20"))
+        self.overflow_policy = os.environ.get("ANYSTEREO_OVERFLOW_POLICY", "poll")  # poll | skip | off
+        self.overflow_events = []   # (step index, waves that saturated, loss scale before, loss scale after)
+        self.skipped_steps = 0
+        self.steps_done = 0
         # the loss as masked sums without host synchronisation (harness/metrics.py); ANYSTEREO_SYNC_FREE_LOSS=0 = the reference's
         # boolean-mask statement (16 + 3 synchronisations per step)
         self.sync_free_loss = os.environ.get("ANYSTEREO_SYNC_FREE_LOSS", "1") != "0"
@@ -90,6 +102,10 @@ class Trainer:
         model = self.model
         mode = os.environ.get("ANYSTEREO_DDP", "probe")  # probe (default) | find_unused | static
         if mode == "probe":
+            # the probe runs in the mode every later step runs in (train + frozen BatchNorm2d), whatever the caller left
+            model.train()
+            model.freeze_bn()
+            self._requires_grad_before = {n: p.requires_grad for n, p in model.named_parameters()}
             model.zero_grad(set_to_none=True)
             image1, image2, hr_coord, gt, scale = batch
             res = model(image1, image2, iters=min(2, self.train_iters), hr_coord=hr_coord.clone(), scale=scale)
@@ -101,6 +117,20 @@ class Trainer:
                     p.requires_grad_(False)
                     self.frozen_unused.append(n)
             model.zero_grad(set_to_none=True)
+            if td.get_world_size() > 1:
+                # every rank must wrap the same parameter set, or the reducers' buckets disagree and the first all-reduce hangs
+                mine = sorted(self.frozen_unused)
+                sets = [None] * td.get_world_size()
+                td.all_gather_object(sets, mine)
+                if any(s_ != mine for s_ in sets):
+                    raise RuntimeError(f"Trainer: the probe pass froze different parameter sets on different ranks: "
+                                       f"{[len(s_) for s_ in sets]} tensors per rank")
+            if self.frozen_unused:
+                import warnings
+                warnings.warn("anystereo Trainer: requires_grad_(False) on %d parameter tensors the loss never reaches (%s%s); "
+                              "Trainer.restore_requires_grad() undoes it" % (
+                                  len(self.frozen_unused), ", ".join(self.frozen_unused[:4]), ", ..." if len(self.frozen_unused) > 4 else ""),
+                              RuntimeWarning)
         p = next(model.parameters())
         ids = [p.device.index] if p.is_cuda else None
         self.module = torch.nn.parallel.DistributedDataParallel(
@@ -108,6 +138,18 @@ class Trainer:
             bucket_cap_mb=self._bucket_cap_mb, gradient_as_bucket_view=True)
         self.ddp_mode = {"probe": f"plain DDP, {len(self.frozen_unused)} gradient-less parameter tensors frozen after a probe pass",
                          "find_unused": "find_unused_parameters", "static": "static_graph"}[mode]
+
+    def restore_requires_grad(self):
+        """Undo the probe pass's requires_grad_(False) on the bare module (e.g. before training it with another loss, or outside
+        this Trainer).  The DDP wrapper built around the frozen set is dropped; the next `step` probes and wraps again."""
+        before = getattr(self, "_requires_grad_before", None)
+        if before:
+            for n, p in self.model.named_parameters():
+                if n in before:
+                    p.requires_grad_(before[n])
+        self.frozen_unused = []
+        self.module = self.model
+        self.ddp_mode = "none"
 
     def step(self, batch, sync_grads: bool = True):
         """One optimisation step.  sync_grads=False (measurement only): DDP's reducer is bypassed (`no_sync`), every rank
@@ -118,9 +160,40 @@ class Trainer:
         if not self.module.training:
             self.module.train()
         self.model.freeze_bn()
+        watch = (self.loss_scale != 1.0 or self.overflow_events) and self.overflow_policy != "off" and self._on_gpu()
+        gate = self._overflow_gate if (watch and self.overflow_policy == "skip") else None
+        kw = dict(max_disp=self.max_disp, loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss, should_step=gate)
         if not sync_grads and self.module is not self.model:
             with self.module.no_sync():
-                return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
-                                  max_disp=self.max_disp, loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss)
-        return train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters,
-                          max_disp=self.max_disp, loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss)
+                out = train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters, **kw)
+        else:
+            out = train_step(self.module, self.optimizer, self.scheduler, self.scaler, batch, self.train_iters, **kw)
+        self.steps_done += 1
+        if watch and gate is None and self.overflow_check_every > 0 and self.steps_done % self.overflow_check_every == 0:
+            self._poll_overflow()
+        return out
+
+    def _on_gpu(self) -> bool:
+        return next(self.model.parameters()).is_cuda
+
+    def _poll_overflow(self) -> int:
+        """Read and reset the split kernels' saturation counters (synchronises); on an event halve the loss scale (never
+        below 1) and record it.  Returns the number of waves that saturated since the last poll."""
+        from .. import ops
+        n = ops.split_overflow_count(reset=True)
+        if n:
+            before = self.loss_scale
+            self.loss_scale = max(1.0, self.loss_scale * 0.5)
+            self.overflow_events.append((self.steps_done, n, before, self.loss_scale))
+            import warnings
+            warnings.warn(f"anystereo Trainer: {n} waves saturated an fp16-split operand (|x| >= 65504 or NaN) by step "
+                          f"{self.steps_done}; loss scale {before:g} -> {self.loss_scale:g}.  Gradients of the affected steps "
+                          "were clipped at the fp16 range; use set_precision('fp32') if this persists.", RuntimeWarning)
+        return n
+
+    def _overflow_gate(self) -> bool:
+        """should_step hook of train_step (policy "skip"): False drops the optimizer step of a backward pass that saturated."""
+        if self._poll_overflow():
+            self.skipped_steps += 1
+            return False
+        return True

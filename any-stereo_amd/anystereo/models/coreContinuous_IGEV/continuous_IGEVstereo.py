@@ -11,6 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
+from ... import grad as G
 from ...nn import blocks as B
 from ...nn import functional as AF
 from ...nn.encoders import Feature, MultiBasicEncoder, _plain_conv
@@ -99,6 +100,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
 
     def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):
         """Estimate disparity between a pair of frames (images are 0..255 float)."""
+        G.begin_forward()  # deferred-gradient anchors are scoped to this forward (grad.py)
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()

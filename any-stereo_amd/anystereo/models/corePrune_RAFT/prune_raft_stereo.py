@@ -8,6 +8,7 @@ import os
 import torch
 import torch.nn as nn
 
+from ... import grad as G
 from ...nn import blocks as B
 from ...nn.encoders import BasicEncoder, MultiBasicEncoder
 from ...nn.geometry import CorrBlock1D
@@ -84,6 +85,7 @@ class continuous_RaftStereo(ContinuousStereoBase):
         return net_list, ctx_list, stem_2x, stem_4x
 
     def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=False):
+        G.begin_forward()  # deferred-gradient anchors are scoped to this forward (grad.py)
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()

@@ -11,6 +11,8 @@ reference always passes (continuous_IGEVstereo.py:280) — it is regenerated in-
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .. import grad as G
@@ -51,7 +53,8 @@ class Combined_Geo_Encoding_Volume:
         if getattr(coords, "_as_pixel_grid", False):
             return
         key = (coords.data_ptr(), coords._version, tuple(coords.shape))
-        if key == getattr(self, "_coords_ok", None):
+        ok = getattr(self, "_coords_ok", None)
+        if ok is not None and ok[0] == key and ok[1]() is coords:  # the verified tensor itself, not a recycled address
             return
         if coords.is_cuda and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("lookup: an unverified `coords` tensor inside a stream capture — call once eagerly first")
@@ -59,7 +62,7 @@ class Combined_Geo_Encoding_Volume:
         if not torch.equal(coords, want.expand(b, h, w, 1)):
             raise RuntimeError("lookup: only coords == arange(w) per row (the grid of continuous_IGEVstereo.py:280) is supported; "
                                "the lookup position is x - disp with x the pixel column")
-        self._coords_ok = key
+        self._coords_ok = (key, weakref.ref(coords))
 
     def __call__(self, disp, coords=None):
         disp = disp.float().contiguous()

@@ -34,6 +34,7 @@ for p in (ROOT, os.path.join(ROOT, "any-stereo_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+RANK_CPUS = None  # this rank's CPU set (pin_rank)
 torch = None  # imported by main() in the worker ranks only: the spawning parent never touches torch or the GPU
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -100,6 +101,29 @@ def launch_ranks(a) -> int:
     return rc
 
 
+def pin_rank(local: int, local_world: int):
+    """Give this rank its own share of the host BEFORE torch (OpenMP pools, the autograd engine's threads) or HIP starts a
+    thread: the allowed CPUs (cgroup / taskset aware) are split into `local_world` contiguous core sets, the process is bound to
+    set `local` (os.sched_setaffinity: every later thread inherits it) and the OpenMP / MKL pools are sized to it.  The
+    training step is host-bound: eight ranks that each start a pool as wide as the machine and migrate across
+    sockets contend for the same cores.  ANYSTEREO_PIN=0 leaves placement to the OS.  Returns the CPU list (for the bench line).
+    No process is re-executed: this runs in the child before its first GPU call."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:  # not Linux
+        return None
+    if os.environ.get("ANYSTEREO_PIN", "1") == "0" or local_world <= 1:
+        return cpus
+    n = len(cpus) // local_world
+    if n < 1:
+        return cpus  # fewer cores than ranks: nothing sensible to pin to
+    mine = cpus[local * n:(local + 1) * n]
+    os.sched_setaffinity(0, mine)
+    for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ[k] = str(len(mine))
+    return mine
+
+
 def _dist_init(backend_gpu: bool, local: int):
     import torch.distributed as td
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -127,7 +151,10 @@ def dry_main(a, rank, world):
         td.barrier()
     dt = time.perf_counter() - t0
     per_rank = [dt]
+    cpu_sets = [RANK_CPUS]
     if td:
+        cpu_sets = [None] * world
+        td.all_gather_object(cpu_sets, RANK_CPUS)
         t = torch.tensor([dt], dtype=torch.float64)
         gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
         td.all_gather(gathered, t)
@@ -142,7 +169,8 @@ def dry_main(a, rank, world):
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                           "config": {"workload": "launch protocol only (no GPU visible)", "parallelism": f"replicas x{world}",
                                      "backend": "gloo"},
-                          "per_rank_step_s": [round(v / a.steps, 5) for v in per_rank], "roofline": None, "cpu_baseline": None}))
+                          "per_rank_step_s": [round(v / a.steps, 5) for v in per_rank], "per_rank_cpus": cpu_sets,
+                          "torch_threads": torch.get_num_threads(), "roofline": None, "cpu_baseline": None}))
     if td:
         td.barrier()
         td.destroy_process_group()
@@ -290,13 +318,19 @@ def train_main(a, rank, world, local):
                                    f"Q={batch[2].shape[1]} queries/sample, AdamW+OneCycleLR, clip 1.0",
                        "global_batch": world * a.batch_per_gpu, "parallelism": f"ddp x{world} (RCCL all-reduce of {nparam} fp32 grads)"},
             "per_rank_samples_per_s": [round(a.batch_per_gpu * a.steps / v, 3) for v in per_rank],
+            "host": {"cpus_per_rank": len(RANK_CPUS or []), "pinned": world > 1 and os.environ.get("ANYSTEREO_PIN", "1") != "0",
+                     "torch_threads": torch.get_num_threads()},
             "allreduce_overlap": overlap,
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
             "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample/pool/interp/gate transposes, forward + dgrad + wgrad of "
                         "every stride-1 1x1 / 3x3 convolution (update block, MLP Linear layers, backbone layers with >= 16 input "
                         "channels; one batched wgrad launch per layer and step); strided / 3-channel / 3-D backbone convs, BatchNorm "
                         "and elementwise glue on MIOpen / ATen",
-            "loss_scale": tr.loss_scale, "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu}))
+            "loss_scale": tr.loss_scale,
+            "split_overflow": {"policy": tr.overflow_policy, "check_every": tr.overflow_check_every,
+                               "saturated_waves_at_end": tr._poll_overflow() if tr._on_gpu() else None,
+                               "events": tr.overflow_events, "skipped_steps": tr.skipped_steps},
+            "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu}))
     if dist:
         td.barrier()
         td.destroy_process_group()
@@ -705,6 +739,8 @@ def infer_main(a, rank, world, local):
                                    f"{nb} pair(s) per GPU, random-init weights", "name": wl.name, "pairs_per_gpu": nb,
                        "parallelism": f"replicas x{world}", "gru_loop": "hipGraph" if run.graph else "eager"},
             "per_rank_pairs_per_s": [round(nb * a.steps / v, 4) for v in per_rank],
+            "host": {"cpus_per_rank": len(RANK_CPUS or []), "pinned": world > 1 and os.environ.get("ANYSTEREO_PIN", "1") != "0",
+                     "torch_threads": torch.get_num_threads()},
             "library": _lib.library_info(),
             "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
@@ -835,12 +871,15 @@ def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a))
-    global torch
-    import torch as _torch
-    torch = _torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    global torch, RANK_CPUS
+    RANK_CPUS = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))  # before torch / HIP start any thread
+    import torch as _torch
+    torch = _torch
+    if RANK_CPUS is not None and world > 1:
+        torch.set_num_threads(max(1, len(RANK_CPUS)))
     if not torch.cuda.is_available():
         return dry_main(a, rank, world)
     if a.mode == "train":

@@ -150,6 +150,13 @@ def test_bench_launcher_spawns_ranks_world2():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None
     assert len(d["per_rank_step_s"]) == 2 and d["config"]["parallelism"] == "replicas x2"
+    # every rank is bound to its own core set before torch starts a thread, and sizes its pools to it (bench.pin_rank)
+    sets = d["per_rank_cpus"]
+    avail = len(os.sched_getaffinity(0))
+    if avail >= 2:
+        assert len(sets) == 2 and not set(sets[0]) & set(sets[1]), sets
+        assert len(sets[0]) == len(sets[1]) == avail // 2
+        assert d["torch_threads"] == avail // 2
     # the parent's code path does not import torch
     src = open(os.path.join(root, "bench.py")).read()
     assert "\nimport torch" not in src.split("def main():")[0]

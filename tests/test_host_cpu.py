@@ -187,6 +187,40 @@ def test_loss_and_metrics_match_reference(golden):
     assert torch.isfinite(l1)
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+def test_loss_ignores_nonfinite_ground_truth_at_invalid_pixels(bad):
+    """Middlebury PFM ground truth holds inf at invalid pixels (frame_utils.readDispMiddlebury returns it raw,
+    evaluation.py replaces isinf explicitly); the reference loss drops them by boolean indexing (train_continuous_IGEV.py:84-86).
+    Both forms of the loss must give the same finite value, metrics and gradients as on sanitised ground truth."""
+    from anystereo.harness import metrics as M
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(2, 1, 300, generator=g) * 100 + 1
+    preds = [gt + torch.randn(2, 1, 300, generator=g) * (i + 1) for i in range(4)]
+    gt_bad = gt.clone()
+    gt_bad[0, 0, 7] = bad
+    gt_bad[1, 0, 123] = bad
+    valid_in = torch.ones_like(gt)
+    valid_in[0, 0, 7] = 0
+    valid_in[1, 0, 123] = 0
+    gt_clean = gt.clone()
+    gt_clean[0, 0, 7] = 0.0
+    gt_clean[1, 0, 123] = 0.0
+    want_p = [p.clone().requires_grad_(True) for p in preds]
+    want, want_m = M.sequence_loss_multiscale(want_p, gt_clean, valid_in, max_disp=700)
+    want.backward()
+    for sync_free in (False, True):
+        pp = [p.clone().requires_grad_(True) for p in preds]
+        loss, met = M.sequence_loss_multiscale(pp, gt_bad, valid_in, max_disp=700, sync_free=sync_free)
+        assert torch.isfinite(loss), (sync_free, loss)
+        assert abs(loss.item() - want.item()) <= 2e-6 * abs(want.item())
+        loss.backward()
+        for a, b in zip(pp, want_p):
+            assert torch.isfinite(a.grad).all(), sync_free
+            assert (a.grad - b.grad).abs().max().item() <= 1e-7 * b.grad.abs().max().item() + 1e-12
+        for k in ("epe", "1px", "3px"):
+            assert abs(float(met[k]) - float(want_m[k])) <= 2e-6, (sync_free, k)
+
+
 def test_fetch_optimizer_schedule():
     """AdamW + linear one-cycle: peak lr after 1 % of num_steps+100, linear decay afterwards
     (train_continuous_IGEV.py:125-134)."""
