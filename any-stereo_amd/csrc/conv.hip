@@ -883,11 +883,13 @@ __device__ unsigned long long as_conv_stamp_buf[kStampBlocks * kStampSlots];
 // block lifetime: absolute s_memtime of thread 0 at 0 = kernel entry, 1 = first unit staged (consumers start), 2 = chunk loop
 // done, 3 = tile parked + barrier (staged epilogue), 4 = kernel end  -> as_debug_conv_life
 __device__ unsigned long long as_conv_life_buf[kStampBlocks * 8];
+// slots 5 / 6: s_memrealtime (constant 100 MHz) at entry / end -> in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
 #define AS_LIFE(I)                                                                       \
   if (threadIdx.x == 0 && blockIdx.x < kStampBlocks) {                                   \
     unsigned long long t_;                                                               \
     AS_STAMP(t_)                                                                         \
     as_conv_life_buf[blockIdx.x * 8 + (I)] = t_;                                         \
+    if ((I) == 0 || (I) == 4) as_conv_life_buf[blockIdx.x * 8 + ((I) == 0 ? 5 : 6)] = __builtin_amdgcn_s_memrealtime(); \
   }
 #define AS_STAMP_DECL unsigned long long st_a = 0, st_b = 0, st_sum[6] = {0, 0, 0, 0, 0, 0};
 #define AS_STAMP_BEGIN AS_STAMP(st_a)
@@ -1920,8 +1922,18 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
     static const int wide_mode = getenv("AS_CONV_WIDE") ? atoi(getenv("AS_CONV_WIDE")) : 1;
     const long long wide_blocks = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, 2) * (p.Cout_pad / 64);
     const long long now_blocks = (long long)p.B * p.tiles_x * p.tiles_y * p.n_tiles;
-    const bool wide_ok = bn == 128 ? as::cdiv64(wide_blocks, kNumCU) <= as::cdiv64(now_blocks, kNumCU)
-                                   : wide_blocks >= 2 * kNumCU;  // bn == 64: a wide block is twice the work of a current one
+    bool wide_ok = bn == 128 ? as::cdiv64(wide_blocks, kNumCU) <= as::cdiv64(now_blocks, kNumCU)
+                             : wide_blocks >= 2 * kNumCU;  // bn == 64: a wide block is twice the work of a current one
+    // 64-channel layers below that bar (the encoder's convc2 || convd2 dual launch: 2 x 255 narrow blocks = two rounds, or 2 x 128
+    // wide blocks = exactly one): rounds x (fixed cost + chunks x chunk time) from the block-lifetime stamps of both forms
+    // (narrow: 6.8 us prologue + park + finish, 1.2 us per chunk; wide: 10.8 us, 2.3 us per chunk; tools/conv_stamps.py)
+    static const int wide64_mode = getenv("AS_CONV_WIDE64") ? atoi(getenv("AS_CONV_WIDE64")) : 1;
+    if (!wide_ok && bn == 64 && wide64_mode) {
+      const int mult = d->dual ? 2 : 1;
+      const double t_now = (double)as::cdiv64(now_blocks * mult, kNumCU) * (6.8 + 1.2 * p.chunks);
+      const double t_wide = (double)as::cdiv64(wide_blocks * mult, kNumCU) * (10.8 + 2.3 * p.chunks);
+      wide_ok = t_wide < t_now;
+    }
     if (wide_mode && p.ksplit == 1 && wide_ok) {
       p.n_tiles = p.Cout_pad / 64;
       if (d->dual) conv_apply_dual(p, d);

@@ -477,6 +477,201 @@ __global__ __launch_bounds__(256, 2) void lookup_convc1_kernel(LookupParams p, F
   lookup_convc1_body<G>(p, f, tile, blockIdx.x, false, 0.f);
 }
 
+// ---- register-direct form of the same fusion (IGEV geometry: G = 8, L = 2, r = 4) ------------------------------------------------
+// The MFMA's K order is free (the weight image is packed to match), so it is chosen such that every B fragment is made of values
+// the lane interpolated ITSELF — no LDS tile, no transpose, no barrier between gather and matrix product:
+//   wave = 32 pixels; lane (n = l & 31, h = l >> 5) owns pixel n, geometry channels 4h .. 4h+3 of BOTH levels, and the
+//   correlation window of level h.  Its loads: 2 levels x 10 taps x one 16-B unit (lanes n and n+32 read the two halves of the same
+//   32-B tap record: every wave load is 64 live lanes on 32 lines, descriptor wave-uniform) + 10 dwords of correlation.
+//   k-step ks < 9  = tap ks:      B[j] = level (j >> 2), channel 4h + (j & 3), tap ks          (8 values = two float4 lerps)
+//   k-step 9, 10   = correlation: B[j] = level h, tap 8 (ks - 9) + j                            (tap 8 alone in k-step 10)
+// A = convc1's weights, permuted likewise by frag_pack_direct_kernel, resident in LDS as fragments (44 KB, one LDS-DMA copy per
+// block instead of 22 KB of global fragment loads per WAVE: the old form pulled 180 KB of weights + 92 KB of windows through a
+// CU's L1 per 128 pixels, this one 44 + 92).  Each wave computes all 64 output channels of its 32 pixels (two 32-row tiles
+// share every B fragment): 11 k-steps x 2 tiles x 3 MFMAs.  Interpolation arithmetic = quad_fill_tile's (same tap_weights).
+constexpr int kDirectKS = 11;
+constexpr int kDirectImgBytes = kDirectKS * 2 * 2 * 1024;  // [ks][tile][hi|lo][lane][8] fp16
+
+__global__ __launch_bounds__(256) void frag_pack_direct_kernel(const float* w, _Float16* img) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= kDirectKS * 2 * 2 * 512) return;
+  const int blk = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7;
+  const int hl = blk & 1, t = (blk >> 1) & 1, ks = blk >> 2;
+  const int h = lane >> 5, co = 32 * t + (lane & 31);
+  int chan = -1;
+  if (ks < 9) chan = (j >> 2) * 81 + (4 * h + (j & 3)) * 9 + ks;
+  else if (ks == 9) chan = h * 81 + 72 + j;
+  else if (j == 0) chan = h * 81 + 72 + 8;
+  const float v = chan >= 0 ? w[(long long)co * 162 + chan] : 0.f;
+  const float x = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+  const _Float16 hk = (_Float16)x;
+  img[idx] = hl == 0 ? hk : (_Float16)((x - (float)hk) * 2048.f);
+}
+
+typedef __attribute__((address_space(3))) void lk_lds_void;
+
+template <int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64, 2) void lookup_convc1_direct_kernel(LookupParams p, FusedParams f, const _Float16* __restrict__ wimg) {
+  constexpr int R = 4, K = 9, NW = 10, G = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // kDirectImgBytes
+  as::fp16_saturate_mode();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  // weight image -> LDS by LDS-DMA (1 KB per wave instruction), in flight during the gather
+  {
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wimg, 0, kDirectImgBytes, 0x00020000);
+    constexpr int PIECES = kDirectImgBytes / 1024;  // 44
+#pragma unroll
+    for (int g = 0; g < (PIECES + NWAVE - 1) / NWAVE; ++g) {
+      const int piece = g * NWAVE + wave;
+      const unsigned vo_ = (unsigned)lane * 16u, so_ = (unsigned)piece * 1024u;
+      if (piece < PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lk_lds_void*)(wlds + piece * 1024), 16, vo_, so_, 0, 0);
+    }
+  }
+  const long long pix = ((long long)blockIdx.x * NWAVE + wave) * 32 + n;
+  const bool live = pix < p.P;
+  const unsigned kOOB = 0x7FFFFFF0u;
+  const float d0 = live ? p.disp[pix] : 0.f;
+  f32x4 gw[2][NW];
+  float cw[NW];
+  float dsl[2];
+  int i0l[2];
+#pragma unroll
+  for (int lv = 0; lv < 2; ++lv) {
+    const int Dl = p.D >> lv;
+    dsl[lv] = ldexpf(d0, -lv);  // disp / 2**level (exact)
+    i0l[lv] = (int)floorf(dsl[lv]);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.geo[lv], 0, p.geo_bytes[lv], 0x00020000);
+    const unsigned rowoff = ((unsigned)pix * (unsigned)Dl * G + 4u * h) * 4u;  // < 2^31 (host check)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int dd = i0l[lv] - R + j;
+      const unsigned off = (live && dd >= 0 && dd < Dl) ? rowoff + (unsigned)dd * (G * 4) : kOOB;
+      gw[lv][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    }
+  }
+  // correlation window of level h.  Every lane issues the loads of BOTH levels through wave-uniform descriptors, with the
+  // out-of-range sentinel for the level it does not own (no fetch, reads 0), and adds the two (x + 0 = x): a per-lane choice of
+  // descriptor would make the compiler wrap each load in a waterfall loop.
+  const int x = (int)((pix % p.HW) % p.W);
+  const float xb = ldexpf((float)x, -h) - (h ? dsl[1] : dsl[0]);  // coords/2**i - disp/2**i
+  const int ci0 = (int)floorf(xb);
+  {
+    const int Wl = p.W2 >> h;
+    const unsigned rowoff = (unsigned)pix * (unsigned)Wl * 4u;
+    float c01[2][NW];
+#pragma unroll
+    for (int lv = 0; lv < 2; ++lv) {
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.corr[lv], 0, p.corr_bytes[lv], 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int dd = ci0 - R + j;
+        const unsigned off = (live && h == lv && dd >= 0 && dd < Wl) ? rowoff + (unsigned)dd * 4u : kOOB;
+        c01[lv][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) cw[j] = c01[0][j] + c01[1][j];
+  }
+  f32x16 acc_h[2], acc_x[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc_h[t][i] = f.bias ? f.bias[32 * t + (i & 3) + 8 * (i >> 2) + 4 * h] : 0.f;
+      acc_x[t][i] = 0.f;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // the weight image has landed (every wave waited for its own pieces)
+  float amax = 0.f;
+  const half8* wfr = reinterpret_cast<const half8*>(wlds) + lane;
+#pragma unroll
+  for (int ks = 0; ks < kDirectKS; ++ks) {
+    float v[8];
+    if (ks < K) {
+#pragma unroll
+      for (int lv = 0; lv < 2; ++lv) {
+        float tt;
+        bool bump;
+        tap_weights(dsl[lv], i0l[lv], ks - R, tt, bump);
+        const float a = bump ? 0.f : 1.f - tt, c = bump ? 1.f : tt;
+        const f32x4 r = a * gw[lv][ks] + c * gw[lv][ks + 1];
+        v[4 * lv + 0] = r.x; v[4 * lv + 1] = r.y; v[4 * lv + 2] = r.z; v[4 * lv + 3] = r.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * (ks - K) + j;  // compile-time
+        if (k < K) {
+          float tt;
+          bool bump;
+          tap_weights(xb, ci0, k - R, tt, bump);
+          const float a = bump ? 0.f : 1.f - tt, c = bump ? 1.f : tt;
+          v[j] = a * cw[k] + c * cw[k + 1];
+        } else {
+          v[j] = 0.f;
+        }
+      }
+    }
+    half8 bh, bl;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) amax = fmaxf(amax, fmaxf(fabsf(v[j]), fabsf(v[j + 1])));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const _Float16 hk = (_Float16)v[j];  // MODE.FP16_OVFL: |v| >= 65504 saturates (counted below), never inf / NaN
+      bh[j] = hk;
+      bl[j] = (_Float16)((v[j] - (float)hk) * 2048.f);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const half8 ah = wfr[((ks * 2 + t) * 2 + 0) * 64];
+      const half8 al = wfr[((ks * 2 + t) * 2 + 1) * 64];
+      acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_h[t], 0, 0, 0);
+      acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_x[t], 0, 0, 0);
+      acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_x[t], 0, 0, 0);
+    }
+  }
+  if (live) {
+    const int b = (int)(pix / p.HW);
+    const int rem = (int)(pix - (long long)b * p.HW);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xo = acc_h[t][4 * qd + k] + acc_x[t][4 * qd + k] * (1.f / 2048.f);
+          o[k] = f.relu ? fmaxf(xo, 0.f) : xo;
+        }
+        const int ch = 32 * t + 8 * qd + 4 * h;  // this lane's four channels of block (4 t + qd)
+        if (f.out_f32) {
+          float* op = f.out_f32 + ((long long)b * 64 + ch) * p.HW + rem;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) op[(long long)k * p.HW] = o[k];
+        }
+        if (f.out_bs) {
+          half4v hi, lo;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            amax = fmaxf(amax, fabsf(o[k]));
+            const _Float16 hk = (_Float16)o[k];
+            hi[k] = hk;
+            lo[k] = (_Float16)((o[k] - (float)hk) * 2048.f);
+          }
+          const long long blk = f.cb_off + 4 * t + qd;
+          const long long e_hi = ((((long long)b * 2 + 0) * f.cb_tot + blk) * p.HW + rem) * 8 + 4 * h;
+          const long long e_lo = ((((long long)b * 2 + 1) * f.cb_tot + blk) * p.HW + rem) * 8 + 4 * h;
+          *reinterpret_cast<u32x2*>(f.out_bs + e_hi) = __builtin_bit_cast(u32x2, hi);
+          *reinterpret_cast<u32x2*>(f.out_bs + e_lo) = __builtin_bit_cast(u32x2, lo);
+        }
+      }
+  }
+  if (__builtin_amdgcn_ballot_w64(!(amax < 65504.f)) != 0ull && lane == 0) atomicAdd(&g_split_overflow_lookup, 1u);
+}
+
 // ---- the front of a GRU iteration in ONE launch -------------------------------------------------------------------------------
 // After the disparity head's first conv (as_conv2d, AS_EPI_RELU_TAPS) three small dependent launches sat on the loop's critical
 // chain: as_tap_shift_sum (disp += delta), the fused lookup + convc1, and the 7x7 conv of the disparity branch (update.py:87).
@@ -935,13 +1130,18 @@ int as_corr_sampler_bwd(const float* coords, const void* corr_grad, void* volume
 }
 
 
-int64_t as_lookup_convc1_pack_bytes(int cin) { return (long long)((cin + 15) / 16) * 2 * 2 * 1024; }
+// fragment image of the LDS-tile kernel, followed (IGEV's 162 columns) by the register-direct kernel's permuted image
+static int64_t convc1_tile_image_bytes(int cin) { return (long long)((cin + 15) / 16) * 2 * 2 * 1024; }
+int64_t as_lookup_convc1_pack_bytes(int cin) { return convc1_tile_image_bytes(cin) + (cin == 162 ? kDirectImgBytes : 0); }
 
 int as_lookup_convc1_pack(const float* w, int cin, void* image, void* stream) {
   AS_REQUIRE(w && image && cin > 0, AS_ERR_BAD_ARG, "lookup_convc1_pack: bad argument");
   const int ks = (cin + 15) / 16;
   hipLaunchKernelGGL(frag_pack_kernel, dim3(as::cdiv(ks * 2 * 2 * 512, 256)), dim3(256), 0, as::as_stream(stream), w, 64, cin, 0, cin, ks,
                      (_Float16*)image);
+  if (cin == 162)
+    hipLaunchKernelGGL(frag_pack_direct_kernel, dim3(as::cdiv(kDirectKS * 2 * 2 * 512, 256)), dim3(256), 0, as::as_stream(stream), w,
+                       (_Float16*)((unsigned char*)image + convc1_tile_image_bytes(cin)));
   return as::check_launch("lookup_convc1_pack");
 }
 
@@ -968,6 +1168,16 @@ int as_lookup_convc1_fwd(const float* const* geo, const float* const* corr, cons
   }
   p.disp = disp;
   FusedParams f{(const _Float16*)wimage, bias, (_Float16*)out_bs, (out_bs_ctot + 7) / 8, out_bs_coff / 8, out_f32, relu};
+  // IGEV geometry: the register-direct kernel (AS_LOOKUP_DIRECT=0: the LDS-tile kernel; =2: 64-pixel blocks)
+  static const int direct_mode = getenv("AS_LOOKUP_DIRECT") ? atoi(getenv("AS_LOOKUP_DIRECT")) : 1;
+  if (G == 8 && L == 2 && direct_mode) {
+    const _Float16* dimg = (const _Float16*)((const unsigned char*)wimage + convc1_tile_image_bytes(p.CH));
+    if (direct_mode == 2)
+      hipLaunchKernelGGL((lookup_convc1_direct_kernel<2>), dim3((unsigned)as::cdiv64(p.P, 64)), dim3(128), kDirectImgBytes, as::as_stream(stream), p, f, dimg);
+    else
+      hipLaunchKernelGGL((lookup_convc1_direct_kernel<4>), dim3((unsigned)as::cdiv64(p.P, 128)), dim3(256), kDirectImgBytes, as::as_stream(stream), p, f, dimg);
+    return as::check_launch("lookup_convc1_fwd(direct)");
+  }
   const size_t lds = (size_t)((p.CH + 15) / 16 * 16 * 65) * sizeof(float);
   const dim3 grid((unsigned)as::cdiv64(p.P, 64));
   if (G == 8) hipLaunchKernelGGL((lookup_convc1_kernel<8>), grid, dim3(256), lds, as::as_stream(stream), p, f);

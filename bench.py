@@ -472,15 +472,23 @@ def micro_time_small_kernels(dev, h, w, reps=20, cold=False):
         disp = det_uniform((1, 1, h, w), 4 + 10 * k, 0.0, 40.0).to(dev)
         return {"f1": f1, "f2": f2, "gev": gev, "disp": disp, "corr": ops.corr_build_pyramid(f1, f2, 2), "geo": ops.geo_pyramid(gev, 2)}
 
+    # convc1 (1x1, 162 -> 64, update.py:78) for the fused lookup + convc1 kernel the GRU loop launches (models/base.py)
+    wc1 = (det_uniform((64, 162, 1, 1), 77) * (3.0 / 162) ** 0.5).to(dev)
+    bc1 = (det_uniform((64,), 78) * 0.1).to(dev)
+    pack = ops.LookupConvPack().get(wc1, bc1)
     P = h * w
     set_mb = {"corr_build": 4 * (2 * 96 * P + P * w * 1.5) / 1e6, "lookup": 4 * (P * 48 * 8 * 1.5 + P * w * 1.5 + 163 * P) / 1e6,
+              "lookup_convc1": 4 * (P * 48 * 8 * 1.5 + P * w * 1.5 + 65 * P) / 1e6,
               "gwc_volume": 4 * (2 * 96 * P + 8 * 48 * P) / 1e6, "geo_pyramid": 4 * (8 * 48 * P * 2.5) / 1e6}
     nsets = 1
     if cold:
         nsets = max(3, int(2.2 * INFINITY_CACHE_MB / min(set_mb.values())) + 1)
     sets = [make_set(k) for k in range(nsets)]
+    for st in sets:
+        st["cor"] = ops.BS8.empty(1, 64, h, w, dev)
     fns = {"corr_build": lambda s: ops.corr_build_pyramid(s["f1"], s["f2"], 2),
            "lookup": lambda s: ops.geo_corr_lookup(s["geo"], s["corr"], s["disp"], 4),
+           "lookup_convc1": lambda s: ops.lookup_convc1(s["geo"], s["corr"], s["disp"], 4, pack, out_bs=s["cor"]),
            "gwc_volume": lambda s: ops.gwc_volume(s["f1"], s["f2"], 48, 8),
            "geo_pyramid": lambda s: ops.geo_pyramid(s["gev"], 2)}
     out = {}
@@ -628,6 +636,7 @@ def infer_main(a, rank, world, local):
         # the short HBM-bound kernels are re-timed as back-to-back launches of one hipGraph between ONE event pair: a
         # start/stop pair around a single launch adds ~3 us of its own (rocprofv3 durations confirm)
         micro = micro_time_small_kernels(dev, h4, w4)
+        serial_loop_lookup = kstats.get("lookup_convc1")  # HIP events around the loop's own launches (one stream)
         for k, v in micro.items():
             kstats[k] = v
         rooflines = roofline_table(kstats, alg, precision, traffic)
@@ -643,23 +652,37 @@ def infer_main(a, rank, world, local):
                 if k in co:
                     r["frac_in_loop"], r["avg_us_in_loop"] = co[k]["frac"], co[k]["avg_us"]
         dominant = max(rooflines, key=lambda k: rooflines[k]["total_ms"]) if rooflines else None
-        # north_star's own bar: >= 40 % of the HBM roofline on volume build + lookup (a1-a3) — each kernel and the pair together
+        # north_star's own bar: >= 40 % of the HBM roofline on volume build + lookup (a1-a3) — each kernel and the group together.
+        # The lookup in that figure is the kernel the timed GRU loop LAUNCHES: lookup_convc1 (lookup fused with the encoder's
+        # first conv, models/base.py::_iterate_pipelined), isolated-warm, cold, and with its in-loop (co-scheduled) duration;
+        # the stand-alone `lookup` kernel (the reference-contract entry, not launched by the loop) is a separate line.
         ns = None
-        lk = "lookup" if "lookup" in rooflines else ("lookup_convc1" if "lookup_convc1" in rooflines else None)
-        if lk and all(k in rooflines for k in ("corr_build", "geo_pyramid")):
+        if all(k in rooflines for k in ("corr_build", "geo_pyramid")) and ("lookup_convc1" in rooflines or "lookup" in rooflines):
+            lk = "lookup_convc1" if "lookup_convc1" in rooflines else "lookup"
             ks = ("corr_build", "geo_pyramid", lk)
+            if serial_loop_lookup and serial_loop_lookup.get("count") and lk == "lookup_convc1":
+                rooflines[lk]["avg_us_loop_serial"] = round(serial_loop_lookup["total_ms"] / serial_loop_lookup["count"] * 1e3, 2)
 
-            def pooled(fk, uk):
-                t_us = sum(rooflines[k][uk] for k in ks)
-                byt = sum(rooflines[k][fk] * HBM_PEAK_GBS * rooflines[k][uk] for k in ks)
+            def pooled(fk, uk, names=ks, over=None):
+                over = over or {}
+                t_us = sum(over.get(k, (None, rooflines[k][uk]))[1] for k in names)
+                byt = sum(rooflines[k]["frac"] * HBM_PEAK_GBS * rooflines[k]["avg_us"] for k in names)  # algorithmic bytes x 1e-3
                 return round(byt / t_us / HBM_PEAK_GBS, 4)
-            ns = {"build_plus_lookup_hbm_frac": pooled("frac", "avg_us"), "target": 0.40,
+            ns = {"build_plus_lookup_hbm_frac": pooled("frac", "avg_us"), "target": 0.40, "lookup_kernel": lk,
                   "per_kernel": {k: rooflines[k]["frac"] for k in ks},
-                  "note": "one build (all-pairs pyramid + geometry pyramid) + one lookup, algorithmic bytes / measured time / 8 TB/s; "
-                          "warm = operands resident in the Infinity Cache, cold = streamed from HBM"}
+                  "note": "one build (all-pairs pyramid + geometry pyramid) + one lookup AS THE GRU LOOP LAUNCHES IT (lookup fused "
+                          "with convc1), algorithmic bytes / measured time / 8 TB/s; warm = operands resident in the Infinity Cache, "
+                          "cold = streamed from HBM, in_loop = the lookup's duration while co-scheduled with the other streams' kernels"}
             if all("frac_cold" in rooflines[k] for k in ks):
                 ns["build_plus_lookup_hbm_frac_cold"] = pooled("frac_cold", "avg_us_cold")
                 ns["per_kernel_cold"] = {k: rooflines[k]["frac_cold"] for k in ks}
+            if "avg_us_in_loop" in rooflines[lk]:
+                ns["build_plus_lookup_hbm_frac_in_loop"] = pooled("frac", "avg_us", over={lk: (None, rooflines[lk]["avg_us_in_loop"])})
+                ns["lookup_in_loop"] = {"avg_us": rooflines[lk]["avg_us_in_loop"], "frac": rooflines[lk]["frac_in_loop"]}
+            if "lookup" in rooflines and lk != "lookup":
+                ns["standalone_lookup_kernel"] = {"frac": rooflines["lookup"]["frac"], "frac_cold": rooflines["lookup"].get("frac_cold"),
+                                                  "avg_us": rooflines["lookup"]["avg_us"],
+                                                  "note": "reference-contract entry ([B,162,h,w] result); not launched by the timed loop"}
         cpu = None
         parity = None
         oracle_out = None

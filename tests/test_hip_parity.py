@@ -768,12 +768,21 @@ def test_liif_gather_and_convex_backward(scale):
     close(ad.grad, rd.grad, 1e-4, 1e-5, "d disp (plain)")
 
 
+G8_TOL = {  # (gradient-norm rel, element-wise rtol of the full tensors) per arithmetic mode — measured values in DESIGN.md §5
+    "fp32": (2e-2, 2e-2),
+    "split": (2e-2, 2e-2),
+}
+
+
+@pytest.mark.parametrize("mode", ["split", "fp32"])
 @pytest.mark.parametrize("name", ["igev", "raft"])
-def test_training_step_vs_reference(name):
+def test_training_step_vs_reference(name, mode):
     """One training forward/backward of the product model (train mode, frozen BatchNorm2d, 3 GRU iterations with the
     LIIF upsampler every iteration, sequence_loss_multiscale) on the GPU vs the loss and parameter gradients captured
-    from the imported reference (tests/golden/train_*.npz, G8)."""
+    from the imported reference (tests/golden/train_*.npz, G8), in both matrix-core modes, the split mode with the trainer's
+    loss scale (harness/train.py) as a training step runs it."""
     import numpy as np
+    from anystereo import ops
     from anystereo.harness.metrics import sequence_loss_multiscale
     from anystereo.harness.synthetic import fill_module_deterministic, tiny_train_case
     from anystereo.models import __models__, default_args
@@ -785,27 +794,38 @@ def test_training_step_vs_reference(name):
     model.freeze_bn()
     h, w, img1, img2, coord, gt, scale = tiny_train_case(name)
     prev = torch.backends.cudnn.deterministic
+    prev_mode = ops.get_precision()
     torch.backends.cudnn.deterministic = True
+    ls = 4096.0 if mode == "split" else 1.0
     try:
+        ops.set_precision(mode)
         res = model(img1.to(DEV), img2.to(DEV), iters=3, hr_coord=coord.to(DEV), scale=scale.to(DEV))
         preds = res[1] if name == "igev" else res
         gtd = gt.to(DEV)
         loss, _ = sequence_loss_multiscale(preds, gtd, ((gtd < 512) & (gtd > 0)).float(), max_disp=args.max_disp)
-        loss.backward()
+        (loss * ls).backward()
     finally:
         torch.backends.cudnn.deterministic = prev
+        ops.set_precision(prev_mode)
     assert abs(loss.item() - float(z["loss"])) < 1e-3 * abs(float(z["loss"])), (loss.item(), float(z["loss"]))
     assert (preds[-1].detach().cpu() - torch.from_numpy(z["last_pred"])).abs().mean().item() < 1e-3
     named = dict(model.named_parameters())
     names = [str(n) for n in z["names"]]
     assert sorted(n for n, p in named.items() if p.grad is not None) == names
-    norms = np.array([float(named[n].grad.double().norm()) for n in names])
+    norms = np.array([float(named[n].grad.double().norm()) / ls for n in names])
     rel = np.abs(norms - z["norms"]) / (z["norms"] + 1e-6 * z["norms"].max())
-    assert rel.max() < 2e-2, f"{name}: grad-norm mismatch {rel.max():.3e} at {names[int(rel.argmax())]}"
-    # element-wise, on one tensor per operator family; 2 % of the tensor's max: the BatchNorm3d scale/shift gradients of
-    # the cost aggregation are sums of large cancelling terms and move by ~1 % between CPU and MIOpen batch statistics
+    order = np.argsort(-rel)[:3]
+    print(f"[G8 {name} {mode}] loss rel {abs(loss.item() - float(z['loss'])) / abs(float(z['loss'])):.2e}; grad-norm rel max "
+          f"{rel.max():.3e}, median {np.median(rel):.3e}; worst: " + ", ".join(f"{names[i]} {rel[i]:.2e}" for i in order))
+    tol_n, tol_e = G8_TOL[mode]
+    assert rel.max() < tol_n, f"{name}: grad-norm mismatch {rel.max():.3e} at {names[int(rel.argmax())]}"
+    # element-wise, on one tensor per operator family, relative to the tensor's max
     for i, n in enumerate(str(x) for x in z["full_names"]):
-        close(named[n].grad, torch.from_numpy(z[f"g{i}"]), rtol=2e-2, atol=1e-6, what=n)
+        want = torch.from_numpy(z[f"g{i}"])
+        got = named[n].grad.detach().cpu() / ls
+        e = ((got - want).abs().max() / want.abs().max()).item()
+        print(f"[G8 {name} {mode}] {n}: max |d| / max |g| = {e:.2e}")
+        close(got, want, rtol=tol_e, atol=1e-6, what=n)
 
 
 @pytest.mark.parametrize("sort", [False, True])
@@ -911,6 +931,87 @@ def test_conv2d_wgrad(b, cin, cout, h, w, k):
     dw4, db4 = ops.conv2d_wgrad(xs, gs, k)
     dw5, db5 = ops.conv2d_wgrad(x.to(DEV), dy.to(DEV), k)
     assert torch.equal(dw4, dw5) and torch.equal(db4, db5)
+
+
+def _log_uniform_grad(shape, seed, lo=1e-9, hi=1e-6):
+    """Upstream gradients as cfg 4 produces them: magnitudes log-uniform in [lo, hi] (the masked-mean loss over 204 800 queries
+    divides every path by the query count), random signs."""
+    import math
+    u = U(shape, seed, 0.0, 1.0)
+    sgn = torch.where(U(shape, seed + 1, -1.0, 1.0) >= 0, 1.0, -1.0)
+    return (sgn * torch.exp(u * (math.log(hi) - math.log(lo)) + math.log(lo))).float().contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,k", [(384, 256, 3), (128, 127, 3), (128, 64, 1)])
+def test_dgrad_wgrad_production_magnitude_gradients(cin, cout, k):
+    """dgrad (split-fp16 forward kernel on the transposed weights) and wgrad (bf16 split) of the update-block / MLP layer shapes
+    with upstream gradients of 1e-9 .. 1e-6 — the magnitude cfg 4 really has — at the cfg-4 map size, against fp64 autograd.
+    x = hi + lo/2048 keeps 22 bits only for |x| above ~6e-5, so the split dgrad is exercised the way harness/train.py runs it:
+    on (gradient x Trainer.loss_scale = 4096), divided afterwards (exact, powers of two).  The same call WITHOUT the scale is
+    evaluated next to it: it must be measurably worse, or the scale would be dead weight."""
+    import torch.nn.functional as F
+    from anystereo import grad as G, ops
+    from anystereo.harness.train import Trainer  # noqa: F401  (the scale under test is the trainer's default)
+    scale = 4096.0
+    b, h, w = 4, 40, 80
+    x, wt = U((b, cin, h, w), 610, -1.5, 1.5), (U((cout, cin, k, k), 611) * (3.0 / (cin * k * k)) ** 0.5).contiguous()
+    bias = U((cout,), 612, -0.1, 0.1)
+    g = _log_uniform_grad((b, cout, h, w), 613)
+    r = [_leaf(t, dt=torch.float64) for t in (x, wt, bias)]
+    F.conv2d(r[0], r[1], r[2], padding=k // 2).backward(g.double())
+    prev = ops.get_precision()
+    errs = {}
+    try:
+        for mode in ("split", "fp32"):
+            ops.set_precision(mode)
+            for s in ((scale, 1.0) if mode == "split" else (1.0,)):
+                a = [_leaf(t, DEV) for t in (x, wt, bias)]
+                y = G.Conv2dSame.apply(a[0], a[1], a[2], False, ops.PackedConv(), ops.PackedConv())
+                y.backward((g * s).to(DEV))
+                dx = a[0].grad.double().cpu() / s
+                dw = a[1].grad.double().cpu() / s
+                db = a[2].grad.double().cpu() / s
+                errs[(mode, s)] = ((dx - r[0].grad).norm() / r[0].grad.norm(), (dw - r[1].grad).norm() / r[1].grad.norm(),
+                                   (db - r[2].grad).norm() / r[2].grad.norm(), (dx - r[0].grad).abs().max() / r[0].grad.abs().max())
+    finally:
+        ops.set_precision(prev)
+    for key, e in errs.items():
+        print(f"[{cin}->{cout} k{k} {key}] dgrad rel {e[0]:.2e} (max-norm {e[3]:.2e}), wgrad rel {e[1]:.2e}, bias rel {e[2]:.2e}")
+    sp, raw, f32 = errs[("split", scale)], errs[("split", 1.0)], errs[("fp32", 1.0)]
+    # with the trainer's scale the split dgrad is as good as the exact-fp32 MFMA path (both limited by fp32 accumulation);
+    # the weight gradient carries the bf16 split's ~2^-16 per product, averaged over K = b*h*w terms
+    assert sp[0] < 2e-6 and sp[3] < 2e-6, sp
+    assert f32[0] < 2e-6, f32
+    assert sp[1] < 3e-5 and sp[2] < 3e-5 and f32[1] < 3e-5, (sp, f32)
+    assert raw[0] > 4 * sp[0], f"unscaled split dgrad is not worse ({raw[0]:.2e} vs {sp[0]:.2e}): the loss scale would be dead weight"
+
+
+@pytest.mark.parametrize("cin,cout,k,iters", [(384, 256, 3, 16), (128, 127, 3, 16), (64, 64, 3, 16), (128, 64, 1, 4)])
+def test_wgrad_hip_vs_library_cfg4_shapes(cin, cout, k, iters):
+    """ANYSTEREO_WGRAD=hip (default) routes every 1x1 / 3x3 weight gradient through as_conv2d_wgrad: bf16 hi + lo per operand,
+    hi*hi + hi*lo + lo*hi, the lo*lo term dropped.  At the cfg-4 shapes (4 x 40 x 80 pixels x 16 iterations reduced in one
+    launch, production-magnitude upstream gradients) it must be as close to the fp64 gradient as the library's fp32 wgrad
+    (MIOpen via aten.convolution_backward) up to a stated factor: both are dominated by fp32 accumulation over K = 204 800
+    terms, the split adds 2^-16 x sqrt-of-K averaging."""
+    import torch.nn.functional as F
+    from anystereo import ops
+    b, h, w = 4, 40, 80
+    xs = [U((b, cin, h, w), 700 + i, -1.5, 1.5) for i in range(iters)]
+    gs = [_log_uniform_grad((b, cout, h, w), 800 + 2 * i) for i in range(iters)]
+    wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    for x, g in zip(xs, gs):
+        F.conv2d(x.double(), wt, None, padding=k // 2).backward(g.double())
+    want = wt.grad
+    dw, _ = ops.conv2d_wgrad([t.to(DEV) for t in xs], [t.to(DEV) for t in gs], k, want_bias=False)
+    xcat, gcat = torch.cat(xs).to(DEV), torch.cat(gs).to(DEV)
+    _, lib, _ = torch.ops.aten.convolution_backward(gcat, xcat, torch.zeros(cout, cin, k, k, device=DEV), None, [1, 1], [k // 2] * 2,
+                                                   [1, 1], False, [0, 0], 1, [False, True, False])
+    e_hip = ((dw.double().cpu() - want).norm() / want.norm()).item()
+    e_lib = ((lib.double().cpu() - want).norm() / want.norm()).item()
+    m_hip = ((dw.double().cpu() - want).abs().max() / want.abs().max()).item()
+    print(f"[wgrad {cin}->{cout} k{k} x{iters}] hip rel {e_hip:.2e} (max-norm {m_hip:.2e}), library fp32 rel {e_lib:.2e}")
+    assert e_hip < 2e-5 and m_hip < 5e-5, (e_hip, m_hip)          # DESIGN.md §2: the stated wgrad tolerance
+    assert e_hip < max(20 * e_lib, 5e-6), (e_hip, e_lib)
 
 
 @pytest.mark.parametrize("kind", ["conv3", "conv1_cat", "linear"])
@@ -1492,8 +1593,9 @@ def test_reduced_precision_mode(golden):
 def test_loop_front_fused_equals_staged(golden, tag, h, w):
     """The front of a GRU iteration as ONE launch (disp += delta from the head's tap planes, lookup + convc1, 7x7 conv of the
     disparity branch; as_loop_front_fwd) against the staged launches it replaces (as_tap_shift_sum -> as_lookup_convc1_fwd ->
-    as_conv7x7_c1_relu): the new disparity and the motion features are bit-identical, for both model geometries and map
-    sizes that do not fill the 64-pixel / 16x16 blocks."""
+    as_conv7x7_c1_relu): the new disparity is bit-identical and the motion features agree — bit for bit for the RAFT geometry;
+    for IGEV the staged path's lookup + convc1 is the register-direct kernel, whose K order differs from the fused front's
+    LDS-tile form (fp32 rounding of a permuted sum) — for both model geometries and map sizes that do not fill the blocks."""
     from anystereo import ops
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.models.base import default_args
@@ -1524,7 +1626,10 @@ def test_loop_front_fused_equals_staged(golden, tag, h, w):
                 ub.encoder.fused_front = mode
                 mf, d_new = ub.encoder.forward_front(taps, ub.disp_head, disp, fn)
                 assert torch.equal(d_new, d_ref) and torch.equal(d_full, d_ref), f"new disparity ({mode})"
-                assert torch.equal(mf.t, mf_ref.t), f"motion features (blocked split-fp16, {mode})"
+                if tag == "raft":
+                    assert torch.equal(mf.t, mf_ref.t), f"motion features (blocked split-fp16, {mode})"
+                else:
+                    close(mf.float(), mf_ref.float(), 2e-5, 2e-6, f"motion features ({mode})")
                 assert (mf.float()[:, 127:128] - d_ref).abs().max().item() <= 2e-6 * max(1.0, d_ref.abs().max().item()), "disparity pass-through"
     finally:
         ops.set_precision(prev)

@@ -30,6 +30,27 @@ def main():
         pk = ops.PackedConv().get([U((256, 384, 3, 3), 30, -0.02, 0.02)], [U((256,), 31)])
         xb = [to_bs(x) for x in xs]
         fn, chunks = (lambda: ops.conv2d(xb, pk, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=xs[0])), 24
+    elif which in ("enc_conv_bs", "enc_c2d2_bs", "gru_q_bs"):
+        if which == "gru_q_bs":
+            xs = [U((b, 128, h, w), 10 + i) for i in range(3)]
+            ctx = U((b, 384, h, w), 20)
+            z = U((b, 128, h, w), 21, 0.0, 1.0)
+            pk = ops.PackedConv().get([U((128, 384, 3, 3), 30, -0.02, 0.02)], [U((128,), 31)])
+            xb = [to_bs(x) for x in xs]
+            ob = ops.BS8.empty(b, 128, h, w, dev)
+            fn, chunks = (lambda: ops.conv2d(xb, pk, add=ctx, add_coff=256, epilogue=Lb.EPI_GRU_Q, h=xs[0], z=z, out_bs=ob)), 24
+        elif which == "enc_conv_bs":
+            xb = to_bs(U((b, 128, h, w), 10))
+            pk = ops.PackedConv().get([U((127, 128, 3, 3), 30, -0.04, 0.04)], [U((127,), 31)])
+            ob = ops.BS8.empty(b, 128, h, w, dev)
+            fn, chunks = (lambda: ops.conv2d([xb], pk, act=Lb.ACT_RELU, out_bs=ob, out_bs_coff=0, bs_only=True)), 8
+        else:
+            xa, xb2 = to_bs(U((b, 64, h, w), 10)), to_bs(U((b, 64, h, w), 11))
+            pk = ops.PackedConv().get([U((64, 64, 3, 3), 30, -0.05, 0.05)], [U((64,), 31)])
+            pk2 = ops.PackedConv().get([U((64, 64, 3, 3), 32, -0.05, 0.05)], [U((64,), 33)])
+            ob = ops.BS8.empty(b, 128, h, w, dev)
+            fn, chunks = (lambda: ops.conv2d([xa], pk, act=Lb.ACT_RELU, out_bs=ob, out_bs_coff=0, bs_only=True,
+                                             dual={"src": xb2, "pack": pk2, "out_coff": 64, "out_bs_coff": 64})), 4
     elif which == "gru_zr":
         xs = [U((b, 128, h, w), 10 + i) for i in range(3)]
         ctx = U((b, 384, h, w), 20)
@@ -97,6 +118,11 @@ def main():
             for name, a, b in seg:
                 d = (ok[:, b] - ok[:, a])
                 print(f"    {name:42s} {d.mean().item():9.0f} ticks {100 * d.mean().item() / tot:5.1f} %  (min {d.min().item():.0f}, max {d.max().item():.0f})")
+            rt = (ok[:, 6] - ok[:, 5])
+            if (rt > 0).all():
+                ghz = ((ok[:, 4] - ok[:, 0]) / rt * 0.1)
+                print(f"    in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz): median {ghz.median().item():.3f} GHz "
+                      f"(min {ghz.min().item():.3f}, max {ghz.max().item():.3f}); block life {rt.median().item() * 0.01:.1f} us")
             first = ok[:, 0].min().item()
             print(f"    block starts span {ok[:, 0].max().item() - first:.0f} ticks, ends span {ok[:, 4].max().item() - first:.0f} ticks after the first start")
 
