@@ -56,8 +56,15 @@ def sequence_loss_multiscale(disp_preds, disp_gt, valid, loss_gamma=0.9, max_dis
     return loss, metrics
 
 
-def fetch_optimizer(lr, wdecay, num_steps, params, lr_fixed=False):
-    opt = torch.optim.AdamW(params, lr=lr, weight_decay=wdecay, eps=1e-8)
+def fetch_optimizer(lr, wdecay, num_steps, params, lr_fixed=False, capturable=False):
+    """AdamW + linear OneCycleLR (train_continuous_IGEV.py:125-134).  capturable=True: the optimizer's step counter and its
+    learning rate live on the device (the scheduler writes the tensor), so `optimizer.step()` can be captured into a hipGraph."""
+    params = list(params)
+    if capturable:
+        dev = params[0].device
+        opt = torch.optim.AdamW(params, lr=torch.tensor(float(lr), device=dev), weight_decay=wdecay, eps=1e-8, capturable=True, foreach=True)
+    else:
+        opt = torch.optim.AdamW(params, lr=lr, weight_decay=wdecay, eps=1e-8)
     sched = None if lr_fixed else torch.optim.lr_scheduler.OneCycleLR(
         opt, lr, num_steps + 100, pct_start=0.01, cycle_momentum=False, anneal_strategy="linear")
     return opt, sched

@@ -63,7 +63,7 @@ class Trainer:
 
     def __init__(self, model, lr: float = 2e-4, wdecay: float = 1e-5, num_steps: int = 100000, train_iters: int = 16,
                  max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int = 25,
-                 force_ddp: bool = False, loss_scale: float | None = None):
+                 force_ddp: bool = False, loss_scale: float | None = None, graph: bool | None = None):
         model.train()
         model.freeze_bn()  # train_continuous_IGEV.py:203
         self.model = model
@@ -72,7 +72,16 @@ class Trainer:
         self._bucket_cap_mb = bucket_cap_mb
         self.ddp_mode = "none"
         self.frozen_unused = []
-        self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed)
+        # Whole-step hipGraph (ANYSTEREO_TRAIN_GRAPH=1 / graph=True): zero_grad + forward + loss + backward + unscale + clip + AdamW as
+        # ONE captured graph replayed per step — the eager step is host-bound (~6 000 launches).  Needs a CUDA model,
+        # no GradScaler and no DDP wrapper (one rank); otherwise the eager step runs.  `graph_warmup` eager steps come first.
+        if graph is None:
+            graph = os.environ.get("ANYSTEREO_TRAIN_GRAPH", "0") == "1"
+        p0 = next(model.parameters())
+        self.use_graph = bool(graph) and p0.is_cuda and not mixed_precision and not self._want_ddp
+        self.graph_warmup = int(os.environ.get("ANYSTEREO_TRAIN_GRAPH_WARMUP", "3"))
+        self._graph = None
+        self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed, capturable=self.use_graph)
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
         self.train_iters, self.max_disp = train_iters, max_disp
         # Power-of-two loss scale (exact in fp32) for the split-precision dgrad kernels only: it keeps the activation gradients
@@ -160,6 +169,8 @@ class Trainer:
         if not self.module.training:
             self.module.train()
         self.model.freeze_bn()
+        if self.use_graph and sync_grads:
+            return self._step_graphed(batch)
         watch = (self.loss_scale != 1.0 or self.overflow_events) and self.overflow_policy != "off" and self._on_gpu()
         gate = self._overflow_gate if (watch and self.overflow_policy == "skip") else None
         kw = dict(max_disp=self.max_disp, loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss, should_step=gate)
@@ -172,6 +183,40 @@ class Trainer:
         if watch and gate is None and self.overflow_check_every > 0 and self.steps_done % self.overflow_check_every == 0:
             self._poll_overflow()
         return out
+
+    def _step_graphed(self, batch):
+        """The step as a hipGraph replay: inputs are copied into static buffers, the captured graph holds zero_grad (gradients
+        re-materialise at fixed addresses in the graph's pool), forward, the synchronisation-free loss, backward, the loss-scale
+        division, clip_grad_norm_ and the capturable AdamW; the OneCycleLR scheduler runs on the host and writes the device-side
+        learning rate between replays.  Returns clones of the static loss / metric tensors."""
+        ent = self._graph
+        if ent is None or any(tuple(a.shape) != tuple(b.shape) for a, b in zip(ent["batch"], batch)):
+            if self.steps_done < self.graph_warmup:  # eager steps first: solver searches, weight packs, allocator, optimizer state
+                out = train_step(self.module, self.optimizer, self.scheduler, None, batch, self.train_iters, max_disp=self.max_disp,
+                                 loss_scale=self.loss_scale, sync_free_loss=True)
+                self.steps_done += 1
+                return out
+            static = tuple(t.detach().clone() for t in batch)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g):
+                loss, metrics = train_step(self.module, self.optimizer, None, None, static, self.train_iters, max_disp=self.max_disp,
+                                           loss_scale=self.loss_scale, sync_free_loss=True)
+            # the capture itself executed nothing: the step below is the first replay
+            ent = self._graph = {"graph": g, "batch": static, "loss": loss, "metrics": metrics}
+        for dst, src in zip(ent["batch"], batch):
+            dst.copy_(src)
+        ent["graph"].replay()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self.steps_done += 1
+        if (self.loss_scale != 1.0 and self.overflow_policy != "off" and self.overflow_check_every > 0
+                and self.steps_done % self.overflow_check_every == 0):
+            self._poll_overflow()  # a changed scale takes effect at the next capture only: drop the graph then
+            if self.overflow_events and self.overflow_events[-1][0] == self.steps_done:
+                self._graph = None
+        return ent["loss"].clone(), {k: v.clone() for k, v in ent["metrics"].items()}
 
     def _on_gpu(self) -> bool:
         return next(self.model.parameters()).is_cuda
