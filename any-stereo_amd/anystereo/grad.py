@@ -9,6 +9,7 @@ to these when gradients are required; under `torch.no_grad()` they call `ops` di
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -238,11 +239,19 @@ _DEFER = os.environ.get("ANYSTEREO_DEFER_WGRAD", "1") != "0"
 # cannot hand its autograd nodes, its stashed activations or its context tensor to the next forward; the autograd nodes of a forward
 # hold their own stash / holder objects, so two forwards followed by their two backward() calls stay independent.
 _EPOCH = 0
+_HOLDERS = weakref.WeakSet()  # modules that cache anchors of the current forward
 
 
 def begin_forward() -> int:
+    """New forward: drop every cached anchor of the previous one NOW (not lazily at a layer's first use) — with it die the
+    autograd nodes it kept alive, in particular the parameters' AccumulateGrad nodes, which are bound to the stream of the
+    forward that created them (a hipGraph capture after eager warm-up steps would otherwise meet default-stream nodes)."""
     global _EPOCH
     _EPOCH += 1
+    for mod in list(_HOLDERS):
+        mod.__dict__.pop("_wgrad_anchors", None)
+        mod.__dict__.pop("_ctx_anchor", None)
+    _HOLDERS.clear()
     return _EPOCH
 
 
@@ -328,6 +337,7 @@ def anchored(mod, name, kind, weights, biases):
     if not (_DEFER and torch.is_grad_enabled() and any(p.requires_grad for p in weights)):
         return (*build(), None)
     slot = mod.__dict__.setdefault("_wgrad_anchors", {})
+    _HOLDERS.add(mod)
     key = tuple((id(p), p._version) for p in (*weights, *biases) if p is not None)
     st = slot.get(name)
     if st is None or st.done or st.key != key or st.epoch != _EPOCH:
@@ -428,6 +438,7 @@ def context_anchor(mod, base):
     ent = mod.__dict__.get("_ctx_anchor")
     if ent is None or ent[0] is not base or ent[1] != base._version or ent[3].get("done") or ent[3].get("epoch") != _EPOCH:
         holder = {"epoch": _EPOCH}
+        _HOLDERS.add(mod)
         ent = mod.__dict__["_ctx_anchor"] = (base, base._version, ContextAnchor.apply(holder, base), holder)
     return ent[2], ent[3]
 

@@ -99,7 +99,7 @@ def thres_metric(d_est, d_gt, mask, thres):
 
 
 def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp=192, clip=1.0, loss_scale=1.0, sync_free_loss=False,
-               should_step=None):
+               should_step=None, phase="all"):
     """One optimisation step with the reference's ordering (train_continuous_IGEV.py:214-239, multi_training branch):
     zero_grad -> forward(train mode) -> sequence_loss_multiscale with valid = (gt < 512) & (gt > 0) -> scaled backward ->
     unscale -> clip_grad_norm_(1.0) -> optimizer step -> scheduler step (unless fixed lr) -> scaler update.
@@ -109,23 +109,30 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
     subnormal range of the split-precision dgrad kernels (x = hi + lo/2048 keeps 22 bits only above |x| ~ 6e-5).
     `should_step` (optional callable, evaluated after backward): False drops this step's optimizer update (the Trainer's
     split-precision overflow gate; the schedule still advances, as under GradScaler).
+    `phase`: "all" (default) | "grads" (zero_grad .. unscaled gradients; returns (loss, metrics)) | "update" (clip .. scheduler
+    on the gradients a "grads" call left; returns None) — the two halves of a step for per-segment graph capture.
     Model-agnostic host logic (any module with the reference's forward signature)."""
-    image1, image2, hr_coord, hr_disp_gt, scale = batch
-    optimizer.zero_grad()
-    assert model.training
-    res = model(image1, image2, iters=train_iters, hr_coord=hr_coord, scale=scale)
-    disp_preds = res[1] if isinstance(res, tuple) else res  # IGEV: (init_disp, preds); RAFT: preds (prune_raft_stereo.py:297)
-    loss, metrics = sequence_loss_multiscale(disp_preds, hr_disp_gt, (hr_disp_gt < 512) & (hr_disp_gt > 0.0), max_disp=max_disp,
-                                             sync_free=sync_free_loss)
-    if scaler is not None:
-        scaler.scale(loss).backward()
-        scaler.unscale_(optimizer)
-    elif loss_scale != 1.0:
-        (loss * loss_scale).backward()
-        grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
-        torch._foreach_mul_(grads, 1.0 / loss_scale)
-    else:
-        loss.backward()
+    loss = metrics = None
+    if phase in ("all", "grads"):
+        image1, image2, hr_coord, hr_disp_gt, scale = batch
+        optimizer.zero_grad()
+        assert model.training
+        res = model(image1, image2, iters=train_iters, hr_coord=hr_coord, scale=scale)
+        disp_preds = res[1] if isinstance(res, tuple) else res  # IGEV: (init_disp, preds); RAFT: preds (prune_raft_stereo.py:297)
+        loss, metrics = sequence_loss_multiscale(disp_preds, hr_disp_gt, (hr_disp_gt < 512) & (hr_disp_gt > 0.0), max_disp=max_disp,
+                                                 sync_free=sync_free_loss)
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            scaler.unscale_(optimizer)
+        elif loss_scale != 1.0:
+            (loss * loss_scale).backward()
+            grads = [p.grad for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+            torch._foreach_mul_(grads, 1.0 / loss_scale)
+        else:
+            loss.backward()
+        loss = loss.detach()
+        if phase == "grads":
+            return loss, metrics
     torch.nn.utils.clip_grad_norm_([p for g in optimizer.param_groups for p in g["params"]], clip)  # = model.parameters(), without the module walk
     if should_step is not None and not should_step():
         optimizer.zero_grad()
@@ -137,4 +144,4 @@ def train_step(model, optimizer, scheduler, scaler, batch, train_iters, max_disp
         scheduler.step()
     if scaler is not None:
         scaler.update()
-    return loss.detach(), metrics
+    return (loss, metrics) if phase == "all" else None

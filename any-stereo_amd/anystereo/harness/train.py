@@ -80,8 +80,11 @@ class Trainer:
         p0 = next(model.parameters())
         self.use_graph = bool(graph) and p0.is_cuda and not mixed_precision and not self._want_ddp
         self.graph_warmup = int(os.environ.get("ANYSTEREO_TRAIN_GRAPH_WARMUP", "3"))
+        # "step": the whole step is one graph; "grads": zero_grad .. unscaled gradients are the graph, clip + AdamW + scheduler eager
+        self.graph_scope = os.environ.get("ANYSTEREO_TRAIN_GRAPH_SCOPE", "step")
         self._graph = None
-        self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed, capturable=self.use_graph)
+        self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed,
+                                                         capturable=self.use_graph and os.environ.get("ANYSTEREO_TRAIN_GRAPH_SCOPE", "step") == "step")
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
         self.train_iters, self.max_disp = train_iters, max_disp
         # Power-of-two loss scale (exact in fp32) for the split-precision dgrad kernels only: it keeps the activation gradients
@@ -191,32 +194,64 @@ class Trainer:
         learning rate between replays.  Returns clones of the static loss / metric tensors."""
         ent = self._graph
         if ent is None or any(tuple(a.shape) != tuple(b.shape) for a, b in zip(ent["batch"], batch)):
+            # warm-up steps and the capture run on ONE side stream (PyTorch's whole-network capture recipe): autograd binds a
+            # parameter's AccumulateGrad node to the stream of the forward that created it
+            if getattr(self, "_gstream", None) is None:
+                self._gstream = torch.cuda.Stream(device=batch[0].device)
+            cur = torch.cuda.current_stream(batch[0].device)
             if self.steps_done < self.graph_warmup:  # eager steps first: solver searches, weight packs, allocator, optimizer state
-                out = train_step(self.module, self.optimizer, self.scheduler, None, batch, self.train_iters, max_disp=self.max_disp,
-                                 loss_scale=self.loss_scale, sync_free_loss=True)
+                self._gstream.wait_stream(cur)
+                single = os.environ.get("ANYSTEREO_TRAIN_GRAPH_SINGLE_THREAD", "1") != "0"
+                # warm-up on the thread (and stream) the capture will use: the BLAS / MIOpen handles are per thread and are
+                # created — device allocations, not capturable — at a thread's first call
+                with torch.autograd.set_multithreading_enabled(not single), torch.cuda.stream(self._gstream):
+                    out = train_step(self.module, self.optimizer, self.scheduler, None, batch, self.train_iters, max_disp=self.max_disp,
+                                     loss_scale=self.loss_scale, sync_free_loss=True)
+                cur.wait_stream(self._gstream)
+                for t in (out[0], *out[1].values()):
+                    t.record_stream(cur)
                 self.steps_done += 1
                 return out
             static = tuple(t.detach().clone() for t in batch)
+            from .. import grad as G
+            G.begin_forward()  # no anchor (and no autograd node) of the warm-up steps survives into the capture
+            self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            self.optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(g):
+            # the backward pass is captured from THIS thread (autograd's device worker thread launching into a stream another
+            # thread put into capture mode loses nodes / dependencies of the graph's tail on this ROCm stack: the last
+            # gradients of a replay came back as garbage, tools/train_graph_check.py)
+            single = os.environ.get("ANYSTEREO_TRAIN_GRAPH_SINGLE_THREAD", "1") != "0"
+            with torch.autograd.set_multithreading_enabled(not single), torch.cuda.graph(g, stream=self._gstream):
                 loss, metrics = train_step(self.module, self.optimizer, None, None, static, self.train_iters, max_disp=self.max_disp,
-                                           loss_scale=self.loss_scale, sync_free_loss=True)
+                                           loss_scale=self.loss_scale, sync_free_loss=True,
+                                           phase="all" if self.graph_scope == "step" else "grads")
             # the capture itself executed nothing: the step below is the first replay
             ent = self._graph = {"graph": g, "batch": static, "loss": loss, "metrics": metrics}
+        # Replay ordering.  On this ROCm stack work enqueued BEHIND a replay of this graph (~6 000 kernel nodes) is not reliably
+        # ordered after the graph's tail: without a device-wide synchronisation between steps the next step's eager work (input
+        # copies, the scheduler's learning-rate write, another model's step) raced the running replay — losses of 0.0, diverging
+        # parameters, NaN — on the default stream and on a stream of the trainer's own alike; with one after every replay all
+        # replays matched the eager trainer step for step (tools/train_graph_check.py, DESIGN.md §5).  So the step ends with
+        # torch.cuda.synchronize(): the host cannot run ahead of a graphed step (it has ~3 ms of work per step left to hide).
+        # ANYSTEREO_TRAIN_GRAPH_SYNC=none removes it (measurement only).
         for dst, src in zip(ent["batch"], batch):
             dst.copy_(src)
         ent["graph"].replay()
+        if self.graph_scope != "step":
+            train_step(self.module, self.optimizer, None, None, None, self.train_iters, phase="update")
         if self.scheduler is not None:
             self.scheduler.step()
+        out = ent["loss"].clone(), {k: v.clone() for k, v in ent["metrics"].items()}
+        if os.environ.get("ANYSTEREO_TRAIN_GRAPH_SYNC", "device") == "device":
+            torch.cuda.synchronize(batch[0].device)
         self.steps_done += 1
         if (self.loss_scale != 1.0 and self.overflow_policy != "off" and self.overflow_check_every > 0
                 and self.steps_done % self.overflow_check_every == 0):
             self._poll_overflow()  # a changed scale takes effect at the next capture only: drop the graph then
             if self.overflow_events and self.overflow_events[-1][0] == self.steps_done:
                 self._graph = None
-        return ent["loss"].clone(), {k: v.clone() for k, v in ent["metrics"].items()}
+        return out
 
     def _on_gpu(self) -> bool:
         return next(self.model.parameters()).is_cuda

@@ -16,6 +16,7 @@ from .. import ops
 
 # ANYSTEREO_FOLD_POINTWISE=0: BasicConv (2-D BatchNorm, 1x1x1 3-D) and the FeatureAtt gate back on MIOpen + separate norm / activation
 _FOLD_POINTWISE = __import__("os").environ.get("ANYSTEREO_FOLD_POINTWISE", "1") != "0"
+_NO_SEARCHED_CONV = __import__("os").environ.get("ANYSTEREO_NO_SEARCHED_CONV", "0") == "1"
 
 
 def fused_ok(x: torch.Tensor, mod: nn.Module) -> bool:
@@ -144,6 +145,8 @@ class _SearchedConv(torch.autograd.Function):
 def conv3d_train(conv, x):
     """conv(x) for an nn.Conv3d / nn.ConvTranspose3d; under autograd on the GPU through _SearchedConv."""
     if not (x.is_cuda and x.dim() == 5 and torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)):
+        return conv(x)
+    if _NO_SEARCHED_CONV:  # diagnostics: MIOpen's immediate mode (naive kernels) instead of the searched solvers
         return conv(x)
     transposed = isinstance(conv, nn.ConvTranspose3d)
     cfg = (list(conv.stride), list(conv.padding), list(conv.dilation), transposed,

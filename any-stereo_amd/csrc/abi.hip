@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_set>
+
 #include "common.h"
 
 namespace as {
@@ -30,6 +33,29 @@ int precision_mode() {
 
 static int g_fast16 = 0;
 int fast16_mode() { return g_fast16; }
+
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (long long k = i; k < n; ++k) p[k] = 0.f;
+  }
+}
+
+int zero_fill(float* p, long long n, hipStream_t s) {
+  if (n <= 0) return AS_OK;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return fail(AS_ERR_BAD_ARG, "zero_fill: buffer not 16-B aligned");
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)cdiv64(cdiv64(n, 4), 256)), dim3(256), 0, s, p, n);
+  return check_launch("zero_fill");
+}
+
+void lds_opt_in(const void* kernel) {
+  static std::mutex m;
+  static std::unordered_set<const void*> done;
+  std::lock_guard<std::mutex> lock(m);
+  if (done.insert(kernel).second) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 
 }  // namespace as
 

@@ -589,8 +589,8 @@ int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat,
   AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Q > 0, AS_ERR_BAD_ARG, "liif_gather_bwd: non-positive size");
   AS_REQUIRE(lat_coff >= 0 && lat_coff + C <= lat_ctot, AS_ERR_BAD_SHAPE, "liif_gather_bwd: latent channel window outside %d", lat_ctot);
   AS_REQUIRE((long long)B * H * W < 2147483647ll, AS_ERR_BAD_SHAPE, "liif_gather_bwd: B*H*W too large for a 32-bit run key");
-  hipError_t e = hipMemsetAsync(d_feat, 0, sizeof(float) * (size_t)B * C * H * W, as::as_stream(stream));
-  if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "liif_gather_bwd: memset: %s", hipGetErrorString(e));
+  const int zrc = as::zero_fill(d_feat, (long long)B * C * H * W, as::as_stream(stream));
+  if (zrc != AS_OK) return zrc;
   hipLaunchKernelGGL(liif_gather_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream),
                      d_latent, coord, d_feat, B, C, H, W, Q, lat_ctot, lat_coff, (float)(-1.0 + 1e-6), (float)(1.0 - 1e-6));
   return as::check_launch("liif_gather_bwd");
@@ -619,8 +619,8 @@ int as_convex_upsample_bwd(const float* disp, const float* scale, const float* m
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && Q > 0, AS_ERR_BAD_ARG, "convex_upsample_bwd: non-positive size");
   AS_REQUIRE((long long)B * H * W < 2147483647ll, AS_ERR_BAD_SHAPE, "convex_upsample_bwd: B*H*W too large for a 32-bit run key");
   if (d_disp) {
-    hipError_t e = hipMemsetAsync(d_disp, 0, sizeof(float) * (size_t)B * H * W, as::as_stream(stream));
-    if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "convex_upsample_bwd: memset: %s", hipGetErrorString(e));
+    const int zrc = as::zero_fill(d_disp, (long long)B * H * W, as::as_stream(stream));
+    if (zrc != AS_OK) return zrc;
   }
   hipLaunchKernelGGL(convex_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream),
                      disp, scale, mask, coord, d_out, d_mask, d_disp, B, H, W, Q, mask_is_logits, (float)(-1.0 + 1e-6),

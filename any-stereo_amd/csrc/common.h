@@ -44,6 +44,17 @@ __device__ __forceinline__ void note_split_overflow(float amax, unsigned* counte
 }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Dynamic LDS beyond 64 KB needs an opt-in per kernel (hipFuncAttributeMaxDynamicSharedMemorySize).  The attribute belongs to
+// the FUNCTION, process-wide — so it is raised ONCE per kernel to the CU's whole 160 KB and never written again: a value that
+// follows the launch at hand (the weight-gradient kernel's LDS plan depends on the layer shape) is read by every later launch
+// of that kernel, including the kernel nodes of a captured hipGraph replayed after an eager launch with a smaller plan.
+void lds_opt_in(const void* kernel);
+
+// Zero-fill as an ordinary KERNEL launch.  hipMemsetAsync becomes a memset NODE under hipGraph capture, and in the captured
+// training step (thousands of nodes) replays showed zero-filled buffers cleared late — after a later kernel had written them
+// (tools/train_graph_check.py); a kernel node is ordered like every other launch of the stream.
+int zero_fill(float* p, long long n, hipStream_t s);
+
 }  // namespace as
 
 #define AS_REQUIRE(cond, code, ...) \

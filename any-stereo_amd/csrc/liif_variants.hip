@@ -370,8 +370,8 @@ int as_liif_latent_bwd(const float* d_latent, const float* coord, float* d_feat,
                       unfold9, n_samp, 0, "liif_latent_bwd");
   if (rc != AS_OK) return rc;
   p.d_feat = d_feat;
-  hipError_t e = hipMemsetAsync(d_feat, 0, sizeof(float) * (size_t)B * C * H * W, as::as_stream(stream));
-  if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "liif_latent_bwd: memset: %s", hipGetErrorString(e));
+  const int zrc = as::zero_fill(d_feat, (long long)B * C * H * W, as::as_stream(stream));
+  if (zrc != AS_OK) return zrc;
   hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream), p);
   return as::check_launch("liif_latent_bwd");
 }
@@ -407,8 +407,8 @@ int as_convex_upsample_quater_bwd(const float* disp, const float* scale, const f
   AS_REQUIRE(disp && mask && coord && d_out && d_mask, AS_ERR_BAD_ARG, "convex_upsample_quater_bwd: null pointer");
   AS_REQUIRE(B > 0 && H > 0 && W > 0 && Q > 0, AS_ERR_BAD_ARG, "convex_upsample_quater_bwd: non-positive size");
   if (d_disp) {
-    hipError_t e = hipMemsetAsync(d_disp, 0, sizeof(float) * (size_t)B * H * W, as::as_stream(stream));
-    if (e != hipSuccess) return as::fail(AS_ERR_LAUNCH, "convex_upsample_quater_bwd: memset: %s", hipGetErrorString(e));
+    const int zrc = as::zero_fill(d_disp, (long long)B * H * W, as::as_stream(stream));
+    if (zrc != AS_OK) return zrc;
   }
   const double ry = 2.0 / H / 2.0, rx = 2.0 / W / 2.0;
   hipLaunchKernelGGL(convex_quater_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream),

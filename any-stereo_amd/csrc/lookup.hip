@@ -1046,7 +1046,7 @@ int as_geo_corr_lookup_fwd(const float* const* geo, const float* const* corr, co
     const size_t lds = (size_t)(64 + p.CH * 65) * sizeof(float);
     const dim3 grid((unsigned)as::cdiv64(p.P, 64));
     if (G == 8) {
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)lookup_fwd_coop_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (lds > 64 * 1024) as::lds_opt_in((const void*)lookup_fwd_coop_kernel<4, 8>);
       hipLaunchKernelGGL((lookup_fwd_coop_kernel<4, 8>), grid, dim3(256), lds, as::as_stream(stream), p);
     } else {
       hipLaunchKernelGGL((lookup_fwd_coop_kernel<4, 0>), grid, dim3(256), lds, as::as_stream(stream), p);

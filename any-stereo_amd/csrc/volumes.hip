@@ -634,8 +634,7 @@ int as_geo_pyramid(const float* gev, float* const* levels, int B, int G, int D, 
   if (G == 8 && D == 48) {
     hipLaunchKernelGGL((geo_pyramid_kernel<8, 48>), grid, dim3(256), lds, as::as_stream(stream), p);
   } else {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)geo_pyramid_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) as::lds_opt_in((const void*)geo_pyramid_kernel<0, 0>);
     hipLaunchKernelGGL((geo_pyramid_kernel<0, 0>), grid, dim3(256), lds, as::as_stream(stream), p);
   }
   return as::check_launch("geo_pyramid");
@@ -659,7 +658,7 @@ int as_gwc_volume_fwd(const float* fl, const float* fr, float* out, int B, int C
   hipStream_t s = as::as_stream(stream);
 #define AS_GWC(CG_, DM_)                                                                                         \
   {                                                                                                              \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)gwc_kernel<CG_, DM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (lds > 64 * 1024) as::lds_opt_in((const void*)gwc_kernel<CG_, DM_>);                                                                     \
     hipLaunchKernelGGL((gwc_kernel<CG_, DM_>), grid, dim3(256), lds, s, fl, fr, out, B, C, H, W, D, G);           \
   }
   if (dmax == 48) { if (cg == 12) AS_GWC(12, 48) else if (cg == 8) AS_GWC(8, 48) else AS_GWC(4, 48) }

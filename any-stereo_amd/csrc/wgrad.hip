@@ -480,10 +480,10 @@ template <int KS, int NT>
 int wgrad_launch(const WgradParams& p, const WgradPlan& q, bool vec, hipStream_t s) {
   const dim3 grid((unsigned)(q.nsplit * q.n_co * q.n_ci));
   if (vec) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<KS, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
+    as::lds_opt_in((const void*)wgrad_kernel<KS, NT, true>);
     hipLaunchKernelGGL((wgrad_kernel<KS, NT, true>), grid, dim3(512), q.lds, s, p);
   } else {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<KS, NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds);
+    as::lds_opt_in((const void*)wgrad_kernel<KS, NT, false>);
     hipLaunchKernelGGL((wgrad_kernel<KS, NT, false>), grid, dim3(512), q.lds, s, p);
   }
   return as::check_launch("conv2d_wgrad");

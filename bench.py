@@ -728,6 +728,12 @@ def infer_main(a, rank, world, local):
                                     "value": round(1.0 / t_step, 3), "unit": "pairs/s", "ms_per_step": round(t_step * 1e3, 2),
                                     "ms_per_gru_iter": round((t_step - t_lo) / (r2.wl.iters - lo2) * 1e3, 4), "steps": 3,
                                     "finite": bool(torch.isfinite(o2).all())}
+                    # the upsampler's kernels at this configuration's query count (HIP events, kernels one at a time)
+                    ks2, _ = kernel_stats(r2, passes=1)
+                    others[name]["liif_us"] = {k: round(v["total_ms"] / max(v["count"], 1) * 1e3, 1) for k, v in ks2.items()
+                                               if k in ("liif_tail", "liif_mlp_lowres", "structure_feature", "convex_upsample", "liif_mlp")}
+                    others[name]["liif_tail_hbm_frac"] = (round(algorithmic(1, r2.hp // 4, r2.wp // 4, r2.Q)["liif_tail"]["bytes"] / (ks2["liif_tail"]["total_ms"] / ks2["liif_tail"]["count"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                          if ks2.get("liif_tail", {}).get("count") else None)
                     del r2, o2
                     model.enable_graph(run.graph)  # drop that shape's graph pool
                 except Exception as ex:

@@ -768,10 +768,12 @@ def test_liif_gather_and_convex_backward(scale):
     close(ad.grad, rd.grad, 1e-4, 1e-5, "d disp (plain)")
 
 
-G8_TOL = {  # (gradient-norm rel, element-wise rtol of the full tensors) per arithmetic mode — measured values in DESIGN.md §5
-    "fp32": (2e-2, 2e-2),
-    "split": (2e-2, 2e-2),
-}
+# Tolerances = what BOTH arithmetic modes achieve on the GPU (round 3, GPUTEST log): gradient norms within 6.5e-3 (worst: the
+# BatchNorm3d affine gradients of the cost-volume stem — sums of large cancelling terms over MIOpen's batch statistics — and the
+# biases under the RAFT feature net's InstanceNorm), elements within 1.1e-3 of the tensor's maximum, 9e-3 for `corr_stem.*`.
+# Split (3 x fp16) and exact-fp32 MFMA mode are indistinguishable here (medians 3e-5 / 5e-5): what is left comes from the
+# library layers (norm statistics, atomics), not from the matrix-core mode, so split mode needs no looser bound.
+G8_TOL = {"fp32": (1e-2, 2e-3, 1.5e-2), "split": (1e-2, 2e-3, 1.5e-2)}  # (gradient-norm rel, element rtol, element rtol of corr_stem.*)
 
 
 @pytest.mark.parametrize("mode", ["split", "fp32"])
@@ -817,7 +819,7 @@ def test_training_step_vs_reference(name, mode):
     order = np.argsort(-rel)[:3]
     print(f"[G8 {name} {mode}] loss rel {abs(loss.item() - float(z['loss'])) / abs(float(z['loss'])):.2e}; grad-norm rel max "
           f"{rel.max():.3e}, median {np.median(rel):.3e}; worst: " + ", ".join(f"{names[i]} {rel[i]:.2e}" for i in order))
-    tol_n, tol_e = G8_TOL[mode]
+    tol_n, tol_e, tol_bn3d = G8_TOL[mode]
     assert rel.max() < tol_n, f"{name}: grad-norm mismatch {rel.max():.3e} at {names[int(rel.argmax())]}"
     # element-wise, on one tensor per operator family, relative to the tensor's max
     for i, n in enumerate(str(x) for x in z["full_names"]):
@@ -825,7 +827,7 @@ def test_training_step_vs_reference(name, mode):
         got = named[n].grad.detach().cpu() / ls
         e = ((got - want).abs().max() / want.abs().max()).item()
         print(f"[G8 {name} {mode}] {n}: max |d| / max |g| = {e:.2e}")
-        close(got, want, rtol=tol_e, atol=1e-6, what=n)
+        close(got, want, rtol=tol_bn3d if n.startswith("corr_stem") else tol_e, atol=1e-6, what=n)
 
 
 @pytest.mark.parametrize("sort", [False, True])
