@@ -432,6 +432,25 @@ class liif_out_multi_scale_Training(nn.Module):
                 and all(p.shape[1] % 16 == 0 for ps in feats_parts for p in ps))
 
     early_static = __import__("os").environ.get("ANYSTEREO_LIIF_EARLY_STATIC", "1") != "0"
+    # Opt-in (ANYSTEREO_LIIF_DIRECT=1), measured and NOT kept as the default: the second input (stem_2x, 32 + 8 channels at 1/2
+    # resolution) handed to the tail as RAW channels-last rows, its first-layer product taken per query there
+    # (ops.liif_tail(direct1=...)).  It removes that input's 128-channel first-layer table (66.8 MB at 960x540, written once and
+    # gathered ~2.3 x; the raw rows are 25 MB) — and is SLOWER: the whole upsampler 180 vs 158 us at cfg 2, 405 vs 339 us at
+    # cfg 3, 1276 vs 1064 us at cfg 5 (hipGraph replays, tools/kbench_liif.py): the tail is bound by its per-tile instruction
+    # stream (36 more MFMAs + three operand splits per tile, 20 spilled registers at 8 waves around one 90 KB LDS image), not by
+    # the bytes it gathers.  Same results (tests/test_hip_parity.py::test_liif_tail_direct_second_input).
+    direct_second_input = __import__("os").environ.get("ANYSTEREO_LIIF_DIRECT", "0") == "1"
+
+    def _direct_slot(self, slot: int, c: int) -> bool:
+        return self.direct_second_input and slot == 1 and c <= 48
+
+    def _input_rows(self, slot, parts, aff, pk):
+        """Rows of LIIF input `slot` for the tail: its first-layer product at low resolution, or (direct slot) its raw channels."""
+        if self._direct_slot(slot, sum(p_.shape[1] for p_ in parts) + 8):
+            with scope("liif_rows"):
+                return ops.liif_rows_cl(parts + [aff])
+        with scope("liif_mlp_lowres"):
+            return ops.liif_lowres_cl(parts + [aff], pk)
 
     def precompute_static(self, feats_parts, slot, stream):
         """Affinity + first MLP layer at low resolution of input `slot`, whose maps do not change during the GRU loop (stem_2x):
@@ -459,8 +478,7 @@ class liif_out_multi_scale_Training(nn.Module):
         with torch.cuda.stream(stream):
             with scope("structure_feature"):
                 aff = ops.liif_affinity(parts)
-            with scope("liif_mlp_lowres"):
-                u = ops.liif_lowres_cl(parts + [aff], pk.get(w1, o_, c))
+            u = self._input_rows(slot, parts, aff, pk.get(w1, o_, c))
             done = torch.cuda.Event()
             done.record(stream)
         for t_ in parts:
@@ -515,8 +533,7 @@ class liif_out_multi_scale_Training(nn.Module):
             with torch.cuda.stream(side if on_side else main):
                 with scope("structure_feature"):
                     aff = ops.liif_affinity(parts)
-                with scope("liif_mlp_lowres"):
-                    us.append(ops.liif_lowres_cl(parts + [aff], pk))
+                us.append(self._input_rows(i, parts, aff, pk))
             if on_side:
                 for t_ in parts:
                     t_.record_stream(side)
@@ -531,9 +548,10 @@ class liif_out_multi_scale_Training(nn.Module):
         if not hasattr(self, "_tail_pack"):
             self._tail_pack = ops.LiifTailPack()
         pack = self._tail_pack.get(lin, rel_cols)
+        direct1 = prep[1][2] if (len(prep) > 1 and self._direct_slot(1, prep[1][1])) else None
         with scope("liif_tail"):
             return ops.liif_tail(us[0], us[1] if len(us) > 1 else None, sizes, coord, pack, disp, scale_vec,
-                                 clamp_inplace=True, want_logits=want_logits)
+                                 clamp_inplace=True, want_logits=want_logits, direct1=direct1)
 
     def _mask_logits_train(self, feats, coord):
         """Differentiable form (liif.py:652-678).  With <= 2 sources the first Linear layer is applied at LOW resolution

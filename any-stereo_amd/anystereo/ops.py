@@ -1206,6 +1206,22 @@ def liif_lowres_cl(srcs: Sequence[torch.Tensor], pack: LiifLowresPack) -> torch.
     return out
 
 
+def liif_rows_cl(srcs: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Channels-last copy of a small input's structure feature: [B, H*W, 48] = cat(srcs)[b, :, y, x], zero padded — the rows
+    the tail gathers when it takes that input's first-layer product per query (as_liif_tail_direct)."""
+    for i, t in enumerate(srcs):
+        _req(t, f"src[{i}]")
+    b, _, h, w = srcs[0].shape
+    pitch = int(L.load().as_liif_rows_pitch())
+    if sum(int(t.shape[1]) for t in srcs) > pitch:
+        raise RuntimeError(f"liif_rows_cl: more than {pitch} channels")
+    out = torch.empty((b, h * w, pitch), device=srcs[0].device, dtype=torch.float32)
+    ptrs, ch, keep = _src_arrays(srcs)
+    with _guard(out.device):
+        L.check(L.load().as_liif_rows_cl(ptrs, ch, len(srcs), _p(out), b, h, w, _stream()), "liif_rows_cl")
+    return out
+
+
 class LiifTailPack:
     """LDS weight image of the fused tail kernel (layers 2-4 + the relative-coordinate columns / bias of layer 1), rebuilt
     when a source tensor changes (identity + version counter; weak references, so a recycled address cannot alias)."""
@@ -1238,9 +1254,12 @@ class LiifTailPack:
         return self
 
 
-def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_inplace=True, want_logits=False):
+def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_inplace=True, want_logits=False,
+              direct1: Optional[LiifLowresPack] = None):
     """The per-query tail: gather + first-layer finish + MLP + softmax + convex upsampling -> [B,1,Q] (and the mask logits
-    [B,9,Q] when asked).  u0 / u1: liif_lowres_cl results; sizes = [(H0,W0)] or [(H0,W0),(H1,W1)]."""
+    [B,9,Q] when asked).  u0 / u1: liif_lowres_cl results; sizes = [(H0,W0)] or [(H0,W0),(H1,W1)].
+    direct1 = the LiifLowresPack of the second input's columns: u1 then is liif_rows_cl's [B, H1*W1, 48] raw rows and the tail
+    takes that input's first-layer product per query (as_liif_tail_direct)."""
     _req(u0, "u0"), _req(coord, "coord"), _req(disp, "disp")
     b, q = coord.shape[:2]
     (h0, w0), (h1, w1) = sizes[0], (sizes[1] if u1 is not None else (0, 0))
@@ -1248,8 +1267,10 @@ def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_
         raise RuntimeError("liif_tail: shape mismatch")
     if u1 is not None:
         _req(u1, "u1")
-        if tuple(u1.shape) != (b, h1 * w1, 128):
+        if tuple(u1.shape) != (b, h1 * w1, 128 if direct1 is None else int(L.load().as_liif_rows_pitch())):
             raise RuntimeError("liif_tail: u1 shape mismatch")
+    elif direct1 is not None:
+        raise RuntimeError("liif_tail: direct1 without a second input")
     if scale is not None:
         _req(scale, "scale")
         if scale.numel() != b:
@@ -1257,9 +1278,14 @@ def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_
     out = torch.empty((b, 1, q), device=coord.device, dtype=torch.float32)
     logits = torch.empty((b, 9, q), device=coord.device, dtype=torch.float32) if want_logits else None
     with _guard(coord.device):
-        L.check(L.load().as_liif_tail(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(disp), _p(scale), _p(out), _p(logits), b, q,
-                                      h0, w0, h1, w1, disp.shape[2], disp.shape[3], 1 if clamp_inplace else 0, _stream()),
-                "liif_tail")
+        if direct1 is not None:
+            L.check(L.load().as_liif_tail_direct(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(direct1.image), _p(disp), _p(scale),
+                                                 _p(out), _p(logits), b, q, h0, w0, h1, w1, disp.shape[2], disp.shape[3],
+                                                 1 if clamp_inplace else 0, _stream()), "liif_tail_direct")
+        else:
+            L.check(L.load().as_liif_tail(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(disp), _p(scale), _p(out), _p(logits), b, q,
+                                          h0, w0, h1, w1, disp.shape[2], disp.shape[3], 1 if clamp_inplace else 0, _stream()),
+                    "liif_tail")
     return (out, logits) if want_logits else out
 
 

@@ -478,7 +478,13 @@ struct TailParams {
   int tiles, tpw;
   float lo, hi;
   float c0y[2], sy[2], c0x[2], sx[2];
+  // DIRECT1: u[1] holds the second input's RAW channels-last rows [B][H1*W1][kDirectCP] (structure feature, zero padded) and
+  // image1 the fragments of W1[:, its columns] (as_liif_lowres_pack layout): its first-layer product is taken per query
+  const _Float16* image1;
 };
+constexpr int kDirectCP = 48;                       // row pitch (floats) of a direct source: 3 k-steps
+constexpr int kDirectKS = kDirectCP / 16;
+constexpr int kImage1Bytes = kDirectKS * 8 * 1024;  // [ks][mt(4)][hi|lo][lane][8]
 
 #define AS_MFMA3(AH, AL, BH, BL, ACCH, ACCX)                               \
   ACCH = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACCH, 0, 0, 0);    \
@@ -494,10 +500,11 @@ struct TileCtx {
   half8 xh, xl;          // B operand of the relative-coordinate / bias product
   f32x16 ga;             // channels [0, 32) of the gathered source-0 row, in accumulator order (C operand of the T product)
   float4 g1[4];          // the same 16-B groups of the source-1 row
+  half8 dh[3], dl[3];    // DIRECT1: the source-1 row (48 raw channels) split into the B operands of its three k-steps
   float dn[5];           // this lane's disparity neighbours (x 4 x scale): k = 4 half + i (i < 4), k = 8 (i = 4, half 0)
 };
 
-template <int NSRC>
+template <int NSRC, bool DIRECT1 = false>
 __device__ __forceinline__ void tile_prepare(const TailParams& p, const float* __restrict__ u0p, const float* __restrict__ u1p,
                                              const float* __restrict__ dispp, long long t, bool valid, float cr, float cc,
                                              int half, float& amax, TileCtx& x) {
@@ -513,8 +520,9 @@ __device__ __forceinline__ void tile_prepare(const TailParams& p, const float* _
 #pragma unroll
   for (int s = 0; s < NSRC; ++s) {
     const int iy = nearest_idx(crc, p.H[s]), ix = nearest_idx(ccc, p.W[s]);
+    const int pitch = (DIRECT1 && s == 1) ? kDirectCP : kHid1;
     const float4* __restrict__ up =
-        reinterpret_cast<const float4*>((s ? u1p : u0p) + (((long long)b * p.H[s] + iy) * p.W[s] + ix) * kHid1) + half;
+        reinterpret_cast<const float4*>((s ? u1p : u0p) + (((long long)b * p.H[s] + iy) * p.W[s] + ix) * pitch) + ((DIRECT1 && s == 1) ? 2 * half : half);
     if (s == 0) x.up0 = up; else x.up1 = up;
     const float qy = __fadd_rn(p.c0y[s], __fmul_rn(p.sy[s], (float)iy));
     const float qx = __fadd_rn(p.c0x[s], __fmul_rn(p.sx[s], (float)ix));
@@ -550,25 +558,49 @@ __device__ __forceinline__ void put4(f32x16& a, int q, const float4 v) {
   a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
 }
 
-template <int NSRC>
-__device__ __forceinline__ void tile_first_gather(TileCtx& x) {
+template <int NSRC, bool DIRECT1 = false>
+__device__ __forceinline__ void tile_first_gather(TileCtx& x, float& amax) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     put4(x.ga, i, x.up0[2 * i]);
-    x.g1[i] = NSRC > 1 ? x.up1[2 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    x.g1[i] = (NSRC > 1 && !DIRECT1) ? x.up1[2 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if constexpr (DIRECT1) {
+    // lane half h supplies k = 8 h .. 8 h + 7 of a k-step = row floats [16 ks + 8 h, +8) = float4 #(4 ks + 2 h), #(4 ks + 2 h + 1)
+    // (up1 already points at float4 #2h)
+    float4 r[kDirectKS][2];
+#pragma unroll
+    for (int ks = 0; ks < kDirectKS; ++ks) { r[ks][0] = x.up1[4 * ks]; r[ks][1] = x.up1[4 * ks + 1]; }
+#pragma unroll
+    for (int ks = 0; ks < kDirectKS; ++ks) {
+      const float v[8] = {r[ks][0].x, r[ks][0].y, r[ks][0].z, r[ks][0].w, r[ks][1].x, r[ks][1].y, r[ks][1].z, r[ks][1].w};
+      split8(v, x.dh[ks], x.dl[ks], amax);
+    }
   }
 }
 
-template <int NSRC>
-__global__ __launch_bounds__(256, 2) void liif_tail_kernel(TailParams p) {
+// DIRECT1 (two inputs): the second input's first-layer rows are not precomputed at its resolution — at 1/2 resolution that table is
+// 4 x the 1/4-resolution one (66.8 MB at 960x540, gathered ~2.3 x) — the tail gathers its 40 RAW channels (192-B rows, 25 MB)
+// and takes the product with W1's columns here: three more k-steps per 32-channel tile into the accumulators the relative-
+// coordinate product already owns (no VALU add of a gathered row).  Its fragments (24 KB) sit behind the main image, so the
+// block is 8 waves sharing one 90 KB copy instead of two 4-wave blocks with 66 KB each.
+template <int NSRC, bool DIRECT1 = false>
+__global__ __launch_bounds__(DIRECT1 ? 512 : 256, DIRECT1 ? 1 : 2) void liif_tail_kernel(TailParams p) {
+  constexpr int NT = DIRECT1 ? 512 : 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   {
     const uint4* src = reinterpret_cast<const uint4*>(p.image);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = threadIdx.x; i < kImageBytes / 16; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < kImageBytes / 16; i += NT) dst[i] = src[i];
+    if constexpr (DIRECT1) {
+      const uint4* src1 = reinterpret_cast<const uint4*>(p.image1);
+      uint4* dst1 = reinterpret_cast<uint4*>(smem + ((kImageBytes + 15) / 16) * 16);
+      for (int i = threadIdx.x; i < kImage1Bytes / 16; i += NT) dst1[i] = src1[i];
+    }
   }
   __syncthreads();
   const half8* W0 = reinterpret_cast<const half8*>(smem);
+  const half8* W1d0 = reinterpret_cast<const half8*>(smem + ((kImageBytes + 15) / 16) * 16);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, half = lane >> 5;
@@ -576,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void liif_tail_kernel(TailParams p) {
   // rows a query neighbourhood shares are fetched into ONE L2
   const int nb = gridDim.x;
   const int mapped = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const long long gw = (long long)mapped * 4 + wave;
+  const long long gw = (long long)mapped * (NT / 64) + wave;
   float amax = 0.f;
   int imax = 0;
   // no-alias views (otherwise a tile's gathers wait for the previous tile's stores)
@@ -596,14 +628,15 @@ __global__ __launch_bounds__(256, 2) void liif_tail_kernel(TailParams p) {
     int opaque = 0;
     asm volatile("" : "+v"(opaque));
     const half8* W = W0 + opaque;
+    const half8* W1d = W1d0 + opaque;
     const float* bias = reinterpret_cast<const float*>(smem + kFragBlocks * 1024) + opaque;
     TileCtx cur;
     {
       long long t = (tile0 + ti) * 32 + c;
       const bool valid = t < p.total;
       if (!valid) t = p.total - 1;
-      tile_prepare<NSRC>(p, u0p, u1p, dispp, t, valid, coordp[t * 2], coordp[t * 2 + 1], half, amax, cur);
-      tile_first_gather<NSRC>(cur);
+      tile_prepare<NSRC, DIRECT1>(p, u0p, u1p, dispp, t, valid, coordp[t * 2], coordp[t * 2 + 1], half, amax, cur);
+      tile_first_gather<NSRC, DIRECT1>(cur, amax);
     }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 a2h[2], a2x[2];
@@ -620,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void liif_tail_kernel(TailParams p) {
     f32x16 ga = cur.ga, gn = zero16;
     float4 g1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g1[i] = cur.g1[i];
+    for (int i = 0; i < 4; ++i) g1[i] = DIRECT1 ? make_float4(0.f, 0.f, 0.f, 0.f) : cur.g1[i];
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
       if (t4 < 3) {
@@ -634,6 +667,13 @@ __global__ __launch_bounds__(256, 2) void liif_tail_kernel(TailParams p) {
         th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur.xh, ga, 0, 0, 0);
         tx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur.xl, zero16, 0, 0, 0);
         tx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, cur.xh, tx, 0, 0, 0);
+        if constexpr (DIRECT1) {
+#pragma unroll
+          for (int kd = 0; kd < kDirectKS; ++kd) {  // + W1[:, source-1 columns] . (its raw row): image1 [ks][mt][hi|lo][lane]
+            const half8 dah = W1d[((kd * 4 + t4) * 2) * 64 + lane], dal = W1d[((kd * 4 + t4) * 2 + 1) * 64 + lane];
+            AS_MFMA3(dah, dal, cur.dh[kd], cur.dl[kd], th, tx)
+          }
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -642,9 +682,10 @@ __global__ __launch_bounds__(256, 2) void liif_tail_kernel(TailParams p) {
         const float q8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = relu_bits(fmaf(tx[8 * s + j], 1.f / 2048.f, th[8 * s + j]) + q8[j]);
+        for (int j = 0; j < 8; ++j)
+          v[j] = relu_bits(DIRECT1 ? fmaf(tx[8 * s + j], 1.f / 2048.f, th[8 * s + j]) : fmaf(tx[8 * s + j], 1.f / 2048.f, th[8 * s + j]) + q8[j]);
         __builtin_amdgcn_sched_barrier(0);
-        if (t4 < 3 && NSRC > 1) {  // this k-step's source-1 registers are free: fetch k-step ks + 2
+        if (t4 < 3 && NSRC > 1 && !DIRECT1) {  // this k-step's source-1 registers are free: fetch k-step ks + 2
 #pragma unroll
           for (int i = 0; i < 2; ++i) g1[2 * s + i] = cur.up1[2 * (2 * (ks + 2) + i)];
         }
@@ -730,6 +771,38 @@ __global__ __launch_bounds__(256, 2) void liif_tail_kernel(TailParams p) {
     if (cur.valid && !half) outp[cur.t] = dsum / ssum;
   }
   note_overflow(fmaxf(amax, __builtin_bit_cast(float, imax)));
+}
+
+// channels-last copy of a (<= 48-channel) structure feature: out[b][p][0..kDirectCP) = cat(srcs)[b, :, p], zero padded — the rows the
+// DIRECT1 tail gathers.  Thread = (pixel, 4-channel group): four coalesced plane reads, one 16-B store.
+struct RowsParams {
+  const float* src[3];
+  int c[3];
+  int n_src, C;
+  float* out;
+  long long P, total;  // pixels per image, B * P
+};
+
+__global__ __launch_bounds__(256) void liif_rows_cl_kernel(RowsParams p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  constexpr int NG = kDirectCP / 4;
+  if (idx >= p.total * NG) return;
+  const int g = (int)(idx / p.total);          // group-major: consecutive threads = consecutive pixels (coalesced reads)
+  const long long pix = idx - (long long)g * p.total;
+  const long long b = pix / p.P, pp = pix - b * p.P;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = 4 * g + j;
+    float x = 0.f;
+    if (ch < p.C) {
+      int s = 0, cl = ch;
+      if (cl >= p.c[0]) { cl -= p.c[0]; s = 1; if (cl >= p.c[1]) { cl -= p.c[1]; s = 2; } }
+      x = p.src[s][(b * p.c[s] + cl) * p.P + pp];
+    }
+    v[j] = x;
+  }
+  *reinterpret_cast<float4*>(p.out + pix * kDirectCP + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 }  // namespace
@@ -826,9 +899,48 @@ int as_liif_tail_pack(const float* wrel, const float* b1, const float* w2, const
   return as::check_launch("liif_tail_pack");
 }
 
+int as_liif_rows_pitch(void) { return kDirectCP; }
+
+int as_liif_rows_cl(const float* const* srcs, const int* channels, int n_src, float* out, int B, int H, int W, void* stream) {
+  AS_REQUIRE(srcs && channels && out, AS_ERR_BAD_ARG, "liif_rows_cl: null pointer");
+  AS_REQUIRE(n_src >= 1 && n_src <= 3 && B > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "liif_rows_cl: bad sizes");
+  RowsParams p{};
+  int C = 0;
+  for (int s = 0; s < n_src; ++s) {
+    AS_REQUIRE(srcs[s] && channels[s] > 0, AS_ERR_BAD_ARG, "liif_rows_cl: source %d is empty", s);
+    p.src[s] = srcs[s];
+    p.c[s] = channels[s];
+    C += channels[s];
+  }
+  for (int s = n_src; s < 3; ++s) { p.src[s] = srcs[n_src - 1]; p.c[s] = 1 << 30; }  // never reached
+  AS_REQUIRE(C <= kDirectCP, AS_ERR_BAD_SHAPE, "liif_rows_cl: %d channels (max %d)", C, kDirectCP);
+  p.n_src = n_src; p.C = C; p.out = out; p.P = (long long)H * W; p.total = p.P * B;
+  const long long n = p.total * (kDirectCP / 4);
+  AS_REQUIRE(n < (1ll << 40), AS_ERR_BAD_SHAPE, "liif_rows_cl: too many pixels");
+  hipLaunchKernelGGL(liif_rows_cl_kernel, dim3((unsigned)as::cdiv64(n, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("liif_rows_cl");
+}
+
+static int liif_tail_impl(const float* u0, const float* u1, float* coord, const void* image, const void* image1, const float* disp,
+                          const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
+                          int clamp_inplace, void* stream);
+
 int as_liif_tail(const float* u0, const float* u1, float* coord, const void* image, const float* disp, const float* scale,
                  float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd, int clamp_inplace,
                  void* stream) {
+  return liif_tail_impl(u0, u1, coord, image, nullptr, disp, scale, out, logits, B, Q, H0, W0, H1, W1, Hd, Wd, clamp_inplace, stream);
+}
+
+int as_liif_tail_direct(const float* u0, const float* rows1, float* coord, const void* image, const void* image1, const float* disp,
+                        const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
+                        int clamp_inplace, void* stream) {
+  AS_REQUIRE(rows1 && image1, AS_ERR_BAD_ARG, "liif_tail_direct: null rows / fragment image of the second input");
+  return liif_tail_impl(u0, rows1, coord, image, image1, disp, scale, out, logits, B, Q, H0, W0, H1, W1, Hd, Wd, clamp_inplace, stream);
+}
+
+static int liif_tail_impl(const float* u0, const float* u1, float* coord, const void* image, const void* image1, const float* disp,
+                          const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
+                          int clamp_inplace, void* stream) {
   AS_REQUIRE(u0 && coord && image && disp && out, AS_ERR_BAD_ARG, "liif_tail: null pointer");
   AS_REQUIRE(B > 0 && Q > 0 && H0 > 0 && W0 > 0 && Hd > 0 && Wd > 0, AS_ERR_BAD_ARG, "liif_tail: non-positive size");
   AS_REQUIRE(!u1 || (H1 > 0 && W1 > 0), AS_ERR_BAD_ARG, "liif_tail: second source without a size");
@@ -845,10 +957,13 @@ int as_liif_tail(const float* u0, const float* u1, float* coord, const void* ima
   const long long tiles = as::cdiv64(p.total, 32);
   AS_REQUIRE(tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "liif_tail: too many queries");
   p.tiles = (int)tiles;
-  // 2 blocks of 4 waves per CU (LDS: 2 x 66 KB weight images); a wave walks `tpw` consecutive tiles
+  p.image1 = (const _Float16*)image1;
+  // 2 blocks of 4 waves per CU (LDS: 2 x 66 KB weight images) — or one block of 8 waves around one 90 KB image pair (direct
+  // second input); a wave walks `tpw` consecutive tiles
   const long long waves = 256ll * 2 * 4;
+  const int wpb = image1 ? 8 : 4;
   p.tpw = (int)std::max<long long>(1, as::cdiv64(tiles, waves));
-  long long blocks = as::cdiv64(tiles, 4ll * p.tpw);
+  long long blocks = as::cdiv64(tiles, (long long)wpb * p.tpw);
   blocks = (blocks + 7) / 8 * 8;  // multiple of 8: the XCD-aware block order is a bijection
   static bool attr_set = false;
   if (!attr_set) {
@@ -856,7 +971,12 @@ int as_liif_tail(const float* u0, const float* u1, float* coord, const void* ima
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(liif_tail_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kImageBytes);
     attr_set = true;
   }
-  if (p.n_src == 2)
+  if (image1) {
+    AS_REQUIRE(p.n_src == 2, AS_ERR_BAD_ARG, "liif_tail_direct: needs the second input");
+    constexpr int lds = ((kImageBytes + 15) / 16) * 16 + kImage1Bytes;
+    as::lds_opt_in(reinterpret_cast<const void*>(liif_tail_kernel<2, true>));
+    hipLaunchKernelGGL((liif_tail_kernel<2, true>), dim3((unsigned)blocks), dim3(512), lds, as::as_stream(stream), p);
+  } else if (p.n_src == 2)
     hipLaunchKernelGGL(liif_tail_kernel<2>, dim3((unsigned)blocks), dim3(256), kImageBytes, as::as_stream(stream), p);
   else
     hipLaunchKernelGGL(liif_tail_kernel<1>, dim3((unsigned)blocks), dim3(256), kImageBytes, as::as_stream(stream), p);

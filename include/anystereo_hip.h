@@ -336,6 +336,12 @@ int as_convex_upsample(const float* disp, const float* scale, const float* mask,
  *                    (row, col); clamp_inplace != 0 writes the clamped coordinates back (the reference's in-place
  *                    `hr_coord.clamp_`, submodule.py:366); logits [B,9,Q]|NULL also receives the mask logits (`liif_up`'s
  *                    return value).  Split-precision arithmetic (3 x fp16 MFMA per product, fp32 accumulate).
+ * as_liif_rows_cl    channels-last copy of a small input's structure feature: out [B][H*W][as_liif_rows_pitch() = 48] =
+ *                    cat(srcs)[b, :, y, x], zero padded (<= 48 channels: stem_2x | its affinity, liif.py:496-499).
+ * as_liif_tail_direct  as_liif_tail with the SECOND input handed over as those raw rows instead of its first-layer rows:
+ *                    image1 = as_liif_lowres_pack of W1[:, that input's columns]; the tail takes the product per query
+ *                    (three k-steps) — the 128-channel table at the second input's resolution (4 x the first one's) is
+ *                    neither written nor gathered.  Same result up to fp32 summation order.
  * as_liif_split_overflow  number of waves (since the last reset) in which an operand of these kernels left the fp16
  *                    range and was saturated to +-65504 (synchronises; diagnostics only).
  * ------------------------------------------------------------------------------------------- */
@@ -351,6 +357,11 @@ int as_liif_tail_pack(const float* wrel, const float* b1, const float* w2, const
 int as_liif_tail(const float* u0, const float* u1, float* coord, const void* image, const float* disp, const float* scale,
                  float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd, int clamp_inplace,
                  void* stream);
+int as_liif_rows_pitch(void);
+int as_liif_rows_cl(const float* const* srcs, const int* channels, int n_src, float* out, int B, int H, int W, void* stream);
+int as_liif_tail_direct(const float* u0, const float* rows1, float* coord, const void* image, const void* image1, const float* disp,
+                        const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
+                        int clamp_inplace, void* stream);
 unsigned as_liif_split_overflow(int reset);
 
 /* ---------------------------------------------------------------------------------------------

@@ -1432,6 +1432,47 @@ def test_liif_fused_tail_vs_staged(two, b, h, w, s, nq):
     up.float().to(DEV)
 
 
+@pytest.mark.parametrize("b,h,w,s,nq", [(1, 17, 29, 1.0, None), (2, 9, 13, 2.95, 777), (1, 24, 40, 1.5, None)])
+def test_liif_tail_direct_second_input(b, h, w, s, nq):
+    """The tail with the second input handed over as raw channels-last rows (its first-layer product taken per query,
+    as_liif_tail_direct) against the form that gathers that input's low-resolution first-layer rows, and against the fp64
+    oracle: same logits and disparity up to the fp32 order of a K = 40 sum; rows are a zero-padded channels-last copy."""
+    from anystereo import ops
+    up = _liif_module(seed=13, two=True)
+    x4 = U((b, 176, h, w), 211, -1.5, 1.5).to(DEV)
+    x2 = U((b, 32, 2 * h, 2 * w), 212, -1.5, 1.5).to(DEV)
+    grid = O.make_coord([round(4 * h * s), round(4 * w * s)])
+    if nq is not None:
+        idx = (U((nq,), 213, 0.0, 1.0) * grid.shape[0]).long().clamp(max=grid.shape[0] - 1)
+        grid = grid[idx]
+        grid[0] = torch.tensor([-1.0, 1.0])
+    coord = grid.view(1, -1, 2).repeat(b, 1, 1).contiguous()
+    disp = U((b, 1, h, w), 214, 0.0, 40.0).to(DEV)
+    sv = torch.full((b,), float(s), device=DEV)
+    parts = [[x4[:, :48].contiguous(), x4[:, 48:].contiguous()], [x2]]
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    outs = {}
+    try:
+        with torch.no_grad():
+            aff = ops.liif_affinity([x2])
+            rows = ops.liif_rows_cl([x2, aff])
+            want_rows = torch.cat([x2, aff, torch.zeros(b, 8, 2 * h, 2 * w, device=DEV)], 1).permute(0, 2, 3, 1).reshape(b, -1, 48)
+            assert torch.equal(rows, want_rows), "rows = channels-last copy"
+            for direct in (True, False):
+                up.direct_second_input = direct
+                outs[direct] = up.upsample_fused(parts, coord.clone().to(DEV), disp, sv, want_logits=True)
+    finally:
+        up.__dict__.pop("direct_second_input", None)
+        ops.set_precision(prev)
+    close(outs[True][1], outs[False][1], 3e-5, 3e-5, "direct vs low-resolution-rows logits")
+    close(outs[True][0], outs[False][0], 3e-5, 3e-5, "direct vs low-resolution-rows disparity")
+    up64 = up.cpu().double()
+    want_mask = O.liif_up_mask(up64, [x4.cpu().double(), x2.cpu().double()], coord.double())
+    close(outs[True][1], want_mask, 3e-5, 3e-5, "direct logits vs fp64 oracle")
+    up.float().to(DEV)
+
+
 def test_liif_lowres_channels_last():
     """First MLP layer at low resolution, channels-last: against the fp64 product; three sources, a column window of the
     weight, pixel counts that are not multiples of 32."""

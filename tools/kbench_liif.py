@@ -36,5 +36,24 @@ with torch.no_grad():
         out = up.upsample_fused([[stem4, net0], [stem2]], c2, disp, sv)
     e.record()
     torch.cuda.synchronize()
+if len(sys.argv) > 3 and sys.argv[3] == "graph":  # the pipeline captured once and replayed: GPU time without the host launch path
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            up.upsample_fused([[stem4, net0], [stem2]], c2, disp, sv)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                out = up.upsample_fused([[stem4, net0], [stem2]], c2, disp, sv)
+        g.replay()
+        torch.cuda.synchronize()
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+    print(f"{cfg}: graph replay {s.elapsed_time(e) / reps * 1e3:.1f} us per upsample_fused call (direct_second_input={up.direct_second_input})")
 print(f"{cfg}: Q={coord.shape[1]} fused LIIF {s.elapsed_time(e) / reps * 1e3:.1f} us per call (host-paced eager launches), "
       f"finite={bool(torch.isfinite(out).all())} overflow_waves={ops.split_overflow_count()}")

@@ -21,7 +21,7 @@ def main():
     j = min(range(1, len(ends)), key=lambda i: rows[ends[i]][1] - rows[ends[i - 1]][1])
     win = rows[ends[j - 1] + 1: ends[j] + 1]
     t0 = win[0][0]
-    first_lookup = next(i for i, r in enumerate(win) if "lookup_convc1_kernel" in r[2] or "lookup_fwd" in r[2])
+    first_lookup = next(i for i, r in enumerate(win) if "lookup_convc1" in r[2] or "lookup_fwd" in r[2])
     pre = win[:first_lookup]
     res = {"pass_ms": (win[-1][1] - t0) / 1e6, "pre_loop_wall_ms": (win[first_lookup][0] - t0) / 1e6,
            "pre_loop_kernel_ms": sum(e - s for s, e, _, _ in pre) / 1e6, "pre_loop_launches": len(pre),
