@@ -75,6 +75,7 @@ struct ConvParams {
   int fast16;   // conv_split_kernel: skip the two cross-term MFMAs (fp16 operands, fp32 accumulate: as_set_fast16)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
+  int stagger;  // conv_split_kernel: start delay per XCD index in units of 64 clocks (AS_CONV_XCD_STAGGER; 0 = none)
 };
 
 constexpr int kNumCU = 256;   // MI355X
@@ -965,6 +966,13 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   const bool loader = !LEAN && wave >= 4;
   const int l31 = lane & 31, half = lane >> 5;
   AS_LIFE(0)
+  if (p.stagger) {
+    // Blocks of one XCD (ids congruent mod 8) keep running in lock-step — they share halo patches and weight lines in that XCD's
+    // L2 — but the eight XCDs start `stagger` x 64 clocks apart, so their staging bursts and store tails do not hit the fabric
+    // at the same instant.
+    const int steps = (int)(blockIdx.x & 7u) * p.stagger;
+    for (int i = 0; i < steps; i += 8) __builtin_amdgcn_s_sleep(8);
+  }
 
   const int ntile = p.tiles_x * p.tiles_y;
   const int ngroup = (ntile + NSUB - 1) / NSUB;
@@ -1629,6 +1637,8 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   static const int xcd_mode = getenv("AS_CONV_XCD") ? atoi(getenv("AS_CONV_XCD")) : 1;
   ConvParams q = p;
   q.xcd_map = (xcd_mode && p.n_tiles > 1) ? 1 : 0;
+  static const int stagger = getenv("AS_CONV_XCD_STAGGER") ? atoi(getenv("AS_CONV_XCD_STAGGER")) : 0;
+  q.stagger = stagger;
   hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST, LEAN>), grid, dim3(LEAN ? 256 : 512), lds, s, q);
   return as::check_launch("conv2d(split)");
 }

@@ -303,8 +303,12 @@ def train_main(a, rank, world, local):
         overlap = {"ms_per_step_with_allreduce": round(ms_sync, 2), "ms_per_step_no_sync": round(ms_nosync, 2),
                    "exposed_allreduce_ms": round(ms_sync - ms_nosync, 2), "gradient_bytes": nbytes,
                    "ddp": tr.ddp_mode}
-    roof = cpu = None
+    roof = cpu = graphed = None
     if rank == 0 and world == 1 and not a.no_extras:
+        try:
+            graphed = train_graphed_step(a, args, batch, dev)
+        except Exception as ex:  # never lose the headline line to the side measurement
+            graphed = {"error": repr(ex)[:300]}
         roof = train_roofline(a, batch, dev)
         if not a.no_cpu_baseline:
             cpu = train_cpu_baseline(a, args, model, batch)
@@ -330,10 +334,55 @@ def train_main(a, rank, world, local):
             "split_overflow": {"policy": tr.overflow_policy, "check_every": tr.overflow_check_every,
                                "saturated_waves_at_end": tr._poll_overflow() if tr._on_gpu() else None,
                                "events": tr.overflow_events, "skipped_steps": tr.skipped_steps},
+            "graphed_step": graphed,
             "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu}))
     if dist:
         td.barrier()
         td.destroy_process_group()
+
+
+def train_graphed_step(a, args, batch, dev, n_cmp=6):
+    """The opt-in whole-step hipGraph (harness/train.py, Trainer(graph=True)), reported NEXT to the eager headline, never as
+    `value`: a fresh model replays the captured step; its loss trajectory is checked against a fresh eager trainer started from
+    the same weights on the same batch (the two phases run one after the other — an eager training step BETWEEN replays is
+    exactly what still corrupts them on this stack), then `steps` replays are timed."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer
+    from anystereo.models import __models__
+
+    def fresh(graph):
+        m = __models__["continuous_IGEVStereo"](args)
+        fill_module_deterministic(m, base_seed=1)
+        return Trainer(m.to(dev), train_iters=a.train_iters, max_disp=args.max_disp, graph=graph)
+
+    def run(tr, n):
+        out = []
+        for _ in range(n):
+            out.append(tr.step(tuple(t.clone() for t in batch))[0])
+        torch.cuda.synchronize()
+        return [float(v) for v in out]
+
+    eager = fresh(False)
+    n = eager_n = 3 + n_cmp  # the graphed trainer's three eager warm-up steps + n_cmp replays
+    want = run(eager, eager_n)
+    del eager
+    torch.cuda.empty_cache()
+    tr = fresh(True)
+    if not tr.use_graph:
+        return {"available": False}
+    got = run(tr, n)
+    rel = [abs(g - w) / max(abs(w), 1e-12) for g, w in zip(got, want)]
+    ok = all(r == r and r < 5e-3 for r in rel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"opt_in": "ANYSTEREO_TRAIN_GRAPH=1 / Trainer(graph=True); one rank, no GradScaler",
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "samples_per_s": round(a.batch_per_gpu * a.steps / dt, 3), "steps": a.steps,
+            "loss_trajectory_matches_eager": ok, "max_rel_loss_diff_over_replays": max(rel[3:]) if len(rel) > 3 else None,
+            "losses_eager": [round(v, 4) for v in want], "losses_graphed": [round(v, 4) for v in got]}
 
 
 def train_roofline(a, batch, dev):
