@@ -76,6 +76,7 @@ struct ConvParams {
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
   int stagger;  // conv_split_kernel: start delay per XCD index in units of 64 clocks (AS_CONV_XCD_STAGGER; 0 = none)
+  int lean_offset;  // conv_split_kernel<LEAN>: start delay of the grid's second half in units of 64 clocks (AS_CONV_LEAN_OFFSET)
 };
 
 constexpr int kNumCU = 256;   // MI355X
@@ -973,6 +974,13 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
     const int steps = (int)(blockIdx.x & 7u) * p.stagger;
     for (int i = 0; i < steps; i += 8) __builtin_amdgcn_s_sleep(8);
   }
+  if (LEAN && p.lean_offset && blockIdx.x >= (gridDim.x >> 1)) {
+    // Two lean blocks share a CU.  Started together they run in lock-step — both stage, both compute, both store at the same
+    // time, so the matrix pipes idle through a prologue and a DOUBLE store tail.  The blocks of the second half of the grid
+    // (the ones that take the CUs' second slots) start `lean_offset` x 64 clocks later: their prologue and the first blocks'
+    // finish then fall into the partner's MFMA loop.
+    for (int i = 0; i < p.lean_offset; i += 8) __builtin_amdgcn_s_sleep(8);
+  }
 
   const int ntile = p.tiles_x * p.tiles_y;
   const int ngroup = (ntile + NSUB - 1) / NSUB;
@@ -1639,6 +1647,8 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   q.xcd_map = (xcd_mode && p.n_tiles > 1) ? 1 : 0;
   static const int stagger = getenv("AS_CONV_XCD_STAGGER") ? atoi(getenv("AS_CONV_XCD_STAGGER")) : 0;
   q.stagger = stagger;
+  static const int lean_offset = getenv("AS_CONV_LEAN_OFFSET") ? atoi(getenv("AS_CONV_LEAN_OFFSET")) : 0;
+  q.lean_offset = lean_offset;
   hipLaunchKernelGGL((conv_split_kernel<KS, TW, BN, EPI, NSUB, S, FAST, LEAN>), grid, dim3(LEAN ? 256 : 512), lds, s, q);
   return as::check_launch("conv2d(split)");
 }
