@@ -38,6 +38,7 @@ def conv_args(name):
 
 # kernel-name substring -> (class, reads are 16 B per lane?)
 RULES = [
+    ("lookup_convc1_direct_kernel", "lookup_convc1", True),  # register-direct form (the one the loop launches): float4 per tap
     ("lookup_convc1_kernel", "lookup_convc1", True),   # geometry windows: float4 per tap
     ("lookup_fwd_quad_kernel", "lookup", True),
     ("lookup_fwd_coop_kernel", "lookup", True),
