@@ -348,6 +348,42 @@ class ContinuousStereoBase(nn.Module):
         disp.record_stream(main)
         return disp
 
+    batched_train_upsample = os.environ.get("ANYSTEREO_BATCHED_TRAIN_LIIF", "1") != "0"
+
+    def _upsample_batched(self, pend, stem_4x, stem_2x, stem_1x, hr_coord, scale):
+        """upsample_disp of all iterations' (disparity, hidden state) pairs as batched calls over (iteration, sample), in groups
+        that keep the per-query activations [n*B,128,Q] under 2^31 bytes -> the list of [B,1,Q] predictions, one per iteration."""
+        b = pend[0][0].shape[0]
+        q = hr_coord.shape[1]
+        group = max(1, min(len(pend), int((1 << 31) * 0.7) // max(1, b * 128 * q * 4)))
+        sc = scale.reshape(-1, 1).float()
+        if sc.shape[0] == 1 and b > 1:
+            sc = sc.expand(b, 1)
+        preds = []
+        base_order = None
+        for g0 in range(0, len(pend), group):
+            part = pend[g0:g0 + group]
+            n = len(part)
+            rep = (lambda t: None if t is None else (t if n == 1 else t.repeat(n, *([1] * (t.dim() - 1)))))
+            hc = rep(hr_coord.detach()).contiguous()
+            if self.sort_queries and stem_1x is None and n > 1:
+                # the query order depends on the coordinates only: sort the B samples once and repeat the permutation, instead of
+                # an argsort over n*B rows (the cache entry _hot_upsample_train looks up is keyed on the repeated tensor)
+                sizes = [tuple(part[0][1].shape[2:])] + ([tuple(stem_2x.shape[2:])] if stem_2x is not None else [])
+                if base_order is None:
+                    base_order = self._query_order(hr_coord.detach(), sizes)
+                perm, inv = base_order
+                self.__dict__["_qorder"] = {(hc.data_ptr(), tuple(hc.shape), tuple(sizes)): (perm.repeat(n, 1), inv.repeat(n, 1))}
+            # stem_2x (the upsampler's second input) goes in ONCE, at batch B: nn/liif.py computes its rows at that batch and
+            # repeats them (16 x less work than a repeated input for the loop-invariant branch); the option sets outside the
+            # default take every input repeated
+            s2 = stem_2x if (stem_1x is None and self.liif_up._default_variant and self.liif_up.fused_first_layer) else rep(stem_2x)
+            up = self.upsample_disp(torch.cat([d for d, _ in part], 0), torch.cat([h for _, h in part], 0), rep(stem_4x), s2,
+                                    rep(stem_1x), hr_coord=hc, scale=rep(sc).contiguous())
+            preds.extend(up.split(b, 0))
+        hr_coord.clamp_(-1 + 1e-6, 1 - 1e-6)  # the reference's side effect on the caller's tensor (submodule.py:366)
+        return list(preds)
+
     def _iterate(self, lookup_fn, net_list, inp_list, disp, coords, iters, test_mode, stem_4x, stem_2x, hr_coord, scale, stem_1x=None):
         """The GRU loop shared by both models (continuous_IGEVstereo.py:284-301, prune_raft_stereo.py:276-291)."""
         a = self.args
@@ -373,6 +409,14 @@ class ContinuousStereoBase(nn.Module):
             if liif is not None and hasattr(liif, "clear_static"):
                 liif.clear_static()
             return disp, disp_up, [disp_up]
+        # Training: the upsampler of every iteration (train_continuous_IGEV.py:219 needs all predictions) does not feed back
+        # into the loop, so its `iters` evaluations are issued AFTER the loop as batched calls over (iteration, sample) — same
+        # values per query (the per-query stage does not look at its batch neighbours), the weight gradients summed over one
+        # big call instead of `iters` small ones — and ~70 launches per iteration leave the host-bound step's launch count.
+        batch_up = (self.batched_train_upsample and not test_mode and iters > 1 and disp.is_cuda and torch.is_grad_enabled()
+                    and type(self)._hot_upsample is ContinuousStereoBase._hot_upsample and type(self)._hot_update is ContinuousStereoBase._hot_update
+                    and torch.is_tensor(scale) and hr_coord is not None)
+        pend = []
         for itr in range(iters):
             disp = disp.detach()
             geo_feat = lookup_fn(disp, coords)
@@ -386,8 +430,14 @@ class ContinuousStereoBase(nn.Module):
             disp = disp + delta
             if test_mode and itr < iters - 1:
                 continue
+            if batch_up:
+                pend.append((disp, net_list[0]))
+                continue
             disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, stem_1x, hr_coord=hr_coord, scale=scale)
             disp_preds.append(disp_up)
+        if pend:
+            disp_preds = self._upsample_batched(pend, stem_4x, stem_2x, stem_1x, hr_coord, scale)
+            disp_up = disp_preds[-1]
         if getattr(self, "liif_up", None) is not None:
             self.liif_up.__dict__.pop("_train_static", None)
         return disp, disp_up, disp_preds

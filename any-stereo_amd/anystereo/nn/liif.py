@@ -575,6 +575,16 @@ class liif_out_multi_scale_Training(nn.Module):
                 u = F.conv2d(s, w1[:, off:off + s.shape[1], None, None]) if lowres else None
                 if cache is not None and i > 0:
                     cache[i] = (f, (f._version, w1._version, torch.is_grad_enabled()), s, u)
+            nb = coord.shape[0]
+            if s.shape[0] != nb:
+                # an input shared by the n batched evaluations of one forward (models/base.py::_upsample_batched hands stem_2x
+                # over ONCE, batch B, beside n*B hidden states): its structure feature and low-resolution first layer are computed
+                # at batch B and the rows repeated — autograd sums the n uses' gradients in repeat's backward
+                if nb % s.shape[0]:
+                    raise RuntimeError(f"liif: input {i} has batch {s.shape[0]}, the queries {nb}")
+                k = nb // s.shape[0]
+                s = s.repeat(k, 1, 1, 1) if not lowres else s
+                u = u.repeat(k, 1, 1, 1) if u is not None else None
             sfs.append(s)
             us.append(u)
             rel_cols.append(w1[:, off + s.shape[1]:off + s.shape[1] + 2])

@@ -830,6 +830,50 @@ def test_training_step_vs_reference(name, mode):
         close(got, want, rtol=tol_bn3d if n.startswith("corr_stem") else tol_e, atol=1e-6, what=n)
 
 
+@pytest.mark.parametrize("name", ["igev", "raft"])
+def test_training_batched_upsampler_equals_per_iteration(name):
+    """Training forward / backward with the upsampler of all iterations issued after the loop as batched calls over (iteration,
+    sample) (models/base.py::_upsample_batched) against the reference's order (one call per iteration): same predictions, same
+    loss, same gradients up to fp32 summation order; the caller's hr_coord is clamped in place either way."""
+    from anystereo.harness.metrics import sequence_loss_multiscale
+    from anystereo.harness.synthetic import fill_module_deterministic, tiny_train_case
+    from anystereo.models import __models__, default_args
+    args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
+    h, w, img1, img2, coord, gt, scale = tiny_train_case(name)
+    coord = coord.clone()
+    coord[0, 0] = torch.tensor([-1.0, 1.0])  # outside the clamp range: the in-place side effect must show
+    res = {}
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        for batched in (False, True):
+            model = __models__[args.model](args)
+            fill_module_deterministic(model, base_seed=1)
+            model = model.to(DEV).train()
+            model.freeze_bn()
+            model.batched_train_upsample = batched
+            c = coord.clone().to(DEV)
+            out = model(img1.to(DEV), img2.to(DEV), iters=4, hr_coord=c, scale=scale.to(DEV))
+            preds = out[1] if name == "igev" else out
+            gtd = gt.to(DEV)
+            loss, _ = sequence_loss_multiscale(preds, gtd, ((gtd < 512) & (gtd > 0)).float(), max_disp=args.max_disp)
+            loss.backward()
+            res[batched] = ([p.detach().clone() for p in preds], loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, c)
+    finally:
+        torch.backends.cudnn.deterministic = prev
+    a, b_ = res[False], res[True]
+    assert len(a[0]) == len(b_[0]) == 4
+    for i, (x, y) in enumerate(zip(a[0], b_[0])):
+        assert x.shape == y.shape
+        close(y, x, 2e-5, 2e-5, f"prediction of iteration {i}")
+    assert abs(a[1] - b_[1]) <= 1e-5 * abs(a[1])
+    assert sorted(a[2]) == sorted(b_[2])
+    gmax = max(g.abs().max().item() for g in a[2].values())
+    for n in a[2]:  # atol: biases in front of an InstanceNorm have a true gradient of zero — what is compared there is rounding noise
+        close(b_[2][n], a[2][n], 2e-3, 1e-6 * gmax, f"gradient of {n}")
+    assert torch.equal(a[3], b_[3]) and a[3].abs().max().item() <= 1 - 1e-6 + 1e-9, "hr_coord clamped in place"
+
+
 @pytest.mark.parametrize("sort", [False, True])
 def test_liif_gather_mlp1_backward(sort):
     """Fused gather + first Linear/ReLU and its backward (scatter-adds with in-wave run pre-summation), on random queries
