@@ -114,6 +114,10 @@ SIGNATURES = {
     "as_liif_rows_pitch": (_i, []),
     "as_liif_rows_cl": (_i, [_pp, C.POINTER(C.c_int), _i, _vp, _i, _i, _i, _vp]),
     "as_liif_tail_direct": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_mlp_bwd_image_bytes": (C.c_int64, []),
+    "as_liif_mlp_bwd_pack": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "as_liif_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_mlp_bwd": (_i, [_vp] * 12 + [_i] * 7 + [_vp]),
     "as_liif_split_overflow": (C.c_uint, [_i]),
     "as_corr_pyramid_bwd": (_i, [_pp, _vp, C.c_longlong, _i, _i, _vp]),
     "as_geo_pyramid_bwd": (_i, [_pp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -224,6 +224,59 @@ class LiifGatherMlp1(torch.autograd.Function):
         return d_u0, d_u1, None, d_wrel, d_bias
 
 
+# ---- a14 + a15 as ONE forward kernel and ONE data-gradient kernel (csrc/liif_fused.hip, as_liif_mlp_fwd / _bwd) ------------
+class LiifMlpTail(torch.autograd.Function):
+    """logits[b,:,q] = MLP(relu(u0[b,:,n0(q)] + u1[b % B1,:,n1(q)] + wrel.rel(q) + b1)) for the default 128-64-64-9 MLP
+    (liif.py:9-25, :644-678).  The forward keeps NO per-query activation; the backward kernel recomputes them per 32-query tile
+    with the forward's instruction sequence, runs the data-gradient chain on the matrix cores and writes the operands of the
+    weight gradients (stashed for the step's batched launches, or reduced here without deferral) and of the first layer's
+    scatter-add.  u0 [B,128,H0,W0], u1 [B1,128,H1,W1] (NCHW, as the low-resolution first layer produces them)."""
+
+    @staticmethod
+    def forward(ctx, u0, u1, coord, wrel, b1, w2, b2, w3, b3, w4, b4, pack, pack_t, stashes):
+        cl = lambda u: u.detach().permute(0, 2, 3, 1).reshape(u.shape[0], -1, u.shape[1]).contiguous()  # noqa: E731
+        u0c, u1c = cl(u0), cl(u1)
+        sizes = [tuple(u0.shape[2:]), tuple(u1.shape[2:])]
+        logits = ops.liif_mlp_fwd(u0c, u1c, sizes, coord, pack)
+        ctx.save_for_backward(u0c, u1c, w2, w3, w4)
+        ctx.coord = coord  # see LiifGather
+        ctx.sizes, ctx.pack, ctx.pack_t, ctx.stashes = sizes, pack, pack_t, stashes
+        ctx.bias = (b1 is not None, b2 is not None, b3 is not None, b4 is not None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        u0c, u1c, w2, w3, w4 = ctx.saved_tensors
+        coord, sizes = ctx.coord, ctx.sizes
+        d_logits = _c(d_logits)
+        h1, h2, h3, d3, d2, d1 = ops.liif_mlp_bwd(u0c, u1c, sizes, coord, ctx.pack, ctx.pack_t.get(w2, w3, w4), d_logits)
+        nb, b1n = u0c.shape[0], u1c.shape[0]
+        (h0, w0), (h1s, w1s) = sizes
+        need = ctx.needs_input_grad
+        d_u0 = ops.liif_scatter_add(d1, coord, 128, h0, w0) if need[0] else None
+        d_u1 = None
+        if need[1]:
+            d_u1 = ops.liif_scatter_add(d1, coord, 128, h1s, w1s)
+            if b1n != nb:  # every use of the shared input: evaluation e = (i, b) read element b
+                d_u1 = d_u1.view(nb // b1n, b1n, 128, h1s, w1s).sum(0)
+        d_wrel = d_b1 = None
+        if need[3]:
+            rel, _ = ops.liif_rel_key(coord, sizes)
+            d_wrel = torch.matmul(d1, rel.transpose(1, 2)).sum(0)
+        if ctx.bias[0] and need[4]:
+            d_b1 = d1.sum((0, 2))
+        grads = [None] * 6  # w2, b2, w3, b3, w4, b4
+        for li, (x, d) in enumerate(((h1, d2), (h2, d3), (h3, d_logits))):
+            want_w, want_b = need[5 + 2 * li], ctx.bias[1 + li] and need[6 + 2 * li]
+            st = None if ctx.stashes is None else ctx.stashes[li]
+            if st is not None:
+                if want_w or want_b:
+                    st.xs.append(x), st.ds.append(d)
+            elif want_w or want_b:
+                grads[2 * li], grads[2 * li + 1] = _wgrad_linear(d, x, want_w, want_b)
+        return (d_u0, d_u1, None, d_wrel, d_b1, *grads, None, None, None)
+
+
 # ---- weight gradients of layers that run once per GRU iteration: one batched reduction per step ----------------------
 # A layer of the update block / the LIIF MLP is applied `iters` times per training step (train_continuous_IGEV.py:214-239), so
 # autograd would run `iters` small wgrad reductions per weight and add them up one by one.  Instead every call's backward only

@@ -62,14 +62,14 @@ class Trainer:
     10 ms of a 129 ms step in round 1) and no dependence on `static_graph`."""
 
     def __init__(self, model, lr: float = 2e-4, wdecay: float = 1e-5, num_steps: int = 100000, train_iters: int = 16,
-                 max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int = 25,
+                 max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int | None = None,
                  force_ddp: bool = False, loss_scale: float | None = None, graph: bool | None = None):
         model.train()
         model.freeze_bn()  # train_continuous_IGEV.py:203
         self.model = model
         self.module = model
         self._want_ddp = td.is_available() and td.is_initialized() and (td.get_world_size() > 1 or force_ddp)
-        self._bucket_cap_mb = bucket_cap_mb
+        self._bucket_cap_mb = int(os.environ.get("ANYSTEREO_DDP_BUCKET_MB", "25")) if bucket_cap_mb is None else bucket_cap_mb
         self.ddp_mode = "none"
         self.frozen_unused = []
         # Whole-step hipGraph (ANYSTEREO_TRAIN_GRAPH=1 / graph=True): zero_grad + forward + loss + backward + unscale + clip + AdamW as
@@ -147,7 +147,12 @@ class Trainer:
         ids = [p.device.index] if p.is_cuda else None
         self.module = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=ids, find_unused_parameters=(mode == "find_unused"), static_graph=(mode == "static"),
-            bucket_cap_mb=self._bucket_cap_mb, gradient_as_bucket_view=True)
+            bucket_cap_mb=self._bucket_cap_mb, gradient_as_bucket_view=True,
+            # BatchNorm2d is frozen for the whole run (train_continuous_IGEV.py:203) and the constructor has already broadcast rank
+            # 0's module state: re-broadcasting ~270 unchanged buffers before every forward is pure overhead.  The hourglass'
+            # BatchNorm3d layers normalise with batch statistics in training; their running statistics then evolve per rank, and
+            # rank 0's — the ones a checkpoint holds, as under the reference's nn.DataParallel — are what they were with the broadcast
+            broadcast_buffers=os.environ.get("ANYSTEREO_DDP_BROADCAST_BUFFERS", "0") == "1")
         self.ddp_mode = {"probe": f"plain DDP, {len(self.frozen_unused)} gradient-less parameter tensors frozen after a probe pass",
                          "find_unused": "find_unused_parameters", "static": "static_graph"}[mode]
 

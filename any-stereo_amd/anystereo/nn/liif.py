@@ -431,6 +431,7 @@ class liif_out_multi_scale_Training(nn.Module):
                 and ops.get_precision() == "split" and all(len(ps) <= 2 for ps in feats_parts)
                 and all(p.shape[1] % 16 == 0 for ps in feats_parts for p in ps))
 
+    fused_train_mlp = __import__("os").environ.get("ANYSTEREO_LIIF_TRAIN_FUSED", "1") != "0"
     early_static = __import__("os").environ.get("ANYSTEREO_LIIF_EARLY_STATIC", "1") != "0"
     # Opt-in (ANYSTEREO_LIIF_DIRECT=1), measured and NOT kept as the default: the second input (stem_2x, 32 + 8 channels at 1/2
     # resolution) handed to the tail as RAW channels-last rows, its first-layer product taken per query there
@@ -565,7 +566,11 @@ class liif_out_multi_scale_Training(nn.Module):
         lin = [m for m in self.imnet.layers if isinstance(m, nn.Linear)]
         lowres = self.fused_first_layer and len(feats) <= 2 and len(lin) > 1
         cache = self.__dict__.get("_train_static")  # installed per forward by the model's GRU loop; None = no reuse
-        w1, off, sfs, us, rel_cols = lin[0].weight, 0, [], [], []
+        w1, off, sfs, us, rel_cols, rel_idx = lin[0].weight, 0, [], [], [], []
+        # the one-kernel MLP (ANYSTEREO_LIIF_TRAIN_FUSED=0: layer by layer) serves the default two-input option set in split mode
+        fused = (self.fused_train_mlp and lowres and len(feats) == 2 and coord.is_cuda and ops.get_precision() == "split"
+                 and lin[0].weight.shape[0] == 128 and [tuple(m.weight.shape) for m in lin[1:]] == [(64, 128), (64, 64), (9, 64)]
+                 and coord.shape[0] * 128 * coord.shape[1] * 4 < 0x7FFFFFF0)
         for i, (sf, f) in enumerate(zip(self.to_sf_l2, feats)):
             ent = cache.get(i) if (cache is not None and i > 0) else None
             if ent is not None and ent[0] is f and ent[1] == (f._version, w1._version, torch.is_grad_enabled()):
@@ -579,16 +584,33 @@ class liif_out_multi_scale_Training(nn.Module):
             if s.shape[0] != nb:
                 # an input shared by the n batched evaluations of one forward (models/base.py::_upsample_batched hands stem_2x
                 # over ONCE, batch B, beside n*B hidden states): its structure feature and low-resolution first layer are computed
-                # at batch B and the rows repeated — autograd sums the n uses' gradients in repeat's backward
+                # at batch B and the rows repeated — autograd sums the n uses' gradients in repeat's backward (the fused MLP
+                # reads element b % B instead of a repeated copy)
                 if nb % s.shape[0]:
                     raise RuntimeError(f"liif: input {i} has batch {s.shape[0]}, the queries {nb}")
                 k = nb // s.shape[0]
-                s = s.repeat(k, 1, 1, 1) if not lowres else s
-                u = u.repeat(k, 1, 1, 1) if u is not None else None
+                if not (fused and i == 1):
+                    s = s.repeat(k, 1, 1, 1) if not lowres else s
+                    u = u.repeat(k, 1, 1, 1) if u is not None else None
             sfs.append(s)
             us.append(u)
             rel_cols.append(w1[:, off + s.shape[1]:off + s.shape[1] + 2])
+            rel_idx.append(off + s.shape[1])
             off += s.shape[1] + 2
+        if fused:
+            # gather + first-layer finish + the three remaining layers as ONE forward kernel; its backward recomputes the
+            # activations per query tile (grad.LiifMlpTail) — no [B,128|64,Q] tensor is written by the forward or saved
+            toks, stashes = [], []
+            for m in lin[1:]:
+                w_, b_, st = G.anchored(self, id(m), "linear", (m.weight,), (m.bias,))
+                toks += [w_, b_]
+                stashes.append(st)
+            if not hasattr(self, "_tail_pack"):
+                self._tail_pack = ops.LiifTailPack()
+            if not hasattr(self, "_tail_pack_t"):
+                self._tail_pack_t = ops.LiifMlpBwdPack()
+            return G.LiifMlpTail.apply(us[0].contiguous(), us[1].contiguous(), coord, torch.cat(rel_cols, dim=1).contiguous(), lin[0].bias,
+                                       *toks, self._tail_pack.get(lin, rel_idx), self._tail_pack_t, stashes)
         if lowres:
             x = G.LiifGatherMlp1.apply(us[0].contiguous(), us[1].contiguous() if len(us) > 1 else None, coord,
                                        torch.cat(rel_cols, dim=1).contiguous(), lin[0].bias)

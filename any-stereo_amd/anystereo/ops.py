@@ -1289,6 +1289,63 @@ def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_
     return (out, logits) if want_logits else out
 
 
+class LiifMlpBwdPack:
+    """Fragments of the TRANSPOSED layers 2-4 of the MLP for as_liif_mlp_bwd, rebuilt when a weight changes."""
+
+    def __init__(self):
+        self._key = None
+        self._refs = None
+        self.image = None
+
+    def get(self, w2, w3, w4):
+        ts = [w2, w3, w4]
+        key = tuple((t.data_ptr(), t._version, t.device) for t in ts)
+        alive = self._refs is not None and all(r() is t for r, t in zip(self._refs, ts))
+        if key != self._key or not alive:
+            if tuple(w2.shape) != (64, 128) or tuple(w3.shape) != (64, 64) or tuple(w4.shape) != (9, 64):
+                raise RuntimeError("LiifMlpBwdPack: built for the default MLP 128-64-64-9")
+            f = lambda t: t.detach().float().contiguous()  # noqa: E731
+            a, b_, c = f(w2), f(w3), f(w4)
+            image = torch.empty(L.load().as_liif_mlp_bwd_image_bytes(), device=w2.device, dtype=torch.uint8)
+            with _guard(w2.device):
+                L.check(L.load().as_liif_mlp_bwd_pack(_p(a), _p(b_), _p(c), _p(image), _stream()), "liif_mlp_bwd_pack")
+            self.image, self._key = image, key
+            self._refs = [weakref.ref(t) for t in ts]
+        return self
+
+
+def liif_mlp_fwd(u0, u1, sizes, coord, pack: LiifTailPack):
+    """Mask logits [B,9,Q] of the per-query MLP from the channels-last first-layer rows (training forward: no activation is kept,
+    the coordinates are not clamped).  u0 [B, H0*W0, 128]; u1 [B1, H1*W1, 128] with B % B1 == 0 (query batch b reads b % B1)."""
+    _req(u0, "u0"), _req(u1, "u1"), _req(coord, "coord")
+    b, q = coord.shape[:2]
+    (h0, w0), (h1, w1) = sizes
+    if tuple(coord.shape) != (b, q, 2) or tuple(u0.shape) != (b, h0 * w0, 128) or tuple(u1.shape[1:]) != (h1 * w1, 128) or b % u1.shape[0]:
+        raise RuntimeError("liif_mlp_fwd: shape mismatch")
+    logits = torch.empty((b, 9, q), device=coord.device, dtype=torch.float32)
+    with _guard(coord.device):
+        L.check(L.load().as_liif_mlp_fwd(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(logits), b, u1.shape[0], q, h0, w0, h1, w1,
+                                         _stream()), "liif_mlp_fwd")
+    return logits
+
+
+def liif_mlp_bwd(u0, u1, sizes, coord, pack: LiifTailPack, pack_t: LiifMlpBwdPack, d_logits):
+    """-> (h1 [B,128,Q], h2, h3 [B,64,Q], d3, d2 [B,64,Q], d1 [B,128,Q]): the MLP's post-ReLU activations (recomputed) and the
+    gradients w.r.t. the pre-activations of layers 3, 2, 1 for d_logits [B,9,Q] (as_liif_mlp_bwd)."""
+    _req(u0, "u0"), _req(u1, "u1"), _req(coord, "coord"), _req(d_logits, "d_logits")
+    b, q = coord.shape[:2]
+    (h0, w0), (h1, w1) = sizes
+    if (tuple(coord.shape) != (b, q, 2) or tuple(u0.shape) != (b, h0 * w0, 128) or tuple(u1.shape[1:]) != (h1 * w1, 128) or b % u1.shape[0]
+            or tuple(d_logits.shape) != (b, 9, q)):
+        raise RuntimeError("liif_mlp_bwd: shape mismatch")
+    mk = lambda c: torch.empty((b, c, q), device=coord.device, dtype=torch.float32)  # noqa: E731
+    h1_, h2_, h3_, d3, d2, d1 = mk(128), mk(64), mk(64), mk(64), mk(64), mk(128)
+    with _guard(coord.device):
+        L.check(L.load().as_liif_mlp_bwd(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(pack_t.image), _p(d_logits), _p(h1_), _p(h2_), _p(h3_),
+                                         _p(d3), _p(d2), _p(d1), b, u1.shape[0], q, h0, w0, h1, w1, _stream()), "liif_mlp_bwd")
+    return h1_, h2_, h3_, d3, d2, d1
+
+
 def split_overflow_count(reset: bool = True) -> int:
     """Split-precision range check: number of waves (since the last reset) in which a kernel met an operand with
     |x| >= 65504 (outside fp16) or NaN.  Such operands are SATURATED to +-65504 — results stay finite but are no longer the

@@ -481,6 +481,9 @@ struct TailParams {
   // DIRECT1: u[1] holds the second input's RAW channels-last rows [B][H1*W1][kDirectCP] (structure feature, zero padded) and
   // image1 the fragments of W1[:, its columns] (as_liif_lowres_pack layout): its first-layer product is taken per query
   const _Float16* image1;
+  // > 0: u[1] holds B1 batch elements and query batch b reads element b % B1 (training: the loop-invariant second input is
+  // shared by the n evaluations (iteration, sample) of one batched call, models/base.py::_upsample_batched)
+  int B1;
 };
 constexpr int kDirectCP = 48;                       // row pitch (floats) of a direct source: 3 k-steps
 constexpr int kDirectKS = kDirectCP / 16;
@@ -521,8 +524,9 @@ __device__ __forceinline__ void tile_prepare(const TailParams& p, const float* _
   for (int s = 0; s < NSRC; ++s) {
     const int iy = nearest_idx(crc, p.H[s]), ix = nearest_idx(ccc, p.W[s]);
     const int pitch = (DIRECT1 && s == 1) ? kDirectCP : kHid1;
+    const int bs = (s == 1 && p.B1 > 0) ? b % p.B1 : b;
     const float4* __restrict__ up =
-        reinterpret_cast<const float4*>((s ? u1p : u0p) + (((long long)b * p.H[s] + iy) * p.W[s] + ix) * pitch) + ((DIRECT1 && s == 1) ? 2 * half : half);
+        reinterpret_cast<const float4*>((s ? u1p : u0p) + (((long long)bs * p.H[s] + iy) * p.W[s] + ix) * pitch) + ((DIRECT1 && s == 1) ? 2 * half : half);
     if (s == 0) x.up0 = up; else x.up1 = up;
     const float qy = __fadd_rn(p.c0y[s], __fmul_rn(p.sy[s], (float)iy));
     const float qx = __fadd_rn(p.c0x[s], __fmul_rn(p.sx[s], (float)ix));
@@ -530,7 +534,7 @@ __device__ __forceinline__ void tile_prepare(const TailParams& p, const float* _
     rel[2 * s + 1] = __fmul_rn(__fsub_rn(cc, qx), (float)p.W[s]);
   }
   if (NSRC == 1) x.up1 = x.up0;
-  {
+  if (dispp) {  // kernel-uniform (the training forward asks for the logits only)
     const int iy = nearest_idx(crc, p.Hd), ix = nearest_idx(ccc, p.Wd);
     const float* __restrict__ dp = dispp + (long long)b * p.Hd * p.Wd;
     const float sc = p.scale ? p.scale[b] : 1.f;
@@ -543,6 +547,9 @@ __device__ __forceinline__ void tile_prepare(const TailParams& p, const float* _
       const float d = dp[(long long)min(max(yy, 0), p.Hd - 1) * p.Wd + min(max(xx, 0), p.Wd - 1)];   // unconditional load
       x.dn[i] = in ? __fmul_rn(__fmul_rn(d, four), sc) : 0.f;
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) x.dn[i] = 0.f;
   }
   // B operand of the relative-coordinate product: k = 0..3 rel, k = 4 the constant 1 (bias row); other k = 0
   float xv[8] = {rel[0], rel[1], rel[2], rel[3], 1.f, 0.f, 0.f, 0.f};
@@ -768,8 +775,303 @@ __global__ __launch_bounds__(DIRECT1 ? 512 : 256, DIRECT1 ? 1 : 2) void liif_tai
     }
     ssum += __shfl_xor(ssum, 32);
     dsum += __shfl_xor(dsum, 32);
-    if (cur.valid && !half) outp[cur.t] = dsum / ssum;
+    if (outp && cur.valid && !half) outp[cur.t] = dsum / ssum;
   }
+  note_overflow(fmaxf(amax, __builtin_bit_cast(float, imax)));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Training: backward of the per-query MLP (liif.py:9-25 under autograd) without its activations in HBM on the way there.
+// The training forward is liif_tail_kernel with logits only (no activation is saved); liif_mlp_bwd_kernel RECOMPUTES a tile's
+// h1 / h2 / h3 with the forward's own instruction sequence (same values, bit for bit — the ReLU masks are the forward's),
+// then runs the data-gradient chain on the matrix cores with the same operand chaining, transposed weights:
+//     d3 = [h3 > 0] . W4^T dlogits     d2 = [h2 > 0] . W3^T d3     d1 = [h1 > 0] . W2^T d2
+// and emits what the step's batched weight-gradient launches and the first layer's scatter-add read: h1, h2, h3 (post-ReLU),
+// d3, d2, d1 (gradients w.r.t. the pre-activations), each [B][C][Q] fp32, written once.  Against the layer-by-layer form
+// (four 1x1 convolutions + three ReLU-backward passes + three data-gradient convolutions over [B,128|64,Q] tensors) the
+// per-query activations cross HBM once instead of ~5 times.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTBlk4 = 0, kTBlk3 = 4, kTBlk2 = 20, kTBlocks = 52;   // W4^T (2 m x hi|lo), W3^T (4 ks x 2 m x 2), W2^T (4 ks x 4 m x 2)
+constexpr int kImageTBytes = kTBlocks * 1024;
+
+struct PackTParams {
+  const float* w2;    // [64][128]
+  const float* w3;    // [64][64]
+  const float* w4;    // [9][64]
+  _Float16* image;    // kImageTBytes
+};
+
+// A fragments of the TRANSPOSED layers: row = input channel of the layer, k = its output channel in the chaining order
+__global__ __launch_bounds__(256) void liif_mlp_bwd_pack_kernel(PackTParams p) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= kTBlocks * 512) return;
+  const int blk = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7;
+  const int r = lane & 31, half = lane >> 5;
+  float v;
+  int hl;
+  if (blk < kTBlk3) {
+    const int m = blk >> 1, rr = perm_k(0, half, j);
+    hl = blk & 1;
+    v = rr < kOut ? p.w4[rr * kHid3 + 32 * m + r] : 0.f;
+  } else if (blk < kTBlk2) {
+    const int t = blk - kTBlk3;
+    hl = t & 1;
+    const int m = (t >> 1) & 1, ks = t >> 2;
+    v = p.w3[perm_k(ks, half, j) * kHid2 + 32 * m + r];
+  } else {
+    const int t = blk - kTBlk2;
+    hl = t & 1;
+    const int m = (t >> 1) & 3, ks = t >> 3;
+    v = p.w2[perm_k(ks, half, j) * kHid1 + 32 * m + r];
+  }
+  const float x = __builtin_amdgcn_fmed3f(v, -kF16Max, kF16Max);
+  const _Float16 hk = (_Float16)x;
+  p.image[idx] = hl == 0 ? hk : (_Float16)((x - (float)hk) * 2048.f);
+}
+
+struct MlpBwdParams {
+  TailParams t;            // sources, coordinates, forward image, sizes (disp / out / logits unused)
+  const _Float16* imageT;  // liif_mlp_bwd_pack_kernel
+  const float* dlogits;    // [B][9][Q]
+  float* h1;               // [B][128][Q]
+  float* h2;               // [B][64][Q]
+  float* h3;               // [B][64][Q]
+  float* d3;               // [B][64][Q]
+  float* d2;               // [B][64][Q]
+  float* d1;               // [B][128][Q]
+};
+
+__global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
+  constexpr int NT = 512;
+  const TailParams& p = P.t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kOffT = ((kImageBytes + 15) / 16) * 16;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(p.image);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (int i = threadIdx.x; i < kImageBytes / 16; i += NT) dst[i] = src[i];
+    const uint4* srcT = reinterpret_cast<const uint4*>(P.imageT);
+    uint4* dstT = reinterpret_cast<uint4*>(smem + kOffT);
+    for (int i = threadIdx.x; i < kImageTBytes / 16; i += NT) dstT[i] = srcT[i];
+  }
+  __syncthreads();
+  const half8* W0 = reinterpret_cast<const half8*>(smem);
+  const half8* WT0 = reinterpret_cast<const half8*>(smem + kOffT);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, half = lane >> 5;
+  const int nb = gridDim.x;
+  const int mapped = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const long long gw = (long long)mapped * (NT / 64) + wave;
+  float amax = 0.f;
+  int imax = 0;
+  const float* __restrict__ u0p = p.u[0];
+  const float* __restrict__ u1p = p.u[1];
+  const float* __restrict__ coordp = p.coord;
+  const long long Q = p.Q;
+  // results / logit gradients through buffer descriptors: ONE per-lane byte offset per tensor width (batch element, lane half's
+  // 4-channel shift, query), the channel row of a register as the instruction's SCALAR offset — no per-store address registers;
+  // lanes past the last query carry an out-of-range offset (the access is dropped by the range check, which ignores soffset)
+  const unsigned n128 = (unsigned)((long long)p.B * kHid1 * Q * 4), n64 = (unsigned)((long long)p.B * kHid2 * Q * 4);
+  const __amdgpu_buffer_rsrc_t r_dl = __builtin_amdgcn_make_buffer_rsrc((void*)P.dlogits, 0, (int)((long long)p.B * kOut * Q * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.h1, 0, (int)n128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_h2 = __builtin_amdgcn_make_buffer_rsrc((void*)P.h2, 0, (int)n64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_h3 = __builtin_amdgcn_make_buffer_rsrc((void*)P.h3, 0, (int)n64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_d3 = __builtin_amdgcn_make_buffer_rsrc((void*)P.d3, 0, (int)n64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_d2 = __builtin_amdgcn_make_buffer_rsrc((void*)P.d2, 0, (int)n64, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_d1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.d1, 0, (int)n128, 0x00020000);
+  const unsigned q4 = (unsigned)(Q * 4);  // byte pitch of a channel row
+#define AS_ROW(I) (((I) & 3) + 8 * ((I) >> 2))  /* acc_row without the lane half (that part sits in the per-lane offset) */
+
+  const long long tile0 = gw * p.tpw;
+  if (tile0 >= p.tiles) return;
+  const int ntile = (int)min((long long)p.tpw, (long long)p.tiles - tile0);
+  for (int ti = 0; ti < ntile; ++ti) {
+    int opaque = 0;
+    asm volatile("" : "+v"(opaque));  // keeps the fragment reads inside the tile loop (see liif_tail_kernel)
+    const half8* W = W0 + opaque;
+    const half8* WT = WT0 + opaque;
+    const float* bias = reinterpret_cast<const float*>(smem + kFragBlocks * 1024) + opaque;
+    TileCtx cur;
+    {
+      long long t = (tile0 + ti) * 32 + c;
+      const bool valid = t < p.total;
+      if (!valid) t = p.total - 1;
+      tile_prepare<2, false>(p, u0p, u1p, nullptr, t, valid, coordp[t * 2], coordp[t * 2 + 1], half, amax, cur);
+      tile_first_gather<2, false>(cur, amax);
+    }
+    const int b = (int)(cur.t / Q);
+    const long long qq = cur.t - (long long)b * Q;   // this lane's query inside its batch element
+    const unsigned vo128 = cur.valid ? (unsigned)((((long long)b * kHid1 + 4 * half) * Q + qq) * 4) : 0xFFFFFFF0u;
+    const unsigned vo64 = cur.valid ? (unsigned)((((long long)b * kHid2 + 4 * half) * Q + qq) * 4) : 0xFFFFFFF0u;
+    const unsigned vo9 = cur.valid ? (unsigned)((((long long)b * kOut + 4 * half) * Q + qq) * 4) : 0xFFFFFFF0u;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ================= forward recompute: liif_tail_kernel's sequence, layer for layer =================
+    unsigned m1[4] = {0u, 0u, 0u, 0u}, m2[2] = {0u, 0u}, m3[2] = {0u, 0u};  // bit i = [activation in accumulator register i > 0]
+    f32x16 a2h[2], a2x[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a2h[m][i] = bias[32 * m + acc_row(i, half)];
+    f32x16 ga = cur.ga, gn = zero16;
+    float4 g1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g1[i] = cur.g1[i];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      if (t4 < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) put4(gn, i, cur.up0[2 * (4 * (t4 + 1) + i)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 th, tx;
+      {
+        const half8 ah = W[(kBlkRel + 2 * t4) * 64 + lane], al = W[(kBlkRel + 2 * t4 + 1) * 64 + lane];
+        th = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur.xh, ga, 0, 0, 0);
+        tx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur.xl, zero16, 0, 0, 0);
+        tx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, cur.xh, tx, 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int ks = 2 * t4 + s;
+        const float4 qa = g1[2 * s], qb = g1[2 * s + 1];
+        const float q8[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = relu_bits(fmaf(tx[8 * s + j], 1.f / 2048.f, th[8 * s + j]) + q8[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t4 < 3) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) g1[2 * s + i] = cur.up1[2 * (2 * (ks + 2) + i)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          m1[t4] |= (v[j] > 0.f ? 1u : 0u) << (8 * s + j);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_h1, (int)vo128, (int)((32 * t4 + AS_ROW(8 * s + j)) * q4), 0);
+        }
+        half8 bh, bl;
+        split8_pos(v, bh, bl, imax);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int blk = kBlkW2 + (ks * 2 + m) * 2;
+          const half8 ah = W[blk * 64 + lane], al = W[(blk + 1) * 64 + lane];
+          a2h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a2h[m], 0, 0, 0);
+          a2x[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ks == 0 ? zero16 : a2x[m], 0, 0, 0);
+          a2x[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a2x[m], 0, 0, 0);
+        }
+      }
+      if (t4 < 3) ga = gn;
+    }
+    f32x16 a3h[2], a3x[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a3h[m][i] = bias[kHid2 + 32 * m + acc_row(i, half)];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int mt = ks >> 1, s = ks & 1;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = relu_bits(fmaf(a2x[mt][8 * s + j], 1.f / 2048.f, a2h[mt][8 * s + j]));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        m2[mt] |= (v[j] > 0.f ? 1u : 0u) << (8 * s + j);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_h2, (int)vo64, (int)((32 * mt + AS_ROW(8 * s + j)) * q4), 0);
+      }
+      half8 bh, bl;
+      split8_pos(v, bh, bl, imax);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int blk = kBlkW3 + (ks * 2 + m) * 2;
+        const half8 ah = W[blk * 64 + lane], al = W[(blk + 1) * 64 + lane];
+        a3h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a3h[m], 0, 0, 0);
+        a3x[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ks == 0 ? zero16 : a3x[m], 0, 0, 0);
+        a3x[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a3x[m], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = relu_bits(fmaf(a3x[mt][i], 1.f / 2048.f, a3h[mt][i]));
+        m3[mt] |= (v > 0.f ? 1u : 0u) << i;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_h3, (int)vo64, (int)((32 * mt + AS_ROW(i)) * q4), 0);
+      }
+    // ================= data-gradient chain =================
+    // B operand of the first product: the 9 logit gradients of this lane's query in the chaining order of one k-step
+    half8 bh, bl;
+    {
+      float dl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // rows 8 (j>>2) + 4 half + (j&3): half 0 holds rows 0..3 and 8, half 1 rows 4..7; everything else is zero padding
+        const bool live = j < 4 || (j == 4 && half == 0);
+        dl[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_dl, live ? (int)vo9 : (int)0xFFFFFFF0u, (int)((8 * (j >> 2) + (j & 3)) * q4), 0));
+      }
+      split8(dl, bh, bl, amax);
+    }
+    // d3 = [h3 > 0] . W4^T dlogits
+    half8 f3h[4], f3l[4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const half8 ah = WT[(kTBlk4 + 2 * m) * 64 + lane], al = WT[(kTBlk4 + 2 * m + 1) * 64 + lane];
+      f32x16 gh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, zero16, 0, 0, 0);
+      f32x16 gx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, zero16, 0, 0, 0);
+      gx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, gx, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = 8 * s + j;
+          v[j] = ((m3[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_d3, (int)vo64, (int)((32 * m + AS_ROW(i)) * q4), 0);
+        }
+        split8(v, f3h[2 * m + s], f3l[2 * m + s], amax);
+      }
+    }
+    // d2 = [h2 > 0] . W3^T d3
+    half8 f2h[4], f2l[4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f32x16 gh = zero16, gx = zero16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int blk = kTBlk3 + (ks * 2 + m) * 2;
+        const half8 ah = WT[blk * 64 + lane], al = WT[(blk + 1) * 64 + lane];
+        AS_MFMA3(ah, al, f3h[ks], f3l[ks], gh, gx)
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int i = 8 * s + j;
+          v[j] = ((m2[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_d2, (int)vo64, (int)((32 * m + AS_ROW(i)) * q4), 0);
+        }
+        split8(v, f2h[2 * m + s], f2l[2 * m + s], amax);
+      }
+    }
+    // d1 = [h1 > 0] . W2^T d2
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      f32x16 gh = zero16, gx = zero16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int blk = kTBlk2 + (ks * 4 + m) * 2;
+        const half8 ah = WT[blk * 64 + lane], al = WT[(blk + 1) * 64 + lane];
+        AS_MFMA3(ah, al, f2h[ks], f2l[ks], gh, gx)
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = ((m1[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_d1, (int)vo128, (int)((32 * m + AS_ROW(i)) * q4), 0);
+      }
+    }
+  }
+#undef AS_ROW
   note_overflow(fmaxf(amax, __builtin_bit_cast(float, imax)));
 }
 
@@ -981,6 +1283,81 @@ static int liif_tail_impl(const float* u0, const float* u1, float* coord, const 
   else
     hipLaunchKernelGGL(liif_tail_kernel<1>, dim3((unsigned)blocks), dim3(256), kImageBytes, as::as_stream(stream), p);
   return as::check_launch("liif_tail");
+}
+
+int64_t as_liif_mlp_bwd_image_bytes(void) { return kImageTBytes; }
+
+int as_liif_mlp_bwd_pack(const float* w2, const float* w3, const float* w4, void* imageT, void* stream) {
+  AS_REQUIRE(w2 && w3 && w4 && imageT, AS_ERR_BAD_ARG, "liif_mlp_bwd_pack: null pointer");
+  PackTParams p{w2, w3, w4, (_Float16*)imageT};
+  hipLaunchKernelGGL(liif_mlp_bwd_pack_kernel, dim3(as::cdiv(kTBlocks * 512, 256)), dim3(256), 0, as::as_stream(stream), p);
+  return as::check_launch("liif_mlp_bwd_pack");
+}
+
+static int mlp_params(TailParams& p, const float* u0, const float* u1, const float* coord, const void* image, int B, int B1, int Q,
+                      int H0, int W0, int H1, int W1, const char* what) {
+  AS_REQUIRE(u0 && coord && image, AS_ERR_BAD_ARG, "%s: null pointer", what);
+  AS_REQUIRE(B > 0 && Q > 0 && H0 > 0 && W0 > 0, AS_ERR_BAD_ARG, "%s: non-positive size", what);
+  AS_REQUIRE(!u1 || (H1 > 0 && W1 > 0), AS_ERR_BAD_ARG, "%s: second source without a size", what);
+  AS_REQUIRE(B1 >= 0 && (B1 == 0 || (u1 && B % B1 == 0)), AS_ERR_BAD_SHAPE, "%s: B1=%d does not divide B=%d", what, B1, B);
+  p.u[0] = u0; p.u[1] = u1; p.coord = const_cast<float*>(coord); p.image = (const _Float16*)image;
+  p.B = B; p.Q = Q; p.n_src = u1 ? 2 : 1; p.clamp_inplace = 0; p.B1 = B1;
+  p.H[0] = H0; p.W[0] = W0; p.H[1] = u1 ? H1 : 1; p.W[1] = u1 ? W1 : 1; p.Hd = 1; p.Wd = 1;
+  p.total = (long long)B * Q;
+  p.lo = (float)(-1.0 + 1e-6); p.hi = (float)(1.0 - 1e-6);
+  for (int s = 0; s < 2; ++s) {
+    p.c0y[s] = (float)(-1.0 + 1.0 / p.H[s]); p.sy[s] = (float)(2.0 * (1.0 / p.H[s]));
+    p.c0x[s] = (float)(-1.0 + 1.0 / p.W[s]); p.sx[s] = (float)(2.0 * (1.0 / p.W[s]));
+  }
+  const long long tiles = as::cdiv64(p.total, 32);
+  AS_REQUIRE(tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "%s: too many queries", what);
+  p.tiles = (int)tiles;
+  return AS_OK;
+}
+
+int as_liif_mlp_fwd(const float* u0, const float* u1, const float* coord, const void* image, float* logits, int B, int B1, int Q,
+                    int H0, int W0, int H1, int W1, void* stream) {
+  AS_REQUIRE(logits, AS_ERR_BAD_ARG, "liif_mlp_fwd: null logits");
+  TailParams p{};
+  const int rc = mlp_params(p, u0, u1, coord, image, B, B1, Q, H0, W0, H1, W1, "liif_mlp_fwd");
+  if (rc != AS_OK) return rc;
+  p.logits = logits;
+  const long long waves = 256ll * 2 * 4;
+  p.tpw = (int)std::max<long long>(1, as::cdiv64(p.tiles, waves));
+  long long blocks = as::cdiv64(p.tiles, 4ll * p.tpw);
+  blocks = (blocks + 7) / 8 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(liif_tail_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kImageBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(liif_tail_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kImageBytes);
+    attr_set = true;
+  }
+  if (p.n_src == 2) hipLaunchKernelGGL(liif_tail_kernel<2>, dim3((unsigned)blocks), dim3(256), kImageBytes, as::as_stream(stream), p);
+  else hipLaunchKernelGGL(liif_tail_kernel<1>, dim3((unsigned)blocks), dim3(256), kImageBytes, as::as_stream(stream), p);
+  return as::check_launch("liif_mlp_fwd");
+}
+
+int as_liif_mlp_bwd(const float* u0, const float* u1, const float* coord, const void* image, const void* imageT, const float* dlogits,
+                    float* h1, float* h2, float* h3, float* d3, float* d2, float* d1, int B, int B1, int Q, int H0, int W0, int H1,
+                    int W1, void* stream) {
+  AS_REQUIRE(imageT && dlogits && h1 && h2 && h3 && d3 && d2 && d1, AS_ERR_BAD_ARG, "liif_mlp_bwd: null pointer");
+  AS_REQUIRE(u1, AS_ERR_BAD_ARG, "liif_mlp_bwd: built for the two-input upsampler");
+  MlpBwdParams P{};
+  const int rc = mlp_params(P.t, u0, u1, coord, image, B, B1, Q, H0, W0, H1, W1, "liif_mlp_bwd");
+  if (rc != AS_OK) return rc;
+  AS_REQUIRE((long long)B * kHid1 * Q * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "liif_mlp_bwd: [B,128,Q] exceeds 2 GiB (32-bit buffer offsets); split the batch");
+  P.imageT = (const _Float16*)imageT; P.dlogits = dlogits;
+  P.h1 = h1; P.h2 = h2; P.h3 = h3; P.d3 = d3; P.d2 = d2; P.d1 = d1;
+  // one block of 8 waves per CU around the forward + transposed weight images (118 KB); a wave walks `tpw` consecutive tiles
+  const long long waves = 256ll * 8;
+  P.t.tpw = (int)std::max<long long>(1, as::cdiv64(P.t.tiles, waves));
+  long long blocks = as::cdiv64(P.t.tiles, 8ll * P.t.tpw);
+  blocks = (blocks + 7) / 8 * 8;
+  constexpr int lds = ((kImageBytes + 15) / 16) * 16 + kImageTBytes;
+  static_assert(lds <= 160 * 1024, "liif_mlp_bwd: LDS budget");
+  as::lds_opt_in(reinterpret_cast<const void*>(liif_mlp_bwd_kernel));
+  hipLaunchKernelGGL(liif_mlp_bwd_kernel, dim3((unsigned)blocks), dim3(512), lds, as::as_stream(stream), P);
+  return as::check_launch("liif_mlp_bwd");
 }
 
 unsigned as_liif_split_overflow(int reset) {

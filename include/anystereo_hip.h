@@ -362,6 +362,26 @@ int as_liif_rows_cl(const float* const* srcs, const int* channels, int n_src, fl
 int as_liif_tail_direct(const float* u0, const float* rows1, float* coord, const void* image, const void* image1, const float* disp,
                         const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
                         int clamp_inplace, void* stream);
+
+/* Training of the per-query MLP (liif.py:9-25, :644-678 under autograd; train_continuous_IGEV.py:214-239) without per-query
+ * activations saved by the forward.
+ * as_liif_mlp_fwd     mask logits [B,9,Q] of as_liif_tail's MLP (same kernel, no softmax / convex combination output, the
+ *                    caller's coordinates are NOT clamped).  B1 > 0: u1 holds B1 batch elements and query batch b reads element
+ *                    b % B1 (B % B1 == 0) — the loop-invariant second input of a call batched over (iteration, sample).
+ * as_liif_mlp_bwd_pack  W2 [64][128], W3 [64][64], W4 [9][64] as the fragments of the TRANSPOSED layers
+ *                    (as_liif_mlp_bwd_image_bytes() bytes).
+ * as_liif_mlp_bwd     recomputes h1, h2, h3 per 32-query tile exactly as the forward did, runs the data-gradient chain
+ *                    d3 = [h3>0] W4^T dlogits, d2 = [h2>0] W3^T d3, d1 = [h1>0] W2^T d2 on the matrix cores and writes h1 [B,128,Q],
+ *                    h2, h3, d3, d2 [B,64,Q], d1 [B,128,Q] (post-ReLU activations / gradients w.r.t. the pre-activations): the
+ *                    operands of the layers' weight gradients (as_conv2d_wgrad) and of the first layer's scatter-add
+ *                    (as_liif_scatter_add).  image = as_liif_tail_pack, imageT = as_liif_mlp_bwd_pack of the same weights. */
+int64_t as_liif_mlp_bwd_image_bytes(void);
+int as_liif_mlp_bwd_pack(const float* w2, const float* w3, const float* w4, void* imageT, void* stream);
+int as_liif_mlp_fwd(const float* u0, const float* u1, const float* coord, const void* image, float* logits, int B, int B1, int Q,
+                    int H0, int W0, int H1, int W1, void* stream);
+int as_liif_mlp_bwd(const float* u0, const float* u1, const float* coord, const void* image, const void* imageT, const float* dlogits,
+                    float* h1, float* h2, float* h3, float* d3, float* d2, float* d1, int B, int B1, int Q, int H0, int W0, int H1,
+                    int W1, void* stream);
 unsigned as_liif_split_overflow(int reset);
 
 /* ---------------------------------------------------------------------------------------------

@@ -874,6 +874,103 @@ def test_training_batched_upsampler_equals_per_iteration(name):
     assert torch.equal(a[3], b_[3]) and a[3].abs().max().item() <= 1 - 1e-6 + 1e-9, "hr_coord clamped in place"
 
 
+@pytest.mark.parametrize("batched", [False, True])
+def test_training_fused_liif_mlp_equals_layered(batched):
+    """Training forward / backward with the upsampler's per-query MLP as one forward kernel + one recomputing data-gradient kernel
+    (grad.LiifMlpTail) against the layer-by-layer form (LiifGatherMlp1 + PointwiseLinear): same predictions, loss and gradients
+    to the split arithmetic's rounding (the first layer's finish runs on the matrix cores in the fused form)."""
+    from anystereo.harness.metrics import sequence_loss_multiscale
+    from anystereo.harness.synthetic import fill_module_deterministic, tiny_train_case
+    from anystereo.models import __models__, default_args
+    args = default_args("continuous_IGEVStereo")
+    h, w, img1, img2, coord, gt, scale = tiny_train_case("igev")
+    res = {}
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        for fused in (False, True):
+            model = __models__[args.model](args)
+            fill_module_deterministic(model, base_seed=1)
+            model = model.to(DEV).train()
+            model.freeze_bn()
+            model.batched_train_upsample = batched
+            model.liif_up.fused_train_mlp = fused
+            out = model(img1.to(DEV), img2.to(DEV), iters=3, hr_coord=coord.clone().to(DEV), scale=scale.to(DEV))
+            gtd = gt.to(DEV)
+            loss, _ = sequence_loss_multiscale(out[1], gtd, ((gtd < 512) & (gtd > 0)).float(), max_disp=args.max_disp)
+            loss.backward()
+            res[fused] = ([p.detach().clone() for p in out[1]], loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        torch.backends.cudnn.deterministic = prev
+    a, b_ = res[False], res[True]
+    for i, (x, y) in enumerate(zip(a[0], b_[0])):
+        close(y, x, 2e-5, 2e-5, f"prediction of iteration {i}")
+    assert abs(a[1] - b_[1]) <= 1e-5 * abs(a[1])
+    assert sorted(a[2]) == sorted(b_[2])
+    gmax = max(g.abs().max().item() for g in a[2].values())
+    worst = ("", 0.0)
+    for n in a[2]:
+        e = ((b_[2][n] - a[2][n]).abs().max() / max(a[2][n].abs().max().item(), 1e-30)).item()
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        close(b_[2][n], a[2][n], 2e-3, 1e-6 * gmax, f"gradient of {n}")
+    print(f"[fused LIIF MLP, batched={batched}] loss {a[1]:.6f} vs {b_[1]:.6f}; worst gradient deviation {worst[1]:.2e} of the tensor's max ({worst[0]})")
+
+
+def test_liif_mlp_tail_function_vs_fp64():
+    """grad.LiifMlpTail alone, with a shared second input (B1 < B) and queries outside the clamp range, against an fp64 torch
+    statement of the same function: logits and every gradient (u0, u1, wrel, biases, the three later layers' weights)."""
+    from anystereo import grad as G, ops
+    from anystereo.nn.liif import make_coord
+    n, b1, h0, w0 = 3, 2, 6, 10
+    nb = n * b1
+    grid = make_coord([8 * h0, 8 * w0])
+    idx = (U((nb, 900), 880, 0.0, 1.0) * grid.shape[0]).long().clamp(max=grid.shape[0] - 1)
+    coord = torch.stack([grid[i] for i in idx]).contiguous()
+    coord[0, 0] = torch.tensor([-1.0, 1.0])
+    coord[1, 5] = torch.tensor([1.0, -1.0])
+    u0, u1 = U((nb, 128, h0, w0), 881), U((b1, 128, 2 * h0, 2 * w0), 882)
+    wrel, bias1 = U((128, 4), 883), U((128,), 884)
+    w2, bb2, w3, bb3, w4, bb4 = U((64, 128), 885, -0.15, 0.15), U((64,), 886), U((64, 64), 887, -0.2, 0.2), U((64,), 888), U((9, 64), 889, -0.2, 0.2), U((9,), 890)
+    gout = U((nb, 9, coord.shape[1]), 891) * 1e-3
+    sizes = [(h0, w0), (2 * h0, 2 * w0)]
+
+    class Lin:  # what LiifTailPack.get reads of an nn.Linear
+        def __init__(self, w_, b_):
+            self.weight, self.bias = w_, b_
+    leaves = [_leaf(t, DEV) for t in (u0, u1, wrel, bias1, w2, bb2, w3, bb3, w4, bb4)]
+    w1full = torch.zeros((128, 4), device=DEV)  # LiifTailPack slices the relative-coordinate columns out of the first layer's weight
+    with torch.no_grad():
+        w1full.copy_(leaves[2])
+    lin = [Lin(w1full, leaves[3]), Lin(leaves[4], leaves[5]), Lin(leaves[6], leaves[7]), Lin(leaves[8], leaves[9])]
+    pack = ops.LiifTailPack().get(lin, [0, 2])
+    c = coord.to(DEV)
+    out = G.LiifMlpTail.apply(leaves[0], leaves[1], c, leaves[2], leaves[3], *leaves[4:], pack, ops.LiifMlpBwdPack(), None)
+    out.backward(gout.to(DEV))
+    # fp64 statement
+    ref = [t.double().requires_grad_(True) for t in (u0, u1, wrel, bias1, w2, bb2, w3, bb3, w4, bb4)]
+    rel, _ = ops.liif_rel_key(c, sizes)
+    rel = rel.cpu().double()
+    cc = coord.clamp(-1 + 1e-6, 1 - 1e-6)
+
+    def nearest(n_, cv):
+        return torch.round(((cv.float() + 1.0) * n_ - 1.0) / 2.0).long().clamp(0, n_ - 1)
+    rows = []
+    for e in range(nb):
+        iy0, ix0 = nearest(h0, cc[e, :, 0]), nearest(w0, cc[e, :, 1])
+        iy1, ix1 = nearest(2 * h0, cc[e, :, 0]), nearest(2 * w0, cc[e, :, 1])
+        rows.append(ref[0][e][:, iy0, ix0] + ref[1][e % b1][:, iy1, ix1])
+    x = torch.relu(torch.stack(rows) + torch.einsum("ck,bkq->bcq", ref[2], rel) + ref[3][None, :, None])
+    x = torch.relu(torch.einsum("oc,bcq->boq", ref[4], x) + ref[5][None, :, None])
+    x = torch.relu(torch.einsum("oc,bcq->boq", ref[6], x) + ref[7][None, :, None])
+    want = torch.einsum("oc,bcq->boq", ref[8], x) + ref[9][None, :, None]
+    want.backward(gout.double())
+    close(out.detach().cpu(), want.detach().float(), 2e-5, 2e-5, "logits")
+    for nm, got, r in zip(("u0", "u1", "wrel", "b1", "w2", "b2", "w3", "b3", "w4", "b4"), leaves, ref):
+        e = ((got.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max()).item()
+        print(f"[LiifMlpTail] d_{nm}: max |d| / max |g| = {e:.2e}")
+        assert e < 2e-4, (nm, e)
+
+
 @pytest.mark.parametrize("sort", [False, True])
 def test_liif_gather_mlp1_backward(sort):
     """Fused gather + first Linear/ReLU and its backward (scatter-adds with in-wave run pre-summation), on random queries
