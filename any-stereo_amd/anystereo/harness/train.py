@@ -222,7 +222,8 @@ class Trainer:
             G.begin_forward()  # no anchor (and no autograd node) of the warm-up steps survives into the capture
             self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
+            # ANYSTEREO_TRAIN_GRAPH_KEEP=1 (diagnostics, tools/train_graph_nodes.py): keep the hipGraph_t for node inspection
+            g = torch.cuda.CUDAGraph(keep_graph=True) if os.environ.get("ANYSTEREO_TRAIN_GRAPH_KEEP") == "1" else torch.cuda.CUDAGraph()
             # the backward pass is captured from THIS thread (autograd's device worker thread launching into a stream another
             # thread put into capture mode loses nodes / dependencies of the graph's tail on this ROCm stack: the last
             # gradients of a replay came back as garbage, tools/train_graph_check.py)
