@@ -366,6 +366,8 @@ class WeightAnchor(torch.autograd.Function):
             if st.kind == "conv" and _hip_wgrad(weight) and want_w and gx[0].is_cuda:
                 # all iterations of the step in one launch, straight from the per-iteration tensors (no stacking copy)
                 d_w, d_b = ops.conv2d_wgrad([_c(t) for t in gx], [_c(t) for t in gd], weight.shape[2], want_bias=want_b)
+            elif st.kind == "conv7" and want_w and gx[0].is_cuda:
+                d_w, d_b = ops.conv7x7_c1_wgrad([_c(t) for t in gx], [_c(t) for t in gd], want_bias=want_b)
             elif st.kind == "linear" and _WGRAD != "library" and want_w and gx[0].is_cuda:
                 # a Linear layer over [B,C,Q] activations = a 1x1 convolution over a one-row image of Q pixels
                 d_w, d_b = ops.conv2d_wgrad([_c(t).unsqueeze(2) for t in gx], [_c(t).unsqueeze(2) for t in gd], 1, want_bias=want_b)
@@ -461,6 +463,47 @@ class Conv2dSame(torch.autograd.Function):
             else:
                 d_w, d_b = _wgrad_conv(d, x, weight, ctx.bias_sizes, want_w, want_b)
         return d_x, d_w, d_b, None, None, None, None
+
+
+# ---- a6: the 7x7 convolution of the one-channel disparity map + ReLU (update.py:81,87) ------------------------------------
+class Conv7x7C1Relu(torch.autograd.Function):
+    """y = relu(conv7x7(disp [B,1,H,W], W [Cout,1,7,7], padding 3) + bias).  The loop detaches the disparity before every
+    iteration (continuous_IGEVstereo.py:285), so the backward is the weight / bias gradient only (as_conv7x7_c1_wgrad_multi, all
+    iterations of a step in one launch through the layer's stash); a caller that does want d_disp gets it from the library."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stash=None):
+        y = ops.conv7x7_c1_relu(x, weight, bias)
+        ctx.save_for_backward(x, weight, y)
+        ctx.has_bias, ctx.stash = bias is not None, stash
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, weight, y = ctx.saved_tensors
+        d = _c(torch.ops.aten.threshold_backward(d_y, y, 0.0))
+        d_x = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_x = torch.ops.aten.convolution_backward(d, x, weight, None, [1, 1], [3, 3], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w or want_b:
+            if ctx.stash is not None:
+                ctx.stash.xs.append(x), ctx.stash.ds.append(d)
+            else:
+                d_w, d_b = ops.conv7x7_c1_wgrad(x, d, want_bias=want_b)
+                d_w = d_w if want_w else None
+        return d_x, d_w, d_b, None
+
+
+def conv7x7_c1_relu(mod, name, x, conv):
+    """relu(conv(x)) of the 7x7, one-input-channel nn.Conv2d `conv` under autograd on this library's kernels (Cout <= 64), else the
+    module + F.relu."""
+    if (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (7, 7) and conv.padding == (3, 3) and conv.stride == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 1 and conv.out_channels <= 64
+            and conv.padding_mode == "zeros" and os.environ.get("ANYSTEREO_TRAIN_CONV7", "1") != "0"):
+        w, b, stash = anchored(mod, name, "conv7", (conv.weight,), (conv.bias,))
+        return Conv7x7C1Relu.apply(_c(x), w, b, stash)
+    return torch.nn.functional.relu(conv(x))
 
 
 # ---- a7: ConvGRU gate math as two fused stages (update.py:36-41) ---------------------------------------------------

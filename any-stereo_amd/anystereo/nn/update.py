@@ -72,7 +72,8 @@ class DispHead(nn.Module):
         """delta = conv2(relu(conv1(x))) (update.py:23-24); with `addend` the result is addend + delta (the loop's
         `disp = disp + delta_disp`, fused into the last kernel)."""
         if _train(x, self.conv1.weight):
-            out = self.conv2(_cs(self, "conv1", x, self.conv1.weight, self.conv1.bias, relu=True))  # update.py:23-24
+            hid = _cs(self, "conv1", x, self.conv1.weight, self.conv1.bias, relu=True)  # update.py:23-24
+            out = _cs(self, "conv2", hid, self.conv2.weight, self.conv2.bias) if self.train_conv2_hip else self.conv2(hid)
             return out if addend is None else addend + out
         links = _links()
         if self.fused_head and self.conv2.out_channels == 1 and ops.get_precision() == "split":
@@ -101,6 +102,9 @@ class DispHead(nn.Module):
 
 
     fused_head = __import__("os").environ.get("ANYSTEREO_FUSED_HEAD", "1") != "0"
+    # training: conv2 (256 -> 1) forward / dgrad / wgrad on this library's kernels like every other layer of the update block
+    # (ANYSTEREO_TRAIN_HEAD_CONV2=0: MIOpen, 16 forward + 16 backward library calls per step)
+    train_conv2_hip = __import__("os").environ.get("ANYSTEREO_TRAIN_HEAD_CONV2", "1") != "0"
 
     def taps_ok(self, x) -> bool:
         return (self.fused_head and self.conv2.out_channels == 1 and ops.get_precision() == "split" and not _train(x, self.conv1.weight))
@@ -242,7 +246,7 @@ class BasicMotionEncoder(nn.Module):
         if _train(disp, corr, self.convc1.weight):  # update.py:84-92
             cor = _cs(self, "c1", corr, self.convc1.weight, self.convc1.bias, relu=True)
             cor = _cs(self, "c2", cor, self.convc2.weight, self.convc2.bias, relu=True)
-            dsp = _cs(self, "d2", F.relu(self.convd1(disp)), self.convd2.weight, self.convd2.bias, relu=True)
+            dsp = _cs(self, "d2", G.conv7x7_c1_relu(self, "d1", disp, self.convd1), self.convd2.weight, self.convd2.bias, relu=True)
             out = _cs(self, "c", torch.cat([cor, dsp], dim=1), self.conv.weight, self.conv.bias, relu=True)
             return torch.cat([out, disp], dim=1)
         disp, corr = _f(disp), _f(corr)

@@ -1289,6 +1289,36 @@ def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_
     return (out, logits) if want_logits else out
 
 
+def conv7x7_c1_wgrad(xs, dys, want_bias: bool = True):
+    """(dW [Cout,1,7,7], db [Cout] | None) of the motion encoder's 7x7 convolution of the one-channel disparity map from its inputs
+    x [B,1,H,W] and output gradients dy [B,Cout,H,W] — lists of equally shaped pairs (one per GRU iteration) are reduced in one
+    launch (as_conv7x7_c1_wgrad_multi; update.py:81,87)."""
+    xs, dys = (list(xs), list(dys)) if isinstance(xs, (list, tuple)) else ([xs], [dys])
+    if len(xs) != len(dys) or not xs:
+        raise RuntimeError("conv7x7_c1_wgrad: x and dy must be lists of the same length")
+    if len(xs) > 32:
+        xs, dys = [torch.cat(xs, 0)], [torch.cat(dys, 0)]
+    for t in xs + dys:
+        _req(t, "x / dy")
+    per, one, h, w = xs[0].shape
+    cout = dys[0].shape[1]
+    if one != 1 or any(tuple(t.shape) != (per, 1, h, w) for t in xs) or any(tuple(t.shape) != (per, cout, h, w) for t in dys):
+        raise RuntimeError("conv7x7_c1_wgrad: expects x [B,1,H,W] and dy [B,Cout,H,W] pairs of one shape")
+    lib = L.load()
+    dev = xs[0].device
+    nbytes = int(lib.as_conv7x7_c1_wgrad_ws_bytes(per * len(xs), cout, h, w))
+    if nbytes < 0:
+        raise RuntimeError(f"conv7x7_c1_wgrad: unsupported problem (Cout={cout})")
+    ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+    dw = torch.empty((cout, 1, 7, 7), device=dev, dtype=torch.float32)
+    db = torch.empty((cout,), device=dev, dtype=torch.float32) if want_bias else None
+    xp, k1 = L.ptr_array([t.data_ptr() for t in xs])
+    dp, k2 = L.ptr_array([t.data_ptr() for t in dys])
+    with _guard(dev):
+        L.check(lib.as_conv7x7_c1_wgrad_multi(xp, dp, len(xs), per, _p(dw), _p(db), cout, h, w, _p(ws), nbytes, _stream()), "conv7x7_c1_wgrad")
+    return dw, db
+
+
 class LiifMlpBwdPack:
     """Fragments of the TRANSPOSED layers 2-4 of the MLP for as_liif_mlp_bwd, rebuilt when a weight changes."""
 

@@ -489,9 +489,119 @@ int wgrad_launch(const WgradParams& p, const WgradPlan& q, bool vec, hipStream_t
   return as::check_launch("conv2d_wgrad");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight / bias gradient of the motion encoder's 7x7 convolution of the ONE-channel disparity map (update.py:81,87:
+// convd1 = Conv2d(1, 64, 7, padding=3)) for all GRU iterations of a step in one launch:
+//     dW[co][ky][kx] = sum_{b,y,x} dy[b][co][y][x] . disp[b][y+ky-3][x+kx-3]      db[co] = sum dy[b][co][y][x]
+// (the disparity is detached per iteration, continuous_IGEVstereo.py:285: there is no input gradient).  49 x 64 outputs over
+// B*H*W pixels: block = (sample, band of 8 rows); the band of the disparity map with its halo sits in LDS; a wave's lane is an
+// output channel, the four waves walk the band's pixels interleaved, every lane keeps its 49 tap sums + the bias sum in
+// registers (the window reads are LDS broadcasts).  Block partials -> fixed-order sum in the finish kernel (deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kW7Band = 8, kW7Out = 50;  // rows per block; 49 taps + bias
+
+struct W7Params {
+  const float* xs[kWgradMaxTensors];
+  const float* dys[kWgradMaxTensors];
+  float* part;  // [blocks][64][kW7Out]
+  int per, B, Cout, H, W, bands;
+};
+
+__global__ __launch_bounds__(256) void conv7x7_c1_wgrad_kernel(W7Params p) {
+  extern __shared__ __attribute__((aligned(16))) float w7_lds[];
+  const int PW = p.W + 6;
+  float* xt = w7_lds;                         // [kW7Band + 6][PW]
+  float* red = w7_lds + (kW7Band + 6) * PW;   // [4][kW7Out][64]
+  const int s = blockIdx.x / p.bands, band = blockIdx.x - s * p.bands;
+  const int r0 = band * kW7Band;
+  const int rows = min(kW7Band, p.H - r0);
+  const float* __restrict__ x = p.xs[s / p.per] + (long long)(s % p.per) * p.H * p.W;
+  const float* __restrict__ d = p.dys[s / p.per] + (long long)(s % p.per) * p.Cout * p.H * p.W;
+  for (int i = threadIdx.x; i < (kW7Band + 6) * PW; i += 256) {
+    const int ry = i / PW, rx = i - ry * PW;
+    const int gy = r0 + ry - 3, gx = rx - 3;
+    xt[i] = (ry < rows + 6 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? x[(long long)gy * p.W + gx] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = lane < p.Cout;
+  const float* __restrict__ dc = d + (long long)(live ? lane : 0) * p.H * p.W + (long long)r0 * p.W;
+  float acc[kW7Out];
+#pragma unroll
+  for (int t = 0; t < kW7Out; ++t) acc[t] = 0.f;
+  const int npx = rows * p.W;
+  for (int i = wave; i < npx; i += 4) {
+    const int r = i / p.W, c = i - r * p.W;
+    const float g = live ? dc[i] : 0.f;
+    const float* win = xt + r * PW + c;  // window origin: input (row r0 + r - 3, column c - 3)
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) acc[ky * 7 + kx] = fmaf(g, win[ky * PW + kx], acc[ky * 7 + kx]);
+    acc[49] += g;
+  }
+#pragma unroll
+  for (int t = 0; t < kW7Out; ++t) red[(wave * kW7Out + t) * 64 + lane] = acc[t];
+  __syncthreads();
+  for (int i = threadIdx.x; i < kW7Out * 64; i += 256) {
+    const int t = i >> 6, co = i & 63;
+    const float v = (red[(0 * kW7Out + t) * 64 + co] + red[(1 * kW7Out + t) * 64 + co]) + (red[(2 * kW7Out + t) * 64 + co] + red[(3 * kW7Out + t) * 64 + co]);
+    p.part[((long long)blockIdx.x * 64 + co) * kW7Out + t] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv7x7_c1_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                                       int Cout, int blocks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Cout * kW7Out) return;
+  const int co = i / kW7Out, t = i - co * kW7Out;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 4 <= blocks; k += 4) {
+    s0 += part[((long long)k * 64 + co) * kW7Out + t];
+    s1 += part[((long long)(k + 1) * 64 + co) * kW7Out + t];
+    s2 += part[((long long)(k + 2) * 64 + co) * kW7Out + t];
+    s3 += part[((long long)(k + 3) * 64 + co) * kW7Out + t];
+  }
+  for (; k < blocks; ++k) s0 += part[((long long)k * 64 + co) * kW7Out + t];
+  const float v = (s0 + s1) + (s2 + s3);
+  if (t < 49) dw[co * 49 + t] = v;
+  else if (db) db[co] = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t as_conv7x7_c1_wgrad_ws_bytes(int B, int Cout, int H, int W) {
+  if (B <= 0 || Cout <= 0 || Cout > 64 || H <= 0 || W <= 0) return -1;
+  return (long long)B * as::cdiv(H, kW7Band) * 64 * kW7Out * 4;
+}
+
+int as_conv7x7_c1_wgrad_multi(const float* const* xs, const float* const* dys, int n, int per, float* dw, float* db, int Cout, int H, int W,
+                              void* ws, int64_t ws_bytes, void* stream) {
+  AS_REQUIRE(xs && dys && dw && ws && n >= 1 && n <= kWgradMaxTensors && per >= 1, AS_ERR_BAD_ARG, "conv7x7_c1_wgrad: null pointer / %d tensors (1..%d)", n, kWgradMaxTensors);
+  const int B = n * per;
+  const int64_t need = as_conv7x7_c1_wgrad_ws_bytes(B, Cout, H, W);
+  AS_REQUIRE(need > 0, AS_ERR_BAD_ARG, "conv7x7_c1_wgrad: B=%d Cout=%d (1..64) H=%d W=%d", B, Cout, H, W);
+  AS_REQUIRE(ws_bytes >= need, AS_ERR_BAD_ARG, "conv7x7_c1_wgrad: workspace of %lld bytes, need %lld", (long long)ws_bytes, (long long)need);
+  const size_t lds = ((size_t)(kW7Band + 6) * (W + 6) + 4 * kW7Out * 64) * sizeof(float);
+  AS_REQUIRE(lds <= 160 * 1024, AS_ERR_BAD_SHAPE, "conv7x7_c1_wgrad: rows of %d pixels do not fit the LDS band", W);
+  W7Params p;
+  for (int i = 0; i < kWgradMaxTensors; ++i) {
+    p.xs[i] = xs[i < n ? i : 0];
+    p.dys[i] = dys[i < n ? i : 0];
+    AS_REQUIRE(p.xs[i] && p.dys[i], AS_ERR_BAD_ARG, "conv7x7_c1_wgrad: null tensor %d", i);
+  }
+  p.part = (float*)ws; p.per = per; p.B = B; p.Cout = Cout; p.H = H; p.W = W; p.bands = as::cdiv(H, kW7Band);
+  const long long blocks = (long long)B * p.bands;
+  AS_REQUIRE(blocks < 2147483647ll, AS_ERR_BAD_SHAPE, "conv7x7_c1_wgrad: grid too large");
+  hipStream_t s = as::as_stream(stream);
+  as::lds_opt_in((const void*)conv7x7_c1_wgrad_kernel);
+  hipLaunchKernelGGL(conv7x7_c1_wgrad_kernel, dim3((unsigned)blocks), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(conv7x7_c1_wgrad_finish_kernel, dim3((unsigned)as::cdiv(Cout * kW7Out, 256)), dim3(256), 0, s, (const float*)ws, dw, db, Cout, (int)blocks);
+  return as::check_launch("conv7x7_c1_wgrad");
+}
 
 int64_t as_conv2d_wgrad_ws_bytes(int B, int Cin, int Cout, int H, int W, int KS) {
   WgradPlan q;

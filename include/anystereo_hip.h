@@ -413,6 +413,13 @@ int as_conv2d_wgrad(const float* x, const float* dy, float* dw, float* db, int B
  * without stacking them into one tensor first (the stacking copies were 3-4 ms of a step); workspace as for B = n * per */
 int as_conv2d_wgrad_multi(const float* const* xs, const float* const* dys, int n, int per, float* dw, float* db, int Cin, int Cout,
                           int H, int W, int KS, void* ws, int64_t ws_bytes, void* stream);
+
+/* Weight [Cout][1][7][7] and bias gradient of the motion encoder's 7x7 convolution of the one-channel disparity map (update.py:81,87,
+ * convd1) for up to 32 (x [per,1,H,W], dy [per,Cout,H,W]) pairs — the GRU iterations of a step — in one launch; Cout <= 64.
+ * ws: as_conv7x7_c1_wgrad_ws_bytes(n*per, Cout, H, W) bytes of scratch.  Fixed summation order (deterministic). */
+int64_t as_conv7x7_c1_wgrad_ws_bytes(int B, int Cout, int H, int W);
+int as_conv7x7_c1_wgrad_multi(const float* const* xs, const float* const* dys, int n, int per, float* dw, float* db, int Cout, int H, int W,
+                              void* ws, int64_t ws_bytes, void* stream);
 /*   a8^T  as_pool2x_bwd / as_interp_bilinear_ac_bwd: d_out [B,C,Ho,Wo] -> d_x [B,C,H,W], the transposes of as_pool2x /
  *         as_interp_bilinear_ac (what autograd derives for F.avg_pool2d / F.interpolate at update.py:94-102); gather form, one
  *         thread per input element, fixed summation order. */

@@ -874,6 +874,47 @@ def test_training_batched_upsampler_equals_per_iteration(name):
     assert torch.equal(a[3], b_[3]) and a[3].abs().max().item() <= 1 - 1e-6 + 1e-9, "hr_coord clamped in place"
 
 
+def test_conv7x7_c1_relu_backward_and_head_conv2():
+    """The two per-iteration layers that used to stay on the library in training: convd1 (7x7, 1 -> 64, ReLU; weight / bias
+    gradient of several iterations in one launch) and the head's conv2 (3x3, 256 -> 1: forward, dgrad with ONE input channel,
+    wgrad with one output channel) against fp64 autograd."""
+    import torch.nn.functional as F
+    from anystereo import grad as G, ops
+    b, h, w = 3, 21, 37
+    wt, bs = U((64, 1, 7, 7), 900, -0.2, 0.2), U((64,), 901)
+    xs = [U((b, 1, h, w), 902 + i, 0.0, 30.0) for i in range(3)]
+    gs = [U((b, 64, h, w), 910 + i) * 1e-3 for i in range(3)]
+    wl, bl = _leaf(wt, DEV), _leaf(bs, DEV)
+    ys = [G.Conv7x7C1Relu.apply(x.to(DEV), wl, bl, None) for x in xs]
+    torch.autograd.backward(ys, [g.to(DEV) for g in gs])
+    wr, br = wt.double().requires_grad_(True), bs.double().requires_grad_(True)
+    yr = [F.relu(F.conv2d(x.double(), wr, br, padding=3)) for x in xs]
+    torch.autograd.backward(yr, [g.double() for g in gs])
+    for y, r in zip(ys, yr):
+        close(y.detach().cpu(), r.detach().float(), 2e-5, 2e-5, "convd1 forward")
+    # the batched form (all iterations in one launch) equals the sum of the per-call gradients
+    masked = [torch.ops.aten.threshold_backward(g.to(DEV), y.detach(), 0.0) for g, y in zip(gs, ys)]
+    dw, db = ops.conv7x7_c1_wgrad([x.to(DEV) for x in xs], masked)
+    for nm, got, want in (("dW", wl.grad, wr.grad), ("db", bl.grad, br.grad), ("dW batched", dw, wr.grad), ("db batched", db, br.grad)):
+        e = ((got.cpu().double() - want).abs().max() / want.abs().max()).item()
+        print(f"[convd1 {nm}] max |d| / max |g| = {e:.2e}")
+        assert e < 1e-5, (nm, e)
+    # head conv2
+    hw2, hb2 = U((1, 256, 3, 3), 920, -0.05, 0.05), U((1,), 921)
+    hx, hg = U((b, 256, h, w), 922, 0.0, 1.0), U((b, 1, h, w), 923) * 1e-2
+    a = [_leaf(t, DEV) for t in (hx, hw2, hb2)]
+    out = G.Conv2dSame.apply(a[0], a[1], a[2], False, ops.PackedConv(), ops.PackedConv(), None)
+    out.backward(hg.to(DEV))
+    r = [t.double().requires_grad_(True) for t in (hx, hw2, hb2)]
+    ref = F.conv2d(r[0], r[1], r[2], padding=1)
+    ref.backward(hg.double())
+    close(out.detach().cpu(), ref.detach().float(), 2e-5, 2e-5, "head conv2 forward")
+    for nm, got, want in zip(("d_x", "d_w", "d_b"), a, r):
+        e = ((got.grad.cpu().double() - want.grad).abs().max() / want.grad.abs().max()).item()
+        print(f"[head conv2 {nm}] max |d| / max |g| = {e:.2e}")
+        assert e < 5e-5, (nm, e)
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_training_fused_liif_mlp_equals_layered(batched):
     """Training forward / backward with the upsampler's per-query MLP as one forward kernel + one recomputing data-gradient kernel

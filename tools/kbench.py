@@ -61,6 +61,8 @@ def main():
         t = torch.stack([hi, lo], 1).view(bb, 2, cc // 8, 8, hh, ww).permute(0, 1, 2, 4, 5, 3).contiguous()
         return ops.BS8(t, cc)
     x128bs = [to_bs(x) for x in x128]
+    xl1bs = to_bs(xl1)
+    xl1o = ops.BS8.empty(1, 64, 4 * h, 4 * w, dev)
     # the loop's other launches, operands as the model hands them over (blocked split-fp16 links)
     wc1 = (det_uniform((64, 162, 1, 1), 77) * (3.0 / 162) ** 0.5).to(dev)
     plc1 = ops.LookupConvPack().get(wc1, det_uniform((64,), 78, -0.1, 0.1).to(dev)) if g else None
@@ -103,6 +105,11 @@ def main():
         "sampler_bwd": lambda: ops.corr_sampler_backward(corr[0], scoord, sgrad, 4),
         "cnet_l1": (lambda: ops.conv2d([xl1], pl1, act=Lb.ACT_RELU)),
         "liif_l2": (lambda: ops.conv2d([xq], pq2, act=Lb.ACT_RELU)),
+        # the context net's full-resolution 64 -> 64 layers with a blocked source (conv2 of a residual block: residual tail, fp32
+        # result) and as a pure link (conv1: blocked in, blocked out)
+        "cnet_l1_bs": (lambda: ops.conv2d([xl1bs], pl1, act=Lb.ACT_RELU, h=xl1)),
+        "cnet_l1_bsbs": (lambda: ops.conv2d([xl1bs], pl1, act=Lb.ACT_RELU, out_bs=xl1o, bs_only=True)),
+        "cnet_l1_bsboth": (lambda: ops.conv2d([xl1bs], pl1, act=Lb.ACT_RELU, h=xl1, out_bs=xl1o)),
         "conv3d_stem": (lambda: ops.conv3d_k3(gev, w3d, None, 1, 5)) if g else None,
         "lookup_convc1": (lambda: ops.lookup_convc1(geo, corr, disp, 4, plc1, out_bs=cor_bs)) if g else None,
         "enc_c2d2": lambda: ops.conv2d([x64bs[0]], pc2, act=Lb.ACT_RELU, out_bs=cd_bs, out_bs_coff=0, bs_only=True,
