@@ -63,7 +63,7 @@ class Trainer:
 
     def __init__(self, model, lr: float = 2e-4, wdecay: float = 1e-5, num_steps: int = 100000, train_iters: int = 16,
                  max_disp: int = 192, lr_fixed: bool = False, mixed_precision: bool = False, bucket_cap_mb: int | None = None,
-                 force_ddp: bool = False, loss_scale: float | None = None, graph: bool | None = None):
+                 force_ddp: bool = False, loss_scale: float | None = None, graph: bool | None = None, ddp_impl: str | None = None):
         model.train()
         model.freeze_bn()  # train_continuous_IGEV.py:203
         self.model = model
@@ -72,19 +72,35 @@ class Trainer:
         self._bucket_cap_mb = int(os.environ.get("ANYSTEREO_DDP_BUCKET_MB", "25")) if bucket_cap_mb is None else bucket_cap_mb
         self.ddp_mode = "none"
         self.frozen_unused = []
-        # Whole-step hipGraph (ANYSTEREO_TRAIN_GRAPH=1 / graph=True): zero_grad + forward + loss + backward + unscale + clip + AdamW as
-        # ONE captured graph replayed per step — the eager step is host-bound (~6 000 launches).  Needs a CUDA model,
-        # no GradScaler and no DDP wrapper (one rank); otherwise the eager step runs.  `graph_warmup` eager steps come first.
+        # The step as a captured hipGraph (default on a CUDA model without GradScaler; ANYSTEREO_TRAIN_GRAPH=0 / graph=False = eager):
+        # zero_grad + forward + loss + backward + unscale replayed as ONE graph per step, then — eagerly — the gradient exchange
+        # between ranks, clip and AdamW (scope "grads", the default), or clip + a capturable AdamW inside the graph too (scope
+        # "step", one rank).  The eager step is host-bound (~4 900 launches, 60-83 ms by host load); the replayed one
+        # takes the GPU's 57 ms on any host.  `graph_warmup` eager steps come first.
         if graph is None:
-            graph = os.environ.get("ANYSTEREO_TRAIN_GRAPH", "0") == "1"
+            graph = os.environ.get("ANYSTEREO_TRAIN_GRAPH", "1") == "1"
         p0 = next(model.parameters())
-        self.use_graph = bool(graph) and p0.is_cuda and not mixed_precision and not self._want_ddp
+        # Gradient exchange between ranks.  "ddp" (default): torch's DistributedDataParallel — bucketed all-reduce overlapped with
+        # the backward pass.  "flat": the bare module computes its local gradients, then ONE all-reduce of the flattened gradient
+        # vector (50 MB for IGEV: ~1 ms over xGMI at 8 ranks) and the update — no reducer hooks, nothing of torch.distributed inside
+        # the forward / backward, so the gradient half of the step can be a captured hipGraph on every rank (the eager step is
+        # host-bound and eight ranks share one host).  Forced when a graph is asked for with more than one rank.
+        self.ddp_impl = os.environ.get("ANYSTEREO_DDP_IMPL", "ddp") if ddp_impl is None else ddp_impl
+        if self.ddp_impl not in ("ddp", "flat"):
+            raise ValueError(f"Trainer: ddp_impl={self.ddp_impl!r} (ddp | flat)")
+        self.use_graph = bool(graph) and p0.is_cuda and not mixed_precision
+        if self.use_graph and self._want_ddp:
+            self.ddp_impl = "flat"
         self.graph_warmup = int(os.environ.get("ANYSTEREO_TRAIN_GRAPH_WARMUP", "3"))
         # "step": the whole step is one graph; "grads": zero_grad .. unscaled gradients are the graph, clip + AdamW + scheduler eager
-        self.graph_scope = os.environ.get("ANYSTEREO_TRAIN_GRAPH_SCOPE", "step")
+        # (with more than one rank: the all-reduce sits between the two halves)
+        self.graph_scope = "grads" if (self.use_graph and self._want_ddp) else os.environ.get("ANYSTEREO_TRAIN_GRAPH_SCOPE", "grads")
+        if self._want_ddp and self.ddp_impl == "flat":
+            nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
+            self.ddp_mode = f"flat: one all-reduce of the concatenated gradients ({nbytes / 1e6:.0f} MB) between backward and the update"
         self._graph = None
         self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed,
-                                                         capturable=self.use_graph and os.environ.get("ANYSTEREO_TRAIN_GRAPH_SCOPE", "step") == "step")
+                                                         capturable=self.use_graph and self.graph_scope == "step")
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
         self.train_iters, self.max_disp = train_iters, max_disp
         # Power-of-two loss scale (exact in fp32) for the split-precision dgrad kernels only: it keeps the activation gradients
@@ -171,14 +187,17 @@ class Trainer:
     def step(self, batch, sync_grads: bool = True):
         """One optimisation step.  sync_grads=False (measurement only): DDP's reducer is bypassed (`no_sync`), every rank
         steps on its local gradient — what a step costs without the all-reduce."""
-        if self._want_ddp and self.module is self.model:
+        flat = self._want_ddp and self.ddp_impl == "flat"
+        if self._want_ddp and not flat and self.module is self.model:
             self._wrap_ddp(batch)
         # BatchNorm2d stays frozen whatever the caller did in between (validation's .eval(), a bare .train())
         if not self.module.training:
             self.module.train()
         self.model.freeze_bn()
-        if self.use_graph and sync_grads:
-            return self._step_graphed(batch)
+        if self.use_graph:
+            return self._step_graphed(batch, sync_grads)
+        if flat:
+            return self._step_flat(batch, sync_grads)
         watch = (self.loss_scale != 1.0 or self.overflow_events) and self.overflow_policy != "off" and self._on_gpu()
         gate = self._overflow_gate if (watch and self.overflow_policy == "skip") else None
         kw = dict(max_disp=self.max_disp, loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss, should_step=gate)
@@ -192,7 +211,35 @@ class Trainer:
             self._poll_overflow()
         return out
 
-    def _step_graphed(self, batch):
+    def allreduce_gradients_flat(self):
+        """Average the gradients over the ranks with ONE all-reduce of their concatenation (ddp_impl "flat").  Parameters without a
+        gradient are the same set on every rank (same model, same autograd graph), so the vectors line up."""
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        if not grads or not (td.is_available() and td.is_initialized()):
+            return 0
+        world = td.get_world_size()
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        td.all_reduce(flat)
+        if world > 1:
+            flat.div_(world)
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+        return flat.numel()
+
+    def _step_flat(self, batch, sync_grads=True):
+        """Eager step with the flat gradient exchange: local gradients -> one all-reduce -> clip + AdamW + schedule."""
+        watch = (self.loss_scale != 1.0 or self.overflow_events) and self.overflow_policy != "off" and self._on_gpu()
+        gate = self._overflow_gate if (watch and self.overflow_policy == "skip") else None
+        out = train_step(self.model, self.optimizer, None, self.scaler, batch, self.train_iters, max_disp=self.max_disp,
+                         loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss, phase="grads")
+        if sync_grads:
+            self.allreduce_gradients_flat()
+        train_step(self.model, self.optimizer, self.scheduler, self.scaler, None, self.train_iters, should_step=gate, phase="update")
+        self.steps_done += 1
+        if watch and gate is None and self.overflow_check_every > 0 and self.steps_done % self.overflow_check_every == 0:
+            self._poll_overflow()
+        return out
+
+    def _step_graphed(self, batch, sync_grads=True):
         """The step as a hipGraph replay: inputs are copied into static buffers, the captured graph holds zero_grad (gradients
         re-materialise at fixed addresses in the graph's pool), forward, the synchronisation-free loss, backward, the loss-scale
         division, clip_grad_norm_ and the capturable AdamW; the OneCycleLR scheduler runs on the host and writes the device-side
@@ -210,8 +257,22 @@ class Trainer:
                 # warm-up on the thread (and stream) the capture will use: the BLAS / MIOpen handles are per thread and are
                 # created — device allocations, not capturable — at a thread's first call
                 with torch.autograd.set_multithreading_enabled(not single), torch.cuda.stream(self._gstream):
-                    out = train_step(self.module, self.optimizer, self.scheduler, None, batch, self.train_iters, max_disp=self.max_disp,
-                                     loss_scale=self.loss_scale, sync_free_loss=True)
+                    if self._want_ddp:  # the ranks stay in step during the warm-up too
+                        out = train_step(self.module, self.optimizer, None, None, batch, self.train_iters, max_disp=self.max_disp,
+                                         loss_scale=self.loss_scale, sync_free_loss=True, phase="grads")
+                    else:
+                        out = train_step(self.module, self.optimizer, self.scheduler, None, batch, self.train_iters, max_disp=self.max_disp,
+                                         loss_scale=self.loss_scale, sync_free_loss=True)
+                if self._want_ddp:
+                    # the collective is issued from the CALLER's stream, as after a replay: the process group records its
+                    # synchronisation events on the issuing stream, and its watchdog thread may not query an event whose last
+                    # recording stream is capturing (hipErrorCapturedEvent) — the capture stream must never have issued one
+                    cur.wait_stream(self._gstream)
+                    if sync_grads:
+                        self.allreduce_gradients_flat()
+                    self._gstream.wait_stream(cur)
+                    with torch.cuda.stream(self._gstream):
+                        train_step(self.module, self.optimizer, self.scheduler, None, None, self.train_iters, phase="update")
                 cur.wait_stream(self._gstream)
                 for t in (out[0], *out[1].values()):
                     t.record_stream(cur)
@@ -222,34 +283,44 @@ class Trainer:
             G.begin_forward()  # no anchor (and no autograd node) of the warm-up steps survives into the capture
             self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.synchronize()
-            # ANYSTEREO_TRAIN_GRAPH_KEEP=1 (diagnostics, tools/train_graph_nodes.py): keep the hipGraph_t for node inspection
-            g = torch.cuda.CUDAGraph(keep_graph=True) if os.environ.get("ANYSTEREO_TRAIN_GRAPH_KEEP") == "1" else torch.cuda.CUDAGraph()
+            # the hipGraph_t is kept: its memset nodes are rewritten before instantiation (below; tools/train_graph_nodes.py reads it)
+            g = torch.cuda.CUDAGraph(keep_graph=True)
             # the backward pass is captured from THIS thread (autograd's device worker thread launching into a stream another
             # thread put into capture mode loses nodes / dependencies of the graph's tail on this ROCm stack: the last
             # gradients of a replay came back as garbage, tools/train_graph_check.py)
             single = os.environ.get("ANYSTEREO_TRAIN_GRAPH_SINGLE_THREAD", "1") != "0"
-            with torch.autograd.set_multithreading_enabled(not single), torch.cuda.graph(g, stream=self._gstream):
+            # with a process group alive its watchdog thread polls events of finished collectives while this thread captures: the
+            # default "global" capture mode turns that query into an error that aborts the process
+            mode = "thread_local" if (td.is_available() and td.is_initialized()) else "global"
+            with torch.autograd.set_multithreading_enabled(not single), torch.cuda.graph(g, stream=self._gstream, capture_error_mode=mode):
                 loss, metrics = train_step(self.module, self.optimizer, None, None, static, self.train_iters, max_disp=self.max_disp,
                                            loss_scale=self.loss_scale, sync_free_loss=True,
                                            phase="all" if self.graph_scope == "step" else "grads")
+            # Memset nodes (ATen's reduction semaphores, MIOpen's split-K zero-fills: 34 in the IGEV step) -> fill kernel nodes.  Inside
+            # a chain this long the runtime does not reliably order them with the kernels around them: from the second replay on
+            # the reductions behind them returned stale values (valid-pixel count, metrics) and gradients came back zero
+            # (csrc/graph.hip).  ANYSTEREO_TRAIN_GRAPH_FILL=0 leaves the graph as captured (diagnostics).
+            self.graph_memsets = (0, 0)
+            if os.environ.get("ANYSTEREO_TRAIN_GRAPH_FILL", "1") != "0":
+                from .. import ops
+                self.graph_memsets = ops.graph_replace_memsets(g)
+            g.instantiate()
             # the capture itself executed nothing: the step below is the first replay
             ent = self._graph = {"graph": g, "batch": static, "loss": loss, "metrics": metrics}
-        # Replay ordering.  On this ROCm stack work enqueued BEHIND a replay of this graph (~6 000 kernel nodes) is not reliably
-        # ordered after the graph's tail: without a device-wide synchronisation between steps the next step's eager work (input
-        # copies, the scheduler's learning-rate write, another model's step) raced the running replay — losses of 0.0, diverging
-        # parameters, NaN — on the default stream and on a stream of the trainer's own alike; with one after every replay all
-        # replays matched the eager trainer step for step (tools/train_graph_check.py).  So the step ends with
-        # torch.cuda.synchronize(): the host cannot run ahead of a graphed step (it has ~3 ms of work per step left to hide).
-        # ANYSTEREO_TRAIN_GRAPH_SYNC=none removes it (measurement only).
+        # Replays are stream-ordered like any other work since the graph holds kernel nodes only where libraries issued memsets
+        # (see the capture above): no synchronisation is needed between steps and the host runs ahead.
+        # ANYSTEREO_TRAIN_GRAPH_SYNC=device ends every step with torch.cuda.synchronize() (diagnostics).
         for dst, src in zip(ent["batch"], batch):
             dst.copy_(src)
         ent["graph"].replay()
         if self.graph_scope != "step":
+            if self._want_ddp and sync_grads:
+                self.allreduce_gradients_flat()
             train_step(self.module, self.optimizer, None, None, None, self.train_iters, phase="update")
         if self.scheduler is not None:
             self.scheduler.step()
         out = ent["loss"].clone(), {k: v.clone() for k, v in ent["metrics"].items()}
-        if os.environ.get("ANYSTEREO_TRAIN_GRAPH_SYNC", "device") == "device":
+        if os.environ.get("ANYSTEREO_TRAIN_GRAPH_SYNC", "none") == "device":
             torch.cuda.synchronize(batch[0].device)
         self.steps_done += 1
         if (self.loss_scale != 1.0 and self.overflow_policy != "off" and self.overflow_check_every > 0

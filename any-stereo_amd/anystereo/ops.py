@@ -1376,6 +1376,14 @@ def liif_mlp_bwd(u0, u1, sizes, coord, pack: LiifTailPack, pack_t: LiifMlpBwdPac
     return h1_, h2_, h3_, d3, d2, d1
 
 
+def graph_replace_memsets(graph: "torch.cuda.CUDAGraph"):
+    """Memset nodes of a captured (keep_graph=True, not yet instantiated) CUDAGraph -> fill kernel nodes (as_graph_replace_memsets).
+    Returns (replaced, left)."""
+    a, b = C.c_int(0), C.c_int(0)
+    L.check(L.load().as_graph_replace_memsets(C.c_void_p(int(graph.raw_cuda_graph())), C.byref(a), C.byref(b)), "graph_replace_memsets")
+    return a.value, b.value
+
+
 def split_overflow_count(reset: bool = True) -> int:
     """Split-precision range check: number of waves (since the last reset) in which a kernel met an operand with
     |x| >= 65504 (outside fp16) or NaN.  Such operands are SATURATED to +-65504 — results stay finite but are no longer the

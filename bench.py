@@ -245,7 +245,8 @@ def load_pmc_traffic():
 def train_main(a, rank, world, local):
     """SURVEY.md §8d cfg 4: IGEV training, 4 samples per GPU at 160x320 network input, 51 200 HR queries per sample, 16 GRU
     iterations with the LIIF upsampler every iteration, AdamW + OneCycleLR; one process per GPU, DDP over RCCL.  A step =
-    zero_grad + forward + loss + backward (+ bucketed gradient all-reduce) + clip + optimizer + scheduler step."""
+    zero_grad + forward + loss + backward (+ gradient all-reduce) + clip + optimizer + scheduler step, as the Trainer issues it by
+    default: the gradient half replayed as one captured hipGraph, then the (flat) gradient exchange, clip and AdamW eager."""
     dist = world > 1 or "RANK" in os.environ  # under a launcher even one rank goes through RCCL + DDP
     td = _dist_init(True, local) if dist else None
     torch.cuda.set_device(local)
@@ -303,12 +304,12 @@ def train_main(a, rank, world, local):
         overlap = {"ms_per_step_with_allreduce": round(ms_sync, 2), "ms_per_step_no_sync": round(ms_nosync, 2),
                    "exposed_allreduce_ms": round(ms_sync - ms_nosync, 2), "gradient_bytes": nbytes,
                    "ddp": tr.ddp_mode}
-    roof = cpu = graphed = None
+    roof = cpu = eager = None
     if rank == 0 and world == 1 and not a.no_extras:
         try:
-            graphed = train_graphed_step(a, args, batch, dev)
+            eager = train_eager_step(a, args, batch, dev)
         except Exception as ex:  # never lose the headline line to the side measurement
-            graphed = {"error": repr(ex)[:300]}
+            eager = {"error": repr(ex)[:300]}
         roof = train_roofline(a, batch, dev)
         if not a.no_cpu_baseline:
             cpu = train_cpu_baseline(a, args, model, batch)
@@ -325,6 +326,8 @@ def train_main(a, rank, world, local):
             "host": {"cpus_per_rank": len(RANK_CPUS or []), "pinned": world > 1 and os.environ.get("ANYSTEREO_PIN", "1") != "0",
                      "torch_threads": torch.get_num_threads()},
             "allreduce_overlap": overlap,
+            "trainer": {"graph": bool(tr.use_graph), "graph_scope": tr.graph_scope if tr.use_graph else None,
+                        "gradient_exchange": tr.ddp_mode},
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
             "backward": "HIP kernels for the volume/lookup/gwc/LIIF/convex-upsample/pool/interp/gate transposes, forward + dgrad + wgrad of "
                         "every stride-1 1x1 / 3x3 convolution (update block, MLP Linear layers, backbone layers with >= 16 input "
@@ -334,18 +337,18 @@ def train_main(a, rank, world, local):
             "split_overflow": {"policy": tr.overflow_policy, "check_every": tr.overflow_check_every,
                                "saturated_waves_at_end": tr._poll_overflow() if tr._on_gpu() else None,
                                "events": tr.overflow_events, "skipped_steps": tr.skipped_steps},
-            "graphed_step": graphed,
+            "eager_step": eager,
             "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu}))
     if dist:
         td.barrier()
         td.destroy_process_group()
 
 
-def train_graphed_step(a, args, batch, dev, n_cmp=6):
-    """The opt-in whole-step hipGraph (harness/train.py, Trainer(graph=True)), reported NEXT to the eager headline, never as
-    `value`: a fresh model replays the captured step; its loss trajectory is checked against a fresh eager trainer started from
-    the same weights on the same batch (the two phases run one after the other — an eager training step BETWEEN replays is
-    exactly what still corrupts them on this stack), then `steps` replays are timed."""
+def train_eager_step(a, args, batch, dev, n_cmp=6):
+    """The EAGER step (Trainer(graph=False)) next to the headline, which is the Trainer's default — the gradient half of the step
+    replayed as one captured hipGraph (harness/train.py): a fresh default trainer's loss trajectory (3 eager warm-up steps + the
+    capture + n_cmp replays) is checked against a fresh eager trainer started from the same weights on the same batch, then
+    `steps` eager steps are timed.  The eager step is host-bound: its time follows the box's host and its load."""
     from anystereo.harness.synthetic import fill_module_deterministic
     from anystereo.harness.train import Trainer
     from anystereo.models import __models__
@@ -362,27 +365,27 @@ def train_graphed_step(a, args, batch, dev, n_cmp=6):
         torch.cuda.synchronize()
         return [float(v) for v in out]
 
-    eager = fresh(False)
-    n = eager_n = 3 + n_cmp  # the graphed trainer's three eager warm-up steps + n_cmp replays
-    want = run(eager, eager_n)
-    del eager
-    torch.cuda.empty_cache()
-    tr = fresh(True)
-    if not tr.use_graph:
-        return {"available": False}
+    n = 3 + n_cmp
+    tr = fresh(None)
     got = run(tr, n)
+    graphed, memsets = bool(tr.use_graph and tr._graph is not None), getattr(tr, "graph_memsets", None)
+    del tr
+    torch.cuda.empty_cache()
+    eager = fresh(False)
+    want = run(eager, n)
     rel = [abs(g - w) / max(abs(w), 1e-12) for g, w in zip(got, want)]
     ok = all(r == r and r < 5e-3 for r in rel)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr.step(batch)
+        eager.step(batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"opt_in": "ANYSTEREO_TRAIN_GRAPH=1 / Trainer(graph=True); one rank, no GradScaler",
+    return {"how": "Trainer(graph=False) / ANYSTEREO_TRAIN_GRAPH=0: every launch issued by the host (host-bound)",
             "ms_per_step": round(dt / a.steps * 1e3, 2), "samples_per_s": round(a.batch_per_gpu * a.steps / dt, 3), "steps": a.steps,
-            "loss_trajectory_matches_eager": ok, "max_rel_loss_diff_over_replays": max(rel[3:]) if len(rel) > 3 else None,
-            "losses_eager": [round(v, 4) for v in want], "losses_graphed": [round(v, 4) for v in got]}
+            "default_step_is_graphed": graphed, "memset_nodes_replaced_left": memsets,
+            "loss_trajectory_default_matches_eager": ok, "max_rel_loss_diff_over_replays": max(rel[3:]) if len(rel) > 3 else None,
+            "losses_eager": [round(v, 4) for v in want], "losses_default": [round(v, 4) for v in got]}
 
 
 def train_roofline(a, batch, dev):

@@ -71,6 +71,12 @@ int as_get_precision(void);
 
 const char* as_last_error_string(void);
 int as_abi_version(void);        /* bumped on any signature change */
+
+/* Post-capture surgery on a captured hipGraph (the training step as one graph, harness/train.py): every memset node — ATen's
+ * reduction semaphores, MIOpen's split-K zero-initialisation — is replaced by a fill KERNEL node with the same edges (memset nodes
+ * inside a ~5 000-node chain are not reliably ordered with their neighbours on this ROCm stack).  graph: the
+ * hipGraph_t before (re-)instantiation; *replaced / *left (optional) count the converted nodes and the ones left alone. */
+int as_graph_replace_memsets(void* graph, int* replaced, int* left);
 /* 16 hex digits: sha256 over the .hip / .h files of csrc and this header at build time (any-stereo_amd/build.py); the Python binding
  * recomputes it from the tree and refuses a library built from other sources */
 const char* as_source_hash(void);

@@ -47,7 +47,7 @@ def test_replica_protocol_world2():
     assert all(r[3] == [7.0, 21.0] for r in res)          # every pair processed exactly once
 
 
-def _train_worker(rank, world, port, q, kind="raft"):
+def _train_worker(rank, world, port, q, kind="raft", impl="ddp"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import sys
@@ -65,13 +65,16 @@ def _train_worker(rank, world, port, q, kind="raft"):
     args = default_args("continuous_RAFTStereo" if kind == "raft" else "continuous_IGEVStereo")
     model = (OracleRAFT if kind == "raft" else OracleIGEV)(args)
     fill_module_deterministic(model, base_seed=1)
-    tr = Trainer(model, num_steps=50, train_iters=3, max_disp=args.max_disp)
+    tr = Trainer(model, num_steps=50, train_iters=3, max_disp=args.max_disp, ddp_impl=impl)
     _, _, img1, img2, coord, gt, scale = tiny_train_case(kind)
     before = {n: p.detach().clone() for n, p in model.named_parameters()}
     loss, met = tr.step(shard_batch((img1, img2, coord, gt, scale), r, w))
-    # wrapped at the first step, after the probe pass that freezes gradient-less parameters: plain DDP, no unused-parameter walk
-    assert isinstance(tr.module, torch.nn.parallel.DistributedDataParallel) and tr.ddp_mode.startswith("plain DDP")
-    assert not tr.module.find_unused_parameters
+    if impl == "ddp":
+        # wrapped at the first step, after the probe pass that freezes gradient-less parameters: plain DDP, no unused-parameter walk
+        assert isinstance(tr.module, torch.nn.parallel.DistributedDataParallel) and tr.ddp_mode.startswith("plain DDP")
+        assert not tr.module.find_unused_parameters
+    else:  # bare module, one all-reduce of the concatenated gradients between backward and the update
+        assert tr.module is model and tr.ddp_mode.startswith("flat")
     z = np.load(os.path.join(root, "tests", "golden", f"train_{kind}.npz"))
     total = float(np.sqrt((z["norms"] ** 2).sum()))          # clip_grad_norm_(1.0) scaled every gradient by 1/total
     named = dict(model.named_parameters())
@@ -92,16 +95,17 @@ def _train_worker(rank, world, port, q, kind="raft"):
 import pytest
 
 
-@pytest.mark.parametrize("kind", ["raft", "igev"])
-def test_ddp_training_step_world2(kind):
+@pytest.mark.parametrize("kind,impl", [("raft", "ddp"), ("igev", "ddp"), ("raft", "flat")])
+def test_ddp_training_step_world2(kind, impl):
     """cfg 4 protocol on CPU: 2 ranks x 1 sample, DDP(gloo) gradient averaging -> the full-batch gradient of the
     reference (G8 fixture; both samples have the same number of valid queries), identical parameters on both ranks
     after the AdamW step.  IGEV: the probe pass freezes the classifier (it only feeds init_disp, which the loss does not
-    see), so plain DDP runs without find_unused_parameters."""
+    see), so plain DDP runs without find_unused_parameters.  impl "flat": the bare module + ONE all-reduce of the concatenated
+    gradients (the exchange a graphed multi-rank step uses) gives the same averaged gradient."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_train_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    ps = [ctx.Process(target=_train_worker, args=(r, 2, port, q, kind, impl)) for r in range(2)]
     for p in ps:
         p.start()
     res = []
@@ -119,7 +123,7 @@ def test_ddp_training_step_world2(kind):
         assert p.exitcode == 0
     for r, worst, sums, moved, mean_loss, ref_loss, frozen in res:
         # IGEV: the classifier and the unused BatchNorm of the hourglass' last (bn=False) transposed conv get no gradient
-        assert ("classifier.weight" in frozen and len(frozen) <= 4) if kind == "igev" else (frozen == []), frozen
+        assert ("classifier.weight" in frozen and len(frozen) <= 4) if (kind == "igev" and impl == "ddp") else (frozen == []), frozen
         assert sums[0] == sums[1], "parameters diverged between ranks"
         assert moved > 200
         if kind == "raft":

@@ -329,7 +329,7 @@ def test_cfg4_step_through_rccl_ddp_one_rank():
     batch = synthetic_train_batch(4, 160, 320, seed=5, device=DEV)
     prev_det = torch.backends.cudnn.deterministic
     torch.backends.cudnn.deterministic = True  # MIOpen's deterministic solvers for the layers it still runs in training
-    plain = Trainer(fresh(), lr=1e-4, num_steps=100, train_iters=16, max_disp=args.max_disp)
+    plain = Trainer(fresh(), lr=1e-4, num_steps=100, train_iters=16, max_disp=args.max_disp, graph=False)
     assert plain.ddp_mode == "none"
     loss_a, _ = plain.step(tuple(t.clone() for t in batch))
     grads_a = {n: p.grad.detach().clone() for n, p in plain.model.named_parameters() if p.grad is not None}
@@ -341,7 +341,7 @@ def test_cfg4_step_through_rccl_ddp_one_rank():
     s.close()
     td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
-        wrapped = Trainer(fresh(), lr=1e-4, num_steps=100, train_iters=16, max_disp=args.max_disp, force_ddp=True)
+        wrapped = Trainer(fresh(), lr=1e-4, num_steps=100, train_iters=16, max_disp=args.max_disp, force_ddp=True, graph=False)
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)  # the probe pass announces the parameters it freezes
@@ -373,6 +373,64 @@ def test_cfg4_step_through_rccl_ddp_one_rank():
     finally:
         torch.backends.cudnn.deterministic = prev_det
         td.destroy_process_group()
+
+
+def test_cfg4_graphed_step_equals_eager_step():
+    """The Trainer's default step — gradient half replayed as ONE captured hipGraph, gradient exchange (here: one rank through
+    RCCL, the flat all-reduce every rank of the 8-GPU job issues), clip and AdamW eager — against the eager step on the same
+    weights and batch, step by step: 3 warm-up steps, the capture, 6 replays.  Also pins the graph surgery: the captured step
+    holds memset nodes (ATen's reduction semaphores; MIOpen's split-K zero-fills without the deterministic solvers) and every one
+    becomes a fill kernel node — left in place they return stale reductions and zero gradients from the second replay on."""
+    import socket
+    import torch.distributed as td
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer, synthetic_train_batch
+    from anystereo.models import __models__, default_args
+    args = default_args("continuous_IGEVStereo")
+
+    def fresh():
+        m = __models__["continuous_IGEVStereo"](args)
+        fill_module_deterministic(m, base_seed=1)
+        return m.to(DEV)
+
+    batch = synthetic_train_batch(4, 160, 320, seed=7, device=DEV)
+    prev_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    n = 9
+    try:
+        eager = Trainer(fresh(), lr=2e-4, num_steps=1000, train_iters=16, max_disp=args.max_disp, graph=False)
+        le = [float(eager.step(tuple(t.clone() for t in batch))[0]) for _ in range(n)]
+        pe = {k: v.detach().clone() for k, v in eager.model.named_parameters()}
+        del eager
+        assert not td.is_initialized()
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+        try:
+            gr = Trainer(fresh(), lr=2e-4, num_steps=1000, train_iters=16, max_disp=args.max_disp, force_ddp=True)
+            assert gr.use_graph and gr.graph_scope == "grads" and gr.ddp_impl == "flat" and gr.ddp_mode.startswith("flat")
+            lg, mets = [], []
+            for _ in range(n):
+                loss, met = gr.step(tuple(t.clone() for t in batch))
+                lg.append(float(loss))
+                mets.append({k: float(v) for k, v in met.items()})
+            assert gr._graph is not None and gr.graph_memsets[0] >= 5 and gr.graph_memsets[1] == 0, gr.graph_memsets
+            for i, (a_, b_) in enumerate(zip(le, lg)):
+                assert abs(a_ - b_) <= 2e-3 * abs(a_), (i, a_, b_, le, lg)
+            for m_ in mets:  # the metrics sit behind the reductions whose semaphores the memset nodes zeroed
+                assert 0.0 < m_["epe"] < 500.0 and 0.0 <= m_["3px"] <= m_["1px"] <= 1.0, mets
+            worst = 0.0
+            for k, v in gr.model.named_parameters():
+                worst = max(worst, ((v.detach() - pe[k]).abs().max() / pe[k].abs().max().clamp_min(1e-12)).item())
+            assert worst < 5e-2, worst  # nine AdamW steps at a rising learning rate on two runs of atomics-ordered kernels
+            print(f"[graphed step over RCCL x1] losses eager {[round(v, 3) for v in le]} graphed {[round(v, 3) for v in lg]}; memset nodes "
+                  f"replaced {gr.graph_memsets[0]}; worst parameter deviation {worst:.2e}")
+        finally:
+            td.destroy_process_group()
+    finally:
+        torch.backends.cudnn.deterministic = prev_det
 
 
 # ---- whole forward at FULL size against the CPU oracle (same weights, same inputs) -----------------------------

@@ -17,7 +17,7 @@ args = default_args("continuous_IGEVStereo")
 model = __models__["continuous_IGEVStereo"](args)
 fill_module_deterministic(model, base_seed=1)
 model = model.to(dev)
-tr = Trainer(model, train_iters=16, max_disp=args.max_disp)
+tr = Trainer(model, train_iters=16, max_disp=args.max_disp, graph=False)
 batch = synthetic_train_batch(4, n_query=51200, device=dev)
 for _ in range(3):
     tr.step(batch)

@@ -66,6 +66,30 @@ def main():
             return "?"
         s = hip.hipKernelNameRefByPtr(C.c_void_p(kp.func), None)
         return (s or b"?").decode(errors="replace")[:110]
+    # shape of the dependency graph: a single-stream capture is ONE chain (every node one predecessor, one successor)
+    def count(nd, fn):
+        k = C.c_size_t(0)
+        return k.value if fn(C.c_void_p(nd), None, C.byref(k)) == 0 else -1
+    roots, leaves, forks, joins = [], [], [], []
+    for nd in nodes:
+        nin, nout = count(nd, hip.hipGraphNodeGetDependencies), count(nd, hip.hipGraphNodeGetDependentNodes)
+        if nin == 0:
+            roots.append(nd)
+        if nout == 0:
+            leaves.append(nd)
+        if nout > 1:
+            forks.append(nd)
+        if nin > 1:
+            joins.append(nd)
+
+    def label(nd):
+        t = C.c_int(-1)
+        hip.hipGraphNodeGetType(C.c_void_p(nd), C.byref(t))
+        return kname(nd)[:90] if t.value == 0 else KINDS[t.value]
+    print(f"dependency shape: {len(roots)} root(s), {len(leaves)} leaf node(s), {len(forks)} node(s) with more than one successor, {len(joins)} with more than one predecessor")
+    for title, lst in (("roots", roots), ("leaves", leaves), ("forks", forks), ("joins", joins)):
+        for nd in lst[:12]:
+            print(f"  {title[:-1]}: {label(nd)}")
     summary = collections.Counter()
 
     def neighbours(nd, fn):
@@ -77,8 +101,17 @@ def main():
             for d in arr:
                 t = C.c_int(-1)
                 hip.hipGraphNodeGetType(C.c_void_p(d), C.byref(t))
-                out.append(kname(d)[:70] if t.value == 0 else KINDS[t.value])
+                out.append(kname(d)[:160] if t.value == 0 else KINDS[t.value])
         return out
+    msum = collections.Counter()
+    for nd in nodes:
+        t = C.c_int(-1)
+        hip.hipGraphNodeGetType(C.c_void_p(nd), C.byref(t))
+        if t.value == 2:
+            msum[(" | ".join(neighbours(nd, hip.hipGraphNodeGetDependencies)), " | ".join(neighbours(nd, hip.hipGraphNodeGetDependentNodes)))] += 1
+    print("memset nodes by (producer kernel) -> (consumer kernel):")
+    for (pre, post), v in msum.most_common():
+        print(f"  m{v:3d}  after [{pre[:120]}]  before [{post[:160]}]")
     for nd in copies:
         summary[(" | ".join(neighbours(nd, hip.hipGraphNodeGetDependencies)), " | ".join(neighbours(nd, hip.hipGraphNodeGetDependentNodes)))] += 1
     print("memcpy nodes by (producer kernels) -> (consumer kernels)  [hipGraphMemcpyNodeGetParams returns nothing usable for captured 1-D copies]:")

@@ -28,7 +28,7 @@ def main():
     args = default_args("continuous_IGEVStereo")
     m = __models__["continuous_IGEVStereo"](args)
     fill_module_deterministic(m, base_seed=1)
-    tr = Trainer(m.to(dev), train_iters=16, max_disp=args.max_disp)
+    tr = Trainer(m.to(dev), train_iters=16, max_disp=args.max_disp, graph=False)
     batch = synthetic_train_batch(4, 160, 320, seed=0, device=dev)
     for _ in range(3):
         tr.step(batch)
