@@ -264,7 +264,9 @@ class LiifMlpTail(torch.autograd.Function):
             rel, _ = ops.liif_rel_key(coord, sizes)
             d_wrel = torch.matmul(d1, rel.transpose(1, 2)).sum(0)
         if ctx.bias[0] and need[4]:
-            d_b1 = d1.sum((0, 2))
+            # every query lands in exactly one pixel of source 0 (the coordinates are clamped into the map), so the sum over the
+            # queries is the sum over that map's pixels: a 92 MB reduction instead of another pass over the 1.5 GB of d1
+            d_b1 = d_u0.sum((0, 2, 3)) if d_u0 is not None else d1.sum((0, 2))
         grads = [None] * 6  # w2, b2, w3, b3, w4, b4
         for li, (x, d) in enumerate(((h1, d2), (h2, d3), (h3, d_logits))):
             want_w, want_b = need[5 + 2 * li], ctx.bias[1 + li] and need[6 + 2 * li]

@@ -88,7 +88,8 @@ class Trainer:
         self.ddp_impl = os.environ.get("ANYSTEREO_DDP_IMPL", "ddp") if ddp_impl is None else ddp_impl
         if self.ddp_impl not in ("ddp", "flat"):
             raise ValueError(f"Trainer: ddp_impl={self.ddp_impl!r} (ddp | flat)")
-        self.use_graph = bool(graph) and p0.is_cuda and not mixed_precision
+        # (ANYSTEREO_OVERFLOW_POLICY=skip decides per step on the host whether the update runs: eager only)
+        self.use_graph = bool(graph) and p0.is_cuda and not mixed_precision and os.environ.get("ANYSTEREO_OVERFLOW_POLICY", "poll") != "skip"
         if self.use_graph and self._want_ddp:
             self.ddp_impl = "flat"
         self.graph_warmup = int(os.environ.get("ANYSTEREO_TRAIN_GRAPH_WARMUP", "3"))
