@@ -118,7 +118,7 @@ SIGNATURES = {
     "as_liif_mlp_bwd_image_bytes": (C.c_int64, []),
     "as_liif_mlp_bwd_pack": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "as_liif_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "as_liif_mlp_bwd": (_i, [_vp] * 12 + [_i] * 7 + [_vp]),
+    "as_liif_mlp_bwd": (_i, [_vp] * 15 + [_i] * 7 + [_vp]),
     "as_liif_split_overflow": (C.c_uint, [_i]),
     "as_corr_pyramid_bwd": (_i, [_pp, _vp, C.c_longlong, _i, _i, _vp]),
     "as_geo_pyramid_bwd": (_i, [_pp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

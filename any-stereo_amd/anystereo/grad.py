@@ -225,6 +225,9 @@ class LiifGatherMlp1(torch.autograd.Function):
 
 
 # ---- a14 + a15 as ONE forward kernel and ONE data-gradient kernel (csrc/liif_fused.hip, as_liif_mlp_fwd / _bwd) ------------
+_LIIF_FUSE_FIRST = os.environ.get("ANYSTEREO_LIIF_TRAIN_FUSE_FIRST", "1") != "0"
+
+
 class LiifMlpTail(torch.autograd.Function):
     """logits[b,:,q] = MLP(relu(u0[b,:,n0(q)] + u1[b % B1,:,n1(q)] + wrel.rel(q) + b1)) for the default 128-64-64-9 MLP
     (liif.py:9-25, :644-678).  The forward keeps NO per-query activation; the backward kernel recomputes them per 32-query tile
@@ -249,20 +252,29 @@ class LiifMlpTail(torch.autograd.Function):
         u0c, u1c, w2, w3, w4 = ctx.saved_tensors
         coord, sizes = ctx.coord, ctx.sizes
         d_logits = _c(d_logits)
-        h1, h2, h3, d3, d2, d1 = ops.liif_mlp_bwd(u0c, u1c, sizes, coord, ctx.pack, ctx.pack_t.get(w2, w3, w4), d_logits)
+        need = ctx.needs_input_grad
         nb, b1n = u0c.shape[0], u1c.shape[0]
         (h0, w0), (h1s, w1s) = sizes
-        need = ctx.needs_input_grad
-        d_u0 = ops.liif_scatter_add(d1, coord, 128, h0, w0) if need[0] else None
-        d_u1 = None
-        if need[1]:
-            d_u1 = ops.liif_scatter_add(d1, coord, 128, h1s, w1s)
-            if b1n != nb:  # every use of the shared input: evaluation e = (i, b) read element b
-                d_u1 = d_u1.view(nb // b1n, b1n, 128, h1s, w1s).sum(0)
         d_wrel = d_b1 = None
-        if need[3]:
-            rel, _ = ops.liif_rel_key(coord, sizes)
-            d_wrel = torch.matmul(d1, rel.transpose(1, 2)).sum(0)
+        if _LIIF_FUSE_FIRST and need[0] and need[1]:
+            # the first layer's consumers inside the kernel: d1 is scattered into both maps (the shared second input's n evaluations add
+            # into its B1 elements directly) and reduced against the relative coordinates; it never reaches memory
+            h1, h2, h3, d3, d2, (d_u0, d_u1, d_wrel) = ops.liif_mlp_bwd(u0c, u1c, sizes, coord, ctx.pack, ctx.pack_t.get(w2, w3, w4), d_logits,
+                                                                         fuse_first=True)
+            d1 = None
+            if not need[3]:
+                d_wrel = None
+        else:
+            h1, h2, h3, d3, d2, d1 = ops.liif_mlp_bwd(u0c, u1c, sizes, coord, ctx.pack, ctx.pack_t.get(w2, w3, w4), d_logits)
+            d_u0 = ops.liif_scatter_add(d1, coord, 128, h0, w0) if need[0] else None
+            d_u1 = None
+            if need[1]:
+                d_u1 = ops.liif_scatter_add(d1, coord, 128, h1s, w1s)
+                if b1n != nb:  # every use of the shared input: evaluation e = (i, b) read element b
+                    d_u1 = d_u1.view(nb // b1n, b1n, 128, h1s, w1s).sum(0)
+            if need[3]:
+                rel, _ = ops.liif_rel_key(coord, sizes)
+                d_wrel = torch.matmul(d1, rel.transpose(1, 2)).sum(0)
         if ctx.bias[0] and need[4]:
             # every query lands in exactly one pixel of source 0 (the coordinates are clamped into the map), so the sum over the
             # queries is the sum over that map's pixels: a 92 MB reduction instead of another pass over the 1.5 GB of d1

@@ -1359,9 +1359,12 @@ def liif_mlp_fwd(u0, u1, sizes, coord, pack: LiifTailPack):
     return logits
 
 
-def liif_mlp_bwd(u0, u1, sizes, coord, pack: LiifTailPack, pack_t: LiifMlpBwdPack, d_logits):
+def liif_mlp_bwd(u0, u1, sizes, coord, pack: LiifTailPack, pack_t: LiifMlpBwdPack, d_logits, fuse_first: bool = False):
     """-> (h1 [B,128,Q], h2, h3 [B,64,Q], d3, d2 [B,64,Q], d1 [B,128,Q]): the MLP's post-ReLU activations (recomputed) and the
-    gradients w.r.t. the pre-activations of layers 3, 2, 1 for d_logits [B,9,Q] (as_liif_mlp_bwd)."""
+    gradients w.r.t. the pre-activations of layers 3, 2, 1 for d_logits [B,9,Q] (as_liif_mlp_bwd).
+    fuse_first: d1 is consumed inside the kernel instead of written — the last element of the result then is the tuple
+    (d_u0 [B,128,H0,W0], d_u1 [B1,128,H1,W1], d_wrel [128,4]) (scatter-adds of d1 into the two first-layer maps, its reduction against
+    the relative coordinates)."""
     _req(u0, "u0"), _req(u1, "u1"), _req(coord, "coord"), _req(d_logits, "d_logits")
     b, q = coord.shape[:2]
     (h0, w0), (h1, w1) = sizes
@@ -1369,11 +1372,19 @@ def liif_mlp_bwd(u0, u1, sizes, coord, pack: LiifTailPack, pack_t: LiifMlpBwdPac
             or tuple(d_logits.shape) != (b, 9, q)):
         raise RuntimeError("liif_mlp_bwd: shape mismatch")
     mk = lambda c: torch.empty((b, c, q), device=coord.device, dtype=torch.float32)  # noqa: E731
-    h1_, h2_, h3_, d3, d2, d1 = mk(128), mk(64), mk(64), mk(64), mk(64), mk(128)
+    h1_, h2_, h3_, d3, d2 = mk(128), mk(64), mk(64), mk(64), mk(64)
+    d1 = du0 = du1 = dwrel = None
+    if fuse_first:
+        du0 = torch.empty((b, 128, h0, w0), device=coord.device, dtype=torch.float32)
+        du1 = torch.empty((u1.shape[0], 128, h1, w1), device=coord.device, dtype=torch.float32)
+        dwrel = torch.empty((128, 4), device=coord.device, dtype=torch.float32)
+    else:
+        d1 = mk(128)
     with _guard(coord.device):
         L.check(L.load().as_liif_mlp_bwd(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(pack_t.image), _p(d_logits), _p(h1_), _p(h2_), _p(h3_),
-                                         _p(d3), _p(d2), _p(d1), b, u1.shape[0], q, h0, w0, h1, w1, _stream()), "liif_mlp_bwd")
-    return h1_, h2_, h3_, d3, d2, d1
+                                         _p(d3), _p(d2), _p(d1), _p(du0), _p(du1), _p(dwrel), b, u1.shape[0], q, h0, w0, h1, w1, _stream()),
+                "liif_mlp_bwd")
+    return h1_, h2_, h3_, d3, d2, (du0, du1, dwrel) if fuse_first else d1
 
 
 def graph_replace_memsets(graph: "torch.cuda.CUDAGraph"):

@@ -505,6 +505,9 @@ struct TileCtx {
   float4 g1[4];          // the same 16-B groups of the source-1 row
   half8 dh[3], dl[3];    // DIRECT1: the source-1 row (48 raw channels) split into the B operands of its three k-steps
   float dn[5];           // this lane's disparity neighbours (x 4 x scale): k = 4 half + i (i < 4), k = 8 (i = 4, half 0)
+  int pix[2];            // nearest pixel (row * W + column) of this lane's query in source 0 / 1 (the training backward scatters there)
+  int bsrc1;             // batch element of source 1 this query reads (b % B1)
+  float rel[4];          // the relative coordinates as fp32 (the backward's wrel gradient)
 };
 
 template <int NSRC, bool DIRECT1 = false>
@@ -528,12 +531,16 @@ __device__ __forceinline__ void tile_prepare(const TailParams& p, const float* _
     const float4* __restrict__ up =
         reinterpret_cast<const float4*>((s ? u1p : u0p) + (((long long)bs * p.H[s] + iy) * p.W[s] + ix) * pitch) + ((DIRECT1 && s == 1) ? 2 * half : half);
     if (s == 0) x.up0 = up; else x.up1 = up;
+    x.pix[s] = iy * p.W[s] + ix;
+    if (s == 1) x.bsrc1 = bs;
     const float qy = __fadd_rn(p.c0y[s], __fmul_rn(p.sy[s], (float)iy));
     const float qx = __fadd_rn(p.c0x[s], __fmul_rn(p.sx[s], (float)ix));
     rel[2 * s] = __fmul_rn(__fsub_rn(cr, qy), (float)p.H[s]);          // (coord_unclamped - cell centre) * (H, W)
     rel[2 * s + 1] = __fmul_rn(__fsub_rn(cc, qx), (float)p.W[s]);
   }
-  if (NSRC == 1) x.up1 = x.up0;
+  if (NSRC == 1) { x.up1 = x.up0; x.pix[1] = 0; x.bsrc1 = b; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x.rel[k] = rel[k];
   if (dispp) {  // kernel-uniform (the training forward asks for the logits only)
     const int iy = nearest_idx(crc, p.Hd), ix = nearest_idx(ccc, p.Wd);
     const float* __restrict__ dp = dispp + (long long)b * p.Hd * p.Wd;
@@ -838,9 +845,18 @@ struct MlpBwdParams {
   float* h3;               // [B][64][Q]
   float* d3;               // [B][64][Q]
   float* d2;               // [B][64][Q]
-  float* d1;               // [B][128][Q]
+  float* d1;               // [B][128][Q], or null with the first layer's consumers fused (du0 / du1 / dwrel below)
+  // fused first-layer backward: d1 is scattered straight into the gradients of the two first-layer maps (NCHW, zero-filled by the
+  // launcher; source 1 holds B1 batch elements: every evaluation of the shared input adds into element b % B1) and reduced against
+  // the relative coordinates for the wrel columns' gradient — d1 itself never reaches memory
+  float* du0;              // [B][128][H0][W0]
+  float* du1;              // [B1][128][H1][W1]
+  float* dwrel;            // [128][4], atomically accumulated
 };
+constexpr int kStageRow = 33;                                   // padded row of a wave's 32 x 32 staging tile (conflict-free column reads)
+constexpr int kStageFloats = 32 * kStageRow + 4 * 32;           // + the tile's relative coordinates [4][32]
 
+template <bool FUSE1>
 __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
   constexpr int NT = 512;
   const TailParams& p = P.t;
@@ -882,6 +898,17 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
   const __amdgpu_buffer_rsrc_t r_d1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.d1, 0, (int)n128, 0x00020000);
   const unsigned q4 = (unsigned)(Q * 4);  // byte pitch of a channel row
 #define AS_ROW(I) (((I) & 3) + 8 * ((I) >> 2))  /* acc_row without the lane half (that part sits in the per-lane offset) */
+  constexpr bool fuse1 = FUSE1;  // the first layer's consumers inside this kernel (P.du0 / du1 / dwrel) or d1 written out
+  const unsigned hw0 = (unsigned)(p.H[0] * p.W[0]), hw1 = (unsigned)(p.H[1] * p.W[1]);
+  const int b1n = p.B1 > 0 ? p.B1 : p.B;
+  const __amdgpu_buffer_rsrc_t r_u0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.du0, 0, fuse1 ? (int)((long long)p.B * kHid1 * hw0 * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_u1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.du1, 0, fuse1 ? (int)((long long)b1n * kHid1 * hw1 * 4) : 0, 0x00020000);
+  float* stage = reinterpret_cast<float*>(smem + kOffT + kImageTBytes) + wave * kStageFloats;  // this wave's 32 x 33 tile + rel [4][32]
+  float accw[4][4];  // lane (channel r of m-tile m, query half): sum over this wave's queries of d1[32 m + r][q] * rel_k(q)
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) accw[m][k] = 0.f;
 
   const long long tile0 = gw * p.tpw;
   if (tile0 >= p.tiles) return;
@@ -905,6 +932,31 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
     const unsigned vo128 = cur.valid ? (unsigned)((((long long)b * kHid1 + 4 * half) * Q + qq) * 4) : 0xFFFFFFF0u;
     const unsigned vo64 = cur.valid ? (unsigned)((((long long)b * kHid2 + 4 * half) * Q + qq) * 4) : 0xFFFFFFF0u;
     const unsigned vo9 = cur.valid ? (unsigned)((((long long)b * kOut + 4 * half) * Q + qq) * 4) : 0xFFFFFFF0u;
+    // fused scatter-add: runs of consecutive queries (lanes of one 32-lane half; the halves hold different channels of the same
+    // queries) that fall into the same source pixel are pre-summed with a segmented suffix sum and only the head of a run issues
+    // the atomic — the scheme of liif_gather_bwd_kernel (the training path sorts the queries by source pixel, ~16 per pixel)
+    unsigned same0 = 0u, same1 = 0u, vo_u0 = 0u, vo_u1 = 0u;
+    bool head0 = false, head1 = false;
+    if constexpr (fuse1) {
+      const int key0 = b * (int)hw0 + cur.pix[0], key1 = cur.bsrc1 * (int)hw1 + cur.pix[1];
+      const int prev0 = __shfl_up(key0, 1, 32), prev1 = __shfl_up(key1, 1, 32);
+      head0 = c == 0 || prev0 != key0;
+      head1 = c == 0 || prev1 != key1;
+      const unsigned long long hb0 = __ballot(head0), hb1 = __ballot(head1);
+      const unsigned after0 = ((unsigned)(half ? (hb0 >> 32) : hb0) >> c) >> 1, after1 = ((unsigned)(half ? (hb1 >> 32) : hb1) >> c) >> 1;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const unsigned msk = (1u << (1 << k)) - 1u;
+        if (c + (1 << k) < 32 && (after0 & msk) == 0u) same0 |= 1u << k;
+        if (c + (1 << k) < 32 && (after1 & msk) == 0u) same1 |= 1u << k;
+      }
+      vo_u0 = head0 ? (unsigned)((((long long)b * kHid1 + 4 * half) * hw0 + cur.pix[0]) * 4) : 0xFFFFFFF0u;
+      vo_u1 = head1 ? (unsigned)((((long long)cur.bsrc1 * kHid1 + 4 * half) * hw1 + cur.pix[1]) * 4) : 0xFFFFFFF0u;
+      if (half == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stage[32 * kStageRow + k * 32 + c] = cur.valid ? cur.rel[k] : 0.f;
+      }
+    }
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // ================= forward recompute: liif_tail_kernel's sequence, layer for layer =================
     unsigned m1[4] = {0u, 0u, 0u, 0u}, m2[2] = {0u, 0u}, m3[2] = {0u, 0u};  // bit i = [activation in accumulator register i > 0]
@@ -1064,14 +1116,54 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
         const half8 ah = WT[blk * 64 + lane], al = WT[(blk + 1) * 64 + lane];
         AS_MFMA3(ah, al, f2h[ks], f2l[ks], gh, gx)
       }
+      if constexpr (!fuse1) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = ((m1[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_d1, (int)vo128, (int)((32 * m + AS_ROW(i)) * q4), 0);
+        for (int i = 0; i < 16; ++i) {
+          const float v = ((m1[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_d1, (int)vo128, (int)((32 * m + AS_ROW(i)) * q4), 0);
+        }
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous m-tile's column reads are done before the tile is overwritten
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = (cur.valid && ((m1[m] >> i) & 1u)) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
+          stage[(AS_ROW(i) + 4 * half) * kStageRow + c] = v;  // [channel row of the m-tile][query]
+          float s0 = v, s1 = v;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const float o0 = __shfl_down(s0, 1 << k, 32), o1 = __shfl_down(s1, 1 << k, 32);
+            s0 += ((same0 >> k) & 1u) ? o0 : 0.f;
+            s1 += ((same1 >> k) & 1u) ? o1 : 0.f;
+          }
+          // lanes that are not the head of a run carry an out-of-range offset: the atomic is dropped by the range check (a branch
+          // around each of the 128 atomics of a tile costs 259 spilled registers)
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(s0, r_u0, (int)vo_u0, (int)((32 * m + AS_ROW(i)) * hw0 * 4u), 0);
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(s1, r_u1, (int)vo_u1, (int)((32 * m + AS_ROW(i)) * hw1 * 4u), 0);
+          if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two registers' shuffle chains in flight, not sixteen (register pressure)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile (and the tile's relative coordinates) have landed in LDS
+        // wrel gradient: lane (channel c of the m-tile, query half) walks its 16 queries of the row
+        const float* rowp = stage + c * kStageRow + 16 * half;
+        const float* relp = stage + 32 * kStageRow + 16 * half;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float dv = rowp[j];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) accw[m][k] = fmaf(dv, relp[k * 32 + j], accw[m][k]);
+        }
       }
     }
   }
 #undef AS_ROW
+  if constexpr (fuse1) {  // the two query halves of a channel, then one atomic per (channel, column) and wave
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float tot = accw[m][k] + __shfl_xor(accw[m][k], 32);
+        if (half == 0) atomicAdd(P.dwrel + (32 * m + c) * 4 + k, tot);
+      }
+  }
   note_overflow(fmaxf(amax, __builtin_bit_cast(float, imax)));
 }
 
@@ -1338,9 +1430,11 @@ int as_liif_mlp_fwd(const float* u0, const float* u1, const float* coord, const 
 }
 
 int as_liif_mlp_bwd(const float* u0, const float* u1, const float* coord, const void* image, const void* imageT, const float* dlogits,
-                    float* h1, float* h2, float* h3, float* d3, float* d2, float* d1, int B, int B1, int Q, int H0, int W0, int H1,
-                    int W1, void* stream) {
-  AS_REQUIRE(imageT && dlogits && h1 && h2 && h3 && d3 && d2 && d1, AS_ERR_BAD_ARG, "liif_mlp_bwd: null pointer");
+                    float* h1, float* h2, float* h3, float* d3, float* d2, float* d1, float* du0, float* du1, float* dwrel, int B, int B1,
+                    int Q, int H0, int W0, int H1, int W1, void* stream) {
+  AS_REQUIRE(imageT && dlogits && h1 && h2 && h3 && d3 && d2, AS_ERR_BAD_ARG, "liif_mlp_bwd: null pointer");
+  AS_REQUIRE((d1 != nullptr) != (du0 != nullptr), AS_ERR_BAD_ARG, "liif_mlp_bwd: either d1 or the fused first-layer outputs (du0, du1, dwrel)");
+  AS_REQUIRE(!du0 || (du1 && dwrel), AS_ERR_BAD_ARG, "liif_mlp_bwd: du0, du1 and dwrel go together");
   AS_REQUIRE(u1, AS_ERR_BAD_ARG, "liif_mlp_bwd: built for the two-input upsampler");
   MlpBwdParams P{};
   const int rc = mlp_params(P.t, u0, u1, coord, image, B, B1, Q, H0, W0, H1, W1, "liif_mlp_bwd");
@@ -1348,15 +1442,31 @@ int as_liif_mlp_bwd(const float* u0, const float* u1, const float* coord, const 
   AS_REQUIRE((long long)B * kHid1 * Q * 4 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "liif_mlp_bwd: [B,128,Q] exceeds 2 GiB (32-bit buffer offsets); split the batch");
   P.imageT = (const _Float16*)imageT; P.dlogits = dlogits;
   P.h1 = h1; P.h2 = h2; P.h3 = h3; P.d3 = d3; P.d2 = d2; P.d1 = d1;
+  P.du0 = du0; P.du1 = du1; P.dwrel = dwrel;
+  if (du0) {
+    const int b1n = B1 > 0 ? B1 : B;
+    AS_REQUIRE((long long)B * kHid1 * H0 * W0 * 4 < 0x7FFFFFF0ll && (long long)b1n * kHid1 * H1 * W1 * 4 < 0x7FFFFFF0ll &&
+               (long long)B * H0 * W0 < 2147483647ll && (long long)b1n * H1 * W1 < 2147483647ll, AS_ERR_BAD_SHAPE,
+               "liif_mlp_bwd: a first-layer map exceeds the 32-bit offsets of the fused scatter");
+    int zrc = as::zero_fill(du0, (long long)B * kHid1 * H0 * W0, as::as_stream(stream));
+    if (zrc == AS_OK) zrc = as::zero_fill(du1, (long long)b1n * kHid1 * H1 * W1, as::as_stream(stream));
+    if (zrc == AS_OK) zrc = as::zero_fill(dwrel, kHid1 * 4, as::as_stream(stream));
+    if (zrc != AS_OK) return zrc;
+  }
   // one block of 8 waves per CU around the forward + transposed weight images (118 KB); a wave walks `tpw` consecutive tiles
   const long long waves = 256ll * 8;
   P.t.tpw = (int)std::max<long long>(1, as::cdiv64(P.t.tiles, waves));
   long long blocks = as::cdiv64(P.t.tiles, 8ll * P.t.tpw);
   blocks = (blocks + 7) / 8 * 8;
-  constexpr int lds = ((kImageBytes + 15) / 16) * 16 + kImageTBytes;
+  constexpr int lds = ((kImageBytes + 15) / 16) * 16 + kImageTBytes + 8 * kStageFloats * 4;  // + one staging tile per wave
   static_assert(lds <= 160 * 1024, "liif_mlp_bwd: LDS budget");
-  as::lds_opt_in(reinterpret_cast<const void*>(liif_mlp_bwd_kernel));
-  hipLaunchKernelGGL(liif_mlp_bwd_kernel, dim3((unsigned)blocks), dim3(512), lds, as::as_stream(stream), P);
+  if (du0) {
+    as::lds_opt_in(reinterpret_cast<const void*>(liif_mlp_bwd_kernel<true>));
+    hipLaunchKernelGGL(liif_mlp_bwd_kernel<true>, dim3((unsigned)blocks), dim3(512), lds, as::as_stream(stream), P);
+  } else {
+    as::lds_opt_in(reinterpret_cast<const void*>(liif_mlp_bwd_kernel<false>));
+    hipLaunchKernelGGL(liif_mlp_bwd_kernel<false>, dim3((unsigned)blocks), dim3(512), lds, as::as_stream(stream), P);
+  }
   return as::check_launch("liif_mlp_bwd");
 }
 

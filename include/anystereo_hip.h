@@ -380,14 +380,18 @@ int as_liif_tail_direct(const float* u0, const float* rows1, float* coord, const
  *                    d3 = [h3>0] W4^T dlogits, d2 = [h2>0] W3^T d3, d1 = [h1>0] W2^T d2 on the matrix cores and writes h1 [B,128,Q],
  *                    h2, h3, d3, d2 [B,64,Q], d1 [B,128,Q] (post-ReLU activations / gradients w.r.t. the pre-activations): the
  *                    operands of the layers' weight gradients (as_conv2d_wgrad) and of the first layer's scatter-add
- *                    (as_liif_scatter_add).  image = as_liif_tail_pack, imageT = as_liif_mlp_bwd_pack of the same weights. */
+ *                    (as_liif_scatter_add).  image = as_liif_tail_pack, imageT = as_liif_mlp_bwd_pack of the same weights.
+ *                    Either d1, or (d1 = NULL) the first layer's consumers fused: du0 [B,128,H0,W0] and du1 [B1,128,H1,W1] receive
+ *                    the scatter-add of d1 (zero-filled here; runs of queries in one source pixel are pre-summed inside the wave,
+ *                    evaluations of a shared second input add into element b % B1), dwrel [128][4] the gradient of the
+ *                    relative-coordinate columns — d1 then never reaches memory. */
 int64_t as_liif_mlp_bwd_image_bytes(void);
 int as_liif_mlp_bwd_pack(const float* w2, const float* w3, const float* w4, void* imageT, void* stream);
 int as_liif_mlp_fwd(const float* u0, const float* u1, const float* coord, const void* image, float* logits, int B, int B1, int Q,
                     int H0, int W0, int H1, int W1, void* stream);
 int as_liif_mlp_bwd(const float* u0, const float* u1, const float* coord, const void* image, const void* imageT, const float* dlogits,
-                    float* h1, float* h2, float* h3, float* d3, float* d2, float* d1, int B, int B1, int Q, int H0, int W0, int H1,
-                    int W1, void* stream);
+                    float* h1, float* h2, float* h3, float* d3, float* d2, float* d1, float* du0, float* du1, float* dwrel, int B, int B1,
+                    int Q, int H0, int W0, int H1, int W1, void* stream);
 unsigned as_liif_split_overflow(int reset);
 
 /* ---------------------------------------------------------------------------------------------

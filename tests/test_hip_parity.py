@@ -957,10 +957,14 @@ def test_training_fused_liif_mlp_equals_layered(batched):
     print(f"[fused LIIF MLP, batched={batched}] loss {a[1]:.6f} vs {b_[1]:.6f}; worst gradient deviation {worst[1]:.2e} of the tensor's max ({worst[0]})")
 
 
-def test_liif_mlp_tail_function_vs_fp64():
+@pytest.mark.parametrize("fuse_first,sort", [(True, True), (True, False), (False, True)])
+def test_liif_mlp_tail_function_vs_fp64(fuse_first, sort, monkeypatch):
     """grad.LiifMlpTail alone, with a shared second input (B1 < B) and queries outside the clamp range, against an fp64 torch
-    statement of the same function: logits and every gradient (u0, u1, wrel, biases, the three later layers' weights)."""
+    statement of the same function: logits and every gradient (u0, u1, wrel, biases, the three later layers' weights).
+    fuse_first: the first layer's scatter-adds and the wrel reduction inside the backward kernel (on queries sorted by source pixel
+    as in training — long runs per pixel — and in random order — every lane its own run) or as separate kernels over d1."""
     from anystereo import grad as G, ops
+    monkeypatch.setattr(G, "_LIIF_FUSE_FIRST", fuse_first)
     from anystereo.nn.liif import make_coord
     n, b1, h0, w0 = 3, 2, 6, 10
     nb = n * b1
@@ -969,6 +973,10 @@ def test_liif_mlp_tail_function_vs_fp64():
     coord = torch.stack([grid[i] for i in idx]).contiguous()
     coord[0, 0] = torch.tensor([-1.0, 1.0])
     coord[1, 5] = torch.tensor([1.0, -1.0])
+    if sort:
+        _, key = ops.liif_rel_key(coord.to(DEV), [(h0, w0), (2 * h0, 2 * w0)], want_rel=False, want_key=True)
+        perm = torch.argsort(key, dim=1).cpu()
+        coord = torch.gather(coord, 1, perm.unsqueeze(-1).expand(-1, -1, 2)).contiguous()
     u0, u1 = U((nb, 128, h0, w0), 881), U((b1, 128, 2 * h0, 2 * w0), 882)
     wrel, bias1 = U((128, 4), 883), U((128,), 884)
     w2, bb2, w3, bb3, w4, bb4 = U((64, 128), 885, -0.15, 0.15), U((64,), 886), U((64, 64), 887, -0.2, 0.2), U((64,), 888), U((9, 64), 889, -0.2, 0.2), U((9,), 890)
