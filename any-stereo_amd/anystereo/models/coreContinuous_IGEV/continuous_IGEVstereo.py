@@ -148,8 +148,8 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 _, _, stem_4y = self._stems_fwd(image2)
                 features_left[0] = torch.cat((features_left[0], stem_4x), 1)
                 features_right[0] = torch.cat((features_right[0], stem_4y), 1)
-                match_left = self.desc(self.conv(features_left[0]))
-                match_right = self.desc(self.conv(features_right[0]))
+                match_left = _plain_conv(self, self.desc, self.conv(features_left[0]))
+                match_right = _plain_conv(self, self.desc, self.conv(features_right[0]))
             gwc_volume = self._hot_gwc(match_left, match_right)
             gwc_volume = self.corr_stem(gwc_volume)
             gwc_volume = self.corr_feature_att(gwc_volume, features_left[0])

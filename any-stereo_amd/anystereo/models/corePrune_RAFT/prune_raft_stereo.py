@@ -75,7 +75,7 @@ class continuous_RaftStereo(ContinuousStereoBase):
         cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
         net_list = [torch.tanh(x[0]) for x in cnet_list]
         inp_list = [torch.relu(x[1]) for x in cnet_list]
-        ctx_list = [conv(i) for i, conv in zip(inp_list, self.context_zqr_convs)]
+        ctx_list = [G.module_conv2d(self, f"ctx{k}", conv, i) for k, (i, conv) in enumerate(zip(inp_list, self.context_zqr_convs))]
         stem_1x = stem_2x = stem_4x = None
         if self._has_stems:
             stem_1x = self.stem_1(image1) if hasattr(self, "stem_1") else None

@@ -230,8 +230,9 @@ class MultiBasicEncoder(_Trunk):
 
 
 def _plain_conv(mod: nn.Module, conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """conv(x) on the implicit-GEMM kernel when the inference fast path applies, else the module itself."""
-    return conv2d_plain(mod, conv, x) if _fused_ok(x, mod) else conv(x)
+    """conv(x) on the implicit-GEMM kernel: the inference fast path, or (training) forward / dgrad / wgrad through grad.Conv2dSame
+    where the layer is a stride-1 "same" 1x1 / 3x3 convolution; else the module itself."""
+    return conv2d_plain(mod, conv, x) if _fused_ok(x, mod) else G.module_conv2d(mod, f"pc{id(conv)}", conv, x)
 
 
 def _multi_head(self, f, x):

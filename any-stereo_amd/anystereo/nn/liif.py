@@ -577,7 +577,7 @@ class liif_out_multi_scale_Training(nn.Module):
                 s, u = ent[2], ent[3]
             else:
                 s = sf(f)
-                u = F.conv2d(s, w1[:, off:off + s.shape[1], None, None]) if lowres else None
+                u = self._lowres_first_layer(i, s, w1[:, off:off + s.shape[1], None, None]) if lowres else None
                 if cache is not None and i > 0:
                     cache[i] = (f, (f._version, w1._version, torch.is_grad_enabled()), s, u)
             nb = coord.shape[0]
@@ -620,6 +620,14 @@ class liif_out_multi_scale_Training(nn.Module):
         for i, m in enumerate(lin):
             x = G.pointwise_linear(self, id(m), x, m, i + 1 < len(lin))
         return x
+
+    def _lowres_first_layer(self, i, s, w):
+        """The first Linear layer's feature block of input i at low resolution under autograd: a 1x1 convolution on this library's
+        kernels (forward, dgrad, wgrad — grad.Conv2dSame; the weight is a column block of the layer's matrix, autograd carries
+        its gradient back into it), else the library's."""
+        if s.is_cuda and s.dtype == torch.float32 and s.shape[1] >= 16:
+            return G.conv2d_same(self, f"u{i}", s, w.contiguous(), None)
+        return F.conv2d(s, w)
 
     def _mask_logits(self, sfs, coord, ctot, pre=None):
         b, q = coord.shape[:2]
