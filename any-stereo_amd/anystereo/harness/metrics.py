@@ -7,6 +7,8 @@ Host-side tensor code (any device); pinned by tests/golden/loss_metrics.npz capt
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -64,7 +66,10 @@ def fetch_optimizer(lr, wdecay, num_steps, params, lr_fixed=False, capturable=Fa
         dev = params[0].device
         opt = torch.optim.AdamW(params, lr=torch.tensor(float(lr), device=dev), weight_decay=wdecay, eps=1e-8, capturable=True, foreach=True)
     else:
-        opt = torch.optim.AdamW(params, lr=lr, weight_decay=wdecay, eps=1e-8)
+        # CUDA parameters: torch's fused multi-tensor AdamW (the same update in ~3 launches instead of ~60 foreach launches:
+        # -0.5 ms per step on the GPU-bound graphed step; ANYSTEREO_FUSED_ADAMW=0 = the foreach form)
+        fused = os.environ.get("ANYSTEREO_FUSED_ADAMW", "1") == "1" and params[0].is_cuda
+        opt = torch.optim.AdamW(params, lr=lr, weight_decay=wdecay, eps=1e-8, **({"fused": True} if fused else {}))
     sched = None if lr_fixed else torch.optim.lr_scheduler.OneCycleLR(
         opt, lr, num_steps + 100, pct_start=0.01, cycle_momentum=False, anneal_strategy="linear")
     return opt, sched
