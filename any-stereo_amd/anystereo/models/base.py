@@ -222,15 +222,17 @@ class ContinuousStereoBase(nn.Module):
                     self._forward_impl(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(image1.device)
-            g = torch.cuda.CUDAGraph(keep_graph=True)
+            keep = os.environ.get("ANYSTEREO_INFER_GRAPH_KEEP", "1") != "0"  # 0 (diagnostics): instantiate at capture end, no node rewrite
+            g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
             st[2].copy_(hr_coord)
             with torch.cuda.graph(g):
                 out = self._forward_impl(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
             # memset nodes (a library zero-filling through hipMemsetAsync) are not reliably ordered inside long graphs on this ROCm
             # stack (csrc/graph.hip): rewritten as fill kernel nodes before instantiation.  This library issues none
             # itself; the count is kept for inspection.
-            self.__dict__["_graph_memsets"] = ops.graph_replace_memsets(g)
-            g.instantiate()
+            if keep:
+                self.__dict__["_graph_memsets"] = ops.graph_replace_memsets(g)
+                g.instantiate()
             ent = (g, st, out)
         graphs[key] = ent  # (re-)insert as most recently used
         g, st, out = ent
