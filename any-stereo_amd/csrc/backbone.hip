@@ -5,6 +5,8 @@
 // (s_load) as SGPR operands of the FMAs, the zero padding comes from the buffer range check (sentinel
 // offset) so there is no branch around a load.  BatchNorm (eval) is folded into weights/bias by the caller;
 // the activation is fused.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -30,9 +32,12 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 constexpr unsigned kOOB = 0x70000000u;  // lane sentinel: stays out of range after adding any in-tensor scalar offset
 
 // ------------------------------------------------------------------------------------------------
-// depthwise 3x3, padding 1, stride S: block = 64 x 4 outputs of one (b, c) plane.
+// depthwise 3x3, padding 1, stride S: block = 64 columns x (4 waves x R output rows) of one (b, c) plane.  A wave walks its R rows
+// with the input rows it has already read kept in registers (stride 1: 3 loads per output instead of 9; stride 2: 6): the
+// MobileNetV2 trunk's half-resolution layers are HBM-bound maps of a few MB per plane set that one-output-per-thread blocks
+// (35 000 of them at 270x480) spent mostly launching.
 // ------------------------------------------------------------------------------------------------
-template <int S>
+template <int S, int R>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ res,
                                                         float* __restrict__ out, int C, int H, int W, int Ho, int Wo, int act) {
@@ -40,9 +45,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bc = blockIdx.z;
   const int c = bc % C;
-  const int oy = blockIdx.y * 4 + wave;
+  const int oy0 = (blockIdx.y * 4 + wave) * R;
   const int ox = blockIdx.x * 64 + lane;
-  if (oy >= Ho) return;
+  if (oy0 >= Ho) return;
   const long long plane = (long long)H * W;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)bc * plane), 0, (int)(plane * 4), 0x00020000);
   float wk[9];
@@ -54,20 +59,40 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
     const int ix = ox * S + k - 1;
     xo[k] = (ox < Wo && ix >= 0 && ix < W) ? (unsigned)(ix * 4) : kOOB;
   }
-  float acc = bias ? bias[c] : 0.f;
+  const float b0 = bias ? bias[c] : 0.f;
+  // input rows of the strip: iy = oy0 * S - 1 + j, j = 0 .. (R - 1) * S + 2; row j feeds output r with kernel row ky = j - r * S
+  constexpr int NR = (R - 1) * S + 3;
+  float acc[R];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy * S + ky - 1;
-    if (iy < 0 || iy >= H) continue;  // wave-uniform
-    const unsigned so = (unsigned)(iy * W * 4);
+  for (int r = 0; r < R; ++r) acc[r] = b0;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) acc = fmaf(bload(rs, xo[kx], so), wk[ky * 3 + kx], acc);
+  for (int j = 0; j < NR; ++j) {
+    const int iy = oy0 * S - 1 + j;
+    float v[3];
+    const bool in = iy >= 0 && iy < H;  // wave-uniform
+    const unsigned so = in ? (unsigned)(iy * W * 4) : 0u;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) v[kx] = bload(rs, in ? xo[kx] : kOOB, so);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ky = j - r * S;  // compile-time after unrolling
+      if (ky >= 0 && ky < 3) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[r] = fmaf(v[kx], wk[ky * 3 + kx], acc[r]);
+      }
+    }
   }
   if (ox < Wo) {
-    const long long o = ((long long)bc * Ho + oy) * Wo + ox;
-    float v = act_apply(acc, act);
-    if (res) v += res[o];
-    out[o] = v;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int oy = oy0 + r;
+      if (oy < Ho) {
+        const long long o = ((long long)bc * Ho + oy) * Wo + ox;
+        float vv = act_apply(acc[r], act);
+        if (res) vv += res[o];
+        out[o] = vv;
+      }
+    }
   }
 }
 
@@ -410,9 +435,16 @@ int as_dwconv3x3(const float* x, const float* weight, const float* bias, const f
   AS_REQUIRE((long long)H * W * 4 < (long long)kOOB, AS_ERR_BAD_SHAPE, "dwconv3x3: plane too large");
   AS_REQUIRE((long long)B * C <= 65535, AS_ERR_BAD_SHAPE, "dwconv3x3: B*C=%lld exceeds the grid limit", (long long)B * C);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  const dim3 grid((unsigned)as::cdiv(Wo, 64), (unsigned)as::cdiv(Ho, 4), (unsigned)(B * C));
-  if (stride == 1) hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, residual, out, C, H, W, Ho, Wo, act);
-  else hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(256), 0, as::as_stream(stream), x, weight, bias, residual, out, C, H, W, Ho, Wo, act);
+  // rows per wave: long strips on big maps (fewer, longer blocks), one row on the small ones (enough blocks to fill the chip)
+  const long long rows_total = (long long)B * C * Ho * as::cdiv(Wo, 64);
+  static const int rows_force = getenv("AS_DW_ROWS") ? atoi(getenv("AS_DW_ROWS")) : 0;  // 1 | 4 | 8 (diagnostics / A-B)
+  const int R = rows_force ? rows_force : (rows_total >= 8ll * 4 * 4 * 256 ? 8 : (rows_total >= 4ll * 4 * 2 * 256 ? 4 : 1));
+  const dim3 grid((unsigned)as::cdiv(Wo, 64), (unsigned)as::cdiv(Ho, 4 * R), (unsigned)(B * C));
+  hipStream_t st = as::as_stream(stream);
+#define AS_DW(S_, R_) hipLaunchKernelGGL((dwconv3x3_kernel<S_, R_>), grid, dim3(256), 0, st, x, weight, bias, residual, out, C, H, W, Ho, Wo, act)
+  if (stride == 1) { if (R == 8) AS_DW(1, 8); else if (R == 4) AS_DW(1, 4); else AS_DW(1, 1); }
+  else { if (R == 8) AS_DW(2, 8); else if (R == 4) AS_DW(2, 4); else AS_DW(2, 1); }
+#undef AS_DW
   return as::check_launch("dwconv3x3");
 }
 

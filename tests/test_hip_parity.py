@@ -329,7 +329,10 @@ def test_residual_block_fused_inference(cin, cout, stride, h, w, precision):
     close(out, ref, 2e-5, 2e-5, "residual block (fused)")
 
 
-@pytest.mark.parametrize("b,c,h,w,stride,act", [(2, 32, 17, 70, 1, 4), (1, 96, 18, 67, 2, 4), (1, 5, 3, 3, 2, 0), (1, 8, 65, 130, 1, 5)])
+@pytest.mark.parametrize("b,c,h,w,stride,act", [(2, 32, 17, 70, 1, 4), (1, 96, 18, 67, 2, 4), (1, 5, 3, 3, 2, 0), (1, 8, 65, 130, 1, 5),
+                                                # the trunk's half-resolution layers at 960x540 (8-row strips per wave), odd sizes at both strides
+                                                # (4-row strips, ragged last strip)
+                                                (2, 32, 270, 480, 1, 4), (2, 96, 269, 479, 2, 4), (1, 48, 131, 250, 1, 0), (1, 40, 133, 251, 2, 5)])
 def test_dwconv3x3(b, c, h, w, stride, act):
     from anystereo import ops
     x, wt, bias = U((b, c, h, w), 170, -3, 3), U((c, 1, 3, 3), 171), U((c,), 172)
