@@ -100,6 +100,7 @@ class Trainer:
             nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
             self.ddp_mode = f"flat: one all-reduce of the concatenated gradients ({nbytes / 1e6:.0f} MB) between backward and the update"
         self._graph = None
+        self.graph_cache_size = int(os.environ.get("ANYSTEREO_TRAIN_GRAPH_CACHE", "2"))
         self.optimizer, self.scheduler = fetch_optimizer(lr, wdecay, num_steps, model.parameters(), lr_fixed,
                                                          capturable=self.use_graph and self.graph_scope == "step")
         self.scaler = torch.amp.GradScaler("cuda", enabled=True) if mixed_precision else None
@@ -245,14 +246,26 @@ class Trainer:
         re-materialise at fixed addresses in the graph's pool), forward, the synchronisation-free loss, backward, the loss-scale
         division, clip_grad_norm_ and the capturable AdamW; the OneCycleLR scheduler runs on the host and writes the device-side
         learning rate between replays.  Returns clones of the static loss / metric tensors."""
-        ent = self._graph
-        if ent is None or any(tuple(a.shape) != tuple(b.shape) for a, b in zip(ent["batch"], batch)):
+        # one captured graph per batch shape (LRU of `graph_cache_size`: each holds a memory pool with a whole step); a shape seen for
+        # the first time runs eagerly first — MIOpen's solver search (timed trial launches) and the allocator's growth cannot happen
+        # inside a capture
+        graphs = self.__dict__.setdefault("_graphs", {})
+        warm = self.__dict__.setdefault("_warm", {})
+        key = tuple(tuple(t.shape) for t in batch)
+        ent = graphs.pop(key, None)
+        if ent is not None:
+            graphs[key] = ent  # most recently used last
+        self._graph = ent
+        if ent is None:
             # warm-up steps and the capture run on ONE side stream (PyTorch's whole-network capture recipe): autograd binds a
             # parameter's AccumulateGrad node to the stream of the forward that created it
             if getattr(self, "_gstream", None) is None:
                 self._gstream = torch.cuda.Stream(device=batch[0].device)
             cur = torch.cuda.current_stream(batch[0].device)
-            if self.steps_done < self.graph_warmup:  # eager steps first: solver searches, weight packs, allocator, optimizer state
+            first = not graphs and all(k == key for k in warm)  # the first shape also initialises the optimizer state and the weight packs
+            need = self.graph_warmup if first else 1
+            if warm.get(key, 0) < need:  # eager steps first: solver searches, weight packs, allocator, optimizer state
+                warm[key] = warm.get(key, 0) + 1
                 self._gstream.wait_stream(cur)
                 single = os.environ.get("ANYSTEREO_TRAIN_GRAPH_SINGLE_THREAD", "1") != "0"
                 # warm-up on the thread (and stream) the capture will use: the BLAS / MIOpen handles are per thread and are
@@ -278,6 +291,7 @@ class Trainer:
                 for t in (out[0], *out[1].values()):
                     t.record_stream(cur)
                 self.steps_done += 1
+                self.__dict__["_active_graph"] = None  # an eager step re-created the gradients
                 return out
             static = tuple(t.detach().clone() for t in batch)
             from .. import grad as G
@@ -307,10 +321,21 @@ class Trainer:
                 self.graph_memsets = ops.graph_replace_memsets(g)
             g.instantiate()
             # the capture itself executed nothing: the step below is the first replay
-            ent = self._graph = {"graph": g, "batch": static, "loss": loss, "metrics": metrics}
+            # the gradients this graph's kernels write (they were materialised at capture time, in this graph's pool): with more
+            # than one cached graph the parameters' .grad must point at the replayed graph's tensors before the eager update
+            ent = self._graph = {"graph": g, "batch": static, "loss": loss, "metrics": metrics,
+                                 "grads": [(p_, p_.grad) for p_ in self.model.parameters()]}
+            self.__dict__["_active_graph"] = ent
+            while len(graphs) >= max(1, self.graph_cache_size):
+                graphs.pop(next(iter(graphs)))
+            graphs[key] = ent
         # Replays are stream-ordered like any other work since the graph holds kernel nodes only where libraries issued memsets
         # (see the capture above): no synchronisation is needed between steps and the host runs ahead.
         # ANYSTEREO_TRAIN_GRAPH_SYNC=device ends every step with torch.cuda.synchronize() (diagnostics).
+        if self.__dict__.get("_active_graph") is not ent:
+            for p_, g_ in ent["grads"]:
+                p_.grad = g_
+            self.__dict__["_active_graph"] = ent
         for dst, src in zip(ent["batch"], batch):
             dst.copy_(src)
         ent["graph"].replay()
@@ -329,6 +354,7 @@ class Trainer:
             self._poll_overflow()  # a changed scale takes effect at the next capture only: drop the graph then
             if self.overflow_events and self.overflow_events[-1][0] == self.steps_done:
                 self._graph = None
+                self.__dict__.get("_graphs", {}).clear()
         return out
 
     def _on_gpu(self) -> bool:

@@ -918,6 +918,57 @@ def test_conv7x7_c1_relu_backward_and_head_conv2():
         assert e < 5e-5, (nm, e)
 
 
+@pytest.mark.parametrize("scope", ["grads", "step"])
+def test_trainer_graphed_step_recaptures_and_matches_eager(scope, monkeypatch):
+    """The Trainer's graphed step on a small problem, against the eager step fed the same sequence of batches: warm-up, capture,
+    replays; a batch of ANOTHER shape (new query count and image size) runs one eager step, then captures its own graph; back to the
+    first shape replays the cached graph (the parameters' .grad follow the replayed graph).
+    Both scopes: the gradient half as the graph with clip + AdamW eager ("grads", the default), the whole step incl. a capturable
+    AdamW as the graph ("step")."""
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer, synthetic_train_batch
+    from anystereo.models import __models__, default_args
+    monkeypatch.setenv("ANYSTEREO_TRAIN_GRAPH_SCOPE", scope)
+    monkeypatch.setenv("ANYSTEREO_FUSED_ADAMW", "0")  # the two scopes then run the same foreach / capturable update arithmetic
+    args = default_args("continuous_IGEVStereo")
+
+    def fresh(graph):
+        m = __models__["continuous_IGEVStereo"](args)
+        fill_module_deterministic(m, base_seed=1)
+        # the reference's schedule length: the first steps sit at the bottom of the one-cycle ramp (lr / 25), so two runs stay within
+        # rounding of each other and a wrong gradient set or a stale graph cannot hide in training's own divergence
+        return Trainer(m.to(DEV), lr=2e-4, num_steps=100000, train_iters=3, max_disp=args.max_disp, graph=graph)
+
+    a = synthetic_train_batch(2, 64, 128, n_query=3000, seed=1, device=DEV)
+    b = synthetic_train_batch(1, 96, 160, n_query=2048, seed=2, device=DEV)
+    seq = [a, a, a, a, a, b, b, b, a, a]
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        eager, gr = fresh(False), fresh(True)
+        assert gr.use_graph and gr.graph_scope == scope
+        graphs, rels = [], []
+        for i, bt in enumerate(seq):
+            le, me = eager.step(tuple(t.clone() for t in bt))
+            lg, mg = gr.step(tuple(t.clone() for t in bt))
+            graphs.append(None if gr._graph is None else id(gr._graph["graph"]))
+            rels.append(abs(float(le) - float(lg)) / abs(float(le)))
+            assert rels[-1] <= 1e-3, (scope, i, float(le), float(lg), rels)
+            for k in me:  # threshold fractions over 2-3 thousand queries: a handful of queries near 1 / 3 px flip between two runs
+                tol = 2e-2 * max(abs(float(me[k])), 1e-3) if k == "epe" else 2e-2
+                assert abs(float(me[k]) - float(mg[k])) <= tol, (scope, i, k, float(me[k]), float(mg[k]))
+        assert graphs[2] is None and graphs[3] is not None and graphs[4] == graphs[3], graphs          # 3 warm-up steps, capture, replay
+        # a new shape: one eager step (solver search), capture, replay; the first shape's graph is still cached
+        assert graphs[5] is None and graphs[6] not in (None, graphs[4]) and graphs[7] == graphs[6] and graphs[8] == graphs[4] == graphs[9], graphs
+        worst = 0.0
+        for (n1, p1), (_, p2) in zip(eager.model.named_parameters(), gr.model.named_parameters()):
+            worst = max(worst, ((p1 - p2).abs().max() / p1.abs().max().clamp_min(1e-12)).item())
+        print(f"[graphed Trainer, scope {scope}] relative loss differences per step {[f'{r:.1e}' for r in rels]}; worst parameter deviation {worst:.2e}")
+        assert worst < 5e-3, worst
+    finally:
+        torch.backends.cudnn.deterministic = prev
+
+
 @pytest.mark.parametrize("batched", [False, True])
 def test_training_fused_liif_mlp_equals_layered(batched):
     """Training forward / backward with the upsampler's per-query MLP as one forward kernel + one recomputing data-gradient kernel
