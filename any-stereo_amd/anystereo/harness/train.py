@@ -50,8 +50,11 @@ def shard_batch(batch, rank: int, world: int):
 
 
 class Trainer:
-    """model.train() + freeze_bn + (DDP when a process group exists) + AdamW/OneCycleLR; `step(batch)` runs
-    harness.metrics.train_step and returns (loss, metrics).
+    """model.train() + freeze_bn + gradient exchange when a process group exists + AdamW/OneCycleLR; `step(batch)` runs
+    harness.metrics.train_step — by default with its gradient half replayed as a captured hipGraph (see __init__) — and returns
+    (loss, metrics).
+
+    Eager multi-rank steps (`graph=False`) go through DDP:
 
     DDP without `find_unused_parameters`: in the `multi_training` branch the loss sees only the GRU predictions
     (train_continuous_IGEV.py:219), and the loop detaches `disp` at every iteration (continuous_IGEVstereo.py:285), so the
@@ -243,9 +246,10 @@ class Trainer:
 
     def _step_graphed(self, batch, sync_grads=True):
         """The step as a hipGraph replay: inputs are copied into static buffers, the captured graph holds zero_grad (gradients
-        re-materialise at fixed addresses in the graph's pool), forward, the synchronisation-free loss, backward, the loss-scale
-        division, clip_grad_norm_ and the capturable AdamW; the OneCycleLR scheduler runs on the host and writes the device-side
-        learning rate between replays.  Returns clones of the static loss / metric tensors."""
+        re-materialise at fixed addresses in the graph's pool), forward, the synchronisation-free loss, backward and the loss-scale
+        division; the gradient exchange, clip_grad_norm_ and AdamW run eagerly behind it (scope "grads") or — scope "step", one
+        rank — clip and a capturable AdamW are part of the graph and the OneCycleLR scheduler writes the device-side learning rate
+        between replays.  Returns clones of the static loss / metric tensors."""
         # one captured graph per batch shape (LRU of `graph_cache_size`: each holds a memory pool with a whole step); a shape seen for
         # the first time runs eagerly first — MIOpen's solver search (timed trial launches) and the allocator's growth cannot happen
         # inside a capture
