@@ -92,7 +92,10 @@ class Trainer:
         if self.ddp_impl not in ("ddp", "flat"):
             raise ValueError(f"Trainer: ddp_impl={self.ddp_impl!r} (ddp | flat)")
         # (ANYSTEREO_OVERFLOW_POLICY=skip decides per step on the host whether the update runs: eager only)
-        self.use_graph = bool(graph) and p0.is_cuda and not mixed_precision and os.environ.get("ANYSTEREO_OVERFLOW_POLICY", "poll") != "skip"
+        # the graphed step computes the loss without host synchronisation (a boolean-mask loss cannot be captured): a caller who
+        # turns that form off (ANYSTEREO_SYNC_FREE_LOSS=0) gets the eager step
+        self.use_graph = (bool(graph) and p0.is_cuda and not mixed_precision and os.environ.get("ANYSTEREO_OVERFLOW_POLICY", "poll") != "skip"
+                          and os.environ.get("ANYSTEREO_SYNC_FREE_LOSS", "1") != "0")
         if self.use_graph and self._want_ddp:
             self.ddp_impl = "flat"
         self.graph_warmup = int(os.environ.get("ANYSTEREO_TRAIN_GRAPH_WARMUP", "3"))
@@ -128,6 +131,34 @@ class Trainer:
         # the loss as masked sums without host synchronisation (harness/metrics.py); ANYSTEREO_SYNC_FREE_LOSS=0 = the reference's
         # boolean-mask statement (16 + 3 synchronisations per step)
         self.sync_free_loss = os.environ.get("ANYSTEREO_SYNC_FREE_LOSS", "1") != "0"
+
+    def _sync_module_state(self):
+        """Rank 0's parameters and buffers on every rank — what DistributedDataParallel's constructor does for the "ddp" exchange
+        and nothing did for the "flat" one (a bare module): ranks that built the model under different RNG state, or where only
+        rank 0 loaded a checkpoint, would otherwise average gradients taken at different weights.  Once, before the first step."""
+        if self.__dict__.get("_state_synced") or not (td.is_available() and td.is_initialized() and td.get_world_size() > 1):
+            return
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + [b for b in self.model.buffers() if b is not None]:
+                if not t.numel():
+                    continue
+                if t.is_contiguous():
+                    td.broadcast(t.data, 0)
+                else:
+                    c = t.data.contiguous()
+                    td.broadcast(c, 0)
+                    t.data.copy_(c)
+        self._state_synced = True
+
+    def _collective_max(self, n: int) -> int:
+        """max over the ranks of a per-rank event count: every decision that changes the loss scale, drops an update or drops a
+        captured graph is taken from this number, so all ranks take the same branch at the same step."""
+        if not (self._want_ddp and td.get_world_size() > 1):
+            return int(n)
+        dev = next(self.model.parameters()).device if td.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return int(t.item())
 
     def _wrap_ddp(self, batch):
         """Probe pass on the bare module -> freeze gradient-less parameters -> wrap (see the class docstring)."""
@@ -193,6 +224,8 @@ class Trainer:
         """One optimisation step.  sync_grads=False (measurement only): DDP's reducer is bypassed (`no_sync`), every rank
         steps on its local gradient — what a step costs without the all-reduce."""
         flat = self._want_ddp and self.ddp_impl == "flat"
+        if flat:
+            self._sync_module_state()
         if self._want_ddp and not flat and self.module is self.model:
             self._wrap_ddp(batch)
         # BatchNorm2d stays frozen whatever the caller did in between (validation's .eval(), a bare .train())
@@ -238,6 +271,12 @@ class Trainer:
                          loss_scale=self.loss_scale, sync_free_loss=self.sync_free_loss, phase="grads")
         if sync_grads:
             self.allreduce_gradients_flat()
+            if self.scaler is not None and td.get_world_size() > 1:
+                # unscale_ ran before the exchange: its per-rank inf/NaN flags become the group's, or some ranks would step (and
+                # shrink their scale) while others do not
+                st = self.scaler._per_optimizer_states.get(id(self.optimizer), {})
+                for f in st.get("found_inf_per_device", {}).values():
+                    td.all_reduce(f, op=td.ReduceOp.MAX)
         train_step(self.model, self.optimizer, self.scheduler, self.scaler, None, self.train_iters, should_step=gate, phase="update")
         self.steps_done += 1
         if watch and gate is None and self.overflow_check_every > 0 and self.steps_done % self.overflow_check_every == 0:
@@ -255,7 +294,7 @@ class Trainer:
         # inside a capture
         graphs = self.__dict__.setdefault("_graphs", {})
         warm = self.__dict__.setdefault("_warm", {})
-        key = tuple(tuple(t.shape) for t in batch)
+        key = tuple(tuple(t.shape) if torch.is_tensor(t) else ("scalar", float(t)) for t in batch)
         ent = graphs.pop(key, None)
         if ent is not None:
             graphs[key] = ent  # most recently used last
@@ -297,6 +336,7 @@ class Trainer:
                 self.steps_done += 1
                 self.__dict__["_active_graph"] = None  # an eager step re-created the gradients
                 return out
+            batch = tuple(t if torch.is_tensor(t) else torch.full((batch[0].shape[0], 1), float(t), device=batch[0].device) for t in batch)
             static = tuple(t.detach().clone() for t in batch)
             from .. import grad as G
             G.begin_forward()  # no anchor (and no autograd node) of the warm-up steps survives into the capture
@@ -323,6 +363,19 @@ class Trainer:
             if os.environ.get("ANYSTEREO_TRAIN_GRAPH_FILL", "1") != "0":
                 from .. import ops
                 self.graph_memsets = ops.graph_replace_memsets(g)
+            left = self._collective_max(self.graph_memsets[1])
+            if left:
+                # a memset node that could not be rewritten (unreadable parameters, an element size the fill kernel does not serve)
+                # would be replayed unordered: stale loss / zero gradients from the second replay on.  No graph then, on any rank.
+                import warnings
+                warnings.warn(f"anystereo Trainer: {left} memset node(s) of the captured step could not be rewritten as kernels; "
+                              "the step stays eager", RuntimeWarning)
+                self.use_graph = False
+                self._graph = None
+                graphs.clear()
+                del g
+                self.optimizer.zero_grad(set_to_none=True)
+                return self.step(batch, sync_grads)
             g.instantiate()
             # the capture itself executed nothing: the step below is the first replay
             # the gradients this graph's kernels write (they were materialised at capture time, in this graph's pool): with more
@@ -343,6 +396,18 @@ class Trainer:
         for dst, src in zip(ent["batch"], batch):
             dst.copy_(src)
         ent["graph"].replay()
+        if self.graph_scope == "step":
+            # the replayed AdamW wrote the parameters behind autograd's back: bump their version counters so that every
+            # (data_ptr, _version)-keyed cache (weight packs, BatchNorm folds, the inference graph's fingerprint) sees the update —
+            # an evaluation pass between training steps would otherwise run on the packs of its first call
+            ps = self.__dict__.get("_all_params")
+            if ps is None:
+                ps = self.__dict__["_all_params"] = [p_ for p_ in self.model.parameters() if p_.requires_grad]
+            try:
+                torch._C._autograd._unsafe_set_version_counter(ps, [p_._version + 1 for p_ in ps])
+            except (AttributeError, TypeError):
+                with torch.no_grad():
+                    torch._foreach_mul_(ps, 1.0)
         if self.graph_scope != "step":
             if self._want_ddp and sync_grads:
                 self.allreduce_gradients_flat()
@@ -368,7 +433,7 @@ class Trainer:
         """Read and reset the split kernels' saturation counters (synchronises); on an event halve the loss scale (never
         below 1) and record it.  Returns the number of waves that saturated since the last poll."""
         from .. import ops
-        n = ops.split_overflow_count(reset=True)
+        n = self._collective_max(ops.split_overflow_count(reset=True))  # every rank polls at the same step index
         if n:
             before = self.loss_scale
             self.loss_scale = max(1.0, self.loss_scale * 0.5)

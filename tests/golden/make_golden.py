@@ -94,6 +94,57 @@ def golden_train(RefIGEV, RefRAFT, ns2):
     torch.set_grad_enabled(False)
 
 
+def golden_train_sensitivity(RefIGEV, RefRAFT, ns2, seeds=32, rel=1e-6):
+    """G8 companion: how far the imported reference's OWN gradients move when its two input images are perturbed by a relative
+    N(0, rel) — the size of the forward differences between two correct fp32 implementations (summation order, another library
+    convolution algorithm).  The gradient of a ReLU network is piecewise constant in its activation pattern: a handful of the
+    ~10^6 pre-activations of the tiny fixture lie within 1e-6 (relative) of zero, each one that changes side moves individual
+    gradient tensors by a DISCRETE amount (RAFT convd1.weight: 5e-4 ... 1e-2 of its maximum per flip; disp_head.conv2.weight:
+    1e-7).  Stored per parameter: the largest relative deviation of its gradient norm; per stored full tensor: the largest
+    max-norm deviation relative to the tensor's maximum.  tests/test_hip_parity.py::test_training_step_vs_reference derives its
+    per-tensor limits from these numbers instead of one fixed tolerance."""
+    torch.set_grad_enabled(True)
+    for name, Ref in (("igev", RefIGEV), ("raft", RefRAFT)):
+        args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
+        model = Ref(args)
+        fill_module_deterministic(model, base_seed=1)
+        model.train()
+        model.freeze_bn()
+        H, W, img1, img2, coord, gt, scale = tiny_train_case(name)
+
+        def run(seed):
+            a, b = img1, img2
+            if seed is not None:
+                g = torch.Generator().manual_seed(1000 + seed)
+                a = a * (1.0 + rel * torch.randn(a.shape, generator=g))
+                b = b * (1.0 + rel * torch.randn(b.shape, generator=g))
+            model.zero_grad(set_to_none=True)
+            res = model(a, b, iters=3, hr_coord=coord.clone(), scale=scale)
+            preds = res[1] if name == "igev" else res
+            loss, _ = ns2["sequence_loss_multiscale"](preds, gt, ((gt < 512) & (gt > 0)).float(), max_disp=args.max_disp)
+            loss.backward()
+            return {n: p.grad.detach().double().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        g0 = run(None)
+        names = sorted(g0)
+        n0 = np.array([float(g0[n].norm()) for n in names])
+        norm_dev = np.zeros(len(names))
+        full_dev = np.zeros(len(TRAIN_FULL[name]))
+        full_dev_p90 = np.zeros(len(TRAIN_FULL[name]))
+        for s in range(seeds):
+            g = run(s)
+            nn_ = np.array([float(g[n].norm()) for n in names])
+            norm_dev = np.maximum(norm_dev, np.abs(nn_ - n0) / (n0 + 1e-6 * n0.max()))
+            for i, n in enumerate(TRAIN_FULL[name]):
+                d = (g[n] - g0[n]).abs() / g0[n].abs().max()
+                full_dev[i] = max(full_dev[i], float(d.max()))
+                full_dev_p90[i] = max(full_dev_p90[i], float(d.flatten().kthvalue(max(1, int(0.9 * d.numel()))).values))
+            print(name, "seed", s, "full_dev", " ".join(f"{v:.1e}" for v in full_dev), flush=True)
+        save(f"train_{name}_sens", names=np.array(names), norm_dev=norm_dev, full_names=np.array(TRAIN_FULL[name]), full_dev=full_dev,
+             full_dev_p90=full_dev_p90, seeds=seeds, rel=rel)
+    torch.set_grad_enabled(False)
+
+
 def main(only=None):
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
@@ -148,13 +199,15 @@ def main(only=None):
 
     if only == "update":
         return gen_update()
-    if only == "train":
+    if only in ("train", "train_sens"):
         import ast
         import torch.nn.functional as F
         tree = ast.parse(open(os.path.join(REF, "train_continuous_IGEV.py")).read())
         fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "sequence_loss_multiscale"][0]
         ns2 = {"torch": torch, "F": F}
         exec(compile(ast.Module(body=[fn], type_ignores=[]), "train_continuous_IGEV.py", "exec"), ns2)
+        if only == "train_sens":
+            return golden_train_sensitivity(RefIGEV, RefRAFT, ns2)
         return golden_train(RefIGEV, RefRAFT, ns2)
 
     # ---- G1/G2/G3: correlation, pyramids, lookup (IGEV: L=2,G=8; RAFT: L=4,G=0) ------------------
@@ -301,10 +354,11 @@ def main(only=None):
 
     # ---- G8: training step (loss + parameter gradients) -------------------------------------------
     golden_train(RefIGEV, RefRAFT, ns2)
+    golden_train_sensitivity(RefIGEV, RefRAFT, ns2)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["train", "update"], default=None,
-                    help="regenerate only the G8 training-step fixtures / only the G5 flag-combination fixtures")
+    ap.add_argument("--only", choices=["train", "train_sens", "update"], default=None,
+                    help="regenerate only the G8 training-step fixtures / their perturbation sensitivities / only the G5 flag-combination fixtures")
     main(ap.parse_args().only)

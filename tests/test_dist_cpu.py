@@ -136,6 +136,74 @@ def test_ddp_training_step_world2(kind, impl):
             assert worst == worst and mean_loss == mean_loss and mean_loss > 0
 
 
+def _state_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path[:0] = [root, os.path.join(root, "any-stereo_amd")]
+    import warnings
+    import torch.distributed as td
+    from anystereo import ops
+    from anystereo.harness import dist
+    from anystereo.harness.synthetic import fill_module_deterministic, tiny_train_case
+    from anystereo.harness.train import Trainer, shard_batch
+    from anystereo.models import default_args
+    from oracle.model import OracleRAFT
+    torch.set_num_threads(2)
+    r, w, _ = dist.init("gloo")
+    args = default_args("continuous_RAFTStereo")
+    model = OracleRAFT(args)
+    fill_module_deterministic(model, base_seed=1 + 17 * r)  # every rank starts from DIFFERENT weights (per-rank RNG / only rank 0 loaded)
+    tr = Trainer(model, num_steps=50, train_iters=2, max_disp=args.max_disp, ddp_impl="flat")
+    _, _, img1, img2, coord, gt, scale = tiny_train_case("raft")
+    tr.step(shard_batch((img1, img2, coord, gt, scale), r, w))
+    flat = torch.cat([t.detach().reshape(-1).double() for t in list(model.parameters()) + list(model.buffers())])
+    sums = [torch.zeros(2, dtype=torch.float64) for _ in range(w)]
+    td.all_gather(sums, torch.stack([flat.sum(), flat.abs().sum()]))
+    # overflow handling is a group decision: only rank 1 "saw" saturated operands, both ranks halve the scale at the same step
+    tr.loss_scale = 4096.0
+    ops_count = ops.split_overflow_count
+    ops.split_overflow_count = lambda reset=True: 3 if r == 1 else 0
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            n = tr._poll_overflow()
+            gate = tr._overflow_gate()
+    finally:
+        ops.split_overflow_count = ops_count
+    dist.finalize()
+    q.put((r, [s_.tolist() for s_ in sums], n, tr.loss_scale, gate, tr.skipped_steps))
+
+
+def test_flat_exchange_broadcasts_rank0_state_and_overflow_is_collective_world2():
+    """ddp_impl "flat" (what a graphed multi-rank step uses) on ranks built from different weights: rank 0's parameters and buffers
+    are broadcast before the first step (the role of DistributedDataParallel's constructor), so the ranks hold identical
+    parameters after it; a split-precision overflow seen by ONE rank halves the loss scale / drops the update on BOTH."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_state_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = []
+    for _ in range(600):
+        try:
+            res.append(q.get(timeout=0.5))
+        except Exception:
+            assert all(p.exitcode in (None, 0) for p in ps), "a rank died"
+        if len(res) == len(ps):
+            break
+    assert len(res) == len(ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r, sums, n, scale, gate, skipped in sorted(res):
+        assert sums[0] == sums[1], "ranks that started from different weights were not synchronised"
+        assert n == 3 and scale == 1024.0, (r, n, scale)      # two collective polls (poll + gate), each halving on both ranks
+        assert gate is False and skipped == 1
+
+
 def test_bench_launcher_spawns_ranks_world2():
     """`python bench.py --gpus 2` without torchrun: the parent spawns 2 ranks itself (it never imports torch or touches a
     GPU), the ranks rendezvous on 127.0.0.1, and rank 0 prints ONE JSON line with n_gpus = 2 and one value per rank.  Here

@@ -771,27 +771,35 @@ def test_liif_gather_and_convex_backward(scale):
     close(ad.grad, rd.grad, 1e-4, 1e-5, "d disp (plain)")
 
 
-# Tolerances = what BOTH arithmetic modes achieve on the GPU (round 3, GPUTEST log): gradient norms within 6.5e-3 (worst: the
-# BatchNorm3d affine gradients of the cost-volume stem — sums of large cancelling terms over MIOpen's batch statistics — and the
-# biases under the RAFT feature net's InstanceNorm), elements within 1.1e-3 of the tensor's maximum, 9e-3 for `corr_stem.*`.
-# Split (3 x fp16) and exact-fp32 MFMA mode are indistinguishable here (medians 3e-5 / 5e-5): what is left comes from the
-# library layers (norm statistics, atomics), not from the matrix-core mode, so split mode needs no looser bound.
-G8_TOL = {"fp32": (1e-2, 2e-3, 1.5e-2), "split": (1e-2, 2e-3, 1.5e-2)}  # (gradient-norm rel, element rtol, element rtol of corr_stem.*)
+# G8 limits.  The gradient of a ReLU network is piecewise constant in its activation pattern, and the tiny fixture has ~10^6
+# pre-activations of which a handful lie within 1e-6 (relative) of zero: whichever side an implementation's rounding puts them on
+# moves individual gradient tensors by a DISCRETE amount — RAFT `convd1.weight` by 5.2e-4, 7.5e-4, 2.5e-3 or 1.47e-2 of its maximum
+# (one element each; the fp64 CPU oracle shows exactly these steps when its input images are perturbed by 1e-6 relative, and the
+# round-3 driver run landed on the 1.47e-2 one because MIOpen picks its forward algorithms by measured time, per box:
+# DESIGN.md §2 "G8", profiles/r04_g8_stress_*.txt).  One fixed element tolerance therefore either hides regressions of the smooth
+# tensors or fails on an unlucky box.  The limits are per tensor: tests/golden/train_*_sens.npz holds, from the IMPORTED REFERENCE
+# itself, the largest deviation of every gradient norm and of every stored gradient under 32 such perturbations (make_golden.py
+# --only train_sens); a tensor's limit is 3x that deviation, floored by 3x the worst value the product showed over the round-4
+# stress leases for tensors the perturbations do not move (G8_FLOOR_*).
+G8_FLOOR_ELEM = 2e-4   # stored gradients: max |d| / max |g|
+G8_FLOOR_NORM = 2e-3   # gradient norms, relative
+G8_CAP_ELEM, G8_CAP_NORM = 5e-2, 5e-2  # no fixture deviation buys more than this
 
 
-@pytest.mark.parametrize("mode", ["split", "fp32"])
-@pytest.mark.parametrize("name", ["igev", "raft"])
-def test_training_step_vs_reference(name, mode):
-    """One training forward/backward of the product model (train mode, frozen BatchNorm2d, 3 GRU iterations with the
-    LIIF upsampler every iteration, sequence_loss_multiscale) on the GPU vs the loss and parameter gradients captured
-    from the imported reference (tests/golden/train_*.npz, G8), in both matrix-core modes, the split mode with the trainer's
-    loss scale (harness/train.py) as a training step runs it."""
+def _g8_limits(name):
     import numpy as np
+    s = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}_sens.npz"))
+    elem = {str(n): min(G8_CAP_ELEM, max(G8_FLOOR_ELEM, 3.0 * float(d))) for n, d in zip(s["full_names"], s["full_dev"])}
+    norm = {str(n): min(G8_CAP_NORM, max(G8_FLOOR_NORM, 3.0 * float(d))) for n, d in zip(s["names"], s["norm_dev"])}
+    return elem, norm
+
+
+def _g8_run(name, mode):
+    """The G8 step of the product model: (loss, predictions, {parameter: gradient / loss scale}, model)."""
     from anystereo import ops
     from anystereo.harness.metrics import sequence_loss_multiscale
     from anystereo.harness.synthetic import fill_module_deterministic, tiny_train_case
     from anystereo.models import __models__, default_args
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}.npz"))
     args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
     model = __models__[args.model](args)
     fill_module_deterministic(model, base_seed=1)
@@ -809,28 +817,67 @@ def test_training_step_vs_reference(name, mode):
         gtd = gt.to(DEV)
         loss, _ = sequence_loss_multiscale(preds, gtd, ((gtd < 512) & (gtd > 0)).float(), max_disp=args.max_disp)
         (loss * ls).backward()
+        torch.cuda.synchronize()
     finally:
         torch.backends.cudnn.deterministic = prev
         ops.set_precision(prev_mode)
-    assert abs(loss.item() - float(z["loss"])) < 1e-3 * abs(float(z["loss"])), (loss.item(), float(z["loss"]))
-    assert (preds[-1].detach().cpu() - torch.from_numpy(z["last_pred"])).abs().mean().item() < 1e-3
-    named = dict(model.named_parameters())
+    grads = {n: p.grad.detach() / ls for n, p in model.named_parameters() if p.grad is not None}
+    return loss.detach(), [p.detach() for p in preds], grads
+
+
+@pytest.mark.parametrize("mode", ["split", "fp32"])
+@pytest.mark.parametrize("name", ["igev", "raft"])
+def test_training_step_vs_reference(name, mode):
+    """One training forward/backward of the product model (train mode, frozen BatchNorm2d, 3 GRU iterations with the
+    LIIF upsampler every iteration, sequence_loss_multiscale) on the GPU vs the loss and parameter gradients captured
+    from the imported reference (tests/golden/train_*.npz, G8), in both matrix-core modes, the split mode with the trainer's
+    loss scale (harness/train.py) as a training step runs it.  Limits per tensor: see _g8_limits."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}.npz"))
+    loss, preds, grads = _g8_run(name, mode)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5 * abs(float(z["loss"])), (loss.item(), float(z["loss"]))
+    assert (preds[-1].cpu() - torch.from_numpy(z["last_pred"])).abs().mean().item() < 2e-4
     names = [str(n) for n in z["names"]]
-    assert sorted(n for n, p in named.items() if p.grad is not None) == names
-    norms = np.array([float(named[n].grad.double().norm()) / ls for n in names])
+    assert sorted(grads) == names
+    lim_e, lim_n = _g8_limits(name)
+    norms = np.array([float(grads[n].double().norm()) for n in names])
     rel = np.abs(norms - z["norms"]) / (z["norms"] + 1e-6 * z["norms"].max())
-    order = np.argsort(-rel)[:3]
+    ratio = rel / np.array([lim_n[n] for n in names])
+    order = np.argsort(-ratio)[:3]
     print(f"[G8 {name} {mode}] loss rel {abs(loss.item() - float(z['loss'])) / abs(float(z['loss'])):.2e}; grad-norm rel max "
-          f"{rel.max():.3e}, median {np.median(rel):.3e}; worst: " + ", ".join(f"{names[i]} {rel[i]:.2e}" for i in order))
-    tol_n, tol_e, tol_bn3d = G8_TOL[mode]
-    assert rel.max() < tol_n, f"{name}: grad-norm mismatch {rel.max():.3e} at {names[int(rel.argmax())]}"
+          f"{rel.max():.3e}, median {np.median(rel):.3e}; closest to their limits: "
+          + ", ".join(f"{names[i]} {rel[i]:.2e} / {lim_n[names[i]]:.1e}" for i in order))
+    assert ratio.max() < 1.0, f"{name}: grad-norm mismatch {rel[int(ratio.argmax())]:.3e} at {names[int(ratio.argmax())]}"
     # element-wise, on one tensor per operator family, relative to the tensor's max
     for i, n in enumerate(str(x) for x in z["full_names"]):
         want = torch.from_numpy(z[f"g{i}"])
-        got = named[n].grad.detach().cpu() / ls
+        got = grads[n].cpu()
         e = ((got - want).abs().max() / want.abs().max()).item()
-        print(f"[G8 {name} {mode}] {n}: max |d| / max |g| = {e:.2e}")
-        close(got, want, rtol=tol_bn3d if n.startswith("corr_stem") else tol_e, atol=1e-6, what=n)
+        print(f"[G8 {name} {mode}] {n}: max |d| / max |g| = {e:.2e} (limit {lim_e[n]:.1e})")
+        close(got, want, rtol=lim_e[n], atol=1e-6 * want.abs().max().item(), what=n)
+
+
+@pytest.mark.parametrize("name", ["igev", "raft"])
+def test_training_step_is_bit_repeatable(name):
+    """The G8 step twice in one process, fresh model each time (a race or an uninitialised read shows up here,
+    on any box, as a difference between two runs of the same program).  The forward is required to be BIT-equal: loss and every
+    prediction.  The backward starts with the upsampler's scatter-adds (float atomics, as in ATen: the summation order of a
+    pixel's queries varies between launches), so every gradient downstream may differ in its last bits; required: every stored
+    full gradient within 2e-6 of its maximum between the two runs, and bit-equal under ANYSTEREO_DETERMINISTIC=1 (gather-form
+    scatter kernels, fixed summation order) when that mode is available."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}.npz"))
+    l0, p0, g0 = _g8_run(name, "split")
+    l1, p1, g1 = _g8_run(name, "split")
+    assert torch.equal(l0, l1), "loss differs between two runs of the same step"
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b), "a prediction differs between two runs of the same step"
+    worst = 0.0
+    for n in (str(x) for x in z["full_names"]):
+        d = ((g0[n] - g1[n]).abs().max() / g0[n].abs().max()).item()
+        worst = max(worst, d)
+        assert d < 2e-6, f"{n}: run-to-run gradient difference {d:.2e} of its maximum"
+    print(f"[G8 repeat {name}] forward bit-equal; stored gradients differ by at most {worst:.1e} of their maxima between two runs")
 
 
 @pytest.mark.parametrize("name", ["igev", "raft"])
