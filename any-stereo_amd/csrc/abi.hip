@@ -3,7 +3,9 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <set>
 #include <unordered_set>
+#include <utility>
 
 #include "common.h"
 
@@ -51,10 +53,25 @@ int zero_fill(float* p, long long n, hipStream_t s) {
 }
 
 void lds_opt_in(const void* kernel) {
+  // keyed on (device, kernel): the attribute is applied to the CURRENT device's copy of the function, so a process that drives
+  // a second GPU must opt that device's copy in as well.  A kernel is marked done only when the runtime accepted the attribute;
+  // a refusal is recorded (as_last_error_string) and retried at the next launch, which then fails in check_launch with the cause.
   static std::mutex m;
-  static std::unordered_set<const void*> done;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = -1;
+  }
   std::lock_guard<std::mutex> lock(m);
-  if (done.insert(kernel).second) (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (done.count({dev, kernel})) return;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) {
+    done.insert({dev, kernel});
+  } else {
+    (void)hipGetLastError();
+    (void)fail(AS_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KB) on device %d: %s", dev, hipGetErrorString(e));
+  }
 }
 
 }  // namespace as

@@ -875,6 +875,10 @@ typedef __attribute__((address_space(1))) const void as_gbl_void;
 //   -DAS_ABL_NO_W / -DAS_ABL_NO_P   timing-only: the loaders skip the global loads of the weight image / the halo patch
 //                     after the first unit (stale registers are stored instead: results are wrong, the instruction
 //                     stream, LDS traffic and barriers stay)
+//   -DAS_ABL_NO_DMA   timing-only, all-DMA path: no unit is staged after the first one (the consumers alone)
+//   -DAS_ABL_MFMA_TAPS=N  timing-only: the consumers run the operand reads + MFMAs of the first N taps of every unit only
+//                     (N = 0: staging alone; N = 4 | 5 of 9: the resource profile of a Winograd F(2x2,3x3) | F(4,3) kernel of
+//                     this tiling — the same bytes staged per block, 1/2.25 | 1/2 of the matrix instructions)
 #ifdef AS_CONV_STAMPS
 constexpr int kStampBlocks = 1024, kStampSlots = 16;
 __device__ unsigned long long as_conv_stamp_buf[kStampBlocks * kStampSlots];
@@ -942,6 +946,11 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   // exactly like four taps of one chunk (weight image [sub-chunk][comp][h][co][8], one patch sub-image per sub-chunk).
   constexpr int NSC = (KS == 1) ? 4 : 1;
   constexpr int NTAPE = NTAP * NSC;          // "taps" of a unit's weight image
+#ifdef AS_ABL_MFMA_TAPS
+  constexpr int NTAPC = (AS_ABL_MFMA_TAPS) < NTAPE ? (AS_ABL_MFMA_TAPS) : NTAPE;  // diagnostic builds: taps the consumers execute
+#else
+  constexpr int NTAPC = NTAPE;
+#endif
   constexpr int WSEG = BN * 16;              // bytes of one (tap, comp, h) weight segment
   constexpr int WCHUNK = NTAPE * 4 * WSEG;   // bytes of one unit's weight image
   constexpr int NWD = WCHUNK / 16 / 256;     // 16-B LDS-DMA pieces per loader thread per chunk
@@ -1053,10 +1062,10 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
     acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0); \
   }
 #define AS_SPLIT_STEP(TAP)                                                                              \
-  if constexpr ((TAP) < NTAPE) {                                                                        \
+  if constexpr ((TAP) < NTAPC) {                                                                        \
     AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if constexpr ((TAP) + 1 < NTAPE) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                          \
+    if constexpr ((TAP) + 1 < NTAPC) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                          \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
     AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
@@ -1276,7 +1285,9 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+#ifndef AS_ABL_NO_DMA
           if (chunk + 1 < chunk_hi) AS_DMA_UNIT(chunk + 1, ((chunk - chunk_lo) & 1) ^ 1)
+#endif
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();  // unit c+1 landed, consumers finished unit c
         }

@@ -67,6 +67,10 @@ def parse(argv=None):
                     help="infer = the headline benchmark (default); train = cfg 4: DDP training steps at 160x320, 16 GRU iterations")
     ap.add_argument("--batch-per-gpu", type=int, default=4, help="train mode: samples per rank (global batch 32 = 4 x 8)")
     ap.add_argument("--train-iters", type=int, default=16)
+    ap.add_argument("--train-quick", action="store_true",
+                    help="train mode: the timed steps and the dominant kernel's roofline only (no eager comparison, no CPU baseline): "
+                         "what the default inference run starts as a child process for its `train_mode` object")
+    ap.add_argument("--no-train-mode", action="store_true", help="infer mode: skip the `train_mode` object (cfg 4, 1 rank, child process)")
     return ap.parse_args(argv)
 
 
@@ -242,6 +246,39 @@ def load_pmc_traffic():
 # ------------------------------------------------------------------------------------------------------------------
 
 
+# arithmetic of the training step, spelled out: storage, accumulation, loss, norms, optimizer in fp32; the
+# matrix-core products of forward and data gradient are the 3 x f16 split (22 significand bits), those of the batched weight
+# gradient a 2-term bf16 split (hi.hi + hi.lo + lo.hi, ~16 significand bits, fp32's exponent range)
+TRAIN_DTYPE = "fp32 storage and accumulation; forward + dgrad 3xf16 split MFMA (22 bits); wgrad 2-term bf16 split MFMA (~16 bits)"
+
+
+def train_mode_child(a, steps=5, warmup=4, timeout=420):
+    """cfg 4 inside the DEFAULT run's line: `bench.py --mode train --train-quick` at 1 rank as a CHILD process
+    (its own HIP context; a crash or a hang there cannot take the headline line with it), 3 eager warm-up steps + the capture +
+    `steps` graphed steps.  Returns the child's line reduced to what the driver should see, or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+           "--train-quick", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    except subprocess.TimeoutExpired:
+        return {"error": f"child timed out after {timeout} s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child exit {r.returncode}: {r.stderr[-300:]}"}
+    d = json.loads(lines[-1])
+    import math
+    return {"workload": d["config"]["workload"], "global_batch": d["config"]["global_batch"], "n_gpus": d["n_gpus"],
+            "metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            "warmup": d["warmup"], "dtype": d["dtype"], "loss_first_last": d["loss_first_last"],
+            "loss_finite": all(math.isfinite(v) for v in d["loss_first_last"]), "trainer": d["trainer"], "loss_scale": d["loss_scale"],
+            "split_overflow_events": d["split_overflow"]["events"], "roofline": d["roofline"],
+            "how": "child process `bench.py --mode train --train-quick`, inputs resident, graphed gradient half + eager clip/AdamW",
+            "child_wall_s": round(time.perf_counter() - t0, 1)}
+
+
 def train_main(a, rank, world, local):
     """SURVEY.md §8d cfg 4: IGEV training, 4 samples per GPU at 160x320 network input, 51 200 HR queries per sample, 16 GRU
     iterations with the LIIF upsampler every iteration, AdamW + OneCycleLR; one process per GPU, DDP over RCCL.  A step =
@@ -305,7 +342,9 @@ def train_main(a, rank, world, local):
                    "exposed_allreduce_ms": round(ms_sync - ms_nosync, 2), "gradient_bytes": nbytes,
                    "ddp": tr.ddp_mode}
     roof = cpu = eager = None
-    if rank == 0 and world == 1 and not a.no_extras:
+    if rank == 0 and world == 1 and a.train_quick:
+        roof = train_roofline(a, batch, dev)
+    elif rank == 0 and world == 1 and not a.no_extras:
         try:
             eager = train_eager_step(a, args, batch, dev)
         except Exception as ex:  # never lose the headline line to the side measurement
@@ -318,7 +357,7 @@ def train_main(a, rank, world, local):
         print(json.dumps({
             "metric": "train_samples_per_s", "value": round(world * a.batch_per_gpu * a.steps / dt, 3), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": TRAIN_DTYPE, "data": "synthetic",
             "config": {"workload": f"cfg4 continuous_IGEVStereo training {h}x{w}, {a.train_iters} GRU iters, LIIF every iter, "
                                    f"Q={batch[2].shape[1]} queries/sample, AdamW+OneCycleLR, clip 1.0",
                        "global_batch": world * a.batch_per_gpu, "parallelism": f"ddp x{world} (RCCL all-reduce of {nparam} fp32 grads)"},
@@ -811,6 +850,14 @@ def infer_main(a, rank, world, local):
                 del r1, m1, o1
             except Exception as ex:
                 others["cfg1"] = {"error": repr(ex)}
+        train_mode = None
+        if extras and world == 1 and wl.name == "cfg2" and not a.no_train_mode:
+            # this process is idle on the GPU now: the child has the chip to itself
+            torch.cuda.synchronize()
+            try:
+                train_mode = train_mode_child(a)
+            except Exception as ex:
+                train_mode = {"error": repr(ex)[:300]}
         line = {
             "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",
             "value": round(world * nb * a.steps / dt, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -838,6 +885,7 @@ def infer_main(a, rank, world, local):
             "reduced_precision_mode": reduced,
             "other_configs": others,
             "throughput_mode": batched,
+            "train_mode": train_mode,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -573,6 +573,11 @@ def test_default_bench_command_produces_its_line():
     assert d["roofline"]["frac"] > 0 and d["fp32_mode"]["value"] > 0 and d["reduced_precision_mode"]["value"] > 0
     assert set(d["other_configs"]) >= {"cfg1", "cfg3", "cfg5"} and all(v["finite"] for v in d["other_configs"].values())
     assert d["library"]["matches_sources"] is True
+    # cfg 4 rides in the same line (a child process: 1 rank, graphed steps)
+    tm = d["train_mode"]
+    assert "error" not in tm, tm
+    assert tm["metric"] == "train_samples_per_s" and tm["value"] > 0 and tm["loss_finite"] and tm["trainer"]["graph"] is True
+    assert tm["roofline"]["frac"] > 0 and "wgrad" in tm["dtype"]
 
 
 @pytest.mark.gpu

@@ -781,8 +781,11 @@ def test_liif_gather_and_convex_backward(scale):
 # itself, the largest deviation of every gradient norm and of every stored gradient under 32 such perturbations (make_golden.py
 # --only train_sens); a tensor's limit is 3x that deviation, floored by 3x the worst value the product showed over the round-4
 # stress leases for tensors the perturbations do not move (G8_FLOOR_*).
-G8_FLOOR_ELEM = 2e-4   # stored gradients: max |d| / max |g|
-G8_FLOOR_NORM = 2e-3   # gradient norms, relative
+G8_FLOOR_ELEM = 3e-5   # stored gradients: max |d| / max |g| (worst observed on a tensor the perturbations leave alone: 4.8e-6)
+G8_FLOOR_NORM = 2e-3   # gradient norms, relative (worst observed / limit over the stress leases: 0.3)
+# parameters whose gradient is identically zero in exact arithmetic (the biases in front of the RAFT feature net's InstanceNorm):
+# the reference's value is rounding noise (1e-9 of the largest norm); required of the product: noise of that size, not its digits
+G8_ZERO_REF, G8_ZERO_GOT = 1e-7, 1e-6
 G8_CAP_ELEM, G8_CAP_NORM = 5e-2, 5e-2  # no fixture deviation buys more than this
 
 
@@ -841,7 +844,9 @@ def test_training_step_vs_reference(name, mode):
     assert sorted(grads) == names
     lim_e, lim_n = _g8_limits(name)
     norms = np.array([float(grads[n].double().norm()) for n in names])
-    rel = np.abs(norms - z["norms"]) / (z["norms"] + 1e-6 * z["norms"].max())
+    zero = z["norms"] < G8_ZERO_REF * z["norms"].max()
+    assert (norms[zero] < G8_ZERO_GOT * z["norms"].max()).all(), [n for n, zz, v in zip(names, zero, norms) if zz and v >= G8_ZERO_GOT * z["norms"].max()]
+    rel = np.where(zero, 0.0, np.abs(norms - z["norms"]) / (z["norms"] + 1e-6 * z["norms"].max()))
     ratio = rel / np.array([lim_n[n] for n in names])
     order = np.argsort(-ratio)[:3]
     print(f"[G8 {name} {mode}] loss rel {abs(loss.item() - float(z['loss'])) / abs(float(z['loss'])):.2e}; grad-norm rel max "
