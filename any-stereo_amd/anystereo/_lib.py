@@ -137,6 +137,7 @@ SIGNATURES = {
     "as_gwc_volume_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_disparity_regression_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "as_liif_gather_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_gather_bwd_det": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_gru_gates_zr": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_gru_gates_zr_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_gru_gates_q": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

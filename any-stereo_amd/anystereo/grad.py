@@ -256,7 +256,7 @@ class LiifMlpTail(torch.autograd.Function):
         nb, b1n = u0c.shape[0], u1c.shape[0]
         (h0, w0), (h1s, w1s) = sizes
         d_wrel = d_b1 = None
-        if _LIIF_FUSE_FIRST and need[0] and need[1]:
+        if _LIIF_FUSE_FIRST and need[0] and need[1] and not ops.get_deterministic():
             # the first layer's consumers inside the kernel: d1 is scattered into both maps (the shared second input's n evaluations add
             # into its B1 elements directly) and reduced against the relative coordinates; it never reaches memory
             h1, h2, h3, d3, d2, (d_u0, d_u1, d_wrel) = ops.liif_mlp_bwd(u0c, u1c, sizes, coord, ctx.pack, ctx.pack_t.get(w2, w3, w4), d_logits,
@@ -789,9 +789,21 @@ class ConvexUpsample(torch.autograd.Function):
         q = coord.shape[1]
         d_out = _c(d_out)
         d_mask = torch.empty_like(mask)
-        d_disp = torch.empty_like(disp) if ctx.needs_input_grad[0] else None
+        det = ops.get_deterministic() and ctx.needs_input_grad[0]
+        d_disp = torch.empty_like(disp) if (ctx.needs_input_grad[0] and not det) else None
         with _guard(disp.device):
             L.check(L.load().as_convex_upsample_bwd(_p(disp), _p(scale), _p(mask), _p(coord), _p(d_out), _p(d_mask), _p(d_disp),
                                                     b, h, w, q, 1 if ctx.logits else 0, _stream()), "convex_upsample_bwd")
+        if det:
+            # d_disp without atomics: the nine per-query contributions g * l_k * (4 * scale) summed per source pixel in a fixed order
+            # (ops.liif_scatter_add's deterministic form), then the nine tap planes shifted onto the pixels they belong to
+            probs = torch.softmax(mask, dim=1) if ctx.logits else mask
+            mul = (4.0 * scale.reshape(-1, 1, 1).float()) if scale is not None else 1.0
+            taps = ops.liif_scatter_add((probs * d_out * mul).contiguous(), coord, 9, h, w)  # [B,9,h,w]: tap k of the queries AT each pixel
+            pad = torch.nn.functional.pad(taps, (1, 1, 1, 1))
+            d_disp = torch.zeros_like(disp)
+            for k in range(9):
+                dy, dx = k // 3 - 1, k % 3 - 1  # a query at (iy, ix) adds tap k to pixel (iy + dy, ix + dx)
+                d_disp = d_disp + pad[:, k:k + 1, 1 - dy:1 - dy + h, 1 - dx:1 - dx + w]
         return d_disp, d_mask, None, None, None
 

@@ -7,6 +7,7 @@ fp32 contiguous tensors and raises RuntimeError otherwise — no silent fallback
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import List, Optional, Sequence
 
@@ -1106,10 +1107,55 @@ def liif_rel_key(coord, sizes, want_rel=True, want_key=False):
     return rel, key
 
 
+# Deterministic training (ANYSTEREO_DETERMINISTIC=1 / set_deterministic(True)): the three places where gradients are summed with
+# float atomics — the upsampler's two scatter-adds onto the low-resolution maps and the convex upsampling's scatter onto the
+# disparity — run in a gather form with a fixed summation order instead (as_liif_gather_bwd_det over the queries sorted once
+# per forward), and the fused first-layer backward (in-kernel atomics) is not used.  With torch.backends.cudnn.deterministic = True
+# for the library layers the parameter gradients of a training step are then the same bits on every run.
+_DETERMINISTIC = [os.environ.get("ANYSTEREO_DETERMINISTIC", "0") == "1"]
+_SEGMENTS = {}
+
+
+def set_deterministic(on: bool) -> None:
+    _DETERMINISTIC[0] = bool(on)
+    _SEGMENTS.clear()
+
+
+def get_deterministic() -> bool:
+    return _DETERMINISTIC[0]
+
+
+def query_segments(coord, h: int, w: int):
+    """(order int32 [B,Q], starts int32 [B,h*w+1]) of the queries' nearest pixels on an h x w map: `order` sorts each batch
+    element's queries by pixel (stable), pixel p's queries sit at sorted positions [starts[p], starts[p+1]).  Cached for the
+    coordinate tensor at hand (one entry per map size)."""
+    key = (coord.data_ptr(), tuple(coord.shape), coord._version, h, w, coord.device)
+    ent = _SEGMENTS.get((h, w))
+    if ent is not None and ent[0] == key and ent[1]() is coord:
+        return ent[2], ent[3]
+    _, k = liif_rel_key(coord, [(h, w)], want_rel=False, want_key=True)
+    pix = (k >> 2).to(torch.int64)
+    sp, order = torch.sort(pix, dim=1, stable=True)
+    bounds = torch.arange(h * w + 1, device=coord.device, dtype=torch.int64).unsqueeze(0).expand(coord.shape[0], -1).contiguous()
+    starts = torch.searchsorted(sp.contiguous(), bounds).to(torch.int32).contiguous()
+    order = order.to(torch.int32).contiguous()
+    if len(_SEGMENTS) > 8:
+        _SEGMENTS.clear()
+    _SEGMENTS[(h, w)] = (key, weakref.ref(coord), order, starts)
+    return order, starts
+
+
 def liif_scatter_add(d_rows, coord, c, h, w, coff=0):
     """Transpose of the nearest gather: d_rows [B,Ctot,Q] channels [coff, coff+c) summed into [B,c,h,w]."""
     _req(d_rows, "d_rows"), _req(coord, "coord")
     b, ctot, q = d_rows.shape
+    if _DETERMINISTIC[0]:
+        order, starts = query_segments(coord, h, w)
+        out = torch.empty((b, c, h, w), device=d_rows.device, dtype=torch.float32)
+        with _guard(d_rows.device):
+            L.check(L.load().as_liif_gather_bwd_det(_p(d_rows), _p(order), _p(starts), _p(out), b, c, h * w, q, ctot, coff, _stream()),
+                    "liif_gather_bwd_det")
+        return out
     out = torch.empty((b, c, h, w), device=d_rows.device, dtype=torch.float32)
     with _guard(d_rows.device):
         L.check(L.load().as_liif_gather_bwd(_p(d_rows), _p(coord), _p(out), b, c, h, w, q, ctot, coff, _stream()), "liif_gather_bwd")

@@ -184,6 +184,28 @@ __global__ __launch_bounds__(256) void liif_gather_bwd_kernel(const float* __res
   }
 }
 
+
+// Deterministic form of the same transpose (ANYSTEREO_DETERMINISTIC=1 / ops.set_deterministic): the queries of a batch element
+// sorted by source pixel once per forward (`order`: a STABLE sort, `starts[b][pix]`: first sorted position of pixel pix, one past
+// the last pixel at [npix]); one thread per (batch, channel, pixel) walks its pixel's queries in that fixed order — no atomics,
+// no zero fill, the same bits on every run.
+__global__ __launch_bounds__(256) void liif_gather_bwd_det_kernel(const float* __restrict__ rows, const int* __restrict__ order,
+                                                                 const int* __restrict__ starts, float* __restrict__ out, int B, int C,
+                                                                 int npix, int Q, int ctot, int coff) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)B * C * npix) return;
+  const int pix = (int)(t % npix);
+  const long long bc = t / npix;
+  const int c = (int)(bc % C);
+  const long long b = bc / C;
+  const int s = starts[b * (npix + 1) + pix], e = starts[b * (npix + 1) + pix + 1];
+  const float* rp = rows + (b * ctot + coff + c) * Q;
+  const int* op = order + b * Q;
+  float acc = 0.f;
+  for (int i = s; i < e; ++i) acc += rp[op[i]];
+  out[t] = acc;
+}
+
 // relative coordinates of a14 alone: out[b, 2s+{0,1}, q] = (coord - centre of the nearest cell of source s) * (H_s, W_s)
 // and the sort key of the training path: (nearest pixel of source 0) * 4 + parity of the nearest pixel of source 1
 struct RelParams {
@@ -594,6 +616,17 @@ int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat,
   hipLaunchKernelGGL(liif_gather_bwd_kernel, dim3((unsigned)as::cdiv64((long long)B * Q, 256)), dim3(256), 0, as::as_stream(stream),
                      d_latent, coord, d_feat, B, C, H, W, Q, lat_ctot, lat_coff, (float)(-1.0 + 1e-6), (float)(1.0 - 1e-6));
   return as::check_launch("liif_gather_bwd");
+}
+
+int as_liif_gather_bwd_det(const float* d_rows, const int* order, const int* starts, float* out, int B, int C, int npix, int Q,
+                           int ctot, int coff, void* stream) {
+  AS_REQUIRE(d_rows && order && starts && out, AS_ERR_BAD_ARG, "liif_gather_bwd_det: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && npix > 0 && Q > 0 && coff >= 0 && coff + C <= ctot, AS_ERR_BAD_SHAPE, "liif_gather_bwd_det: bad size / channel window");
+  const long long total = (long long)B * C * npix;
+  AS_REQUIRE(total < 2147483647ll * 256, AS_ERR_BAD_SHAPE, "liif_gather_bwd_det: grid too large");
+  hipLaunchKernelGGL(liif_gather_bwd_det_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream),
+                     d_rows, order, starts, out, B, C, npix, Q, ctot, coff);
+  return as::check_launch("liif_gather_bwd_det");
 }
 
 int as_liif_rel_key(const float* coord, float* rel, int* key, int B, int Q, int n_src, int H0, int W0, int H1, int W1, void* stream) {

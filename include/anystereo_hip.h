@@ -461,6 +461,10 @@ int as_disparity_regression_bwd(const float* cost, const float* d_out, float* d_
                                 int apply_softmax, void* stream);
 int as_liif_gather_bwd(const float* d_latent, const float* coord, float* d_feat,
                        int B, int C, int H, int W, int Q, int lat_ctot, int lat_coff, void* stream);
+/* deterministic form (no atomics): `order` [B,Q] = the queries of each batch element stably sorted by source pixel, `starts`
+ * [B,npix+1] = first sorted position of every pixel (and Q at npix); out [B,C,npix] is written completely, in a fixed summation order */
+int as_liif_gather_bwd_det(const float* d_rows, const int* order, const int* starts, float* out, int B, int C, int npix, int Q,
+                           int ctot, int coff, void* stream);
 /* a7 in training: the ConvGRU gate math (update.py:33-41) as two fused pointwise stages and their transposes (the convs
  *   run through as_conv2d with the LINEAR epilogue; inference uses the fused GRU epilogues instead).
  *   ZR: lin [B,2C,H,W] = convz||convr output, ctx [B,ctx_ctot,H,W] with [cz||cr] at channel ctx_coff, h [B,C,H,W]

@@ -865,12 +865,15 @@ def test_training_step_vs_reference(name, mode):
 @pytest.mark.parametrize("name", ["igev", "raft"])
 def test_training_step_is_bit_repeatable(name):
     """The G8 step twice in one process, fresh model each time (a race or an uninitialised read shows up here,
-    on any box, as a difference between two runs of the same program).  The forward is required to be BIT-equal: loss and every
-    prediction.  The backward starts with the upsampler's scatter-adds (float atomics, as in ATen: the summation order of a
-    pixel's queries varies between launches), so every gradient downstream may differ in its last bits; required: every stored
-    full gradient within 2e-6 of its maximum between the two runs, and bit-equal under ANYSTEREO_DETERMINISTIC=1 (gather-form
-    scatter kernels, fixed summation order) when that mode is available."""
+    on any box, as a difference between two runs of the same program).
+    Default mode: the forward must be BIT-equal (loss, every prediction).  Its backward starts with the upsampler's scatter-adds
+    (float atomics, as in ATen: the order in which a pixel's queries are summed varies between launches), so every gradient
+    downstream may differ in its last bits: every stored full gradient within 1e-5 of its maximum (observed over the round-4
+    stress leases: <= 1.9e-6).
+    Deterministic mode (ops.set_deterministic: gather-form scatters with a fixed summation order, library layers under
+    torch.backends.cudnn.deterministic): EVERY parameter gradient must be bit-equal between the two runs."""
     import numpy as np
+    from anystereo import ops
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}.npz"))
     l0, p0, g0 = _g8_run(name, "split")
     l1, p1, g1 = _g8_run(name, "split")
@@ -881,8 +884,23 @@ def test_training_step_is_bit_repeatable(name):
     for n in (str(x) for x in z["full_names"]):
         d = ((g0[n] - g1[n]).abs().max() / g0[n].abs().max()).item()
         worst = max(worst, d)
-        assert d < 2e-6, f"{n}: run-to-run gradient difference {d:.2e} of its maximum"
-    print(f"[G8 repeat {name}] forward bit-equal; stored gradients differ by at most {worst:.1e} of their maxima between two runs")
+        assert d < 1e-5, f"{n}: run-to-run gradient difference {d:.2e} of its maximum"
+    ops.set_deterministic(True)
+    try:
+        ld0, pd0, gd0 = _g8_run(name, "split")
+        ld1, pd1, gd1 = _g8_run(name, "split")
+    finally:
+        ops.set_deterministic(False)
+    assert torch.equal(ld0, l0) and all(torch.equal(a, b) for a, b in zip(pd0, p0)), "the deterministic mode changed the forward"
+    differing = [n for n in gd0 if not torch.equal(gd0[n], gd1[n])]
+    # ... and it is the same gradient as the default mode's up to summation order
+    for n in (str(x) for x in z["full_names"]):
+        d = ((gd0[n] - g0[n]).abs().max() / g0[n].abs().max()).item()
+        assert d < 1e-5, f"{n}: deterministic vs default gradient {d:.2e} of its maximum"
+    print(f"[G8 repeat {name}] forward bit-equal; default mode: stored gradients differ by at most {worst:.1e} of their maxima between two "
+          f"runs; deterministic mode: {len(gd0) - len(differing)} of {len(gd0)} parameter gradients bit-equal" +
+          (f"; differing: {differing[:8]}" if differing else ""))
+    assert not differing, f"deterministic mode: {len(differing)} gradients differ between two runs: {differing[:8]}"
 
 
 @pytest.mark.parametrize("name", ["igev", "raft"])
