@@ -180,6 +180,90 @@ def dry_main(a, rank, world):
         td.destroy_process_group()
 
 
+def dry_train_main(a, rank, world):
+    """No GPU visible, --mode train: rehearse the N-rank TRAINING protocol over gloo — per-rank batch shard, the Trainer's flat
+    gradient exchange (rank 0's weights broadcast before the first step, one all-reduce of the concatenated gradients between
+    backward and the update, collective overflow decisions), barrier-bracketed timed steps, MAX over ranks, the same steps with
+    the exchange off (`exposed_allreduce_ms`) — on a small stand-in module with the reference's forward signature.  Nothing of the
+    hot path runs and no throughput is claimed (`value` is null): what is checked is that the line the 8-GPU driver run prints
+    has its fields and that the ranks end a step with identical parameters."""
+    td = _dist_init(False, 0) if world > 1 else None
+    from anystereo.harness.train import Trainer
+
+    class DryStereo(torch.nn.Module):  # (image1, image2, iters=, hr_coord=, scale=) -> list of [B,1,Q] predictions
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(6, 8, 3, padding=1)
+            self.head = torch.nn.Linear(10, 1)
+
+        def freeze_bn(self):
+            pass
+
+        def forward(self, image1, image2, iters=2, hr_coord=None, scale=None, **_):
+            f = torch.relu(self.conv(torch.cat([image1, image2], 1) / 255.0)).mean((2, 3))  # [B,8]
+            x = torch.cat([f.unsqueeze(1).expand(-1, hr_coord.shape[1], -1), hr_coord], -1)  # [B,Q,10]
+            d = self.head(x).transpose(1, 2)
+            return [d * (i + 1) for i in range(iters)]
+
+    torch.manual_seed(100 + rank)  # every rank builds DIFFERENT weights: the Trainer must make them rank 0's
+    model = DryStereo()
+    tr = Trainer(model, train_iters=2, max_disp=192, ddp_impl="flat", num_steps=100)
+    g = torch.Generator().manual_seed(7 + rank)
+    bsz, q = a.batch_per_gpu, 64
+    batch = (torch.rand(bsz, 3, 16, 32, generator=g) * 255, torch.rand(bsz, 3, 16, 32, generator=g) * 255,
+             torch.rand(bsz, q, 2, generator=g) * 2 - 1, torch.rand(bsz, 1, q, generator=g) * 60 + 0.5, torch.ones(bsz, 1))
+    for _ in range(max(1, a.warmup)):
+        tr.step(batch)
+
+    def timed(n, sync_grads=True):
+        if td:
+            td.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss, _ = tr.step(batch, sync_grads=sync_grads)
+        if td:
+            td.barrier()
+        return time.perf_counter() - t0, float(loss)
+
+    dt, loss = timed(a.steps)
+    flat = torch.cat([p.detach().reshape(-1).double() for p in model.parameters()])
+    check = torch.stack([flat.sum(), flat.abs().sum()])
+    per_rank, sums, cpu_sets, overlap = [dt], [check.tolist()], [RANK_CPUS], None
+    if td:
+        t = torch.tensor([dt], dtype=torch.float64)
+        gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        td.all_gather(gathered, t)
+        per_rank = [float(v.item()) for v in gathered]
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+        gs = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        td.all_gather(gs, check)
+        sums = [v.tolist() for v in gs]
+        cpu_sets = [None] * world
+        td.all_gather_object(cpu_sets, RANK_CPUS)
+        dt_ns, _ = timed(max(2, a.steps), sync_grads=False)  # last: the ranks' parameters diverge from here on
+        t2 = torch.tensor([dt_ns], dtype=torch.float64)
+        td.all_reduce(t2, op=td.ReduceOp.MAX)
+        ms_sync, ms_nosync = dt / a.steps * 1e3, float(t2.item()) / max(2, a.steps) * 1e3
+        overlap = {"ms_per_step_with_allreduce": round(ms_sync, 3), "ms_per_step_no_sync": round(ms_nosync, 3),
+                   "exposed_allreduce_ms": round(ms_sync - ms_nosync, 3), "gradient_bytes": 4 * flat.numel(), "ddp": tr.ddp_mode}
+    if rank == 0:
+        sys.stderr.write("bench.py: no GPU visible - dry run of the training launch protocol over gloo; the hot path has no CPU fallback\n")
+        print(json.dumps({"metric": "train_samples_per_s", "value": None, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": TRAIN_DTYPE, "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "training launch protocol only (no GPU visible; stand-in module)",
+                                     "global_batch": world * bsz, "parallelism": f"ddp x{world} (flat all-reduce over gloo)"},
+                          "per_rank_samples_per_s": [round(bsz * a.steps / v, 3) for v in per_rank],
+                          "samples_per_s_protocol": round(world * bsz * a.steps / dt, 3),
+                          "allreduce_overlap": overlap, "per_rank_cpus": cpu_sets, "torch_threads": torch.get_num_threads(),
+                          "parameters_equal_across_ranks": all(v == sums[0] for v in sums), "loss_last": loss,
+                          "trainer": {"graph": bool(tr.use_graph), "gradient_exchange": tr.ddp_mode}, "roofline": None, "cpu_baseline": None}))
+    if td:
+        td.barrier()
+        td.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # algorithmic work (SURVEY.md §8d)
 # ------------------------------------------------------------------------------------------------------------------
@@ -1010,7 +1094,7 @@ def main():
     if RANK_CPUS is not None and world > 1:
         torch.set_num_threads(max(1, len(RANK_CPUS)))
     if not torch.cuda.is_available():
-        return dry_main(a, rank, world)
+        return dry_train_main(a, rank, world) if a.mode == "train" else dry_main(a, rank, world)
     if a.mode == "train":
         return train_main(a, rank, world, local)
     return infer_main(a, rank, world, local)

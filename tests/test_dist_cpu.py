@@ -232,3 +232,31 @@ def test_bench_launcher_spawns_ranks_world2():
     # the parent's code path does not import torch
     src = open(os.path.join(root, "bench.py")).read()
     assert "\nimport torch" not in src.split("def main():")[0]
+
+
+def test_bench_train_launcher_dry_protocol_world2():
+    """`python bench.py --mode train --gpus 2` without a GPU: the launcher spawns 2 ranks, they run the Trainer's flat gradient
+    exchange over gloo on a stand-in module (every rank built with DIFFERENT weights) and rank 0 prints ONE JSON line with the
+    fields the 8-GPU driver run reads: summed samples/s, one value per rank, `allreduce_overlap.exposed_allreduce_ms`, disjoint
+    core sets — and the ranks hold identical parameters after the steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["metric"] == "train_samples_per_s" and d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None
+    assert len(d["per_rank_samples_per_s"]) == 2 and d["config"]["global_batch"] == 8
+    ov = d["allreduce_overlap"]
+    assert {"ms_per_step_with_allreduce", "ms_per_step_no_sync", "exposed_allreduce_ms", "gradient_bytes"} <= set(ov)
+    assert d["parameters_equal_across_ranks"] is True and d["trainer"]["gradient_exchange"].startswith("flat")
+    assert "wgrad" in d["dtype"]
+    sets = d["per_rank_cpus"]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert len(sets) == 2 and not set(sets[0]) & set(sets[1]), sets

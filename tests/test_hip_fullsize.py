@@ -375,6 +375,67 @@ def test_cfg4_step_through_rccl_ddp_one_rank():
         td.destroy_process_group()
 
 
+def test_cfg4_graphed_step_with_flat_exchange_over_rccl_has_no_host_sync():
+    """What every rank of the 8-GPU training job runs per step: the gradient half replayed as a captured
+    hipGraph, then ONE all-reduce of the flattened gradients through RCCL, then clip + AdamW — with one rank the exchange is the
+    identity, the launch sequence is the 8-rank one.  A steady-state step must not synchronise the host anywhere (sync debug
+    mode: every synchronising call warns): the collective is issued on the stream the graph was replayed on and the host runs
+    ahead of the GPU, which is what lets eight ranks share one host."""
+    import socket
+    import warnings
+    import torch.distributed as td
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer, synthetic_train_batch
+    from anystereo.models import __models__, default_args
+    args = default_args("continuous_IGEVStereo")
+    model = __models__["continuous_IGEVStereo"](args)
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV)
+    batch = synthetic_train_batch(4, 160, 320, seed=5, device=DEV)
+    assert not td.is_initialized()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    td.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        tr = Trainer(model, lr=1e-4, num_steps=100, train_iters=16, max_disp=args.max_disp, force_ddp=True, graph=True)
+        assert tr.use_graph and tr.ddp_impl == "flat" and tr.graph_scope == "grads"
+        tr.overflow_check_every = 0  # the saturation poll (every 20th step) is a deliberate synchronisation
+        losses = [tr.step(batch)[0] for _ in range(tr.graph_warmup + 3)]  # eager warm-up, capture, replays
+        torch.cuda.synchronize()
+        assert tr._graph is not None and tr.graph_memsets[1] == 0
+        calls = []
+        real = td.all_reduce
+
+        def spy(t, *a, **k):
+            calls.append((t.numel(), torch.cuda.current_stream(t.device).cuda_stream, torch.cuda.is_current_stream_capturing()))
+            return real(t, *a, **k)
+
+        td.all_reduce = spy
+        cur = torch.cuda.current_stream(DEV).cuda_stream
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                loss, _ = tr.step(batch)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+            td.all_reduce = real
+        syncs = [str(x.message)[:120] for x in w if "synchroniz" in str(x.message).lower()]
+        assert not syncs, f"a steady-state graphed step synchronised the host: {syncs[:4]}"
+        nparam = sum(p.numel() for p in model.parameters() if p.grad is not None)
+        assert len(calls) == 1 and calls[0][0] == nparam, calls           # ONE collective over the whole gradient vector
+        assert calls[0][1] == cur and calls[0][2] is False                  # on the caller's stream, the one the graph replays on
+        torch.cuda.synchronize()
+        vals = [float(v) for v in losses] + [float(loss)]
+        assert all(v == v and v > 0 for v in vals) and vals[-1] < vals[0], vals
+        print(f"[graphed step + flat exchange over RCCL x1] no host synchronisation in a steady-state step; one all-reduce of {nparam} "
+              f"gradients on the replay stream; loss {vals[0]:.3f} -> {vals[-1]:.3f}")
+    finally:
+        td.destroy_process_group()
+
+
 def test_cfg4_graphed_step_equals_eager_step():
     """The Trainer's default step — gradient half replayed as ONE captured hipGraph, gradient exchange (here: one rank through
     RCCL, the flat all-reduce every rank of the 8-GPU job issues), clip and AdamW eager — against the eager step on the same
