@@ -854,6 +854,19 @@ def infer_main(a, rank, world, local):
             if "avg_us_in_loop" in rooflines[lk]:
                 ns["build_plus_lookup_hbm_frac_in_loop"] = pooled("frac", "avg_us", over={lk: (None, rooflines[lk]["avg_us_in_loop"])})
                 ns["lookup_in_loop"] = {"avg_us": rooflines[lk]["avg_us_in_loop"], "frac": rooflines[lk]["frac_in_loop"]}
+            # as a pair actually runs: ONE build (both pyramids) and `iters` lookups — algorithmic bytes of all of them over the sum
+            # of their durations (lookup: in-loop where measured, else isolated)
+            def abytes(k):
+                return rooflines[k]["frac"] * HBM_PEAK_GBS * rooflines[k]["avg_us"]
+            lk_us_loop = rooflines[lk].get("avg_us_in_loop", rooflines[lk]["avg_us"])
+            t_build = rooflines["corr_build"]["avg_us"] + rooflines["geo_pyramid"]["avg_us"]
+            b_build = abytes("corr_build") + abytes("geo_pyramid")
+            ns["pair_weighted"] = {
+                "iters": wl.iters,
+                "hbm_frac_lookup_in_loop": round((b_build + wl.iters * abytes(lk)) / (t_build + wl.iters * lk_us_loop) / HBM_PEAK_GBS, 4),
+                "hbm_frac_lookup_isolated": round((b_build + wl.iters * abytes(lk)) / (t_build + wl.iters * rooflines[lk]["avg_us"]) / HBM_PEAK_GBS, 4),
+                "note": "(build + geo + iters x lookup algorithmic bytes) / (their durations) / 8 TB/s: the figure weighted as one stereo pair "
+                        "runs (1 build : iters lookups); the lookup dominates it"}
             if "lookup" in rooflines and lk != "lookup":
                 ns["standalone_lookup_kernel"] = {"frac": rooflines["lookup"]["frac"], "frac_cold": rooflines["lookup"].get("frac_cold"),
                                                   "avg_us": rooflines["lookup"]["avg_us"],
