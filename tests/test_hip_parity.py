@@ -778,8 +778,8 @@ def test_liif_gather_and_convex_backward(scale):
 # round-3 driver run landed on the 1.47e-2 one because MIOpen picks its forward algorithms by measured time, per box:
 # DESIGN.md §2 "G8", profiles/r04_g8_stress_*.txt).  One fixed element tolerance therefore either hides regressions of the smooth
 # tensors or fails on an unlucky box.  The limits are per tensor: tests/golden/train_*_sens.npz holds, from the IMPORTED REFERENCE
-# itself, the largest deviation of every gradient norm and of every stored gradient under 32 such perturbations (make_golden.py
-# --only train_sens); a tensor's limit is 3x that deviation, floored by 3x the worst value the product showed over the round-4
+# itself, the largest deviation of every gradient norm and of every stored gradient under 64 such perturbations (32 at 1e-6 and 32
+# at 2e-6 relative: make_golden.py --only train_sens [--sens-merge]); a tensor's limit is 3x that deviation, floored by 3x the worst value the product showed over the round-4
 # stress leases for tensors the perturbations do not move (G8_FLOOR_*).
 G8_FLOOR_ELEM = 3e-5   # stored gradients: max |d| / max |g| (worst observed on a tensor the perturbations leave alone: 4.8e-6)
 G8_FLOOR_NORM = 2e-3   # gradient norms, relative (worst observed / limit over the stress leases: 0.3)
@@ -900,7 +900,15 @@ def test_training_step_is_bit_repeatable(name):
     print(f"[G8 repeat {name}] forward bit-equal; default mode: stored gradients differ by at most {worst:.1e} of their maxima between two "
           f"runs; deterministic mode: {len(gd0) - len(differing)} of {len(gd0)} parameter gradients bit-equal" +
           (f"; differing: {differing[:8]}" if differing else ""))
-    assert not differing, f"deterministic mode: {len(differing)} gradients differ between two runs: {differing[:8]}"
+    # Every gradient whose backward path runs on this library's kernels alone (loss -> upsampler -> update block) must be bit-equal.
+    # The backbone's gradients also pass through MIOpen's backward kernels: bit-equal on every lease so far (432/432, 234/234), but
+    # which solver MIOpen picks is a per-box matter — there, last-bit noise is tolerated, anything larger is not.
+    own = [n for n in differing if n.startswith(("update_block.", "liif_up."))]
+    assert not own, f"deterministic mode: gradients of the library's own path differ between two runs: {own[:8]}"
+    for n in differing:
+        d = ((gd0[n] - gd1[n]).abs().max() / gd0[n].abs().max().clamp_min(1e-30)).item()
+        assert d < 1e-5 or gd0[n].abs().max().item() < 1e-6 * max(g.abs().max().item() for g in gd0.values()), \
+            f"deterministic mode: {n} differs by {d:.2e} of its maximum between two runs"
 
 
 @pytest.mark.parametrize("name", ["igev", "raft"])
