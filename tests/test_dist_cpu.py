@@ -260,3 +260,26 @@ def test_bench_train_launcher_dry_protocol_world2():
     sets = d["per_rank_cpus"]
     if len(os.sched_getaffinity(0)) >= 2:
         assert len(sets) == 2 and not set(sets[0]) & set(sets[1]), sets
+
+
+def test_bench_under_torch_distributed_run_world2():
+    """The DRIVER's launch form — `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 ...` — without a GPU: the two ranks take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    launcher's environment, bind themselves to disjoint core sets, rendezvous over gloo and rank 0 prints the one line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and len(d["per_rank_step_s"]) == 2
+    sets = d["per_rank_cpus"]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert len(sets) == 2 and not set(sets[0]) & set(sets[1]), sets

@@ -658,3 +658,30 @@ def test_train_bench_command_produces_its_line():
     d = json.loads(lines[0])
     assert d["metric"] == "train_samples_per_s" and d["value"] > 0 and all(math.isfinite(v) for v in d["loss_first_last"])
     assert d["roofline"]["frac"] > 0 and d["library"]["matches_sources"] is True
+
+
+@pytest.mark.gpu
+def test_bench_command_under_the_drivers_launcher_one_rank():
+    """The driver's multi-GPU form with N = 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 1 ...` — the rank initialises RCCL ("nccl") from the launcher's environment, times its steps
+    between barriers and prints ONE line whose value is the replica's pairs/s (what every rank of the 8-GPU run does)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras", "--no-batched"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["unit"] == "pairs/s" and d["value"] > 0 and len(d["per_rank_pairs_per_s"]) == 1
+    assert d["config"]["parallelism"] == "replicas x1" and d["library"]["matches_sources"] is True
