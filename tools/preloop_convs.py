@@ -56,7 +56,7 @@ for s, e, cin, cout, ks, stride, b, ho, wo, mult, epi, bs in recs:
     rows.append((us, gf, cin, cout, ks, stride, b, ho, wo, mult, epi, bs))
     tot_us += us
     tot_gf += gf
-print(f"{len(rows)} conv launches, {tot_us / 1e3:.2f} ms (host-inclusive event spans, eager), {tot_gf:.1f} GFLOP, {tot_gf / tot_us / 1e3 * 1e3:.0f} TFLOP/s overall" if tot_us else "none")
+print(f"{len(rows)} conv launches, {tot_us / 1e3:.2f} ms (host-inclusive event spans, eager), {tot_gf:.1f} GFLOP, {tot_gf / tot_us * 1e3:.0f} TFLOP/s overall" if tot_us else "none")
 agg = {}
 for r in rows:
     k = r[2:]
