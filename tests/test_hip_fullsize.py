@@ -308,6 +308,60 @@ def test_cfg4_training_steps_fullsize():
     assert (outs[0] - outs[1]).abs().max().item() < 1e-3
 
 
+def test_cfg4_deterministic_mode_fullsize():
+    """The deterministic training mode (ops.set_deterministic: gather-form scatters over the sorted queries, fixed summation order) at
+    cfg-4 size — 4 x 51 200 random queries over 40 x 80 / 80 x 160 maps, the upsampler of all 16 iterations batched after the loop:
+    same loss as the default mode bit for bit (the forward is untouched), gradients equal up to the summation order of a pixel's
+    queries, and two deterministic runs give bit-equal gradients on the library's own path."""
+    from anystereo import ops
+    from anystereo.harness.metrics import sequence_loss_multiscale
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import synthetic_train_batch
+    from anystereo.models import __models__, default_args
+    args = default_args("continuous_IGEVStereo")
+    model = __models__["continuous_IGEVStereo"](args)
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV).train()
+    model.freeze_bn()
+    img1, img2, coord, gt, scale = synthetic_train_batch(4, 160, 320, seed=9, device=DEV)
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+
+    def run(det):
+        ops.set_deterministic(det)
+        try:
+            model.zero_grad(set_to_none=True)
+            _, preds = model(img1, img2, iters=16, hr_coord=coord.clone(), scale=scale)
+            loss = sequence_loss_multiscale(preds, gt, ((gt < 512) & (gt > 0)).float(), max_disp=args.max_disp)[0]
+            (loss * 4096.0).backward()
+            torch.cuda.synchronize()
+            return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops.set_deterministic(False)
+
+    try:
+        l_def, g_def = run(False)
+        l_a, g_a = run(True)
+        l_b, g_b = run(True)
+    finally:
+        torch.backends.cudnn.deterministic = prev
+    assert torch.equal(l_def, l_a) and torch.equal(l_a, l_b)
+    worst = 0.0
+    for n, g in g_def.items():
+        mx = g.abs().max().item()
+        if mx == 0.0:
+            continue
+        d = (g - g_a[n]).abs().max().item() / mx
+        worst = max(worst, d)
+        # BatchNorm3d affine gradients of the cost aggregation: sums of large cancelling terms (run-to-run noise of one mode ~1e-3)
+        assert d < (5e-3 if ".bn" in n or "bn." in n else 5e-4), (n, d)
+    own = [n for n in g_a if n.startswith(("update_block.", "liif_up.")) and not torch.equal(g_a[n], g_b[n])]
+    assert not own, f"deterministic mode at cfg-4 size: gradients differ between two runs: {own[:6]}"
+    rest = [n for n in g_a if not torch.equal(g_a[n], g_b[n])]
+    print(f"[cfg 4 deterministic] loss bit-equal in both modes; worst gradient deviation deterministic vs default {worst:.1e} of the tensor's max; "
+          f"{len(g_a) - len(rest)} of {len(g_a)} gradients bit-equal between two deterministic runs")
+
+
 def test_cfg4_step_through_rccl_ddp_one_rank():
     """The cfg-4 training step through the DDP wrapper over RCCL ("nccl" backend) with ONE rank — what every rank of the 8-GPU
     job runs (train_continuous_IGEV.py:184 shards with nn.DataParallel; here one process per GPU): process group on
