@@ -28,6 +28,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using half4v = __attribute__((ext_vector_type(4))) _Float16;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
@@ -801,6 +802,68 @@ __global__ __launch_bounds__(256) void pool2x_bs_kernel(const float* __restrict_
     v[j] = sacc / 9.f;
   }
   bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v, ovf_amax);
+  as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
+}
+
+// pool2x_bs for an even input width: the three columns of a window row are ONE 8-byte load (columns 2xo, 2xo+1; rows of an even
+// width keep it 8-B aligned) plus the left neighbour's second element through a lane shift — 24 wide loads per thread instead of
+// 72 dword loads, every wave-load a fully used contiguous 512 B.  Same summation order as pool2x_at (row-major, zeros for the
+// padding): bit-identical results.
+__global__ __launch_bounds__(256) void pool2x_bs_even_kernel(const float* __restrict__ x, _Float16* __restrict__ out_bs, int C, int H, int W,
+                                                             int Ho, int Wo, long long total) {
+  const long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  as::fp16_saturate_mode();
+  float ovf_amax = 0.f;
+  const bool live = idx0 < total;  // no early return: every lane takes part in the shifts
+  const long long idx = live ? idx0 : total - 1;
+  const int c8 = (C + 7) >> 3;
+  const int xo = (int)(idx % Wo);
+  long long t = idx / Wo;
+  const int yo = (int)(t % Ho);
+  t /= Ho;
+  const int blk = (int)(t % c8);
+  const long long b = t / c8;
+  const long long plane = (long long)H * W;
+  const int nch = min(8, C - blk * 8);
+  const int lane = threadIdx.x & 63;
+  // the left column comes from the previous lane when that lane holds the previous output column of the same row
+  const bool own_left = lane == 0 || xo == 0;
+  // plain 8-byte global loads (this compiler lowers raw_buffer_load_b64 with a select-valued offset to ONE dword load): rows outside
+  // the image and channels >= C are predicated off and read as zeros
+  const float* xb = x + (b * C + blk * 8) * plane;
+  f32x2 raw[8][3];
+  float left[8][3];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = 2 * yo - 1 + dy;
+    const bool rin = yy >= 0 && yy < H;
+    const long long e2 = (long long)(rin ? yy : 0) * W + 2 * xo;  // columns 2xo, 2xo+1 (< W: W even)
+    const bool lin = rin && own_left && xo > 0;                    // column 2xo-1 for lanes without a donor
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool cin = j < nch;
+      f32x2 z2;
+      z2.x = 0.f; z2.y = 0.f;
+      raw[j][dy] = (rin && cin) ? *reinterpret_cast<const f32x2*>(xb + (long long)j * plane + e2) : z2;
+      left[j][dy] = (lin && cin) ? xb[(long long)j * plane + e2 - 1] : 0.f;
+    }
+  }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const float c0 = raw[j][dy].x, c1 = raw[j][dy].y;
+      const float donor = __shfl_up(c1, 1);
+      const float l = own_left ? left[j][dy] : donor;
+      sacc += l;
+      sacc += c0;
+      sacc += c1;
+    }
+    v[j] = sacc / 9.f;
+  }
+  if (live) bs8_store(out_bs, b, c8, blk, (long long)Ho * Wo, (long long)yo * Wo + xo, v, ovf_amax);
   as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
 }
 
@@ -2544,8 +2607,13 @@ int as_pool2x_bs(const float* x, void* out_bs, int B, int C, int H, int W, void*
   AS_REQUIRE((reinterpret_cast<uintptr_t>(out_bs) & 15) == 0, AS_ERR_BAD_ARG, "pool2x_bs: out_bs not 16-B aligned");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long total = (long long)B * ((C + 7) / 8) * Ho * Wo;
-  hipLaunchKernelGGL(pool2x_bs_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x,
-                     reinterpret_cast<_Float16*>(out_bs), C, H, W, Ho, Wo, total);
+  static const int even_mode = getenv("AS_POOL2X_EVEN") ? atoi(getenv("AS_POOL2X_EVEN")) : 1;
+  if (even_mode && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0 && (long long)H * W * 4 * 8 < 0x7FFFFFF0ll)
+    hipLaunchKernelGGL(pool2x_bs_even_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x,
+                       reinterpret_cast<_Float16*>(out_bs), C, H, W, Ho, Wo, total);
+  else
+    hipLaunchKernelGGL(pool2x_bs_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), x,
+                       reinterpret_cast<_Float16*>(out_bs), C, H, W, Ho, Wo, total);
   return as::check_launch("pool2x_bs");
 }
 

@@ -110,8 +110,13 @@ def main():
             "wino_tr384": lambda: ops.wino_transform(xsb, out=wv),
             "wino_tr128": lambda: ops.wino_transform([xsb[0]], out=wv, c_off=0),
         }
+    h8 = det_uniform((b, 128, h // 2, w // 2), 120).to(dev)
+    h16 = det_uniform((b, 128, h // 4, w // 4), 121).to(dev)
     fns = {
         **wino,
+        # the loop's resamplers (update.py:94-102) with blocked split-fp16 results
+        "pool04_bs": lambda: ops.pool2x_bs(x128[0]), "pool08_bs": lambda: ops.pool2x_bs(h8),
+        "interp08to04_bs": lambda: ops.interp_bs(h8, h, w), "interp16to08_bs": lambda: ops.interp_bs(h16, h // 2, w // 2),
         "corr_build": lambda: ops.corr_build_pyramid(f1, f2, L),
         "geo_pyramid": (lambda: ops.geo_pyramid(gev, L)) if g else None,
         "lookup": lambda: ops.geo_corr_lookup(geo, corr, disp, 4),
