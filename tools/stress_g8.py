@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--nanfill", action="store_true")
     ap.add_argument("--perturb", type=float, default=0.0)
     ap.add_argument("--truth", action="store_true", help="also compare with the fp64 CPU oracle (adds ~1 min of CPU time)")
+    ap.add_argument("--limits", action="store_true", help="report every value as a fraction of the G8 test's per-tensor limit")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     z = np.load(os.path.join(ROOT, "tests", "golden", f"train_{a.name}.npz"))
@@ -165,6 +166,18 @@ def main():
               + ", ".join(f"{n.split('.', 1)[-1]} {((gold[n] - truth[n]).abs().max() / truth[n].abs().max()).item():.2e}" for n in full), flush=True)
     if a.nanfill:
         install_nanfill()
+    lim_e = lim_n = None
+    if a.limits:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ.setdefault("PYTEST_DISABLE_PLUGIN_AUTOLOAD", "1")
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("g8_limits_src", os.path.join(ROOT, "tests", "test_hip_parity.py"))
+        src = open(spec.origin).read()
+        ns = {"os": os, "__file__": spec.origin}
+        start = src.index("G8_FLOOR_ELEM")
+        end = src.index("def _g8_run")
+        exec(compile(src[start:end], spec.origin, "exec"), ns)  # the limit constants and _g8_limits only
+        lim_e, lim_n = ns["_g8_limits"](a.name)
     recs, first = [], None
     for r in range(a.reps):
         o = run_once(a.name, a.mode, perturb=a.perturb, seed=r)
@@ -192,6 +205,14 @@ def main():
             rec["stored_diff_vs_rep0"] = {n: ((first["grads"][n] - o["grads"][n]).abs().max() / first["grads"][n].abs().max()).item() for n in full}
             rec["grads_differing_from_rep0"] = len(dg)
             rec["worst_grad_diffs"] = sorted(dg.items(), key=lambda kv: -kv[1])[:6]
+        if lim_e is not None:
+            re_ = {n: errs[n] / lim_e[n] for n in full}
+            zero = z["norms"] < 1e-7 * z["norms"].max()
+            rn_ = {n: (0.0 if zz else float(v) / lim_n[n]) for n, v, zz in zip(names, norm_rel, zero)}
+            rec["worst_elem_ratio"] = max(re_.items(), key=lambda kv: kv[1])
+            rec["worst_norm_ratio"] = max(rn_.items(), key=lambda kv: kv[1])
+            print(f"[stress] rep {r}: fraction of the G8 limits used: elements {rec['worst_elem_ratio'][1]:.2f} ({rec['worst_elem_ratio'][0]}), "
+                  f"norms {rec['worst_norm_ratio'][1]:.2f} ({rec['worst_norm_ratio'][0]})", flush=True)
         recs.append(rec)
         w = max(errs, key=errs.get)
         line = (f"[stress] rep {r}: loss rel {rec['loss_rel']:.1e} pred|d| {rec['last_pred_abs']:.1e} convd1.weight {errs['update_block.encoder.convd1.weight']:.3e}"
