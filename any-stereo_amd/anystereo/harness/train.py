@@ -138,16 +138,25 @@ class Trainer:
         rank 0 loaded a checkpoint, would otherwise average gradients taken at different weights.  Once, before the first step."""
         if self.__dict__.get("_state_synced") or not (td.is_available() and td.is_initialized() and td.get_world_size() > 1):
             return
+        # One flat buffer per dtype goes through the collective and every tensor is then overwritten with `copy_` through
+        # `t.detach()` — NOT `t.data`, and not by broadcasting into the tensor itself: a c10d collective does not bump a tensor's
+        # VERSION COUNTER and `.data` has one of its own, while every cache of the library (PackedConv / BN folds, grad.py's
+        # transposed packs, the inference graph's fingerprint) is keyed on (data_ptr, _version).  A rank that ran a forward
+        # before its first step must drop the packs of its pre-broadcast weights, frozen BatchNorm statistics included (no
+        # optimizer step ever bumps those); `copy_` on a detached alias bumps the shared counter.
         with torch.no_grad():
+            groups = {}
             for t in list(self.model.parameters()) + [b for b in self.model.buffers() if b is not None]:
-                if not t.numel():
-                    continue
-                if t.is_contiguous():
-                    td.broadcast(t.data, 0)
-                else:
-                    c = t.data.contiguous()
-                    td.broadcast(c, 0)
-                    t.data.copy_(c)
+                if t.numel():
+                    groups.setdefault((t.dtype, t.device), []).append(t)
+            for ts in groups.values():
+                flat = torch.cat([t.detach().reshape(-1) for t in ts])
+                td.broadcast(flat, 0)
+                off = 0
+                for t in ts:
+                    n = t.numel()
+                    t.detach().copy_(flat[off:off + n].view(t.shape))
+                    off += n
         self._state_synced = True
 
     def _collective_max(self, n: int) -> int:

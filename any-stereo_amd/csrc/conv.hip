@@ -1032,6 +1032,17 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   constexpr bool PDB = KS == 3 && 2 * WCHUNK + 2 * NSC * PIMG <= 160 * 1024;
   const bool dma = PDB && p.all_bs;  // kernel-uniform
   static_assert(PTW == 1 || PTW == 2, "consumer tile is 64 co x 32|64 px");
+  // Operand reads of tap t+1 are issued at the START of tap t (LD_EARLY) or between its two MFMA groups.  A 64 co x 32 px consumer
+  // tile (PTW = 1) has only 3 MFMAs = 96 cycles per group: too short to cover a ds_read_b128 round trip beside three other waves.
+  // X_FIRST: with one pixel tile the two cross-term MFMAs of a group would be back to back on one accumulator; hi.lo goes first.
+#ifndef AS_X_EARLY
+#define AS_X_EARLY 1
+#endif
+#ifndef AS_X_XFIRST
+#define AS_X_XFIRST 1
+#endif
+  constexpr bool LD_EARLY = (AS_X_EARLY == 2) || (AS_X_EARLY == 1 && PTW == 1);
+  constexpr bool X_FIRST = (AS_X_XFIRST == 2) || (AS_X_XFIRST == 1 && PTW == 1);
   static_assert(WCHUNK % (16 * 256) == 0, "weight chunk must split evenly over the loader threads");
   // [W image 0][W image 1][patch image]
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1120,8 +1131,9 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   }
 #define AS_SPLIT_MFMA_C(S, c)                                                                           \
   _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                      \
+    if (X_FIRST && !fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
     acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);   \
-    if (!fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
+    if (!X_FIRST && !fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
   }                                                                                                     \
   if (!fast16) {                                                                                        \
   _Pragma("unroll") for (int q = 0; q < PTW; ++q)  /* second cross term: not back to back with the first on the same accumulator */ \
@@ -1129,10 +1141,16 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   }
 #define AS_SPLIT_STEP(TAP)                                                                              \
   if constexpr ((TAP) < NTAPC) {                                                                        \
+    if constexpr (LD_EARLY) {                                                                           \
+      if constexpr ((TAP) + 1 < NTAPC) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+    }                                                                                                   \
     AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if constexpr ((TAP) + 1 < NTAPC) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if constexpr (!LD_EARLY) {                                                                          \
+      if constexpr ((TAP) + 1 < NTAPC) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+    }                                                                                                   \
     AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
   }

@@ -157,6 +157,12 @@ def _state_worker(rank, world, port, q):
     fill_module_deterministic(model, base_seed=1 + 17 * r)  # every rank starts from DIFFERENT weights (per-rank RNG / only rank 0 loaded)
     tr = Trainer(model, num_steps=50, train_iters=2, max_disp=args.max_disp, ddp_impl="flat")
     _, _, img1, img2, coord, gt, scale = tiny_train_case("raft")
+    # the broadcast must be visible to every (data_ptr, _version)-keyed cache (weight packs, BN folds, graph fingerprints): a rank
+    # that ran a forward before its first step holds packs of its pre-broadcast weights
+    state = list(model.parameters()) + [b_ for b_ in model.buffers() if b_ is not None and b_.numel()]
+    v0 = [t._version for t in state]
+    tr._sync_module_state()
+    bumped = all(t._version > a for t, a in zip(state, v0))
     tr.step(shard_batch((img1, img2, coord, gt, scale), r, w))
     flat = torch.cat([t.detach().reshape(-1).double() for t in list(model.parameters()) + list(model.buffers())])
     sums = [torch.zeros(2, dtype=torch.float64) for _ in range(w)]
@@ -173,7 +179,7 @@ def _state_worker(rank, world, port, q):
     finally:
         ops.split_overflow_count = ops_count
     dist.finalize()
-    q.put((r, [s_.tolist() for s_ in sums], n, tr.loss_scale, gate, tr.skipped_steps))
+    q.put((r, [s_.tolist() for s_ in sums], n, tr.loss_scale, gate, tr.skipped_steps, bumped))
 
 
 def test_flat_exchange_broadcasts_rank0_state_and_overflow_is_collective_world2():
@@ -198,8 +204,9 @@ def test_flat_exchange_broadcasts_rank0_state_and_overflow_is_collective_world2(
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    for r, sums, n, scale, gate, skipped in sorted(res):
+    for r, sums, n, scale, gate, skipped, bumped in sorted(res):
         assert sums[0] == sums[1], "ranks that started from different weights were not synchronised"
+        assert r == 0 or bumped, "the state broadcast did not bump the tensors' version counters (stale weight packs on this rank)"
         assert n == 3 and scale == 1024.0, (r, n, scale)      # two collective polls (poll + gate), each halving on both ranks
         assert gate is False and skipped == 1
 
