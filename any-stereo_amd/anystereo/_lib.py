@@ -78,11 +78,6 @@ SIGNATURES = {
     "as_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv_pack_size_split": (C.c_int64, [_i, _i, _i]),
     "as_conv_pack_weights_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "as_wino_v_elems": (C.c_int64, [_i, _i, _i, _i]),
-    "as_wino_transform": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
-    "as_conv_pack_size_wino": (C.c_int64, [_i, _i]),
-    "as_conv_pack_weights_wino": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
-    "as_conv2d_wino": (_i, [C.POINTER(ConvDesc), _vp]),
     "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -767,6 +767,8 @@ class ConvexUpsampleQuater(torch.autograd.Function):
         d_out = _c(d_out)
         d_mask = torch.empty_like(mask)
         d_disp = torch.empty_like(disp) if ctx.needs_input_grad[0] else None
+        if d_disp is not None:
+            ops.warn_nondeterministic("ConvexUpsampleQuater.backward (quarter-nearest convex upsampling)")
         with _guard(disp.device):
             L.check(L.load().as_convex_upsample_quater_bwd(_p(disp), _p(scale), _p(mask), _p(coord), _p(d_out), _p(d_mask), _p(d_disp),
                                                            b, h, w, q, 1 if ctx.logits else 0, _stream()), "convex_upsample_quater_bwd")

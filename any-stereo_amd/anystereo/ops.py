@@ -378,7 +378,6 @@ class PackedConv:
         self.bias = None
         self.cin = self.cout = self.ks = 0
         self.split = False
-        self.wino = False  # Winograd F(4,3) pack (as_conv_pack_weights_wino): consumed by conv2d with a WinoV source
 
     def invalidate(self):
         """Force a rebuild at the next use (after edits through `.data`, which do not bump version counters)."""
@@ -405,39 +404,30 @@ class PackedConv:
             self._remember(ts)
         return self
 
-    def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], transform=None, wino: bool = False):
+    def get(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], transform=None):
         split = L.load().as_get_precision() == 1
-        key = (split, bool(wino)) + tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
+        key = (split,) + tuple((w.data_ptr(), w._version, w.device) for w in weights) + \
             tuple((None if b is None else (b.data_ptr(), b._version)) for b in biases)
         ts = list(weights) + list(biases)
         if key != self._key or not self._alive(ts):
             ws = [w.detach() if transform is None else transform(w.detach()) for w in weights]
-            self._build(ws, biases, split, key, wino=wino)
+            self._build(ws, biases, split, key)
             self._remember(ts)
         return self
 
-    def _build(self, ws, biases, split, key, wino=False):
+    def _build(self, ws, biases, split, key):
         ws = [w.reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1))) for w in ws]
         w = torch.cat(ws, dim=0).contiguous().float() if len(ws) > 1 else ws[0].contiguous().float()
         _req(w, "conv weight")
         cout, cin, ks, ks2 = w.shape
         if ks != ks2:
             raise RuntimeError("PackedConv: non-square kernel")
-        if wino:
-            if not split or ks != 3:
-                raise RuntimeError("PackedConv(wino): the Winograd pack serves 3x3 convolutions in split precision")
-            n = L.load().as_conv_pack_size_wino(cin, cout)
-        else:
-            n = (L.load().as_conv_pack_size_split if split else L.load().as_conv_pack_size)(cin, cout, ks)
+        n = (L.load().as_conv_pack_size_split if split else L.load().as_conv_pack_size)(cin, cout, ks)
         if n <= 0:
-            raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}" + (" (Winograd: Cin must be a multiple of 16)" if wino else ""))
+            raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}")
         wp = torch.empty(n, device=w.device, dtype=torch.float16 if split else torch.float32)
-        self.wino = bool(wino)
         with _guard(w.device):
-            if wino:
-                scratch = torch.empty(cout * cin * 18, device=w.device, dtype=torch.float32)
-                L.check(L.load().as_conv_pack_weights_wino(_p(w), _p(wp), _p(scratch), cin, cout, _stream()), "conv_pack_weights_wino")
-            elif split:
+            if split:
                 L.check(L.load().as_conv_pack_weights_split(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights_split")
             else:
                 L.check(L.load().as_conv_pack_weights(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights")
@@ -499,58 +489,6 @@ class BS8:
         return v.permute(0, 1, 4, 2, 3).reshape(b, c8 * 8, h, w)[:, :self.c].contiguous()
 
 
-class WinoV:
-    """Winograd F(4,3)-transformed activations of a 3x3 convolution's input (as_wino_transform): t [B, 2, C/8, H, ceil(W/4), 6, 8]
-    float16 — per 8-channel block, image row and quad of 4 output columns the six position values B^T d, as a hi and a lo plane
-    set.  Built once per activation tensor and read by every convolution over it (the GRU's z|r and q convolutions share the
-    x part: update.py:34-39)."""
-
-    __slots__ = ("t", "c", "w")
-
-    def __init__(self, t: torch.Tensor, c: int, w: int):
-        self.t, self.c, self.w = t, c, w
-
-    @staticmethod
-    def empty(b: int, c: int, h: int, w: int, device) -> "WinoV":
-        if c % 8:
-            raise RuntimeError("WinoV: channels must be a multiple of 8")
-        return WinoV(torch.empty((b, 2, c // 8, h, (w + 3) // 4, 6, 8), device=device, dtype=torch.float16), c, w)
-
-    @property
-    def shape(self):  # logical NCHW shape of the activations it stands for
-        return (self.t.shape[0], self.c, self.t.shape[3], self.w)
-
-    @property
-    def device(self):
-        return self.t.device
-
-    def record_stream(self, stream) -> None:
-        self.t.record_stream(stream)
-
-
-def wino_transform(srcs, out: Optional[WinoV] = None, c_off: int = 0) -> WinoV:
-    """B^T d of the channel concat of `srcs` (fp32 tensors or BS8) into channels [c_off, ...) of `out` (a fresh WinoV of exactly
-    these channels when None).  Every source but the last must hold a multiple of 8 channels."""
-    b, _, hh, ww = srcs[0].shape
-    ctot = sum(s_.shape[1] for s_ in srcs)
-    if out is None:
-        out = WinoV.empty(b, (c_off + ctot + 7) // 8 * 8, hh, ww, srcs[0].device)
-    if tuple(out.shape[2:]) != (hh, ww) or out.shape[0] != b or c_off % 8 or c_off + ctot > out.c:
-        raise RuntimeError("wino_transform: out does not fit the sources")
-    lib = L.load()
-    off = c_off
-    with _guard(out.device):
-        for i, s_ in enumerate(srcs):
-            bs = isinstance(s_, BS8)
-            _req(s_.t if bs else s_, f"src[{i}]", torch.float16 if bs else torch.float32)
-            if tuple(s_.shape[2:]) != (hh, ww) or s_.shape[0] != b or (s_.shape[1] % 8 and i + 1 < len(srcs)):
-                raise RuntimeError("wino_transform: sources must share [B,*,H,W]; all but the last hold a multiple of 8 channels")
-            L.check(lib.as_wino_transform(_p(s_.t if bs else s_), 1 if bs else 0, s_.shape[1], _p(out.t), out.c, off, b, hh, ww, _stream()),
-                    "wino_transform")
-            off += s_.shape[1]
-    return out
-
-
 def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE, add: Optional[torch.Tensor] = None,
            add_coff: int = 0, out: Optional[torch.Tensor] = None, out_coff: int = 0, epilogue: int = L.EPI_LINEAR,
            h: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
@@ -566,13 +504,9 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     b, _, hin, win = srcs[0].shape
     if stride not in (1, 2):
         raise RuntimeError("conv2d: stride must be 1 or 2")
-    wino = isinstance(srcs[0], WinoV)
-    if wino != bool(pack.wino) or (wino and (len(srcs) != 1 or stride != 1 or dual is not None or epilogue == L.EPI_RELU_TAPS)):
-        raise RuntimeError("conv2d: a WinoV source goes with a PackedConv.get(..., wino=True) pack (one source, stride 1, "
-                           "LINEAR / GRU epilogues) and vice versa")
     hh, ww = (hin, win) if stride == 1 else ((hin - 1) // 2 + 1, (win - 1) // 2 + 1)
     kc = 16 if pack.split else (8 if pack.ks == 3 else 32)  # channels per K chunk of the kernel (csrc/conv.hip)
-    if not wino and any(s.shape[1] % kc for s in srcs[:-1]):
+    if any(s.shape[1] % kc for s in srcs[:-1]):
         # a K chunk must not straddle two tensors: materialise the concat for odd splits (never on the model path)
         srcs = [torch.cat([s.float() if isinstance(s, BS8) else s for s in srcs], dim=1)]
     if (out_bs is not None or any(isinstance(s, BS8) for s in srcs)) and not (pack.split and stride == 1):
@@ -582,14 +516,14 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     if len(srcs) > L.AS_MAX_SRCS:
         raise RuntimeError(f"conv2d: at most {L.AS_MAX_SRCS} sources")
     for i, s in enumerate(srcs):
-        if isinstance(s, (BS8, WinoV)):
+        if isinstance(s, BS8):
             _req(s.t, f"src[{i}]", torch.float16)
             d.src_bs[i] = 1
         else:
             _req(s, f"src[{i}]")
         if s.shape[0] != b or tuple(s.shape[2:]) != (hin, win):
             raise RuntimeError(f"conv2d: src[{i}] shape {tuple(s.shape)} does not match {(b, '*', hin, win)}")
-        d.src[i] = s.t.data_ptr() if isinstance(s, (BS8, WinoV)) else s.data_ptr()
+        d.src[i] = s.t.data_ptr() if isinstance(s, BS8) else s.data_ptr()
         d.src_c[i] = s.shape[1]
         cin += s.shape[1]
     if cin != pack.cin:
@@ -680,10 +614,6 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     d.act, d.epilogue = act, epilogue
     d.precision = 1 if pack.split else 0
     ws = None
-    if wino:
-        with _guard(dev):
-            L.check(L.load().as_conv2d_wino(C.byref(d), _stream()), "conv2d_wino")
-        return (out, out2) if epilogue == L.EPI_GRU_ZR else out
     if pack.split and stride == 1:
         n_ws = L.load().as_conv_ws_elems(b, cout, hh, ww)
         if n_ws > 0:  # small feature map: give the kernel split-K scratch (caching allocator: no sync)
@@ -1125,12 +1055,27 @@ def get_deterministic() -> bool:
     return _DETERMINISTIC[0]
 
 
+_NONDET_WARNED = set()
+
+
+def warn_nondeterministic(what: str) -> None:
+    """Deterministic mode covers the default option set's three float-atomic sums; the off-by-default upsampler options
+    (`liif_latent_backward`, `ConvexUpsampleQuater.backward`) still scatter with float atomics.  Say so once per path
+    instead of handing out non-repeatable gradients silently."""
+    if _DETERMINISTIC[0] and what not in _NONDET_WARNED:
+        _NONDET_WARNED.add(what)
+        import warnings
+        warnings.warn(f"anystereo deterministic mode: {what} accumulates with float atomics (not covered by the gather-form "
+                      "scatters); its gradients are not bit-repeatable", RuntimeWarning, stacklevel=3)
+
+
 def query_segments(coord, h: int, w: int):
     """(order int32 [B,Q], starts int32 [B,h*w+1]) of the queries' nearest pixels on an h x w map: `order` sorts each batch
     element's queries by pixel (stable), pixel p's queries sit at sorted positions [starts[p], starts[p+1]).  Cached for the
     coordinate tensor at hand (one entry per map size)."""
     key = (coord.data_ptr(), tuple(coord.shape), coord._version, h, w, coord.device)
-    ent = _SEGMENTS.get((h, w))
+    slot = (str(coord.device), h, w)   # one entry per (device, map size): two devices alternating at one size do not evict each other
+    ent = _SEGMENTS.get(slot)
     if ent is not None and ent[0] == key and ent[1]() is coord:
         return ent[2], ent[3]
     _, k = liif_rel_key(coord, [(h, w)], want_rel=False, want_key=True)
@@ -1139,9 +1084,9 @@ def query_segments(coord, h: int, w: int):
     bounds = torch.arange(h * w + 1, device=coord.device, dtype=torch.int64).unsqueeze(0).expand(coord.shape[0], -1).contiguous()
     starts = torch.searchsorted(sp.contiguous(), bounds).to(torch.int32).contiguous()
     order = order.to(torch.int32).contiguous()
-    if len(_SEGMENTS) > 8:
+    if len(_SEGMENTS) > 32:
         _SEGMENTS.clear()
-    _SEGMENTS[(h, w)] = (key, weakref.ref(coord), order, starts)
+    _SEGMENTS[slot] = (key, weakref.ref(coord), order, starts)
     return order, starts
 
 
@@ -1216,6 +1161,7 @@ def liif_latent_backward(d_latent, coord, lat_coff, c, h, w, unfold9=False, n_sa
     _req(d_latent, "d_latent"), _req(coord, "coord")
     b, ctot, q = d_latent.shape
     d_feat = torch.empty((b, c, h, w), device=d_latent.device, dtype=torch.float32)
+    warn_nondeterministic("liif_latent_backward (upsampler option sets other than the default)")
     with _guard(d_latent.device):
         L.check(L.load().as_liif_latent_bwd(_p(d_latent), _p(coord), _p(d_feat), b, c, h, w, q, ctot, lat_coff, 1 if unfold9 else 0,
                                             n_samp, _stream()), "liif_latent_bwd")

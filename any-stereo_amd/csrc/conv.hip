@@ -78,9 +78,6 @@ struct ConvParams {
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
   int stagger;  // conv_split_kernel: start delay per XCD index in units of 64 clocks (AS_CONV_XCD_STAGGER; 0 = none)
   int lean_offset;  // conv_split_kernel<LEAN>: start delay of the grid's second half in units of 64 clocks (AS_CONV_LEAN_OFFSET)
-  // conv_wino_kernel: the Winograd-transformed activations [B][2][Cin/8][H][vT][6][8 halves] (as_wino_transform) and their quads per row
-  const _Float16* vsrc;
-  int vT;
 };
 
 constexpr int kNumCU = 256;   // MI355X
@@ -1032,17 +1029,13 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   constexpr bool PDB = KS == 3 && 2 * WCHUNK + 2 * NSC * PIMG <= 160 * 1024;
   const bool dma = PDB && p.all_bs;  // kernel-uniform
   static_assert(PTW == 1 || PTW == 2, "consumer tile is 64 co x 32|64 px");
-  // Operand reads of tap t+1 are issued at the START of tap t (LD_EARLY) or between its two MFMA groups.  A 64 co x 32 px consumer
-  // tile (PTW = 1) has only 3 MFMAs = 96 cycles per group: too short to cover a ds_read_b128 round trip beside three other waves.
-  // X_FIRST: with one pixel tile the two cross-term MFMAs of a group would be back to back on one accumulator; hi.lo goes first.
-#ifndef AS_X_EARLY
-#define AS_X_EARLY 1
+  // Operand reads of tap t+1: ONE behind each of tap t's first MFMAs (default) or, with -DAS_CONV_LD_BURST (the round-4 form, kept
+  // for A/B builds: tools/conv_variant.sh), a burst of eight between tap t's two MFMA groups.
+#ifdef AS_CONV_LD_BURST
+  constexpr bool LD_IL = false;
+#else
+  constexpr bool LD_IL = true;
 #endif
-#ifndef AS_X_XFIRST
-#define AS_X_XFIRST 1
-#endif
-  constexpr bool LD_EARLY = (AS_X_EARLY == 2) || (AS_X_EARLY == 1 && PTW == 1);
-  constexpr bool X_FIRST = (AS_X_XFIRST == 2) || (AS_X_XFIRST == 1 && PTW == 1);
   static_assert(WCHUNK % (16 * 256) == 0, "weight chunk must split evenly over the loader threads");
   // [W image 0][W image 1][patch image]
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1117,6 +1110,32 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   const int co_base = (BN == 128) ? (cw >> 1) * 64 : 0;
   const int px_base = (BN == 128) ? (cw & 1) * (PTW * 32) : cw * (PTW * 32);
 
+  // ---- staged epilogue: one thread per (pixel, 8-channel block); its global operands (context term, h, z) ----
+  // EPG thread groups along the channel dimension, ENB8 blocks of 8 channels per thread.  On the all-DMA path the LOADER waves
+  // fetch the operands of their blocks during the LAST chunks of the K loop (their registers are idle there): the epilogue's read
+  // burst — every CU at once, HBM-bound — shrinks by the loaders' half, which moves under the MFMAs.
+  constexpr bool STAGED = EPI != kEpiTaps && EPI != kEpiPartial;
+  constexpr int EPG = NT / BM;
+  constexpr int ENB8 = STAGED ? BN / 8 / EPG : 1;
+  constexpr int EOPS = (EPI == AS_EPI_GRU_Q) ? 3 : 2;                  // buffer loads per channel (add; h; z)
+  float pav[ENB8][8], phv[ENB8][8], pzv[ENB8][8];
+  bool pre = false;  // wave-uniform: this wave's epilogue operands are already in pav / phv / pzv
+#define AS_EPI_SETUP                                                                                   \
+  const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);                                            \
+  [[maybe_unused]] const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);                    \
+  const int mt = tid % BM, cg = tid / BM;                                                              \
+  const int su = mt >> 7, m = mt & 127;                                                                \
+  const int gy = ((NSUB > 1 && su) ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = ((NSUB > 1 && su) ? sx0[NSUB - 1] : sx0[0]) + m % TW; \
+  const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
+#define AS_EPI_LOADK(K)                                                                               \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
+    const int col = (cg * ENB8 + (K)) * 8 + j;                                                        \
+    const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff;                 \
+    pav[K][j] = as_bload(e.r_add, off);                                                               \
+    if (EPI == AS_EPI_GRU_ZR || EPI == AS_EPI_LINEAR) phv[K][j] = as_bload(e.r_h, off);                \
+    if (EPI == AS_EPI_GRU_Q) { phv[K][j] = as_bload(e.r_h, off); pzv[K][j] = as_bload(e.r_z, off); }   \
+  }
+
 #define AS_SPLIT_LDOPS(TAP, S)                                                                          \
   {                                                                                                     \
     _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                      \
@@ -1131,26 +1150,63 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   }
 #define AS_SPLIT_MFMA_C(S, c)                                                                           \
   _Pragma("unroll") for (int q = 0; q < PTW; ++q) {                                                      \
-    if (X_FIRST && !fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
     acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);   \
-    if (!X_FIRST && !fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
+    if (!fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);   \
   }                                                                                                     \
   if (!fast16) {                                                                                        \
   _Pragma("unroll") for (int q = 0; q < PTW; ++q)  /* second cross term: not back to back with the first on the same accumulator */ \
     acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0); \
   }
-#define AS_SPLIT_STEP(TAP)                                                                              \
+  // LD_IL: ONE operand read of tap t+1 behind each of tap t's first MFMAs instead of a burst of eight between its two MFMA groups:
+  // an MFMA holds the SIMD's vector issue for 8 of its 32 cycles and a ds_read_b128 issued in the remaining gap is free, while a
+  // burst delays the MFMA behind it by what does not fit one gap.  Same MFMAs on the same accumulators in the same order.
+#define AS_LD_A(TAPN, SN, c, comp)                                                                      \
+  if constexpr ((TAPN) < NTAPC) {                                                                       \
+    if ((comp) == 0) a_hi[SN][c] = *reinterpret_cast<const half8*>(wb + (((TAPN) * 2 + 0) * 2) * WSEG + (c) * 512);          \
+    else if (!fast16) a_lo[SN][c] = *reinterpret_cast<const half8*>(wb + (((TAPN) * 2 + 1) * 2) * WSEG + (c) * 512);         \
+  }
+#define AS_LD_B(TAPN, SN, q, comp)                                                                      \
+  if constexpr ((TAPN) < NTAPC) {                                                                       \
+    constexpr int tapoffn_ = (KS == 1) ? (TAPN) * PIMG : (((TAPN) / KS) * PW + ((TAPN) % KS)) * 16;      \
+    if ((comp) == 0) b_hi[SN][q] = *reinterpret_cast<const half8*>(pb + plane_off[q] + tapoffn_);       \
+    else if (!fast16) b_lo[SN][q] = *reinterpret_cast<const half8*>(pb + 2 * PATCHT * 16 + plane_off[q] + tapoffn_); \
+  }
+#define AS_MM_HH(S, c, q) acc_h[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_hi[S][q], acc_h[c][q], 0, 0, 0);
+#define AS_MM_HX(S, c, q) if (!fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[S][c], b_lo[S][q], acc_x[c][q], 0, 0, 0);
+#define AS_MM_LH(S, c, q) if (!fast16) acc_x[c][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[S][c], b_hi[S][q], acc_x[c][q], 0, 0, 0);
+#define AS_SB __builtin_amdgcn_sched_barrier(0);
+#define AS_SPLIT_STEP_IL(TAP)                                                                           \
   if constexpr ((TAP) < NTAPC) {                                                                        \
-    if constexpr (LD_EARLY) {                                                                           \
-      if constexpr ((TAP) + 1 < NTAPC) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                        \
-      __builtin_amdgcn_sched_barrier(0);                                                                \
+    constexpr int S_ = (TAP) & 1, N_ = ((TAP) + 1) & 1, T1_ = (TAP) + 1;                                \
+    if constexpr (PTW == 2) {                                                                           \
+      AS_MM_HH(S_, 0, 0) AS_LD_A(T1_, N_, 0, 0) AS_SB                                                    \
+      AS_MM_HX(S_, 0, 0) AS_LD_A(T1_, N_, 0, 1) AS_SB                                                    \
+      AS_MM_HH(S_, 0, 1) AS_LD_B(T1_, N_, 0, 0) AS_SB                                                    \
+      AS_MM_HX(S_, 0, 1) AS_LD_B(T1_, N_, 0, 1) AS_SB                                                    \
+      AS_MM_LH(S_, 0, 0) AS_LD_A(T1_, N_, 1, 0) AS_SB                                                    \
+      AS_MM_LH(S_, 0, 1) AS_LD_A(T1_, N_, 1, 1) AS_SB                                                    \
+      AS_MM_HH(S_, 1, 0) AS_LD_B(T1_, N_, 1, 0) AS_SB                                                    \
+      AS_MM_HX(S_, 1, 0) AS_LD_B(T1_, N_, 1, 1) AS_SB                                                    \
+      AS_MM_HH(S_, 1, 1) AS_SB                                                                           \
+      AS_MM_HX(S_, 1, 1) AS_SB                                                                           \
+      AS_MM_LH(S_, 1, 0) AS_SB                                                                           \
+      AS_MM_LH(S_, 1, 1) AS_SB                                                                           \
+    } else {                                                                                            \
+      AS_MM_HX(S_, 0, 0) AS_LD_A(T1_, N_, 0, 0) AS_SB                                                    \
+      AS_MM_HH(S_, 0, 0) AS_LD_B(T1_, N_, 0, 0) AS_SB                                                    \
+      AS_MM_LH(S_, 0, 0) AS_LD_B(T1_, N_, 0, 1) AS_SB                                                    \
+      AS_MM_HX(S_, 1, 0) AS_LD_A(T1_, N_, 0, 1) AS_SB                                                    \
+      AS_MM_HH(S_, 1, 0) AS_LD_A(T1_, N_, 1, 0) AS_SB                                                    \
+      AS_MM_LH(S_, 1, 0) AS_LD_A(T1_, N_, 1, 1) AS_SB                                                    \
     }                                                                                                   \
+  }
+#define AS_SPLIT_STEP(TAP)                                                                              \
+  if constexpr (LD_IL) { AS_SPLIT_STEP_IL(TAP) } else                                                   \
+  if constexpr ((TAP) < NTAPC) {                                                                        \
     AS_SPLIT_MFMA_C((TAP) & 1, 0)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if constexpr (!LD_EARLY) {                                                                          \
-      if constexpr ((TAP) + 1 < NTAPC) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                        \
-      __builtin_amdgcn_sched_barrier(0);                                                                \
-    }                                                                                                   \
+    if constexpr ((TAP) + 1 < NTAPC) AS_SPLIT_LDOPS((TAP) + 1, ((TAP) + 1) & 1)                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
     AS_SPLIT_MFMA_C((TAP) & 1, 1)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
   }
@@ -1368,10 +1424,40 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
         AS_DMA_UNIT(chunk_lo, 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // epilogue operands of this loader thread: ONE of its ENB8 blocks per unit, the last one three units before the end (a
+        // thin stream beside the unit's DMA instead of a burst: chip-wide a block is 6 MB) — issued behind the unit's DMA (pinned
+        // by sched_barriers), so that the counted wait covers the DMA and every older load and leaves only this block's loads
+        // in flight.  From the first block on the loader's barriers are bare s_barriers: __syncthreads' fence would wait for
+        // every outstanding load, and a loader issues no LDS instruction.
+        int pre0 = chunk_hi;  // first unit of the prefetch window (none)
+        if constexpr (STAGED && !FAST) {
+#ifndef AS_CONV_NO_EPI_PREFETCH
+          if (chunk_hi - chunk_lo >= ENB8 + 3 && (p.add != nullptr || EPI != AS_EPI_LINEAR || p.h != nullptr)) pre0 = chunk_hi - (ENB8 + 2);
+#endif
+        }
         for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
 #ifndef AS_ABL_NO_DMA
           if (chunk + 1 < chunk_hi) AS_DMA_UNIT(chunk + 1, ((chunk - chunk_lo) & 1) ^ 1)
 #endif
+          if constexpr (STAGED && !FAST) {
+            if (chunk >= pre0) {
+              const int bi = chunk - pre0;  // wave-uniform
+              if (bi < ENB8) {
+                __builtin_amdgcn_sched_barrier(0);
+                AS_EPI_SETUP
+#pragma unroll
+                for (int k = 0; k < ENB8; ++k)
+                  if (bi == k) AS_EPI_LOADK(k)
+                pre = true;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * EOPS) : "memory");
+              } else if (chunk + 1 < chunk_hi) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last unit, issued behind the last block's loads
+              }
+              __builtin_amdgcn_s_barrier();
+              continue;
+            }
+          }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();  // unit c+1 landed, consumers finished unit c
         }
@@ -1517,25 +1603,9 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
     // the epilogue's global operands (context term, h, z) do not depend on the tile: the first block's loads are issued
     // BEFORE the consumers park it and before the barrier (issued after it they cost one exposed round trip per block:
     // gru04 z|r 149.7 -> 148.0 us, +0.6 % pairs/s)
-    const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);
-    const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
-    constexpr int PG = NT / BM;            // thread groups along the channel dimension
-    constexpr int NB8 = BN / 8 / PG;       // 8-channel blocks per thread
-    const int mt = tid % BM, cg = tid / BM;
-    const int su = mt >> 7, m = mt & 127;
-    const int gy = ((NSUB > 1 && su) ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = ((NSUB > 1 && su) ? sx0[NSUB - 1] : sx0[0]) + m % TW;
-    const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
-    // operand loads of block k+1 are issued before block k is finished
-    float av[2][8], hv[2][8], zv[2][8];
-#define AS_EPI_LOAD8(K, S)                                                                            \
-  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
-    const int col = (cg * NB8 + (K)) * 8 + j;                                                         \
-    const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff;                 \
-    av[S][j] = as_bload(e.r_add, off);                                                                \
-    if (EPI == AS_EPI_GRU_ZR || EPI == AS_EPI_LINEAR) hv[S][j] = as_bload(e.r_h, off);                 \
-    if (EPI == AS_EPI_GRU_Q) { hv[S][j] = as_bload(e.r_h, off); zv[S][j] = as_bload(e.r_z, off); }     \
-  }
-    AS_EPI_LOAD8(0, 0)
+    AS_EPI_SETUP
+    constexpr int NB8 = ENB8;              // 8-channel blocks per thread
+    if (!pre) AS_EPI_LOADK(0)
     if (!loader) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -1549,24 +1619,28 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
     }
     __syncthreads();
     AS_LIFE(3)
+    // the accumulators are dead: the loads of ALL remaining blocks go out together (a wave that prefetched has them already)
+    if (!pre) {
+#pragma unroll
+      for (int k = 1; k < NB8; ++k) AS_EPI_LOADK(k)
+    }
 #pragma unroll
     for (int k = 0; k < NB8; ++k) {
-      if (k + 1 < NB8) AS_EPI_LOAD8(k + 1, (k + 1) & 1)
       float ov[8];
       const int col0 = (cg * NB8 + k) * 8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int col = col0 + j;
-        const float x = stage[col * BM + mt] + bias_s[col] + av[k & 1][j];
+        const float x = stage[col * BM + mt] + bias_s[col] + pav[k][j];
         float o;
         if (EPI == AS_EPI_LINEAR) {
           o = act_apply(x, p.act);
-          if (p.h) o = fmaxf(o + hv[k & 1][j], 0.f);
+          if (p.h) o = fmaxf(o + phv[k][j], 0.f);
         } else if (EPI == AS_EPI_GRU_ZR) {
           const float gte = 1.f / (1.f + expf(-x));
-          o = is_r ? gte * hv[k & 1][j] : gte;
+          o = is_r ? gte * phv[k][j] : gte;
         } else {
-          o = (1.f - zv[k & 1][j]) * hv[k & 1][j] + zv[k & 1][j] * tanhf(x);
+          o = (1.f - pzv[k][j]) * phv[k][j] + pzv[k][j] * tanhf(x);
         }
         ov[j] = o;
         if (!e.skip_out) as_bstore(e.r_out, poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff, o);
@@ -1599,7 +1673,6 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
         }
       }
     }
-#undef AS_EPI_LOAD8
   } else if (!loader) {
     const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, second);
     const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
@@ -1617,7 +1690,16 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
 }
 
+#undef AS_EPI_SETUP
+#undef AS_EPI_LOADK
 #undef AS_SPLIT_STEP
+#undef AS_SPLIT_STEP_IL
+#undef AS_LD_A
+#undef AS_LD_B
+#undef AS_MM_HH
+#undef AS_MM_HX
+#undef AS_MM_LH
+#undef AS_SB
 #undef AS_SPLIT_MFMA_C
 #undef AS_SPLIT_LDOPS
 
@@ -1809,367 +1891,6 @@ void conv_apply_dual(ConvParams& p, const as_conv_desc* d) {
   p.out_bs_coff8_2 = d->out_bs_coff2 / 8;
 }
 
-
-// =====================================================================================================================
-// Winograd F(4,3) along x for the split-precision 3x3, stride-1 convolutions (update.py:29-31,18: the GRU gate convolutions and
-// the head's first layer are matrix-instruction-bound at the chip's power-limited fp16 rate — profiles/r04_winograd_resource_profile.txt).
-// Per image row, 4 consecutive outputs ("quad" q: x = 4q .. 4q+3) come from 6 inputs x = 4q-1 .. 4q+4 through 6 products instead of
-// 12:   Y = A^T [ (G g) . (B^T d) ]   with the interpolation points 0, +-1, +-2, inf.  The three kernel ROWS stay a direct sum, so a
-// 16-channel chunk is 3 x 6 = 18 MFMA steps for 4 output columns (direct: 9 steps per column-... 36 for the same 4): HALF the
-// matrix instructions.  B^T d is computed ONCE per activation tensor by wino_transform_kernel (fp32 arithmetic, then the usual
-// hi/lo split) into V [B][comp][Cin/8][H][T][6][8]; G g is folded into the weight pack ([chunk][ky*6+xi][comp][h][co][8]); the six
-// position sums are separate accumulators (6 x (hi.hi | cross) x 16 VGPRs per 32 co x 32 quads wave tile) combined by A^T in
-// fp32 when the tile is parked for the staged epilogue — which is conv_split_kernel's, unchanged (same pixel order in LDS).
-// Block = 64 co x 2 sub-tiles of 8 rows x 16 px (= 32 quads each), 4 consumer waves (co half x sub-tile) + 4 loader waves that
-// only issue LDS-DMA: per (chunk, ky) unit a 24 KB weight image [xi][comp][h][co][8], per chunk a 30 KB V image
-// [comp][h][sub-tile][xi][10 rows][4 quads][8], both double buffered; one barrier per unit.
-// Error: the transforms are exact small-integer combinations in fp32; measured against the fp64 convolution the result is as
-// close as PyTorch's own fp32 conv (rms 2.8e-7 relative; tests/test_hip_parity.py::test_conv_winograd_*).
-// =====================================================================================================================
-constexpr int kWinoU = 6 * 4 * 64 * 16;            // bytes of one (chunk, ky) weight unit image
-constexpr int kWinoV = 2 * 2 * 2 * 6 * 40 * 16;    // bytes of one chunk's V image
-constexpr int kWinoVItems = 2 * 2 * 6 * 40;        // 16-B units of one comp of it
-
-struct WinoTParams {
-  const float* src;   // fp32 [B,C,H,W] or blocked split-fp16 [B][2][ceil(C/8)][H][W][8]
-  int src_bs, C;
-  _Float16* v;        // [B][2][c8_tot][H][T][6][8]
-  int c8_tot, c8_off;
-  int B, H, W, T;
-};
-
-// one thread per (batch, 8-channel block, row, quad): 6 pixels x 8 channels in, 6 positions x 8 channels x (hi, lo) out
-__global__ __launch_bounds__(256) void wino_transform_kernel(WinoTParams p) {
-  as::fp16_saturate_mode();
-  const int c8s = (p.C + 7) >> 3;
-  const long long total = (long long)p.B * c8s * p.H * p.T;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  float amax = 0.f;
-  if (idx < total) {
-    const int q = (int)(idx % p.T);
-    long long t = idx / p.T;
-    const int y = (int)(t % p.H);
-    t /= p.H;
-    const int c8 = (int)(t % c8s);
-    const int b = (int)(t / c8s);
-    float d[6][8];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int x = 4 * q - 1 + j;
-      const bool in = x >= 0 && x < p.W;
-      if (p.src_bs) {
-        const half8* sp = reinterpret_cast<const half8*>(p.src);
-        const long long u = (((long long)b * 2 * c8s + c8) * p.H + y) * p.W + (in ? x : 0);
-        half8 hi = sp[u], lo = sp[u + (long long)c8s * p.H * p.W];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) d[j][c] = in ? (float)hi[c] + (float)lo[c] * (1.f / 2048.f) : 0.f;
-      } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int ch = c8 * 8 + c;
-          d[j][c] = (in && ch < p.C) ? p.src[(((long long)b * p.C + ch) * p.H + y) * p.W + x] : 0.f;
-        }
-      }
-    }
-    _Float16* vp = p.v + (((((long long)b * 2 * p.c8_tot + p.c8_off + c8) * p.H + y) * p.T + q) * 6) * 8;
-    const long long comp = (long long)p.c8_tot * p.H * p.T * 6 * 8;
-#pragma unroll
-    for (int xi = 0; xi < 6; ++xi) {
-      half8 hi, lo;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
-        float v;
-        if (xi == 0) v = 4.f * d0 - 5.f * d2 + d4;
-        else if (xi == 1) v = -4.f * (d1 + d2) + d3 + d4;
-        else if (xi == 2) v = 4.f * (d1 - d2) - d3 + d4;
-        else if (xi == 3) v = -2.f * d1 - d2 + 2.f * d3 + d4;
-        else if (xi == 4) v = 2.f * d1 - d2 - 2.f * d3 + d4;
-        else v = 4.f * d1 - 5.f * d3 + d5;
-        const _Float16 h = (_Float16)v;
-        hi[c] = h;
-        lo[c] = (_Float16)((v - (float)h) * 2048.f);
-        amax = fmaxf(amax, fabsf(v));
-      }
-      *reinterpret_cast<half8*>(vp + xi * 8) = hi;
-      *reinterpret_cast<half8*>(vp + comp + xi * 8) = lo;
-    }
-  }
-  as::note_split_overflow(amax, &g_split_overflow_conv);
-}
-
-// [Cout][Cin][3][3] fp32 -> G g along kx -> [Cout][Cin][3][6] fp32 (then as_conv_pack_weights_split_taps with 18 taps)
-__global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ u, long long rows) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // (co, ci, ky)
-  if (i >= rows) return;
-  const float g0 = w[i * 3], g1 = w[i * 3 + 1], g2 = w[i * 3 + 2];
-  float* o = u + i * 6;
-  o[0] = g0 * 0.25f;
-  o[1] = -(g0 + g1 + g2) * (1.f / 6.f);
-  o[2] = -(g0 - g1 + g2) * (1.f / 6.f);
-  o[3] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-  o[4] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-  o[5] = g2;
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void conv_wino_kernel(ConvParams p) {
-  constexpr int BN = 64, TW = 16, TH = 8, NSUB = 2, BM = 256, NT = 512;
-  as::fp16_saturate_mode();
-  float ovf_amax = 0.f;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // [U 0][U 1][V 0][V 1]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave >= 4;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int ntile = p.tiles_x * p.tiles_y;
-  const int ngroup = (ntile + NSUB - 1) / NSUB;
-  int group, b, nt;
-  {
-    const int T_ = ngroup * p.B;  // pixel groups incl. batch
-    const int id = blockIdx.x;
-    int pt;
-    if (p.xcd_map) {  // the channel tiles of one pixel group on the same XCD (conv_split_kernel's order)
-      const int per = 8 * p.n_tiles;
-      const int chunk = id / per, r = id - chunk * per;
-      const int m = min(8, T_ - chunk * 8);
-      nt = r / m;
-      pt = chunk * 8 + (r - nt * m);
-    } else {
-      pt = id % T_;
-      nt = id / T_;
-    }
-    group = pt % ngroup;
-    b = pt / ngroup;
-  }
-  int sx0[NSUB], sy0[NSUB];
-#pragma unroll
-  for (int u = 0; u < NSUB; ++u) {
-    const int t = group * NSUB + u;
-    sx0[u] = (t % p.tiles_x) * TW;
-    sy0[u] = t < ntile ? (t / p.tiles_x) * TH : p.H + 2;  // a missing sub-tile sits below the image
-  }
-  const int n0 = nt * BN;
-  const int T = p.vT;
-  const int nchunk = p.chunks;
-  f32x16 acc_h[6], acc_x[6];
-  const int cw = wave & 3;
-  const int co_base = (cw & 1) * 32, su_c = cw >> 1;
-
-  if (loader) {
-    const int ltid = tid - 256, lwave = wave - 4;
-    unsigned v_off[4];
-    bool v_slot[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int idx = ltid + i * 256;
-      const bool slot = idx < kWinoVItems;
-      if (!slot) idx = kWinoVItems - 1;
-      const int quad = idx & 3;
-      int r = idx >> 2;
-      const int row = r % 10;
-      r /= 10;
-      const int xi = r % 6;
-      r /= 6;
-      const int su = r & 1, hh = r >> 1;
-      const int gy = sy0[su] - 1 + row, gq = (sx0[su] >> 2) + quad;
-      const bool in = slot && gy >= 0 && gy < p.H && gq < T;
-      v_off[i] = in ? (unsigned)(((((long long)hh * p.H + gy) * T + gq) * 6 + xi) * 16) : 0x7FFFFFF0u;
-      v_slot[i] = slot;
-    }
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpack, 0, 0x7FFFFFF0, 0x00020000);
-    const unsigned wvoff = (unsigned)((n0 + (long long)(ltid >> 6) * p.Cout_pad + (ltid & 63)) * 16);
-    const long long wstep16 = 4ll * p.Cout_pad;    // four (xi, comp, h) segments per DMA round of the 256 loader threads
-    const long long wunit16 = 24ll * p.Cout_pad;   // one (chunk, ky) unit
-    const int C8 = p.Cin >> 3;
-    const long long plane6 = (long long)p.H * T * 6;  // 16-B units of one 8-channel block of one comp of V
-#define AS_WINO_DMA_U(UNIT, BUF)                                                                                        \
-  _Pragma("unroll") for (int g = 0; g < 6; ++g)                                                                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (as_lds_void*)(lds + (BUF) * kWinoU + g * 4096 + lwave * 1024), 16, wvoff, \
-                                             (unsigned)(((long long)(UNIT) * wunit16 + (long long)g * wstep16) * 16), 0, 0);
-#define AS_WINO_DMA_V(CHUNK, BUF, I)                                                                                    \
-  {                                                                                                                     \
-    const _Float16* vb_ = p.vsrc + (((long long)b * 2 * C8 + 2 * (CHUNK)) * plane6) * 8;                                 \
-    const int recs_ = (int)(2 * plane6 * 16);                                                                           \
-    const __amdgpu_buffer_rsrc_t rh_ = __builtin_amdgcn_make_buffer_rsrc((void*)vb_, 0, recs_, 0x00020000);             \
-    const __amdgpu_buffer_rsrc_t rl_ = __builtin_amdgcn_make_buffer_rsrc((void*)(vb_ + (long long)C8 * plane6 * 8), 0, recs_, 0x00020000); \
-    const int vo_ = (int)v_off[I];                                                                                      \
-    if (v_slot[I]) {                                                                                                    \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rh_, (as_lds_void*)(lds + 2 * kWinoU + (BUF) * kWinoV + ((I) * 256 + lwave * 64) * 16), 16, vo_, 0, 0, 0); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rl_, (as_lds_void*)(lds + 2 * kWinoU + (BUF) * kWinoV + kWinoV / 2 + ((I) * 256 + lwave * 64) * 16), 16, vo_, 0, 0, 0); \
-    }                                                                                                                   \
-  }
-    AS_WINO_DMA_V(0, 0, 0) AS_WINO_DMA_V(0, 0, 1) AS_WINO_DMA_V(0, 0, 2) AS_WINO_DMA_V(0, 0, 3)
-    AS_WINO_DMA_U(0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int u = 0;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const bool more = chunk + 1 < nchunk;
-      const int vnext = (chunk + 1) & 1;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        if (more || ky < 2) AS_WINO_DMA_U(u + 1, (u + 1) & 1)
-        if (more) {  // the next chunk's V image, a third of it per unit
-          if (ky == 0) { AS_WINO_DMA_V(chunk + 1, vnext, 0) AS_WINO_DMA_V(chunk + 1, vnext, 3) }
-          if (ky == 1) AS_WINO_DMA_V(chunk + 1, vnext, 1)
-          if (ky == 2) AS_WINO_DMA_V(chunk + 1, vnext, 2)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // unit u + 1 landed, the consumers finished unit u
-        ++u;
-      }
-    }
-#undef AS_WINO_DMA_U
-#undef AS_WINO_DMA_V
-  } else {
-#pragma unroll
-    for (int xi = 0; xi < 6; ++xi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_h[xi][r] = 0.f; acc_x[xi][r] = 0.f; }
-    const unsigned char* ua = lds + half * 1024 + (co_base + l31) * 16;
-    const unsigned char* va = lds + 2 * kWinoU + half * (kWinoV / 4) + su_c * (6 * 40 * 16) + l31 * 16;
-    __syncthreads();
-    int u = 0;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const unsigned char* vb = va + (chunk & 1) * kWinoV;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const unsigned char* ub = ua + (u & 1) * kWinoU;
-        half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
-#define AS_WINO_LD(XI, S)                                                                         \
-  {                                                                                               \
-    a_hi[S] = *reinterpret_cast<const half8*>(ub + ((XI) * 4) * 1024);                             \
-    a_lo[S] = *reinterpret_cast<const half8*>(ub + ((XI) * 4 + 2) * 1024);                         \
-    b_hi[S] = *reinterpret_cast<const half8*>(vb + ((XI) * 40 + ky * 4) * 16);                     \
-    b_lo[S] = *reinterpret_cast<const half8*>(vb + kWinoV / 2 + ((XI) * 40 + ky * 4) * 16);        \
-  }
-#define AS_WINO_STEP(XI)                                                                          \
-  {                                                                                               \
-    acc_h[XI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[(XI) & 1], b_hi[(XI) & 1], acc_h[XI], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    if constexpr ((XI) + 1 < 6) AS_WINO_LD((XI) + 1, ((XI) + 1) & 1)                               \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-    acc_x[XI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[(XI) & 1], b_lo[(XI) & 1], acc_x[XI], 0, 0, 0); \
-    acc_x[XI] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[(XI) & 1], b_hi[(XI) & 1], acc_x[XI], 0, 0, 0); \
-    __builtin_amdgcn_sched_barrier(0);                                                            \
-  }
-        AS_WINO_LD(0, 0)
-        AS_WINO_STEP(0) AS_WINO_STEP(1) AS_WINO_STEP(2) AS_WINO_STEP(3) AS_WINO_STEP(4) AS_WINO_STEP(5)
-#undef AS_WINO_LD
-#undef AS_WINO_STEP
-        __syncthreads();
-        ++u;
-      }
-    }
-  }
-
-  // ---- epilogue: A^T while the tile is parked, then conv_split_kernel's staged finish (all eight waves) ----
-  float* bias_s = reinterpret_cast<float*>(lds);  // the operand images are dead after the last barrier
-  if (tid < BN) bias_s[tid] = (p.bias && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;
-  __syncthreads();
-  float* stage = bias_s + 256;  // fp32 [BN channels][BM pixels], pixel = sub-tile * 128 + row * 16 + column
-  const EpiCtx e = make_epi_ctx<EPI>(p, b, n0, BN, false);
-  const bool is_r = (EPI == AS_EPI_GRU_ZR) && n0 >= (p.Cout >> 1);
-  constexpr int PG = NT / BM;       // thread groups along the channel dimension
-  constexpr int NB8 = BN / 8 / PG;  // 8-channel blocks per thread
-  const int mt = tid % BM, cg = tid / BM;
-  const int su = mt >> 7, m = mt & 127;
-  const int gy = (su ? sy0[1] : sy0[0]) + m / TW, gx = (su ? sx0[1] : sx0[0]) + m % TW;
-  const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
-  float av[2][8], hv[2][8], zv[2][8];
-#define AS_EPI_LOAD8(K, S)                                                                            \
-  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
-    const int col = (cg * NB8 + (K)) * 8 + j;                                                         \
-    const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff;                 \
-    av[S][j] = as_bload(e.r_add, off);                                                                \
-    if (EPI == AS_EPI_GRU_ZR || EPI == AS_EPI_LINEAR) hv[S][j] = as_bload(e.r_h, off);                 \
-    if (EPI == AS_EPI_GRU_Q) { hv[S][j] = as_bload(e.r_h, off); zv[S][j] = as_bload(e.r_z, off); }     \
-  }
-  AS_EPI_LOAD8(0, 0)
-  if (!loader) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int col = co_base + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float m0 = acc_h[0][r] + acc_x[0][r] * (1.f / 2048.f), m1 = acc_h[1][r] + acc_x[1][r] * (1.f / 2048.f);
-      const float m2 = acc_h[2][r] + acc_x[2][r] * (1.f / 2048.f), m3 = acc_h[3][r] + acc_x[3][r] * (1.f / 2048.f);
-      const float m4 = acc_h[4][r] + acc_x[4][r] * (1.f / 2048.f), m5 = acc_h[5][r] + acc_x[5][r] * (1.f / 2048.f);
-      const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-      f32x4 y;
-      y[0] = m0 + s12 + s34;
-      y[1] = d12 + 2.f * d34;
-      y[2] = s12 + 4.f * s34;
-      y[3] = d12 + 8.f * d34 + m5;
-      *reinterpret_cast<f32x4*>(stage + col * BM + su_c * 128 + l31 * 4) = y;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NB8; ++k) {
-    if (k + 1 < NB8) AS_EPI_LOAD8(k + 1, (k + 1) & 1)
-    float ov[8];
-    const int col0 = (cg * NB8 + k) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int col = col0 + j;
-      const float x = stage[col * BM + mt] + bias_s[col] + av[k & 1][j];
-      float o;
-      if (EPI == AS_EPI_LINEAR) {
-        o = act_apply(x, p.act);
-        if (p.h) o = fmaxf(o + hv[k & 1][j], 0.f);
-      } else if (EPI == AS_EPI_GRU_ZR) {
-        const float gte = 1.f / (1.f + expf(-x));
-        o = is_r ? gte * hv[k & 1][j] : gte;
-      } else {
-        o = (1.f - zv[k & 1][j]) * hv[k & 1][j] + zv[k & 1][j] * tanhf(x);
-      }
-      ov[j] = o;
-      if (!e.skip_out) as_bstore(e.r_out, poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff, o);
-    }
-    if (e.has_bs) {
-      half8 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const _Float16 hj = (_Float16)ov[j];
-        hi[j] = hj;
-        lo[j] = (_Float16)((ov[j] - (float)hj) * 2048.f);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) ovf_amax = fmaxf(ovf_amax, fmaxf(fabsf(ov[j]), fabsf(ov[j + 1])));
-      const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)(col0 >> 3) * (e.plane4 * 4u) + poff * 4u;
-      if (col0 + 8 <= e.cvalid) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), e.r_bs, (int)off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), e.r_bsl, (int)off, 0, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool own = col0 + j < e.cvalid, pad = col0 + j >= e.cend;
-          if (own || pad) {
-            const unsigned ok = off == 0x7FFFFFF0u ? off : off + 2u * j;
-            const _Float16 zero = (_Float16)0.f;
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, own ? hi[j] : zero), e.r_bs, (int)ok, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, own ? lo[j] : zero), e.r_bsl, (int)ok, 0, 0);
-          }
-        }
-      }
-    }
-  }
-#undef AS_EPI_LOAD8
-  as::note_split_overflow(ovf_amax, &g_split_overflow_conv);
-}
-
-template <int EPI>
-int launch_conv_wino(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = 2 * kWinoU + 2 * kWinoV;
-  static_assert(lds <= 160 * 1024 && lds >= 1024 + 64 * 256 * 4, "conv_wino: LDS budget (operand images, staged tile)");
-  as::lds_opt_in((const void*)conv_wino_kernel<EPI>);
-  const long long groups = as::cdiv64((long long)p.tiles_x * p.tiles_y, 2);
-  const dim3 grid((unsigned)((long long)p.B * groups * p.n_tiles));
-  hipLaunchKernelGGL((conv_wino_kernel<EPI>), grid, dim3(512), lds, s, p);
-  return as::check_launch("conv2d(winograd)");
-}
-
 }  // namespace
 
 extern "C" {
@@ -2221,104 +1942,6 @@ int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Co
   hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream),
                      weight, (_Float16*)wpack, Cin, Cout, conv_cout_pad(Cout), KS * KS, (long long)total);
   return as::check_launch("conv_pack_weights_split");
-}
-
-// ---- Winograd F(4,3) along x (conv_wino_kernel) ----
-int64_t as_conv_pack_size_wino(int Cin, int Cout) {
-  if (Cin <= 0 || Cout <= 0 || Cin % kSplitKC != 0) return -1;
-  return (int64_t)(Cin / kSplitKC) * 18 * 4 * conv_cout_pad(Cout) * 8;  // fp16 elements: [chunk][ky*6+xi][comp][h][Cout_pad][8]
-}
-
-int as_conv_pack_weights_wino(const float* weight, void* wpack, float* scratch, int Cin, int Cout, void* stream) {
-  AS_REQUIRE(weight && wpack && scratch, AS_ERR_BAD_ARG, "conv_pack_wino: null pointer (scratch: Cout*Cin*18 floats)");
-  const int64_t total = as_conv_pack_size_wino(Cin, Cout);
-  AS_REQUIRE(total > 0, AS_ERR_BAD_ARG, "conv_pack_wino: Cin=%d (a multiple of 16) Cout=%d", Cin, Cout);
-  const long long rows = (long long)Cout * Cin * 3;
-  hipStream_t s = as::as_stream(stream);
-  hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)as::cdiv64(rows, 256)), dim3(256), 0, s, weight, scratch, rows);
-  hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, s,
-                     (const float*)scratch, (_Float16*)wpack, Cin, Cout, conv_cout_pad(Cout), 18, (long long)total);
-  return as::check_launch("conv_pack_weights_wino");
-}
-
-int64_t as_wino_v_elems(int B, int Cin, int H, int W) {
-  if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0) return -1;
-  return (int64_t)B * 2 * (Cin / 8) * H * ((W + 3) / 4) * 6 * 8;  // fp16 elements
-}
-
-int as_wino_transform(const void* src, int src_bs, int C, void* v, int Cin_total, int c_off, int B, int H, int W, void* stream) {
-  AS_REQUIRE(src && v, AS_ERR_BAD_ARG, "wino_transform: null pointer");
-  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cin_total % 8 == 0 && c_off % 8 == 0 && c_off >= 0 && c_off + (C + 7) / 8 * 8 <= Cin_total, AS_ERR_BAD_SHAPE,
-             "wino_transform: channel window [%d,%d) inside %d channels (multiples of 8)", c_off, c_off + C, Cin_total);
-  AS_REQUIRE((reinterpret_cast<uintptr_t>(v) & 15) == 0 && (!src_bs || (reinterpret_cast<uintptr_t>(src) & 15) == 0), AS_ERR_BAD_ARG, "wino_transform: 16-B alignment");
-  WinoTParams p;
-  p.src = (const float*)src; p.src_bs = src_bs ? 1 : 0; p.C = C;
-  p.v = (_Float16*)v; p.c8_tot = Cin_total / 8; p.c8_off = c_off / 8;
-  p.B = B; p.H = H; p.W = W; p.T = (W + 3) / 4;
-  const long long total = (long long)B * ((C + 7) / 8) * H * p.T;
-  AS_REQUIRE(total < 2147483647ll * 256, AS_ERR_BAD_SHAPE, "wino_transform: grid too large");
-  hipLaunchKernelGGL(wino_transform_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), p);
-  return as::check_launch("wino_transform");
-}
-
-int as_conv2d_wino(const as_conv_desc* d, void* stream) {
-  AS_REQUIRE(d, AS_ERR_BAD_ARG, "conv2d_wino: null descriptor");
-  AS_REQUIRE(d->KS == 3 && (d->stride == 0 || d->stride == 1) && d->precision == 1 && !d->dual, AS_ERR_BAD_ARG,
-             "conv2d_wino: 3x3, stride 1, split precision, no dual launch");
-  AS_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Cin % kSplitKC == 0, AS_ERR_BAD_ARG,
-             "conv2d_wino: Cin=%d must be a multiple of 16", d->Cin);
-  AS_REQUIRE(d->n_src == 1 && d->src[0] && d->src_c[0] == d->Cin, AS_ERR_BAD_ARG, "conv2d_wino: src[0] = the transformed activations of all %d channels", d->Cin);
-  AS_REQUIRE(d->wpack && (reinterpret_cast<uintptr_t>(d->wpack) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->src[0]) & 15) == 0, AS_ERR_BAD_ARG, "conv2d_wino: null / misaligned wpack or V");
-  AS_REQUIRE(!as::fast16_mode(), AS_ERR_BAD_ARG, "conv2d_wino: not available in the reduced-precision (fast16) mode");
-  const int epi = d->epilogue;
-  AS_REQUIRE(epi == AS_EPI_LINEAR || epi == AS_EPI_GRU_ZR || epi == AS_EPI_GRU_Q, AS_ERR_BAD_ARG, "conv2d_wino: epilogue=%d", epi);
-  const bool bs_only = d->out_bs && d->bs_only;
-  AS_REQUIRE(d->out || (bs_only && epi == AS_EPI_LINEAR), AS_ERR_BAD_ARG, "conv2d_wino: null out");
-  ConvParams p{};
-  p.vsrc = reinterpret_cast<const _Float16*>(d->src[0]);
-  p.vT = (d->W + 3) / 4;
-  AS_REQUIRE(2ll * d->H * p.vT * 6 * 16 < 0x7FFFFFF0ll, AS_ERR_BAD_SHAPE, "conv2d_wino: plane too large");
-  if (d->out_bs) {
-    AS_REQUIRE((reinterpret_cast<uintptr_t>(d->out_bs) & 15) == 0, AS_ERR_BAD_ARG, "conv2d_wino: out_bs not 16-B aligned");
-    const int cres = epi == AS_EPI_GRU_ZR ? d->Cout / 2 : d->Cout;
-    const int ctot = d->out_bs_ctot > 0 ? d->out_bs_ctot : cres;
-    AS_REQUIRE(d->out_bs_coff >= 0 && d->out_bs_coff % 8 == 0 && d->out_bs_coff + cres <= (ctot + 7) / 8 * 8, AS_ERR_BAD_SHAPE,
-               "conv2d_wino: out_bs channel window [%d,%d) must start at a multiple of 8 inside %d channels", d->out_bs_coff, d->out_bs_coff + cres, ctot);
-    AS_REQUIRE(epi != AS_EPI_GRU_Q || !d->bs_only, AS_ERR_BAD_ARG, "conv2d_wino(GRU_Q): the fp32 hidden state is always written");
-    p.out_bs = reinterpret_cast<_Float16*>(d->out_bs);
-    p.out_bs_c8tot = (ctot + 7) / 8;
-    p.out_bs_ctot = ctot;
-    p.out_bs_coff8 = d->out_bs_coff / 8;
-    p.bs_only = d->bs_only ? 1 : 0;
-  }
-  p.wpack = d->wpack; p.bias = d->bias; p.add = d->add;
-  p.add_ctot = d->add_ctot; p.add_coff = d->add_coff;
-  AS_REQUIRE(!d->add || (d->add_coff >= 0 && d->add_coff + d->Cout <= d->add_ctot), AS_ERR_BAD_SHAPE, "conv2d_wino: add channel window outside add_ctot");
-  p.h = d->h; p.z = d->z; p.out = d->out; p.out2 = d->out2;
-  p.B = d->B; p.H = d->H; p.W = d->W; p.Hi = d->H; p.Wi = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.act = d->act;
-  p.Cout_pad = conv_cout_pad(d->Cout);
-  if (epi == AS_EPI_LINEAR) {
-    p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
-    p.out_coff = d->out_coff;
-    AS_REQUIRE(bs_only || (p.out_coff >= 0 && p.out_coff + d->Cout <= p.out_ctot), AS_ERR_BAD_SHAPE, "conv2d_wino: out channel window outside out_ctot");
-    AS_REQUIRE(d->act >= AS_ACT_NONE && d->act <= AS_ACT_LEAKY, AS_ERR_BAD_ARG, "conv2d_wino: act=%d", d->act);
-  } else if (epi == AS_EPI_GRU_ZR) {
-    AS_REQUIRE(d->h && (d->out2 || bs_only) && (d->Cout % (2 * kBN)) == 0, AS_ERR_BAD_ARG, "conv2d_wino(GRU_ZR): needs h, out2 and Cout %% 128 == 0");
-  } else {
-    AS_REQUIRE(d->h && d->z, AS_ERR_BAD_ARG, "conv2d_wino(GRU_Q): needs h and z");
-  }
-  p.chunks = d->Cin / kSplitKC;
-  p.n_tiles = p.Cout_pad / 64;
-  p.tiles_x = as::cdiv(p.W, 16);
-  p.tiles_y = as::cdiv(p.H, 8);
-  p.ksplit = 1;
-  static const int xcd_mode = getenv("AS_CONV_XCD") ? atoi(getenv("AS_CONV_XCD")) : 1;
-  p.xcd_map = (xcd_mode && p.n_tiles > 1) ? 1 : 0;
-  AS_REQUIRE((long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, 2) * p.n_tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "conv2d_wino: grid too large");
-  hipStream_t s = as::as_stream(stream);
-  if (epi == AS_EPI_LINEAR) return launch_conv_wino<AS_EPI_LINEAR>(p, s);
-  if (epi == AS_EPI_GRU_ZR) return launch_conv_wino<AS_EPI_GRU_ZR>(p, s);
-  return launch_conv_wino<AS_EPI_GRU_Q>(p, s);
 }
 
 int64_t as_conv_ws_elems(int B, int Cout, int H, int W) {

@@ -587,6 +587,29 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_convc1_direct_kernel(Loo
   __syncthreads();  // the weight image has landed (every wave waited for its own pieces)
   float amax = 0.f;
   const half8* wfr = reinterpret_cast<const half8*>(wlds) + lane;
+#ifdef AS_LK_TRAFFIC_ONLY
+  // Diagnostic build only (tools/variant.sh lookup.hip lk_traffic -DAS_LK_TRAFFIC_ONLY; never defined in the product build): the
+  // kernel's loads and stores on the same grid and nothing else — no interpolation, no operand split, no matrix instruction, one
+  // LDS read so the weight image's DMA is still waited for.  Every loaded value reaches a stored one through a sum (results are
+  // wrong); its time is the floor any arithmetic of this kernel sits on.
+  {
+    f32x4 s4 = gw[0][0];
+#pragma unroll
+    for (int lv = 0; lv < 2; ++lv)
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+        if (lv || j) s4 += gw[lv][j];
+    float s1 = s4.x + s4.y + s4.z + s4.w;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) s1 += cw[j];
+    const half8 a0 = wfr[0];
+    s1 += (float)a0[0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc_h[t][i] += s1;
+  }
+#else
 #pragma unroll
   for (int ks = 0; ks < kDirectKS; ++ks) {
     float v[8];
@@ -633,6 +656,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void lookup_convc1_direct_kernel(Loo
       acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_x[t], 0, 0, 0);
     }
   }
+#endif
   if (live) {
     const int b = (int)(pix / p.HW);
     const int rem = (int)(pix - (long long)b * p.HW);

@@ -269,6 +269,80 @@ def dry_train_main(a, rank, world):
 # ------------------------------------------------------------------------------------------------------------------
 
 
+class GpuTelemetry:
+    """Socket power and shader clock of the rank's GPU, sampled from sysfs (hwmon of the amdgpu device: `power1_average` /
+    `power1_input` in microwatts, `freq1_input` in Hz) by a host thread WHILE the timed loop runs — so that "power-limited
+    clock" in DESIGN.md is a measurement of the run that produced `value`.  Reads are plain file reads (no tool is spawned,
+    nothing touches the GPU); a box that does not expose the files yields nulls."""
+
+    def __init__(self, dev_index: int, period_s: float = 0.01):
+        import glob
+        self.period, self.samples, self._stop, self._thread = period_s, [], False, None
+        self.power_file = self.clock_file = self.cap_file = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            want = None
+        cards = []
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            if "-" in os.path.basename(c):
+                continue
+            try:
+                addr = os.path.basename(os.path.realpath(os.path.join(c, "device")))
+            except OSError:
+                continue
+            cards.append((c, addr))
+        pick = [c for c, addr in cards if want and addr.lower().startswith(want)] or ([cards[0][0]] if len(cards) == 1 else [])
+        if not pick:
+            return
+        for hw in glob.glob(os.path.join(pick[0], "device", "hwmon", "hwmon*")):
+            for f in ("power1_average", "power1_input"):
+                if self.power_file is None and os.path.exists(os.path.join(hw, f)):
+                    self.power_file = os.path.join(hw, f)
+            if os.path.exists(os.path.join(hw, "freq1_input")):
+                self.clock_file = os.path.join(hw, "freq1_input")
+            if os.path.exists(os.path.join(hw, "power1_cap")):
+                self.cap_file = os.path.join(hw, "power1_cap")
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            pw = self._read(self.power_file) if self.power_file else None
+            ck = self._read(self.clock_file) if self.clock_file else None
+            self.samples.append((pw, ck))
+            time.sleep(self.period)
+
+    def start(self):
+        if self.power_file or self.clock_file:
+            import threading
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self) -> dict:
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(1.0)
+        pw = [p * 1e-6 for p, _ in self.samples if p is not None]
+        ck = [c * 1e-6 for _, c in self.samples if c is not None]
+        cap = self._read(self.cap_file) if self.cap_file else None
+        return {"gpu_power_w": round(sum(pw) / len(pw), 1) if pw else None, "gpu_power_w_max": round(max(pw), 1) if pw else None,
+                "gpu_power_cap_w": round(cap * 1e-6, 1) if cap else None,
+                "gpu_sclk_mhz": round(sum(ck) / len(ck), 1) if ck else None, "gpu_sclk_mhz_min": round(min(ck), 1) if ck else None,
+                "telemetry_samples": len(self.samples),
+                "telemetry_source": "sysfs hwmon (power1_average, freq1_input), host thread sampling every %.0f ms during the timed loop" % (self.period * 1e3)
+                                    if (pw or ck) else "unavailable on this box (no readable amdgpu hwmon files)"}
+
+
 def algorithmic(B, h, w, Q, C=96, L=2, G=8, D=48, r=4):
     """Algorithmic bytes / flops per launch."""
     P = B * h * w
@@ -749,6 +823,7 @@ def infer_main(a, rank, world, local):
     from anystereo.harness import timing
     if not run.graph:
         timing.enable(True)       # HIP events around every hot-kernel launch, on the launch stream
+    telemetry = GpuTelemetry(local).start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = run.step()
@@ -757,6 +832,7 @@ def infer_main(a, rank, world, local):
         td.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    telemetry = telemetry.stop()
     out_split = out.float().cpu() if precision == "split" else None
     out_this = out.float().cpu()
     per_rank = [dt]
@@ -965,7 +1041,7 @@ def infer_main(a, rank, world, local):
                        "parallelism": f"replicas x{world}", "gru_loop": "hipGraph" if run.graph else "eager"},
             "per_rank_pairs_per_s": [round(nb * a.steps / v, 4) for v in per_rank],
             "host": {"cpus_per_rank": len(RANK_CPUS or []), "pinned": world > 1 and os.environ.get("ANYSTEREO_PIN", "1") != "0",
-                     "torch_threads": torch.get_num_threads()},
+                     "torch_threads": torch.get_num_threads(), **telemetry},
             "library": _lib.library_info(),
             "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,

@@ -229,24 +229,6 @@ int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, i
 int64_t as_conv_pack_size_split(int Cin, int Cout, int KS);
 int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream);
 
-/* Winograd F(4,3) along x for the split-precision 3x3, stride-1 convolutions of the update block (the GRU gate convolutions
- * update.py:29-31 and DispHead.conv1 update.py:18; the reference gets its FLOP-reducing algorithm from cuDNN): half the matrix
- * instructions of as_conv2d for the same result within fp32 rounding (rms 3e-7 relative to the fp64 convolution).
- *   as_wino_transform   B^T d of one source tensor (fp32 [B,C,H,W] or a blocked split-fp16 tensor, src_bs != 0) into channels
- *                       [c_off, c_off + C) of V = [B][2][Cin_total/8][H][ceil(W/4)][6][8] fp16 (hi plane set, lo plane set); the
- *                       concatenation of the reference's torch.cat([h, x...]) (update.py:34) is the channel window.  C and c_off
- *                       multiples of 8 (the last source may end short of a block: zero filled).  as_wino_v_elems = fp16 elements of V.
- *   as_conv_pack_weights_wino   weight [Cout,Cin,3,3] -> G g along kx -> pack [Cin/16][ky*6+xi][comp][h][Cout_pad][8] fp16
- *                       (as_conv_pack_size_wino elements); scratch: Cout*Cin*18 floats.  Cin a multiple of 16.
- *   as_conv2d_wino      the convolution: descriptor as for as_conv2d with KS = 3, precision = 1, n_src = 1, src[0] = V, src_c[0] = Cin;
- *                       epilogues LINEAR / GRU_ZR / GRU_Q with every option of as_conv2d (bias, act, add window, residual h, blocked
- *                       copy, bs_only) except dual, stride 2, RELU_TAPS and the reduced-precision mode. */
-int64_t as_wino_v_elems(int B, int Cin, int H, int W);
-int as_wino_transform(const void* src, int src_bs, int C, void* v, int Cin_total, int c_off, int B, int H, int W, void* stream);
-int64_t as_conv_pack_size_wino(int Cin, int Cout);
-int as_conv_pack_weights_wino(const float* weight, void* wpack, float* scratch, int Cin, int Cout, void* stream);
-int as_conv2d_wino(const as_conv_desc* d, void* stream);
-
 /* direct (VALU) convolutions for the two shapes where an MFMA tile would be mostly padding:
  *   convd1: 7x7, 1 -> Cout, +bias, ReLU   (update.py:81,87);   conv2 of DispHead: 3x3, Cin -> 1, +bias (update.py:19,24)
  *   tap_major = 0: weight is the module's [Cout,1,7,7]; tap_major = 1: weight is its transpose [49][Cout_pad], Cout_pad =

@@ -152,7 +152,142 @@ def golden_train_sensitivity(RefIGEV, RefRAFT, ns2, seeds=32, rel=1e-6, seed0=10
     torch.set_grad_enabled(False)
 
 
+def margin_case(name, cand):
+    """Inputs of candidate `cand` for the margin-screened G8 fixture: ONE small pair (a tenth of the main fixture's pre-activations,
+    so a seed can be found whose ReLU pattern has a margin), 200 queries on the s = 1.5 grid, 2 GRU iterations."""
+    from anystereo.nn.liif import make_coord
+    h, w = 32, 64
+    img1, img2 = synthetic_pair(1, h, w, shift=4, seed=500 + cand)
+    s, nq = 1.5, 200
+    grid = make_coord([round(h * s), round(w * s)])
+    idx = (det_uniform((nq,), 900 + cand, 0.0, 1.0) * grid.shape[0]).long().clamp(max=grid.shape[0] - 1)
+    coord = grid[idx].unsqueeze(0).contiguous()
+    gt = det_uniform((1, 1, nq), 950 + cand, 0.5, 30.0)
+    return img1, img2, coord, gt, torch.tensor([[s]])
+
+
+class KinkMargin:
+    """While active, every piecewise-linear activation the reference evaluates (relu / relu_ / leaky_relu / relu6 / hardtanh, as
+    functions and as modules) reports how close its input comes to a kink, relative to the input's RMS: the smallest such ratio
+    of a forward pass is the pass's MARGIN — a forward difference below it (summation order, another convolution algorithm,
+    the 22-bit operand split) cannot change the activation pattern, so the gradient stays on the same linear piece."""
+
+    def __init__(self):
+        self.margin, self.count, self.where = float("inf"), 0, None
+
+    def _see(self, x, kinks, tag):
+        if not torch.is_tensor(x) or not x.is_floating_point() or x.numel() == 0:
+            return
+        xd = x.detach().double()
+        rms = float(xd.pow(2).mean().sqrt())
+        if rms == 0.0:
+            return
+        # exact hits are structural (zero padding, a ReLU of a ReLU's output): they stay on their side under any small perturbation
+        m = min(float(d[d > 0].min()) if bool((d > 0).any()) else float("inf") for d in ((xd - k).abs() for k in kinks)) / rms
+        self.count += x.numel()
+        if m < self.margin:
+            self.margin, self.where = m, f"{tag}{tuple(x.shape)}"
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._saved = []
+        def wrap(mod, name, kinks):
+            orig = getattr(mod, name)
+            def f(x, *a, **k):
+                self._see(x, kinks if not callable(kinks) else kinks(a, k), name)
+                return orig(x, *a, **k)
+            self._saved.append((mod, name, orig))
+            setattr(mod, name, f)
+        for mod in (F, torch):
+            for name, kinks in (("relu", (0.0,)), ("relu_", (0.0,)), ("leaky_relu", (0.0,)), ("leaky_relu_", (0.0,)),
+                                ("relu6", (0.0, 6.0))):
+                if hasattr(mod, name):
+                    wrap(mod, name, kinks)
+        wrap(F, "hardtanh", lambda a, k: (float(k.get("min_val", a[0] if a else -1.0)), float(k.get("max_val", a[1] if len(a) > 1 else 1.0))))
+        return self
+
+    def __exit__(self, *exc):
+        for mod, name, orig in self._saved:
+            setattr(mod, name, orig)
+
+
+def golden_train_margin(RefIGEV, RefRAFT, ns2, candidates=400, confirm=128, bar=3e-4, only_model=None, cand0=0):
+    """G8, second fixture (review of round 4, item 4): a training step whose activation pattern has a MARGIN.  The gradient of a
+    ReLU network is piecewise constant in its activation pattern; the main fixture has pre-activations within 1e-7 (relative)
+    of zero, so eps-level forward differences move individual gradients in discrete steps (train_*_sens.npz: up to 5e-2) and
+    its per-tensor limits are wide exactly where a regression would hide.  Here the imported reference screens `candidates`
+    input seeds by the margin of their forward pass (KinkMargin) and keeps the one whose closest pre-activation is farthest from
+    its kink; `confirm` perturbed runs of the reference (relative N(0, 2e-7) and N(0, 1e-6) on both images — the forward
+    difference of two correct fp32 implementations and five times that) then show how far its own gradients move.  Stored: the
+    inputs, loss, last prediction, all gradient norms, the TRAIN_FULL tensors, the margin and the deviations; the test's limit is
+    a uniform 1e-3 for every tensor, which needs every deviation below `bar`."""
+    torch.set_grad_enabled(True)
+    for name, Ref in (("igev", RefIGEV), ("raft", RefRAFT)):
+        if only_model and name != only_model:
+            continue
+        args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
+        model = Ref(args)
+        fill_module_deterministic(model, base_seed=1)
+        model.train()
+        model.freeze_bn()
+
+        def run(case, seed, rel, backward=True):
+            img1, img2, coord, gt, scale = case
+            a, b = img1, img2
+            if seed is not None:
+                g = torch.Generator().manual_seed(7000 + seed)
+                a = a * (1.0 + rel * torch.randn(a.shape, generator=g))
+                b = b * (1.0 + rel * torch.randn(b.shape, generator=g))
+            model.zero_grad(set_to_none=True)
+            res = model(a, b, iters=2, hr_coord=coord.clone(), scale=scale)
+            preds = res[1] if name == "igev" else res
+            loss, _ = ns2["sequence_loss_multiscale"](preds, gt, ((gt < 512) & (gt > 0)).float(), max_disp=args.max_disp)
+            if not backward:
+                return loss.detach(), preds[-1].detach(), None
+            loss.backward()
+            return loss.detach(), preds[-1].detach(), {n: p.grad.detach().double().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        best = (-1.0, None, None, 0)
+        for cand in range(cand0, cand0 + candidates):
+            case = margin_case(name, cand)
+            with KinkMargin() as km, torch.no_grad():
+                run(case, None, 0.0, backward=False)
+            if km.margin > best[0]:
+                best = (km.margin, cand, km.where, km.count)
+                print(name, "candidate", cand, "margin %.2e at %s over %d pre-activations" % (km.margin, km.where, km.count), flush=True)
+        margin, cand, where, count = best
+        print(name, "best margin %.2e (candidate %d) of %d candidates; %d pre-activations per pass" % (margin, cand, candidates, count), flush=True)
+        if margin < 1e-5:
+            # 2e-7 relative image noise (two correct fp32 forwards) reaches the pre-activations at ~1e-6 of their RMS: below 1e-5 a
+            # pattern change, hence a discrete gradient step, stays likely and the fixture would be as fragile as the main one
+            print(name, "no candidate has a margin >= 1e-5: no fixture written", flush=True)
+            continue
+        case = margin_case(name, cand)
+        loss0, pred0, g0 = run(case, None, 0.0)
+        names = sorted(g0)
+        n0 = np.array([float(g0[n].norm()) for n in names])
+        floor = 1e-3 * float(np.median(n0))   # tensors whose gradient is rounding noise (a bias in front of a normalisation)
+        nd_all, fd_all = np.zeros(len(names)), np.zeros(len(TRAIN_FULL[name]))
+        for s_ in range(confirm):
+            _, _, g = run(case, 100 + s_, 2e-7 if s_ % 2 == 0 else 1e-6)
+            nn_ = np.array([float(g[n].norm()) for n in names])
+            nd_all = np.maximum(nd_all, np.abs(nn_ - n0) / np.maximum(n0, floor))
+            fd_all = np.maximum(fd_all, np.array([float(((g[n] - g0[n]).abs() / g0[n].abs().max()).max()) for n in TRAIN_FULL[name]]))
+            if s_ % 16 == 15:
+                print(name, "candidate", cand, "after", s_ + 1, "perturbed runs: norm dev %.2e (%s) full dev %.2e" %
+                      (nd_all.max(), names[int(nd_all.argmax())], fd_all.max()), flush=True)
+        assert nd_all.max() < bar and fd_all.max() < bar, f"{name}: candidate {cand} (margin {margin:.2e}) still moves by {nd_all.max():.2e} / {fd_all.max():.2e}"
+        img1, img2, coord, gt, scale = case
+        full = {f"g{i}": g0[n].float() for i, n in enumerate(TRAIN_FULL[name])}
+        save(f"train_margin_{name}", img1=img1, img2=img2, coord=coord, gt=gt, scale=scale, iters=2, candidate=cand, loss=loss0,
+             last_pred=pred0, names=np.array(names), norms=n0, norm_floor=floor, full_names=np.array(TRAIN_FULL[name]), norm_dev=nd_all,
+             full_dev=fd_all, margin=margin, margin_at=where, pre_activations=count,
+             screen=f"best margin of {candidates} candidates from {cand0}; {confirm} perturbed reference runs alternating 2e-7 / 1e-6 relative", **full)
+    torch.set_grad_enabled(False)
+
+
 SENS_ARGS = {}
+MARGIN_ARGS = {}
 
 
 def main(only=None):
@@ -209,7 +344,7 @@ def main(only=None):
 
     if only == "update":
         return gen_update()
-    if only in ("train", "train_sens"):
+    if only in ("train", "train_sens", "train_margin"):
         import ast
         import torch.nn.functional as F
         tree = ast.parse(open(os.path.join(REF, "train_continuous_IGEV.py")).read())
@@ -218,6 +353,8 @@ def main(only=None):
         exec(compile(ast.Module(body=[fn], type_ignores=[]), "train_continuous_IGEV.py", "exec"), ns2)
         if only == "train_sens":
             return golden_train_sensitivity(RefIGEV, RefRAFT, ns2, **SENS_ARGS)
+        if only == "train_margin":
+            return golden_train_margin(RefIGEV, RefRAFT, ns2, **MARGIN_ARGS)
         return golden_train(RefIGEV, RefRAFT, ns2)
 
     # ---- G1/G2/G3: correlation, pyramids, lookup (IGEV: L=2,G=8; RAFT: L=4,G=0) ------------------
@@ -369,12 +506,17 @@ def main(only=None):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["train", "train_sens", "update"], default=None,
+    ap.add_argument("--only", choices=["train", "train_sens", "train_margin", "update"], default=None,
                     help="regenerate only the G8 training-step fixtures / their perturbation sensitivities / only the G5 flag-combination fixtures")
     ap.add_argument("--sens-seeds", type=int, default=32)
     ap.add_argument("--sens-rel", type=float, default=1e-6)
     ap.add_argument("--sens-seed0", type=int, default=1000)
     ap.add_argument("--sens-merge", action="store_true", help="train_sens: keep the maximum of this run and the stored file")
+    ap.add_argument("--margin-model", choices=["igev", "raft"], default=None)
+    ap.add_argument("--margin-candidates", type=int, default=400)
+    ap.add_argument("--margin-cand0", type=int, default=0)
+    ap.add_argument("--margin-confirm", type=int, default=128)
     a_ = ap.parse_args()
+    MARGIN_ARGS.update(only_model=a_.margin_model, candidates=a_.margin_candidates, cand0=a_.margin_cand0, confirm=a_.margin_confirm)
     SENS_ARGS.update(seeds=a_.sens_seeds, rel=a_.sens_rel, seed0=a_.sens_seed0, merge=a_.sens_merge)
     main(a_.only)

@@ -1487,12 +1487,17 @@ def pc_swap(ops, dev):
     return ops.PackedConv().get([(U((127, 176, 3, 3), 316) * 0.05).to(dev)], [U((127,), 317).to(dev)])
 
 
-def test_resamplers_blocked_split_output():
-    """pool2x / interp with a BS8 result hold exactly the split of the fp32 kernels' values (C not a multiple of 8 too)."""
+@pytest.mark.parametrize("hw", [(9, 14), (9, 15), (10, 128), (7, 2), (34, 60), (68, 120)])
+def test_resamplers_blocked_split_output(hw):
+    """pool2x / interp with a BS8 result hold exactly the split of the fp32 kernels' values (C not a multiple of 8 too).  Even
+    widths take `pool2x_bs_even_kernel` (8-byte row loads), odd ones `pool2x_bs_kernel`: both are held to the same fp32 kernel,
+    on one-block and multi-block shapes, on output widths that are and are not multiples of 64, and on the loop's own 1/8- and
+    1/16-resolution maps."""
     from anystereo import ops
+    hh, ww = hw
     for c in (16, 13):
-        x = U((2, c, 9, 14), 330 + c).to(DEV)
-        for bs, ref in ((ops.pool2x_bs(x), ops.pool2x(x)), (ops.interp_bs(x, 18, 27), ops.interp(x, 18, 27))):
+        x = U((2, c, hh, ww), 330 + c).to(DEV)
+        for bs, ref in ((ops.pool2x_bs(x), ops.pool2x(x)), (ops.interp_bs(x, 2 * hh, 2 * ww - 1), ops.interp(x, 2 * hh, 2 * ww - 1))):
             assert tuple(bs.shape) == tuple(ref.shape)
             hi = ref.half()
             lo = ((ref - hi.float()) * 2048.0).half()
@@ -1996,89 +2001,5 @@ def test_loop_front_fused_equals_staged(golden, tag, h, w):
                 else:
                     close(mf.float(), mf_ref.float(), 2e-5, 2e-6, f"motion features ({mode})")
                 assert (mf.float()[:, 127:128] - d_ref).abs().max().item() <= 2e-6 * max(1.0, d_ref.abs().max().item()), "disparity pass-through"
-    finally:
-        ops.set_precision(prev)
-
-
-# ---------------------------------------------------------------------------------------------
-# Winograd F(4,3) along x for the split-precision 3x3 convolutions (as_wino_transform / as_conv2d_wino)
-# ---------------------------------------------------------------------------------------------
-
-def _to_bs(x):
-    """fp32 [B,C,H,W] -> ops.BS8 with the split the kernels compute."""
-    from anystereo import ops
-    b, c, h, w = x.shape
-    c8 = (c + 7) // 8
-    xp = torch.zeros((b, c8 * 8, h, w), device=x.device, dtype=torch.float32)
-    xp[:, :c] = x
-    hi = xp.half()
-    lo = ((xp - hi.float()) * 2048.0).half()
-    t = torch.stack([hi, lo], 1).view(b, 2, c8, 8, h, w).permute(0, 1, 2, 4, 5, 3).contiguous()
-    return ops.BS8(t, c)
-
-
-@pytest.mark.parametrize("b,cin,cout,h,w,blocked", [(1, 32, 64, 8, 16, False), (2, 48, 100, 13, 37, True), (1, 128, 128, 17, 62, True),
-                                                   (1, 16, 64, 3, 5, False), (1, 384, 256, 24, 40, True)])
-def test_conv_winograd_linear(b, cin, cout, h, w, blocked):
-    """act(conv3x3(x) + bias) through the Winograd path against the fp64 convolution and against the direct split-precision
-    kernel: ragged sizes (rows / columns that are no multiple of the 8 x 16 tile or of a quad, a missing second sub-tile),
-    Cout that is no multiple of 64, fp32 and blocked split-fp16 sources, batch > 1."""
-    from anystereo import _lib as L
-    from anystereo import ops
-    import torch.nn.functional as F
-    prev = ops.get_precision()
-    ops.set_precision("split")
-    try:
-        x = (U((b, cin, h, w), 700) * 2.0).to(DEV)
-        wt = (U((cout, cin, 3, 3), 701) * (3.0 / (cin * 9)) ** 0.5).to(DEV)
-        bias = (U((cout,), 702) * 0.1).to(DEV)
-        ref = torch.relu(F.conv2d(x.double().cpu(), wt.double().cpu(), bias.double().cpu(), padding=1))
-        src = _to_bs(x) if blocked else x
-        v = ops.wino_transform([src])
-        pw = ops.PackedConv().get([wt], [bias], wino=True)
-        got = ops.conv2d([v], pw, act=L.ACT_RELU)
-        direct = ops.conv2d([src], ops.PackedConv().get([wt], [bias]), act=L.ACT_RELU)
-        sc = ref.abs().max().item()
-        e_w = (got.double().cpu() - ref).abs().max().item() / sc
-        e_d = (direct.double().cpu() - ref).abs().max().item() / sc
-        print(f"[winograd] {b}x{cin}->{cout} {h}x{w}: max err / max |y|: winograd {e_w:.2e}, direct {e_d:.2e}")
-        assert torch.isfinite(got).all()
-        assert e_w < 3e-6, f"winograd conv error {e_w:.2e}"
-    finally:
-        ops.set_precision(prev)
-
-
-def test_conv_winograd_gru_epilogues_and_shared_transform():
-    """The GRU's two gate convolutions through the Winograd path (update.py:33-41): z|r over V = B^T [h, x1, x2] with the
-    context window, r*h as a blocked copy; then the q convolution over the SAME V with its h window overwritten by B^T (r*h) —
-    against the direct kernel's results for the same operands."""
-    from anystereo import _lib as L
-    from anystereo import ops
-    prev = ops.get_precision()
-    ops.set_precision("split")
-    try:
-        b, h, w = 1, 19, 44
-        xs = [torch.tanh(U((b, 128, h, w), 710 + i, -2, 2)).to(DEV) for i in range(3)]
-        ctx = U((b, 384, h, w), 720).to(DEV)
-        wzr = (U((256, 384, 3, 3), 721) * 0.03).to(DEV)
-        bzr = (U((256,), 722) * 0.1).to(DEV)
-        wq = (U((128, 384, 3, 3), 723) * 0.03).to(DEV)
-        bq = (U((128,), 724) * 0.1).to(DEV)
-        bs = [_to_bs(t) for t in xs]
-        # direct
-        z0, rh0 = ops.conv2d(bs, ops.PackedConv().get([wzr], [bzr]), add=ctx, add_coff=0, epilogue=L.EPI_GRU_ZR, h=xs[0])
-        hn0 = ops.conv2d([_to_bs(rh0), bs[1], bs[2]], ops.PackedConv().get([wq], [bq]), add=ctx, add_coff=256, epilogue=L.EPI_GRU_Q, h=xs[0], z=z0)
-        # winograd
-        v = ops.wino_transform(bs)
-        rh_bs = ops.BS8.empty(b, 128, h, w, DEV)
-        z1, rh1 = ops.conv2d([v], ops.PackedConv().get([wzr], [bzr], wino=True), add=ctx, add_coff=0, epilogue=L.EPI_GRU_ZR, h=xs[0], out_bs=rh_bs)
-        close(z1, z0, rtol=3e-6, atol=1e-6, what="z")
-        close(rh1, rh0, rtol=3e-6, atol=1e-6, what="r*h")
-        close(rh_bs.float(), rh1, rtol=0, atol=1e-6, what="blocked copy of r*h")
-        ops.wino_transform([rh_bs], out=v, c_off=0)
-        hn_bs = ops.BS8.empty(b, 128, h, w, DEV)
-        hn1 = ops.conv2d([v], ops.PackedConv().get([wq], [bq], wino=True), add=ctx, add_coff=256, epilogue=L.EPI_GRU_Q, h=xs[0], z=z1, out_bs=hn_bs)
-        close(hn1, hn0, rtol=5e-6, atol=2e-6, what="h'")
-        close(hn_bs.float(), hn1, rtol=0, atol=1e-6, what="blocked copy of h'")
     finally:
         ops.set_precision(prev)

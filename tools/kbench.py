@@ -96,24 +96,9 @@ def main():
         if q:
             return lambda: ops.conv2d(xs, pq, add=cx, add_coff=256, epilogue=Lb.EPI_GRU_Q, h=xs32[0], z=z_, out_bs=o2)
         return lambda: ops.conv2d(xs, pzr, add=cx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=xs32[0], out_bs=o1, bs_only=True)
-    # Winograd F(4,3) forms of the gate convolutions (opt-in path; as_wino_transform + as_conv2d_wino)
-    wino = {}
-    if ops.get_precision() == "split":
-        xsb = x128bs
-        wv = ops.wino_transform(xsb)
-        pzr_w = ops.PackedConv().get([wzr], [bzr], wino=True)
-        pq_w = ops.PackedConv().get([wq], [det_uniform((128,), 102).to(dev)], wino=True)
-        ow1, ow2 = ops.BS8.empty(b, 128, h, w, dev), ops.BS8.empty(b, 128, h, w, dev)
-        wino = {
-            "gru04_zr_wino": lambda: ops.conv2d([wv], pzr_w, add=ctx, add_coff=0, epilogue=Lb.EPI_GRU_ZR, h=x128[0], out_bs=ow1, bs_only=True),
-            "gru04_q_wino": lambda: ops.conv2d([wv], pq_w, add=ctx, add_coff=256, epilogue=Lb.EPI_GRU_Q, h=x128[0], z=zt, out_bs=ow2),
-            "wino_tr384": lambda: ops.wino_transform(xsb, out=wv),
-            "wino_tr128": lambda: ops.wino_transform([xsb[0]], out=wv, c_off=0),
-        }
     h8 = det_uniform((b, 128, h // 2, w // 2), 120).to(dev)
     h16 = det_uniform((b, 128, h // 4, w // 4), 121).to(dev)
     fns = {
-        **wino,
         # the loop's resamplers (update.py:94-102) with blocked split-fp16 results
         "pool04_bs": lambda: ops.pool2x_bs(x128[0]), "pool08_bs": lambda: ops.pool2x_bs(h8),
         "interp08to04_bs": lambda: ops.interp_bs(h8, h, w), "interp16to08_bs": lambda: ops.interp_bs(h16, h // 2, w // 2),
