@@ -1873,6 +1873,10 @@ void conv_pick_ksplit(ConvParams& p, const as_conv_desc* d) {
   const long long slab = (long long)p.B * p.Cout_pad * p.H * p.W;
   // one block per CU (the tile's LDS footprint): more blocks than CUs would just queue a second round
   int ks = (int)(kNumCU / blocks);
+  // AS_CONV_KSPLIT_MAX (A/B knob): 1 = never split.  Alone a split launch is shorter; beside the other chain's kernels the
+  // unsplit one costs fewer CU-microseconds (no partial slabs, no finish launch) on half the CUs.
+  static const int ks_max = getenv("AS_CONV_KSPLIT_MAX") ? atoi(getenv("AS_CONV_KSPLIT_MAX")) : 8;
+  if (ks > ks_max) ks = ks_max;
   if (ks > 8) ks = 8;
   while (ks > 1 && (p.chunks / ks < 2 || slab * ks > d->ws_elems)) --ks;
   if (ks > 1) { p.ksplit = ks; p.ws = d->ws; }

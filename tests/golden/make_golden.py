@@ -286,6 +286,40 @@ def golden_train_margin(RefIGEV, RefRAFT, ns2, candidates=400, confirm=128, bar=
     torch.set_grad_enabled(False)
 
 
+def golden_model_options(RefIGEV, RefRAFT, rliif):
+    """G7 companion (review of round 4, item 6): the forward() branches evaluation.py can reach that the main G7 fixture does not
+    take — `args.slow_fast_gru = True` (continuous_IGEVstereo.py:288-291, prune_raft_stereo.py:280-283: the low-resolution GRUs
+    are pre-updated before every full update), RAFT's `output_raw=True` return tuple (prune_raft_stereo.py:293-296) and a
+    `flow_init` argument (accepted and never read by either reference forward: outputs with and without it are stored)."""
+    outs = {}
+    for name, Ref, (H, W) in (("igev", RefIGEV, (64, 128)), ("raft", RefRAFT, (64, 96))):
+        args = default_args("continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo")
+        args.slow_fast_gru = True
+        model = Ref(args).eval()
+        fill_module_deterministic(model, base_seed=1)
+        img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+        s = 1.5
+        coord = rliif.make_coord([round(H * s), round(W * s)]).unsqueeze(0)
+        sc = torch.tensor([[s]])
+        outs[f"{name}_slowfast"] = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        model.args.slow_fast_gru = False
+        base = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        fi = det_uniform((1, 1, H // 4, W // 4), 123, 0.0, 20.0)
+        with_fi = model(img1, img2, iters=3, flow_init=fi, test_mode=True, hr_coord=coord.clone(), scale=sc)
+        outs[f"{name}_base"], outs[f"{name}_flow_init_out"], outs[f"{name}_flow_init"] = base, with_fi, fi
+        assert torch.equal(base, with_fi), "the reference reads flow_init after all: the fixture's premise is wrong"
+        if name == "raft":
+            raw = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc, output_raw=True)
+            assert isinstance(raw, tuple) and len(raw) == 2
+            outs["raft_raw_disp"], outs["raft_raw_up"] = raw
+        else:
+            r2 = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc, output_raw=True)
+            assert torch.is_tensor(r2), "IGEV's forward ignores output_raw (continuous_IGEVstereo.py:303-305)"
+            outs["igev_output_raw"] = r2
+        outs[f"{name}_HW"] = np.array([H, W])
+    save("model_opts", **outs)
+
+
 SENS_ARGS = {}
 MARGIN_ARGS = {}
 
@@ -344,6 +378,8 @@ def main(only=None):
 
     if only == "update":
         return gen_update()
+    if only == "model_opts":
+        return golden_model_options(RefIGEV, RefRAFT, rliif)
     if only in ("train", "train_sens", "train_margin"):
         import ast
         import torch.nn.functional as F
@@ -446,6 +482,7 @@ def main(only=None):
             k: list(v.shape) for k, v in model.state_dict().items()}
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(sd_keys, f, indent=0, sort_keys=True)
+    golden_model_options(RefIGEV, RefRAFT, rliif)
 
     # ---- §8(f1): query grid of pad_for_multi_train (evaluation.py:67-89) ---------------------------
     # evaluation.py itself cannot be imported (missing tensorboardX / fvcore / a dangling model import,
@@ -506,7 +543,7 @@ def main(only=None):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["train", "train_sens", "train_margin", "update"], default=None,
+    ap.add_argument("--only", choices=["train", "train_sens", "train_margin", "update", "model_opts"], default=None,
                     help="regenerate only the G8 training-step fixtures / their perturbation sensitivities / only the G5 flag-combination fixtures")
     ap.add_argument("--sens-seeds", type=int, default=32)
     ap.add_argument("--sens-rel", type=float, default=1e-6)

@@ -620,6 +620,42 @@ def test_whole_model(name, golden, precision):
             assert (p.cpu() - g[f"pred_{i}"]).abs().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize("name", ["igev", "raft"])
+def test_model_options_vs_reference(name, golden, precision):
+    """forward() branches beyond the main G7 fixture, HIP path vs the imported reference (tests/golden/model_opts.npz):
+    `slow_fast_gru = True` (continuous_IGEVstereo.py:288-291, prune_raft_stereo.py:280-283 — the un-pipelined loop with the two
+    pre-updates of the low-resolution GRUs), `flow_init` (read by neither reference forward), `output_raw=True` (RAFT: the
+    (low-resolution disparity, upsampled) tuple, prune_raft_stereo.py:293-296; IGEV: ignored, continuous_IGEVstereo.py:303-305)."""
+    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
+    from anystereo.models import __models__, default_args
+    g = golden("model_opts")
+    H, W = (int(v) for v in g[f"{name}_HW"])
+    key = "continuous_IGEVStereo" if name == "igev" else "continuous_RAFTStereo"
+    model = __models__[key](default_args(key)).eval()
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV)
+    img1, img2 = (t.to(DEV) for t in synthetic_pair(1, H, W, shift=6, seed=99))
+    coord = O.make_coord([round(H * 1.5), round(W * 1.5)]).view(1, -1, 2).to(DEV)
+    sc = torch.tensor([[1.5]], device=DEV)
+    with torch.no_grad():
+        base = model(img1, img2, iters=3, test_mode=True, hr_coord=coord, scale=sc)
+        assert (base.cpu() - g[f"{name}_base"]).abs().mean().item() < 1e-3
+        with_fi = model(img1, img2, iters=3, flow_init=g[f"{name}_flow_init"].to(DEV), test_mode=True, hr_coord=coord, scale=sc)
+        assert torch.equal(with_fi, base), "flow_init must not change the result (the reference never reads it)"
+        raw = model(img1, img2, iters=3, test_mode=True, hr_coord=coord, scale=sc, output_raw=True)
+        if name == "raft":
+            assert isinstance(raw, tuple) and len(raw) == 2
+            assert raw[0].shape == g["raft_raw_disp"].shape and (raw[0].cpu() - g["raft_raw_disp"]).abs().mean().item() < 1e-3
+            assert (raw[1].cpu() - g["raft_raw_up"]).abs().mean().item() < 1e-3
+        else:
+            assert torch.is_tensor(raw) and (raw.cpu() - g["igev_output_raw"]).abs().mean().item() < 1e-3
+        model.args.slow_fast_gru = True
+        sf = model(img1, img2, iters=3, test_mode=True, hr_coord=coord, scale=sc)
+        epe = (sf.cpu() - g[f"{name}_slowfast"]).abs().mean().item()
+        assert epe < 1e-3, f"{name} slow_fast_gru: EPE vs reference {epe:.3e} (bar 1e-3)"
+        assert (sf - base).abs().mean().item() > 1e-3, "the slow-fast branch was not taken"
+
+
 def test_ops_reject_cpu_tensors():
     """No silent CPU fallback in the product path."""
     from anystereo import ops

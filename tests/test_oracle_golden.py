@@ -180,6 +180,38 @@ def test_whole_model_vs_reference(golden):
                 assert (p - g[f"pred_{i}"]).abs().mean().item() < 1e-3
 
 
+def test_model_options_vs_reference(golden):
+    """The forward() branches evaluation.py can reach beyond the main G7 fixture (tests/golden/model_opts.npz, generated from the
+    imported reference): `slow_fast_gru = True` (continuous_IGEVstereo.py:288-291, prune_raft_stereo.py:280-283), a `flow_init`
+    argument (never read by either reference forward), RAFT's `output_raw=True` tuple (prune_raft_stereo.py:293-296) and IGEV's
+    ignored `output_raw` (continuous_IGEVstereo.py:303-305) — oracle model vs reference, EPE bar 1e-3."""
+    g = golden("model_opts")
+    for name in ("igev", "raft"):
+        H, W = (int(v) for v in g[f"{name}_HW"])
+        model, synthetic_pair = _whole(name)
+        img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+        coord = O.make_coord([round(H * 1.5), round(W * 1.5)]).view(1, -1, 2)
+        sc = torch.tensor([[1.5]])
+        with torch.no_grad():
+            base = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            assert (base - g[f"{name}_base"]).abs().mean().item() < 1e-3
+            with_fi = model(img1, img2, iters=3, flow_init=g[f"{name}_flow_init"], test_mode=True, hr_coord=coord.clone(), scale=sc)
+            assert torch.equal(with_fi, base), "flow_init must not change the result (the reference never reads it)"
+            raw = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc, output_raw=True)
+            if name == "raft":
+                assert isinstance(raw, tuple) and len(raw) == 2
+                assert raw[0].shape == g["raft_raw_disp"].shape and (raw[0] - g["raft_raw_disp"]).abs().mean().item() < 1e-3
+                assert (raw[1] - g["raft_raw_up"]).abs().mean().item() < 1e-3
+            else:
+                assert torch.is_tensor(raw) and (raw - g["igev_output_raw"]).abs().mean().item() < 1e-3
+            model.args.slow_fast_gru = True
+            sf = model(img1, img2, iters=3, test_mode=True, hr_coord=coord.clone(), scale=sc)
+            epe = (sf - g[f"{name}_slowfast"]).abs().mean().item()
+            assert epe < 1e-3, f"{name} slow_fast_gru: EPE vs reference {epe:.3e}"
+            # the branch is really taken: its result differs from the default schedule's
+            assert (g[f"{name}_slowfast"] - g[f"{name}_base"]).abs().mean().item() > 1e-3
+
+
 def test_training_step_vs_reference(golden):
     """G8: loss and parameter gradients of one training forward/backward (train mode, frozen BatchNorm2d, LIIF every
     iteration, sequence_loss_multiscale) of the oracle model vs the imported reference."""
