@@ -128,6 +128,9 @@ SIGNATURES = {
     "as_conv7x7_c1_wgrad_ws_bytes": (C.c_int64, [_i, _i, _i, _i]),
     "as_conv7x7_c1_wgrad_multi": (_i, [_pp, _pp, _i, _i, _vp, _vp, _i, _i, _i, _vp, C.c_int64, _vp]),
     "as_pool2x_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_dwconv3x3_s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "as_dwconv3x3_wgrad_slices": (_i, [_i, _i, _i, _i, _i]),
+    "as_dwconv3x3_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_interp_bilinear_ac_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_gwc_volume_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_disparity_regression_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

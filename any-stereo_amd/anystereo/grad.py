@@ -649,6 +649,45 @@ def module_conv2d(mod, name, conv, x):
     return conv(x)
 
 
+class DwConv3x3(torch.autograd.Function):
+    """Depthwise 3x3 convolution (padding 1, stride 1|2, no bias) of MobileNetV2's conv_dw layers: forward, data gradient and weight
+    gradient on this library's kernels — MIOpen serves fp32 convolutions with groups == channels with its naive reference solvers
+    only (72 calls, 1.65 ms per cfg-4 step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride):
+        x = _c(x)
+        ctx.save_for_backward(x, weight)
+        ctx.stride = stride
+        return ops.dwconv3x3(x, weight.detach().contiguous(), None, stride)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, weight = ctx.saved_tensors
+        d_out = _c(d_out)
+        d_x = d_w = None
+        if ctx.needs_input_grad[0]:
+            d_x = ops.dwconv3x3_backward_data(d_out, weight.detach().contiguous(), x.shape[2], x.shape[3], ctx.stride)
+        if ctx.needs_input_grad[1]:
+            d_w = ops.dwconv3x3_wgrad(x, d_out, ctx.stride)
+        return d_x, d_w, None
+
+
+_TRAIN_DW = os.environ.get("ANYSTEREO_TRAIN_DWCONV", "1") != "0"
+
+
+def module_dwconv(conv, x):
+    """`conv(x)` of a depthwise nn.Conv2d under autograd: 3x3 / padding 1 / stride 1|2 / no bias / groups == channels on CUDA fp32
+    runs on DwConv3x3; anything else is the module itself (ANYSTEREO_TRAIN_DWCONV=0: always the module)."""
+    c = x.shape[1]
+    if (_TRAIN_DW and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and isinstance(conv, torch.nn.Conv2d)
+            and conv.groups == c and conv.in_channels == c and conv.out_channels == c and conv.kernel_size == (3, 3)
+            and conv.padding == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.dilation == (1, 1) and conv.bias is None
+            and conv.padding_mode == "zeros" and x.shape[0] * c <= 65535 and (x.requires_grad or conv.weight.requires_grad)):
+        return DwConv3x3.apply(x, conv.weight, conv.stride[0])
+    return conv(x)
+
+
 def pointwise_linear(mod, key, x, lin, relu):
     """PointwiseLinear of the nn.Linear `lin` with packs and the step's weight anchor cached on `mod` under `key`."""
     packs = mod.__dict__.setdefault("_train_packs", {})

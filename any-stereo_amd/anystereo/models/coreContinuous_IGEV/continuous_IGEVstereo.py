@@ -84,6 +84,9 @@ class continuous_IGEVStereo(ContinuousStereoBase):
 
     parallel_context = os.environ.get("ANYSTEREO_PARALLEL_CONTEXT", "1") != "0"
     parallel_stems = os.environ.get("ANYSTEREO_PARALLEL_STEMS", "1") != "0"
+    # which branch of the forked pre-loop is ISSUED first (the feature trunk on the main stream, or the stems + context network on
+    # the side stream): same kernels, same dependencies, bit-identical results — only the node order of the captured graph
+    trunk_first = os.environ.get("ANYSTEREO_TRUNK_FIRST", "0") != "0"
 
     def _stems_fwd(self, image):
         """(stem_1x | None, stem_2x, stem_4x) of one image batch (continuous_IGEVstereo.py:247-256)."""
@@ -118,7 +121,15 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 # branch); the main stream picks the stems up before the descriptor head and the context before the GRU loop
                 main = torch.cuda.current_stream(image1.device)
                 side = self.update_block._side_stream(image1.device)
-                side.wait_stream(main)
+                if self.trunk_first:
+                    # node order of the captured graph = issue order, and a replay feeds its queues in node order: the trunk's ~100
+                    # short kernels go first, the second branch forks off the point BEFORE them (an event, not wait_stream)
+                    forked = torch.cuda.Event()
+                    forked.record(main)
+                    feats = self.feature(both)
+                    side.wait_event(forked)
+                else:
+                    side.wait_stream(main)
                 with torch.cuda.stream(side):
                     if self.parallel_stems:
                         stem_1b, stem_2b, stem_4b = self._stems_fwd(both)
@@ -126,7 +137,8 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                         stems_done.record(side)
                     net_list, ctx_list = self._context(image1)
             if fast:
-                feats = self.feature(both)
+                if not (side is not None and self.trunk_first):
+                    feats = self.feature(both)
                 if side is not None and self.parallel_stems:
                     main.wait_event(stems_done)
                     stem_2b.record_stream(main)

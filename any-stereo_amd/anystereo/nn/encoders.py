@@ -264,7 +264,7 @@ class _DSConv(nn.Module):
             w, b = self._fdw.get(self.conv_dw, self.bn1)
             y = ops.dwconv3x3(x, w, b, self.conv_dw.stride[0], L.ACT_RELU6)
             return ops.conv2d([y], self._pk.get_folded(self.conv_pw, self.bn2), add=x if self.res else None)
-        y = nn.functional.relu6(self.bn1(self.conv_dw(x)))
+        y = nn.functional.relu6(self.bn1(G.module_dwconv(self.conv_dw, x)))  # training: own forward / dgrad / wgrad kernels
         y = self.bn2(self.conv_pw(y))
         return x + y if self.res else y
 
@@ -292,7 +292,7 @@ class _InvRes(nn.Module):
             y = ops.dwconv3x3(y, w, b, self.conv_dw.stride[0], L.ACT_RELU6)
             return ops.conv2d([y], self._pk3.get_folded(self.conv_pwl, self.bn3), add=x if self.res else None)
         y = nn.functional.relu6(self.bn1(self.conv_pw(x)))
-        y = nn.functional.relu6(self.bn2(self.conv_dw(y)))
+        y = nn.functional.relu6(self.bn2(G.module_dwconv(self.conv_dw, y)))
         y = self.bn3(self.conv_pwl(y))
         return x + y if self.res else y
 

@@ -840,6 +840,37 @@ def dwconv3x3(x, weight, bias=None, stride: int = 1, act: int = L.ACT_NONE, resi
     return out
 
 
+def dwconv3x3_backward_data(d_out, weight, h: int, w: int, stride: int):
+    """d_x [B,C,h,w] of the depthwise 3x3 convolution (padding 1, stride 1|2) with output gradient d_out."""
+    _req(d_out, "d_out"), _req(weight, "weight")
+    b, c, ho, wo = d_out.shape
+    if (ho, wo) != ((h - 1) // stride + 1, (w - 1) // stride + 1) or tuple(weight.shape) != (c, 1, 3, 3):
+        raise RuntimeError("dwconv3x3_backward_data: shapes do not belong to one convolution")
+    if stride == 1:  # the forward kernel on the flipped taps
+        return dwconv3x3(d_out, weight.flip(2, 3).contiguous())
+    d_x = torch.empty((b, c, h, w), device=d_out.device, dtype=torch.float32)
+    with _guard(d_out.device):
+        L.check(L.load().as_dwconv3x3_s2_bwd_data(_p(d_out), _p(weight), _p(d_x), b, c, h, w, _stream()), "dwconv3x3_s2_bwd_data")
+    return d_x
+
+
+def dwconv3x3_wgrad(x, d_out, stride: int):
+    """d_weight [C,1,3,3]: nine products summed over (batch, output pixels) per channel, in a fixed order (block partials per
+    slice of the positions, then the slices in order)."""
+    _req(x, "x"), _req(d_out, "d_out")
+    b, c, h, w = x.shape
+    if tuple(d_out.shape) != (b, c, (h - 1) // stride + 1, (w - 1) // stride + 1):
+        raise RuntimeError("dwconv3x3_wgrad: d_out shape does not match x and the stride")
+    lib = L.load()
+    n = lib.as_dwconv3x3_wgrad_slices(b, c, h, w, stride)
+    if n < 1:
+        raise RuntimeError("dwconv3x3_wgrad: bad size / stride")
+    part = torch.empty((c, n, 9), device=x.device, dtype=torch.float32)
+    with _guard(x.device):
+        L.check(lib.as_dwconv3x3_wgrad(_p(x), _p(d_out), _p(part), n, b, c, h, w, stride, _stream()), "dwconv3x3_wgrad")
+    return (part[:, 0] if n == 1 else part.sum(dim=1)).view(c, 1, 3, 3)
+
+
 def conv3d_k3(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
     """act(Conv3d 3x3x3(x, padding 1, stride) + bias); wpack = weight.permute(1,2,3,4,0) as [Cin,27,Cout]."""
     _req(x, "x"), _req(wpack, "wpack")

@@ -427,6 +427,80 @@ __global__ __launch_bounds__(256) void pool2x_bwd_kernel(const float* __restrict
   dx[idx] = s / 9.f;
 }
 
+// ---- depthwise 3x3 (padding 1, stride S), training: MobileNetV2's conv_dw layers (extractor.py:331-342 via timm's block names) ----
+// MIOpen serves fp32 grouped convolutions with groups == channels with its naive reference solvers only (forward, data and
+// weight gradient: 72 calls, 1.65 ms per cfg-4 step).  Forward = as_dwconv3x3; the data gradient at stride 1 is the forward kernel
+// on the flipped taps; at stride 2 it is this gather (one thread per INPUT element: the outputs whose window covers it, fixed
+// order, no atomics); the weight gradient is a per-channel reduction of nine products over (batch, output pixels), in two
+// deterministic stages (slices of the pixel range per block, then a fixed-order sum over the slices by the caller).
+__global__ __launch_bounds__(256) void dwconv3x3_s2_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                                    float* __restrict__ dx, int C, int H, int W, int Ho, int Wo, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  long long t = idx / W;
+  const int y = (int)(t % H);
+  const long long bc = t / H;
+  const int c = (int)(bc % C);
+  const float* gp = g + bc * Ho * Wo;
+  float s = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = y + 1 - ky;  // = 2 * oy
+    if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = x + 1 - kx;
+      if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+      s = fmaf(w[c * 9 + ky * 3 + kx], gp[(long long)(ty >> 1) * Wo + (tx >> 1)], s);
+    }
+  }
+  dx[idx] = s;
+}
+
+// grid (slices, C): block (slice, c) sums d_out[b,c,oy,ox] * x[b,c,oy*S+ky-1,ox*S+kx-1] over its share of the B*Ho*Wo positions
+// -> partial[c][slice][9]
+template <int S>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              float* __restrict__ partial, int B, int C, int H, int W, int Ho, int Wo) {
+  const int c = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x;
+  const long long npos = (long long)B * Ho * Wo;
+  const long long per = (npos + nslice - 1) / nslice;
+  const long long lo = per * slice, hi = lo + per < npos ? lo + per : npos;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int ox = (int)(i % Wo);
+    const long long r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const float gv = g[(((long long)b * C + c) * Ho + oy) * Wo + ox];
+    const float* xp = x + ((long long)b * C + c) * H * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * S + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * S + kx - 1;
+        if (ix >= 0 && ix < W) acc[ky * 3 + kx] = fmaf(gv, xp[(long long)iy * W + ix], acc[ky * 3 + kx]);
+      }
+    }
+  }
+  __shared__ float red[4][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v = acc[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wave][t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) partial[((long long)c * nslice + slice) * 9 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // interp (bilinear, align_corners): the weight of output o on input i along one axis, with the forward kernel's arithmetic
 __device__ __forceinline__ float interp_axis_weight(int o, int i, int n_in, float sc) {
   const float f = sc * (float)o;
@@ -476,6 +550,38 @@ int as_pool2x_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, vo
   const long long total = (long long)B * C * H * W;
   hipLaunchKernelGGL(pool2x_bwd_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), d_out, d_x, H, W, Ho, Wo, total);
   return as::check_launch("pool2x_bwd");
+}
+
+int as_dwconv3x3_s2_bwd_data(const float* d_out, const float* weight, float* d_x, int B, int C, int H, int W, void* stream) {
+  AS_REQUIRE(d_out && weight && d_x, AS_ERR_BAD_ARG, "dwconv3x3_s2_bwd_data: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "dwconv3x3_s2_bwd_data: non-positive size");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)B * C * H * W;
+  AS_REQUIRE(as::cdiv64(total, 256) < 2147483647ll, AS_ERR_BAD_SHAPE, "dwconv3x3_s2_bwd_data: grid too large");
+  hipLaunchKernelGGL(dwconv3x3_s2_bwd_data_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream), d_out, weight, d_x,
+                     C, H, W, Ho, Wo, total);
+  return as::check_launch("dwconv3x3_s2_bwd_data");
+}
+
+int as_dwconv3x3_wgrad_slices(int B, int C, int H, int W, int stride) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return -1;
+  const long long npos = (long long)B * ((H - 1) / stride + 1) * ((W - 1) / stride + 1);
+  long long n = npos / 4096;  // >= 16 positions per thread and block
+  const long long fill = 1024 / C;  // about four blocks per CU over all channels
+  if (n > fill) n = fill;
+  if (n < 1) n = 1;
+  return (int)(n > 64 ? 64 : n);
+}
+
+int as_dwconv3x3_wgrad(const float* x, const float* d_out, float* partial, int slices, int B, int C, int H, int W, int stride, void* stream) {
+  AS_REQUIRE(x && d_out && partial, AS_ERR_BAD_ARG, "dwconv3x3_wgrad: null pointer");
+  AS_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), AS_ERR_BAD_ARG, "dwconv3x3_wgrad: bad size / stride");
+  AS_REQUIRE(slices >= 1 && slices <= 65535 && C <= 65535, AS_ERR_BAD_SHAPE, "dwconv3x3_wgrad: slices=%d C=%d", slices, C);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const dim3 grid((unsigned)slices, (unsigned)C);
+  if (stride == 1) hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<1>, grid, dim3(256), 0, as::as_stream(stream), x, d_out, partial, B, C, H, W, Ho, Wo);
+  else hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<2>, grid, dim3(256), 0, as::as_stream(stream), x, d_out, partial, B, C, H, W, Ho, Wo);
+  return as::check_launch("dwconv3x3_wgrad");
 }
 
 int as_interp_bilinear_ac_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, int Ho, int Wo, void* stream) {

@@ -928,6 +928,11 @@ __global__ __launch_bounds__(256) void interp_bs_kernel(const float* __restrict_
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 
 constexpr int kSplitKC = 16;
+// cache policy bits of the staged epilogue's result stores (buffer-store aux: 1 = sc0, 2 = nt, 16 = sc1).  0 = write-back: the
+// results stay dirty in the XCD's L2 and are written out at the kernel boundary.  A/B builds only (tools/conv_variant.sh).
+#ifndef AS_EPI_STORE_AUX
+#define AS_EPI_STORE_AUX 0
+#endif
 
 typedef __attribute__((address_space(3))) void as_lds_void;
 typedef __attribute__((address_space(1))) const void as_gbl_void;
@@ -1643,7 +1648,7 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
           o = (1.f - pzv[k][j]) * phv[k][j] + pzv[k][j] * tanhf(x);
         }
         ov[j] = o;
-        if (!e.skip_out) as_bstore(e.r_out, poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff, o);
+        if (!e.skip_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), e.r_out, (int)(poff == 0x7FFFFFF0u ? poff : (unsigned)col * e.plane4 + poff), 0, AS_EPI_STORE_AUX);
       }
       if (e.has_bs) {
         half8 hi, lo;
@@ -1657,8 +1662,8 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
         for (int j = 0; j < 8; j += 2) ovf_amax = fmaxf(ovf_amax, fmaxf(fabsf(ov[j]), fabsf(ov[j + 1])));
         const unsigned off = poff == 0x7FFFFFF0u ? poff : (unsigned)(col0 >> 3) * (e.plane4 * 4u) + poff * 4u;
         if (col0 + 8 <= e.cvalid) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), e.r_bs, (int)off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), e.r_bsl, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), e.r_bs, (int)off, 0, AS_EPI_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), e.r_bsl, (int)off, 0, AS_EPI_STORE_AUX);
         } else {  // the result's last channels end inside or before this block: own slots + zeroed padding, 2 B each
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -1800,7 +1805,9 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
     // other's MFMAs (gru04 z|r 149.3 -> 146.6 us, head conv1 58.9 -> 54.4); with fewer blocks a CU holds ONE single-buffered
     // block and loses (gru04 q 85.5 -> 102.8, gru08 z|r 62 -> 87), as do 128-pixel lean blocks at three per CU (156.6 vs 144.4)
     const long long nblk = (long long)p.B * as::cdiv64((long long)p.tiles_x * p.tiles_y, NSUB) * p.n_tiles * p.ksplit;
-    if (p.all_bs && (lean_mode >= 2 || (lean_mode == 1 && NSUB == 2 && nblk >= 2 * kNumCU)))
+    // 3 (A/B knob): mode 1 + the 128-pixel blocks of the small maps (49 KB: up to three per CU, co-resident with another
+    // launch's blocks) — never the big maps' 256-block launches, which run alone and need their own double buffering
+    if (p.all_bs && (lean_mode == 2 || ((lean_mode == 1 || lean_mode == 3) && NSUB == 2 && nblk >= 2 * kNumCU) || (lean_mode == 3 && NSUB == 1)))
       return launch_conv_split_epi<KS, TW, BN, EPI, NSUB, S, false, true>(p, s);
   }
   constexpr int TH = 128 / TW, PATCHP = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);

@@ -434,6 +434,14 @@ int as_conv7x7_c1_wgrad_multi(const float* const* xs, const float* const* dys, i
  *         as_interp_bilinear_ac (what autograd derives for F.avg_pool2d / F.interpolate at update.py:94-102); gather form, one
  *         thread per input element, fixed summation order. */
 int as_pool2x_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, void* stream);
+/*   f4^T  depthwise 3x3 (padding 1) under autograd — conv_dw of the MobileNetV2 blocks (extractor.py:331-342; MIOpen has only
+ *         its naive reference solvers for fp32 convolutions with groups == channels).  Forward: as_dwconv3x3.  Data gradient:
+ *         stride 1 = as_dwconv3x3 on the flipped taps; stride 2 = as_dwconv3x3_s2_bwd_data (d_out [B,C,Ho,Wo] -> d_x [B,C,H,W],
+ *         gather form).  Weight gradient: as_dwconv3x3_wgrad writes partial[C][slices][9] (slices = as_dwconv3x3_wgrad_slices);
+ *         the caller sums the slices in order (deterministic). */
+int as_dwconv3x3_s2_bwd_data(const float* d_out, const float* weight, float* d_x, int B, int C, int H, int W, void* stream);
+int as_dwconv3x3_wgrad_slices(int B, int C, int H, int W, int stride);
+int as_dwconv3x3_wgrad(const float* x, const float* d_out, float* partial, int slices, int B, int C, int H, int W, int stride, void* stream);
 int as_interp_bilinear_ac_bwd(const float* d_out, float* d_x, int B, int C, int H, int W, int Ho, int Wo, void* stream);
 int as_corr_pyramid_bwd(const float* const* d_levels, float* d_corr0, long long rows, int W2, int L, void* stream);
 int as_geo_pyramid_bwd(const float* const* d_levels, float* d_gev, int B, int G, int D, int H, int W, int L, void* stream);

@@ -2039,3 +2039,29 @@ def test_loop_front_fused_equals_staged(golden, tag, h, w):
                 assert (mf.float()[:, 127:128] - d_ref).abs().max().item() <= 2e-6 * max(1.0, d_ref.abs().max().item()), "disparity pass-through"
     finally:
         ops.set_precision(prev)
+
+@pytest.mark.parametrize("b,c,h,w,stride", [(2, 32, 20, 40, 1), (1, 144, 13, 37, 2), (3, 16, 9, 14, 2), (2, 96, 10, 20, 1), (1, 8, 3, 5, 1),
+                                            (4, 32, 80, 160, 1)])
+def test_dwconv3x3_backward(b, c, h, w, stride):
+    """Depthwise 3x3 under autograd (grad.DwConv3x3: MobileNetV2's conv_dw layers in training, extractor.py:331-342): forward, data
+    gradient (stride 1: the forward kernel on flipped taps; stride 2: the gather kernel) and weight gradient (two-stage fixed-order
+    reduction) against the fp64 grouped convolution; odd sizes, both strides, a multi-slice reduction.  The weight gradient is
+    the same bits on every run."""
+    import torch.nn.functional as F
+    from anystereo import grad as G
+    x = U((b, c, h, w), 700 + c).to(DEV).requires_grad_(True)
+    wt = (U((c, 1, 3, 3), 701 + c) * 0.3).to(DEV).requires_grad_(True)
+    gout = U((b, c, (h - 1) // stride + 1, (w - 1) // stride + 1), 702 + c).to(DEV)
+    y = G.DwConv3x3.apply(x, wt, stride)
+    y.backward(gout)
+    xd, wd = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, stride, 1, 1, c)
+    yd.backward(gout.double())
+    for got, want, what in ((y, yd, "forward"), (x.grad, xd.grad, "d_x"), (wt.grad, wd.grad, "d_weight")):
+        err = (got.double() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        assert err < 2e-6, f"dwconv3x3 {what}: max err / max |ref| = {err:.2e}"
+    g1 = wt.grad.clone()
+    wt.grad = None
+    x.grad = None
+    G.DwConv3x3.apply(x, wt, stride).backward(gout)
+    assert torch.equal(wt.grad, g1), "dwconv3x3 weight gradient is not bit-repeatable"

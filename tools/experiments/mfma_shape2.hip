@@ -1,0 +1,255 @@
+// Round 5: the MFMA-shape question of mfma_shape.hip asked again with BOTH consumer loops software-pipelined the way the product
+// kernel now issues them (operand reads of tap t+1 interleaved with the MFMAs of tap t, one ds_read_b128 per MFMA gap or per
+// three 16x16x32 MFMAs) and with the 16x16x32 form on proper 32-channel chunks (no half-empty K step).  Same work per wave for
+// both: a 64 x 64 output tile, split precision (hi*hi, hi*lo, lo*hi), every operand re-read from LDS, random full-range fp16,
+// four waves per CU (one per SIMD), 256 blocks, >= 50 ms.  Reports us per 16-channel-chunk equivalent (108 MFMAs of 32x32x16),
+// the in-kernel clock and cycles per chunk.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_shape2 tools/experiments/mfma_shape2.hip && /tmp/mfma_shape2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(4))) float f4v;
+
+constexpr int kLdsBytes = 128 * 1024;
+__device__ unsigned long long g_clk[256 * 4];
+
+
+template <int SHAPE>  // 0: 32x32x16 (tap = 12 MFMAs + 8 reads), 1: 16x16x32 (tap of a 32-channel chunk = 48 MFMAs + 16 reads)
+__global__ __launch_bounds__(256, 1) void k(const unsigned* __restrict__ in, float* __restrict__ out, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  for (int i = threadIdx.x; i < kLdsBytes / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = in[i];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  const unsigned char* base = lds + lane * 16 + wave * 2048;
+  if constexpr (SHAPE == 0) {
+    f16v ah[2][2], ax[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ah[c][q][i] = 0.f; ax[c][q][i] = 0.f; }
+    half8 a_hi[2][2], a_lo[2][2], b_hi[2][2], b_lo[2][2];
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define LDA0(T, comp, c) *reinterpret_cast<const half8*>(base + (T) * 4096 + (comp) * 8192 + (c) * 1024)
+#define LDB0(T, comp, c) *reinterpret_cast<const half8*>(base + 81920 + (T) * 256 + (comp) * 16384 + (c) * 1024)
+    a_hi[0][0] = LDA0(0, 0, 0); a_lo[0][0] = LDA0(0, 1, 0); a_hi[0][1] = LDA0(0, 0, 1); a_lo[0][1] = LDA0(0, 1, 1);
+    b_hi[0][0] = LDB0(0, 0, 0); b_lo[0][0] = LDB0(0, 1, 0); b_hi[0][1] = LDB0(0, 0, 1); b_lo[0][1] = LDB0(0, 1, 1);
+    // a pair of taps per trip: 2 x 12 MFMAs; 4.5 trips = one 16-channel chunk -> `chunks` * 9 / 2 trips
+    const int trips = chunks * 9 / 2;
+    for (int t = 0; t < trips; ++t) {
+      const int T1 = (2 * t + 1) & 15, T0 = (2 * t + 2) & 15;
+      ah[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][0], b_hi[0][0], ah[0][0], 0, 0, 0); a_hi[1][0] = LDA0(T1, 0, 0); SB
+      ax[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][0], b_lo[0][0], ax[0][0], 0, 0, 0); a_lo[1][0] = LDA0(T1, 1, 0); SB
+      ah[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][0], b_hi[0][1], ah[0][1], 0, 0, 0); b_hi[1][0] = LDB0(T1, 0, 0); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][0], b_lo[0][1], ax[0][1], 0, 0, 0); b_lo[1][0] = LDB0(T1, 1, 0); SB
+      ax[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][0], b_hi[0][0], ax[0][0], 0, 0, 0); a_hi[1][1] = LDA0(T1, 0, 1); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][0], b_hi[0][1], ax[0][1], 0, 0, 0); a_lo[1][1] = LDA0(T1, 1, 1); SB
+      ah[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][1], b_hi[0][0], ah[1][0], 0, 0, 0); b_hi[1][1] = LDB0(T1, 0, 1); SB
+      ax[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][1], b_lo[0][0], ax[1][0], 0, 0, 0); b_lo[1][1] = LDB0(T1, 1, 1); SB
+      ah[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][1], b_hi[0][1], ah[1][1], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][1], b_lo[0][1], ax[1][1], 0, 0, 0); SB
+      ax[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][1], b_hi[0][0], ax[1][0], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][1], b_hi[0][1], ax[1][1], 0, 0, 0); SB
+      ah[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][0], b_hi[1][0], ah[0][0], 0, 0, 0); a_hi[0][0] = LDA0(T0, 0, 0); SB
+      ax[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][0], b_lo[1][0], ax[0][0], 0, 0, 0); a_lo[0][0] = LDA0(T0, 1, 0); SB
+      ah[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][0], b_hi[1][1], ah[0][1], 0, 0, 0); b_hi[0][0] = LDB0(T0, 0, 0); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][0], b_lo[1][1], ax[0][1], 0, 0, 0); b_lo[0][0] = LDB0(T0, 1, 0); SB
+      ax[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][0], b_hi[1][0], ax[0][0], 0, 0, 0); a_hi[0][1] = LDA0(T0, 0, 1); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][0], b_hi[1][1], ax[0][1], 0, 0, 0); a_lo[0][1] = LDA0(T0, 1, 1); SB
+      ah[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][1], b_hi[1][0], ah[1][0], 0, 0, 0); b_hi[0][1] = LDB0(T0, 0, 1); SB
+      ax[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][1], b_lo[1][0], ax[1][0], 0, 0, 0); b_lo[0][1] = LDB0(T0, 1, 1); SB
+      ah[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][1], b_hi[1][1], ah[1][1], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][1], b_lo[1][1], ax[1][1], 0, 0, 0); SB
+      ax[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][1], b_hi[1][0], ax[1][0], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][1], b_hi[1][1], ax[1][1], 0, 0, 0); SB
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += ah[c][q][i] + ax[c][q][i] * (1.f / 2048.f);
+  } else {
+    f4v ah[4][4], ax[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ah[c][q][i] = 0.f; ax[c][q][i] = 0.f; }
+    half8 a_hi[2][4], a_lo[2][4], b_hi[2][4], b_lo[2][4];
+#define LDA1(T, comp, c) *reinterpret_cast<const half8*>(base + (T) * 8192 + (comp) * 4096 + (c) * 1024)
+#define LDB1(T, comp, c) *reinterpret_cast<const half8*>(base + 81920 + (T) * 512 + (comp) * 16384 + (c) * 1024)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { a_hi[0][c] = LDA1(0, 0, c); a_lo[0][c] = LDA1(0, 1, c); b_hi[0][c] = LDB1(0, 0, c); b_lo[0][c] = LDB1(0, 1, c); }
+    // a pair of taps of a 32-channel chunk per trip: 2 x 48 MFMAs = the FLOPs of 4 taps of a 16-channel chunk -> chunks * 9 / 4 trips
+    const int trips = chunks * 9 / 4;
+    for (int t = 0; t < trips; ++t) {
+      const int T1 = (2 * t + 1) & 7, T0 = (2 * t + 2) & 7;
+      ah[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_hi[0][0], ah[0][0], 0, 0, 0); a_hi[1][0] = LDA1(T1, 0, 0); SB
+      ax[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_lo[0][0], ax[0][0], 0, 0, 0);
+      ah[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_hi[0][1], ah[0][1], 0, 0, 0); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_lo[0][1], ax[0][1], 0, 0, 0); a_lo[1][0] = LDA1(T1, 1, 0); SB
+      ah[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_hi[0][2], ah[0][2], 0, 0, 0);
+      ax[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_lo[0][2], ax[0][2], 0, 0, 0); SB
+      ah[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_hi[0][3], ah[0][3], 0, 0, 0); b_hi[1][0] = LDB1(T1, 0, 0); SB
+      ax[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][0], b_lo[0][3], ax[0][3], 0, 0, 0);
+      ax[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][0], b_hi[0][0], ax[0][0], 0, 0, 0); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][0], b_hi[0][1], ax[0][1], 0, 0, 0); b_lo[1][0] = LDB1(T1, 1, 0); SB
+      ax[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][0], b_hi[0][2], ax[0][2], 0, 0, 0);
+      ax[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][0], b_hi[0][3], ax[0][3], 0, 0, 0); SB
+      ah[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_hi[0][0], ah[1][0], 0, 0, 0); a_hi[1][1] = LDA1(T1, 0, 1); SB
+      ax[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_lo[0][0], ax[1][0], 0, 0, 0);
+      ah[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_hi[0][1], ah[1][1], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_lo[0][1], ax[1][1], 0, 0, 0); a_lo[1][1] = LDA1(T1, 1, 1); SB
+      ah[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_hi[0][2], ah[1][2], 0, 0, 0);
+      ax[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_lo[0][2], ax[1][2], 0, 0, 0); SB
+      ah[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_hi[0][3], ah[1][3], 0, 0, 0); b_hi[1][1] = LDB1(T1, 0, 1); SB
+      ax[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][1], b_lo[0][3], ax[1][3], 0, 0, 0);
+      ax[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][1], b_hi[0][0], ax[1][0], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][1], b_hi[0][1], ax[1][1], 0, 0, 0); b_lo[1][1] = LDB1(T1, 1, 1); SB
+      ax[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][1], b_hi[0][2], ax[1][2], 0, 0, 0);
+      ax[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][1], b_hi[0][3], ax[1][3], 0, 0, 0); SB
+      ah[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_hi[0][0], ah[2][0], 0, 0, 0); a_hi[1][2] = LDA1(T1, 0, 2); SB
+      ax[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_lo[0][0], ax[2][0], 0, 0, 0);
+      ah[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_hi[0][1], ah[2][1], 0, 0, 0); SB
+      ax[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_lo[0][1], ax[2][1], 0, 0, 0); a_lo[1][2] = LDA1(T1, 1, 2); SB
+      ah[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_hi[0][2], ah[2][2], 0, 0, 0);
+      ax[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_lo[0][2], ax[2][2], 0, 0, 0); SB
+      ah[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_hi[0][3], ah[2][3], 0, 0, 0); b_hi[1][2] = LDB1(T1, 0, 2); SB
+      ax[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][2], b_lo[0][3], ax[2][3], 0, 0, 0);
+      ax[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][2], b_hi[0][0], ax[2][0], 0, 0, 0); SB
+      ax[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][2], b_hi[0][1], ax[2][1], 0, 0, 0); b_lo[1][2] = LDB1(T1, 1, 2); SB
+      ax[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][2], b_hi[0][2], ax[2][2], 0, 0, 0);
+      ax[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][2], b_hi[0][3], ax[2][3], 0, 0, 0); SB
+      ah[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_hi[0][0], ah[3][0], 0, 0, 0); a_hi[1][3] = LDA1(T1, 0, 3); SB
+      ax[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_lo[0][0], ax[3][0], 0, 0, 0);
+      ah[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_hi[0][1], ah[3][1], 0, 0, 0); SB
+      ax[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_lo[0][1], ax[3][1], 0, 0, 0); a_lo[1][3] = LDA1(T1, 1, 3); SB
+      ah[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_hi[0][2], ah[3][2], 0, 0, 0);
+      ax[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_lo[0][2], ax[3][2], 0, 0, 0); SB
+      ah[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_hi[0][3], ah[3][3], 0, 0, 0); b_hi[1][3] = LDB1(T1, 0, 3); SB
+      ax[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[0][3], b_lo[0][3], ax[3][3], 0, 0, 0);
+      ax[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][3], b_hi[0][0], ax[3][0], 0, 0, 0); SB
+      ax[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][3], b_hi[0][1], ax[3][1], 0, 0, 0); b_lo[1][3] = LDB1(T1, 1, 3); SB
+      ax[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][3], b_hi[0][2], ax[3][2], 0, 0, 0);
+      ax[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[0][3], b_hi[0][3], ax[3][3], 0, 0, 0); SB
+      ah[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_hi[1][0], ah[0][0], 0, 0, 0); a_hi[0][0] = LDA1(T0, 0, 0); SB
+      ax[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_lo[1][0], ax[0][0], 0, 0, 0);
+      ah[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_hi[1][1], ah[0][1], 0, 0, 0); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_lo[1][1], ax[0][1], 0, 0, 0); a_lo[0][0] = LDA1(T0, 1, 0); SB
+      ah[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_hi[1][2], ah[0][2], 0, 0, 0);
+      ax[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_lo[1][2], ax[0][2], 0, 0, 0); SB
+      ah[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_hi[1][3], ah[0][3], 0, 0, 0); b_hi[0][0] = LDB1(T0, 0, 0); SB
+      ax[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][0], b_lo[1][3], ax[0][3], 0, 0, 0);
+      ax[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][0], b_hi[1][0], ax[0][0], 0, 0, 0); SB
+      ax[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][0], b_hi[1][1], ax[0][1], 0, 0, 0); b_lo[0][0] = LDB1(T0, 1, 0); SB
+      ax[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][0], b_hi[1][2], ax[0][2], 0, 0, 0);
+      ax[0][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][0], b_hi[1][3], ax[0][3], 0, 0, 0); SB
+      ah[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_hi[1][0], ah[1][0], 0, 0, 0); a_hi[0][1] = LDA1(T0, 0, 1); SB
+      ax[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_lo[1][0], ax[1][0], 0, 0, 0);
+      ah[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_hi[1][1], ah[1][1], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_lo[1][1], ax[1][1], 0, 0, 0); a_lo[0][1] = LDA1(T0, 1, 1); SB
+      ah[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_hi[1][2], ah[1][2], 0, 0, 0);
+      ax[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_lo[1][2], ax[1][2], 0, 0, 0); SB
+      ah[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_hi[1][3], ah[1][3], 0, 0, 0); b_hi[0][1] = LDB1(T0, 0, 1); SB
+      ax[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][1], b_lo[1][3], ax[1][3], 0, 0, 0);
+      ax[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][1], b_hi[1][0], ax[1][0], 0, 0, 0); SB
+      ax[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][1], b_hi[1][1], ax[1][1], 0, 0, 0); b_lo[0][1] = LDB1(T0, 1, 1); SB
+      ax[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][1], b_hi[1][2], ax[1][2], 0, 0, 0);
+      ax[1][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][1], b_hi[1][3], ax[1][3], 0, 0, 0); SB
+      ah[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_hi[1][0], ah[2][0], 0, 0, 0); a_hi[0][2] = LDA1(T0, 0, 2); SB
+      ax[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_lo[1][0], ax[2][0], 0, 0, 0);
+      ah[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_hi[1][1], ah[2][1], 0, 0, 0); SB
+      ax[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_lo[1][1], ax[2][1], 0, 0, 0); a_lo[0][2] = LDA1(T0, 1, 2); SB
+      ah[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_hi[1][2], ah[2][2], 0, 0, 0);
+      ax[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_lo[1][2], ax[2][2], 0, 0, 0); SB
+      ah[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_hi[1][3], ah[2][3], 0, 0, 0); b_hi[0][2] = LDB1(T0, 0, 2); SB
+      ax[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][2], b_lo[1][3], ax[2][3], 0, 0, 0);
+      ax[2][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][2], b_hi[1][0], ax[2][0], 0, 0, 0); SB
+      ax[2][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][2], b_hi[1][1], ax[2][1], 0, 0, 0); b_lo[0][2] = LDB1(T0, 1, 2); SB
+      ax[2][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][2], b_hi[1][2], ax[2][2], 0, 0, 0);
+      ax[2][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][2], b_hi[1][3], ax[2][3], 0, 0, 0); SB
+      ah[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_hi[1][0], ah[3][0], 0, 0, 0); a_hi[0][3] = LDA1(T0, 0, 3); SB
+      ax[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_lo[1][0], ax[3][0], 0, 0, 0);
+      ah[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_hi[1][1], ah[3][1], 0, 0, 0); SB
+      ax[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_lo[1][1], ax[3][1], 0, 0, 0); a_lo[0][3] = LDA1(T0, 1, 3); SB
+      ah[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_hi[1][2], ah[3][2], 0, 0, 0);
+      ax[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_lo[1][2], ax[3][2], 0, 0, 0); SB
+      ah[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_hi[1][3], ah[3][3], 0, 0, 0); b_hi[0][3] = LDB1(T0, 0, 3); SB
+      ax[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[1][3], b_lo[1][3], ax[3][3], 0, 0, 0);
+      ax[3][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][3], b_hi[1][0], ax[3][0], 0, 0, 0); SB
+      ax[3][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][3], b_hi[1][1], ax[3][1], 0, 0, 0); b_lo[0][3] = LDB1(T0, 1, 3); SB
+      ax[3][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][3], b_hi[1][2], ax[3][2], 0, 0, 0);
+      ax[3][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[1][3], b_hi[1][3], ax[3][3], 0, 0, 0); SB
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += ah[c][q][i] + ax[c][q][i] * (1.f / 2048.f);
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && wave == 0 && blockIdx.x < 256) { g_clk[blockIdx.x * 4] = t1 - t0; g_clk[blockIdx.x * 4 + 1] = r1 - r0; }
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+int main() {
+  std::vector<unsigned> h(kLdsBytes / 4);
+  unsigned* din;
+  float* dout;
+  (void)hipMalloc(&din, h.size() * 4);
+  (void)hipMalloc(&dout, 256 * 256 * 4);
+  srand(1);
+  auto rnd_half = [] {
+    float x = (rand() / (float)RAND_MAX) * 2.f - 1.f;
+    _Float16 hx = (_Float16)x;
+    unsigned short u;
+    __builtin_memcpy(&u, &hx, 2);
+    return (unsigned)u;
+  };
+  (void)hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  (void)hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  for (int mode = 1; mode >= 0; --mode) {
+    for (auto& v : h) v = mode ? (rnd_half() | (rnd_half() << 16)) : 0u;
+    (void)hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    const int chunks = 24 * 1200;
+    for (int rep = 0; rep < 3; ++rep)
+      for (int shape = 0; shape < 2; ++shape) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        auto launch = [&](int n) {
+          if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), kLdsBytes, 0, din, dout, n);
+          else hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), kLdsBytes, 0, din, dout, n);
+        };
+        launch(chunks / 4);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        launch(chunks);
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> c(256 * 4);
+        (void)hipMemcpyFromSymbol(c.data(), HIP_SYMBOL(g_clk), c.size() * 8);
+        std::vector<double> ghz;
+        for (int b = 0; b < 256; ++b) ghz.push_back((double)c[b * 4] / (double)c[b * 4 + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        const double flop = 256.0 * 4 * chunks * 108.0 * 32768.0;
+        printf("%s data, %s: %.2f ms, %.3f us per 16-channel chunk, %.0f TFLOP/s fp16 (= %.0f algorithmic), clock median %.3f GHz, "
+               "cycles per chunk %.0f (ideal 3456)\n",
+               mode ? "random" : "zero  ", shape ? "16x16x32" : "32x32x16", ms, ms * 1e3 / chunks, flop / (ms * 1e-3) / 1e12,
+               flop / (ms * 1e-3) / 1e12 / 3, ghz[128], (double)c[0] / chunks);
+      }
+  }
+  return 0;
+}
