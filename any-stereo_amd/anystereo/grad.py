@@ -688,6 +688,45 @@ def module_dwconv(conv, x):
     return conv(x)
 
 
+_TRAIN_FOLD_BN = os.environ.get("ANYSTEREO_TRAIN_FOLD_BN", "1") != "0"
+_FOLD_MIN_ELEMS = 1 << 21  # output elements from which two BatchNorm passes cost more than the fold's ~11 weight-sized launches
+
+
+def conv_frozen_bn(mod, name, conv, bn, x, relu=False):
+    """act(bn(conv(x))) under autograd for a FROZEN BatchNorm2d — eval mode inside the training step (`freeze_bn`,
+    train_continuous_IGEV.py:189), so its statistics are constants: y = conv(x; W * s) + (beta - mean * s [+ bias * s]),
+    s = gamma / sqrt(var + eps), with W * s and the bias built by differentiable operations on the WEIGHT-sized tensors.  The
+    convolution then runs forward, dgrad and wgrad on this library's kernels with bias and ReLU in the epilogue and the bias gradient
+    in the weight-gradient launch: the BatchNorm forward pass, its backward pass and the ReLU passes over the activation tensor
+    (0.6 ms per step for the context network's five full-resolution layers alone) disappear.  Same function as bn(conv(x)); the
+    gradients of gamma / beta / W follow from the chain rule through the fold.  Small maps keep the plain form."""
+    cout = conv.out_channels
+    big = x.shape[0] * cout * x.shape[2] * x.shape[3] >= _FOLD_MIN_ELEMS
+    if not (_TRAIN_FOLD_BN and big and isinstance(bn, torch.nn.BatchNorm2d) and not bn.training and bn.affine and bn.track_running_stats
+            and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and isinstance(conv, torch.nn.Conv2d)
+            and conv.kernel_size in ((1, 1), (3, 3)) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding == (conv.kernel_size[0] // 2,) * 2 and conv.padding_mode == "zeros" and x.shape[1] >= 16
+            and _TRAIN_BACKBONE):
+        y = bn(module_conv2d(mod, name, conv, x))
+        return torch.relu(y) if relu else y
+    # 1 / sqrt(var + eps) and mean / sqrt(var + eps): constants while the layer is frozen (cached per buffer version)
+    cache = mod.__dict__.setdefault("_frozen_bn_consts", {})
+    key = (bn.running_mean.data_ptr(), bn.running_mean._version, bn.running_var.data_ptr(), bn.running_var._version, bn.eps)
+    ent = cache.get(name)
+    if ent is None or ent[0] != key:
+        with torch.no_grad():
+            rs = torch.rsqrt(bn.running_var.float() + bn.eps)
+            ent = (key, rs, bn.running_mean.float() * rs)
+        cache[name] = ent
+    _, rs, mrs = ent
+    s_ = bn.weight * rs
+    w = conv.weight * s_.view(-1, 1, 1, 1)
+    b = torch.addcmul(bn.bias, bn.weight, mrs, value=-1.0)
+    if conv.bias is not None:
+        b = torch.addcmul(b, conv.bias, s_)
+    return conv2d_same(mod, name, x, w, b, relu=relu)
+
+
 def pointwise_linear(mod, key, x, lin, relu):
     """PointwiseLinear of the nn.Linear `lin` with packs and the step's weight anchor cached on `mod` under `key`."""
     packs = mod.__dict__.setdefault("_train_packs", {})

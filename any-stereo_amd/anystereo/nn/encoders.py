@@ -63,8 +63,9 @@ class ResidualBlock(nn.Module):
             return self._forward_fused(x)
         if _fused_ok(x, self) and _plain_in(self.norm1) and _plain_in(self.norm2):
             return self._forward_fused_in(x)
-        y = self.relu(self.norm1(G.module_conv2d(self, "t1", self.conv1, x)))  # training: own kernels where the shape allows
-        y = self.relu(self.norm2(G.module_conv2d(self, "t2", self.conv2, y)))
+        # training: own kernels where the shape allows; a frozen BatchNorm (+ ReLU) rides in the convolution (grad.conv_frozen_bn)
+        y = G.conv_frozen_bn(self, "t1", self.conv1, self.norm1, x, relu=True)
+        y = G.conv_frozen_bn(self, "t2", self.conv2, self.norm2, y, relu=True)
         if self.downsample is not None:
             x = self.downsample(x)
         return self.relu(x + y)

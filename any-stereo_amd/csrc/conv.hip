@@ -2156,6 +2156,18 @@ int as_conv2d(const as_conv_desc* d, void* stream) {
       conv_pick_ksplit(p, d);
       use64 = true;
     }
+    // A/B knob AS_CONV_PREFER64=1 (off by default: measured slower on the cfg-4 step, 53.6 vs 52.8 ms): fp32 sources, 64-channel
+    // tiles when they need NO K split where the 128-channel tiles do — one fused launch instead of partial sums + a finish launch
+    static const int prefer64 = getenv("AS_CONV_PREFER64") ? atoi(getenv("AS_CONV_PREFER64")) : 0;
+    if (prefer64 && !use64 && bn == 128 && !d->dual && p.ksplit > 1) {
+      const long long blocks64 = (long long)p.B * p.tiles_x * p.tiles_y * (p.Cout_pad / 64);
+      if (blocks64 <= kNumCU) {
+        p.n_tiles = p.Cout_pad / 64;
+        p.ksplit = 1;
+        p.ws = nullptr;
+        use64 = true;
+      }
+    }
     if (d->dual) conv_apply_dual(p, d);
     if (tw == 16) return use64 ? launch_conv_split<3, 16, 64>(p, epi, s) : launch_conv_split<3, 16, 128>(p, epi, s);
     return use64 ? launch_conv_split<3, 32, 64>(p, epi, s) : launch_conv_split<3, 32, 128>(p, epi, s);

@@ -40,6 +40,13 @@ torch = None  # imported by main() in the worker ranks only: the spawning parent
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16/bf16 MFMA dense peak (~2.5 PF)
+# What the chip sustains on this instruction mix with RANDOM operands (it lowers its clock under MFMA load; MI355X_MICROARCH.md "DVFS
+# give-back"): tools/experiments/mfma_shape2.hip — the conv consumer's exact work per wave (64 x 64 tile, 3 MFMAs per product, every
+# operand re-read from LDS), software-pipelined to 98.5 % issue efficiency, four waves per CU on 256 CUs: 1.51 PFLOP/s fp16 =
+# 503 TFLOP/s of algorithmic (split) flops at an in-kernel clock of 1.52 GHz; the less tightly issued round-4 form of the same loop
+# gives the same 2.39 us per 16-channel chunk at 1.70 GHz (profiles/r05_mfma_shape_microbench.txt).  Reported beside `frac`, which stays
+# against the nominal dense peak.
+MFMA_F16_RANDOM_DATA_TFLOPS = 1510.0
 INFINITY_CACHE_MB = 256
 
 
@@ -824,6 +831,8 @@ def roofline_table(kstats, alg, precision, traffic):
             rooflines[name] = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic.get(name),
                                "avg_us": round(avg_s * 1e6, 2), "launches": st["count"], "total_ms": round(st["total_ms"], 3)}
+            if precision == "split":
+                rooflines[name]["frac_of_measured_mfma_rate"] = round(ach / (MFMA_F16_RANDOM_DATA_TFLOPS / 3.0), 4)
             if "flops_executed" in e:  # a kernel that executes fewer flops than the reference's statement of the operator
                 rooflines[name]["algorithmic_gflop"] = round(e["flops"] / 1e9, 2)
                 rooflines[name]["executed_gflop"] = round(e["flops_executed"] / 1e9, 2)

@@ -2065,3 +2065,51 @@ def test_dwconv3x3_backward(b, c, h, w, stride):
     x.grad = None
     G.DwConv3x3.apply(x, wt, stride).backward(gout)
     assert torch.equal(wt.grad, g1), "dwconv3x3 weight gradient is not bit-repeatable"
+
+@pytest.mark.parametrize("cin,cout,ks,bias", [(64, 64, 3, True), (32, 96, 1, False)])
+def test_conv_frozen_bn_backward(cin, cout, ks, bias):
+    """relu(bn(conv(x))) with a FROZEN BatchNorm2d under autograd (grad.conv_frozen_bn: the context network's residual blocks in the
+    training step, extractor.py:10-62 with train_continuous_IGEV.py:189): the affine map folded into the convolution's weights by
+    differentiable weight-sized operations — output and the gradients of x, W, bias, gamma, beta against the fp64 modules."""
+    import torch.nn as nn
+    from anystereo import grad as G
+    from anystereo import ops
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        b, h, w = 2, 128, 128   # 2 * cout * 128 * 128 >= 2^21 output elements: the folded branch
+        conv = nn.Conv2d(cin, cout, ks, padding=ks // 2, bias=bias).to(DEV)
+        bn = nn.BatchNorm2d(cout).to(DEV).eval()
+        with torch.no_grad():
+            conv.weight.copy_((U(tuple(conv.weight.shape), 810 + ks) * 0.1).to(DEV))
+            if bias:
+                conv.bias.copy_(U((cout,), 811).to(DEV))
+            bn.weight.copy_(U((cout,), 812, 0.5, 1.5).to(DEV)), bn.bias.copy_(U((cout,), 813).to(DEV))
+            bn.running_mean.copy_(U((cout,), 814).to(DEV)), bn.running_var.copy_(U((cout,), 815, 0.5, 2.0).to(DEV))
+        holder = nn.Module()
+        x = U((b, cin, h, w), 816).to(DEV).requires_grad_(True)
+        gout = U((b, cout, h, w), 817).to(DEV)
+        G.begin_forward()
+        y = G.conv_frozen_bn(holder, "t", conv, bn, x, relu=True)
+        assert "_frozen_bn_consts" in holder.__dict__, "the folded branch was not taken"
+        y.backward(gout)
+        got = {"y": y, "d_x": x.grad, "d_w": conv.weight.grad, "d_gamma": bn.weight.grad, "d_beta": bn.bias.grad}
+        if bias:
+            got["d_bias"] = conv.bias.grad
+        import copy
+        convd, bnd = copy.deepcopy(conv).double(), copy.deepcopy(bn).double().eval()
+        for p_ in list(convd.parameters()) + list(bnd.parameters()):
+            p_.grad = None
+        xd = x.detach().double().requires_grad_(True)
+        yd = torch.relu(bnd(convd(xd)))
+        yd.backward(gout.double())
+        want = {"y": yd, "d_x": xd.grad, "d_w": convd.weight.grad, "d_gamma": bnd.weight.grad, "d_beta": bnd.bias.grad}
+        if bias:
+            want["d_bias"] = convd.bias.grad
+        for k_, tol in (("y", 5e-6), ("d_x", 1e-5), ("d_w", 1e-4), ("d_gamma", 1e-4), ("d_beta", 1e-4), ("d_bias", 1e-4)):
+            if k_ not in got:
+                continue
+            err = (got[k_].double() - want[k_]).abs().max().item() / max(want[k_].abs().max().item(), 1e-30)
+            assert err < tol, f"conv_frozen_bn {k_}: max err / max |ref| = {err:.2e} (limit {tol:g})"
+    finally:
+        ops.set_precision(prev)

@@ -22,8 +22,8 @@ print("STEP DONE", flush=True)
 PY
 echo "rc=$?"
 grep -c . gpurun_out/miopen_log.txt
-# the solver chosen per call and the driver command of that call
-grep -n -i "naive" gpurun_out/miopen_log.txt | cut -c1-260 | head -80 > gpurun_out/r05_naive_convs.txt
-grep -B 30 -i "ConvDirectNaive" gpurun_out/miopen_log.txt | grep -i "MIOpenDriver" | sort | uniq -c | sort -rn | head -40 >> gpurun_out/r05_naive_convs.txt
-tail -c 3000000 gpurun_out/miopen_log.txt > gpurun_out/miopen_log_tail.txt; rm -f gpurun_out/miopen_log.txt
-cat gpurun_out/r05_naive_convs.txt | head -60
+# every distinct problem whose chosen solver is a naive one (forward / data gradient / weight gradient), with the find-time estimate
+grep -o "SetValues\] [^,]*, content inserted: ConvDirectNaiveConv[A-Za-z]*:[0-9.e+-]*" gpurun_out/miopen_log.txt | sort | uniq -c | sort -rn > gpurun_out/r05_naive_convs.txt
+grep -c "kernel_name = naive_conv" gpurun_out/miopen_log.txt >> gpurun_out/r05_naive_convs.txt
+rm -f gpurun_out/miopen_log.txt
+cat gpurun_out/r05_naive_convs.txt
