@@ -18,7 +18,7 @@ constexpr int kLdsBytes = 128 * 1024;
 __device__ unsigned long long g_clk[256 * 4];
 
 
-template <int SHAPE>  // 0: 32x32x16 (tap = 12 MFMAs + 8 reads), 1: 16x16x32 (tap of a 32-channel chunk = 48 MFMAs + 16 reads)
+template <int SHAPE>  // 0: 32x32x16 (tap = 12 MFMAs + 8 reads), 1: 16x16x32 (tap of a 32-channel chunk = 48 MFMAs + 16 reads), 2: one accumulator set, 128 x 64 wave tile
 __global__ __launch_bounds__(256, 1) void k(const unsigned* __restrict__ in, float* __restrict__ out, int chunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   for (int i = threadIdx.x; i < kLdsBytes / 4; i += 256) reinterpret_cast<unsigned*>(lds)[i] = in[i];
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void k(const unsigned* __restrict__ in, flo
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) s += ah[c][q][i] + ax[c][q][i] * (1.f / 2048.f);
-  } else {
+  } else if constexpr (SHAPE == 1) {
     f4v ah[4][4], ax[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -197,6 +197,93 @@ __global__ __launch_bounds__(256, 1) void k(const unsigned* __restrict__ in, flo
 #pragma unroll
         for (int i = 0; i < 4; ++i) s += ah[c][q][i] + ax[c][q][i] * (1.f / 2048.f);
   }
+  if constexpr (SHAPE == 2) {
+    // ONE fp32 accumulator set: acc += (2^11 w_hi) x_hi + w_hi x_lo + w_lo x_hi (the scaled hi plane made in registers by a packed multiply),
+    // wave tile 128 co x 64 px: 12 operand reads per 24 MFMAs instead of 8 per 12 — twice the FLOPs per wave and tap, so a "chunk" here
+    // is TWO 16-channel-chunk equivalents of the 64 x 64 forms
+    f16v acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][q][i] = 0.f;
+    half8 a_hi[2][4], a_lo[2][4], b_hi[2][2], b_lo[2][2], a_sc[4];
+    const half8 k2048 = {(_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f, (_Float16)2048.f};
+#define LDA2(T, comp, c) *reinterpret_cast<const half8*>(base + (T) * 8192 + (comp) * 4096 + (c) * 1024)
+#define LDB2(T, comp, c) *reinterpret_cast<const half8*>(base + 81920 + (T) * 256 + (comp) * 16384 + (c) * 1024)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { a_hi[0][c] = LDA2(0, 0, c); a_lo[0][c] = LDA2(0, 1, c); }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { b_hi[0][q] = LDB2(0, 0, q); b_lo[0][q] = LDB2(0, 1, q); }
+    // a pair of taps per trip: 2 x 24 MFMAs = the FLOPs of 4 taps of a 64 x 64 tile -> chunks * 9 / 4 trips
+    const int trips = chunks * 9 / 4;
+    for (int t = 0; t < trips; ++t) {
+      const int T1 = (2 * t + 1) & 7, T0 = (2 * t + 2) & 7;
+      a_sc[0] = a_hi[0][0] * k2048;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[0], b_hi[0][0], acc[0][0], 0, 0, 0); SB
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][0], b_lo[0][0], acc[0][0], 0, 0, 0); a_hi[1][0] = LDA2(T1, 0, 0); SB
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[0], b_hi[0][1], acc[0][1], 0, 0, 0); SB
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][0], b_lo[0][1], acc[0][1], 0, 0, 0); a_lo[1][0] = LDA2(T1, 1, 0); SB
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][0], b_hi[0][0], acc[0][0], 0, 0, 0); SB
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][0], b_hi[0][1], acc[0][1], 0, 0, 0); a_hi[1][1] = LDA2(T1, 0, 1); SB
+      a_sc[1] = a_hi[0][1] * k2048;
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[1], b_hi[0][0], acc[1][0], 0, 0, 0); SB
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][1], b_lo[0][0], acc[1][0], 0, 0, 0); a_lo[1][1] = LDA2(T1, 1, 1); SB
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[1], b_hi[0][1], acc[1][1], 0, 0, 0); SB
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][1], b_lo[0][1], acc[1][1], 0, 0, 0); a_hi[1][2] = LDA2(T1, 0, 2); SB
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][1], b_hi[0][0], acc[1][0], 0, 0, 0); SB
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][1], b_hi[0][1], acc[1][1], 0, 0, 0); a_lo[1][2] = LDA2(T1, 1, 2); SB
+      a_sc[2] = a_hi[0][2] * k2048;
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[2], b_hi[0][0], acc[2][0], 0, 0, 0); SB
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][2], b_lo[0][0], acc[2][0], 0, 0, 0); a_hi[1][3] = LDA2(T1, 0, 3); SB
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[2], b_hi[0][1], acc[2][1], 0, 0, 0); SB
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][2], b_lo[0][1], acc[2][1], 0, 0, 0); a_lo[1][3] = LDA2(T1, 1, 3); SB
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][2], b_hi[0][0], acc[2][0], 0, 0, 0); SB
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][2], b_hi[0][1], acc[2][1], 0, 0, 0); b_hi[1][0] = LDB2(T1, 0, 0); SB
+      a_sc[3] = a_hi[0][3] * k2048;
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[3], b_hi[0][0], acc[3][0], 0, 0, 0); SB
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][3], b_lo[0][0], acc[3][0], 0, 0, 0); b_lo[1][0] = LDB2(T1, 1, 0); SB
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[3], b_hi[0][1], acc[3][1], 0, 0, 0); SB
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][3], b_lo[0][1], acc[3][1], 0, 0, 0); b_hi[1][1] = LDB2(T1, 0, 1); SB
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][3], b_hi[0][0], acc[3][0], 0, 0, 0); SB
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][3], b_hi[0][1], acc[3][1], 0, 0, 0); b_lo[1][1] = LDB2(T1, 1, 1); SB
+      a_sc[0] = a_hi[1][0] * k2048;
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[0], b_hi[1][0], acc[0][0], 0, 0, 0); SB
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][0], b_lo[1][0], acc[0][0], 0, 0, 0); a_hi[0][0] = LDA2(T0, 0, 0); SB
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[0], b_hi[1][1], acc[0][1], 0, 0, 0); SB
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][0], b_lo[1][1], acc[0][1], 0, 0, 0); a_lo[0][0] = LDA2(T0, 1, 0); SB
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][0], b_hi[1][0], acc[0][0], 0, 0, 0); SB
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][0], b_hi[1][1], acc[0][1], 0, 0, 0); a_hi[0][1] = LDA2(T0, 0, 1); SB
+      a_sc[1] = a_hi[1][1] * k2048;
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[1], b_hi[1][0], acc[1][0], 0, 0, 0); SB
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][1], b_lo[1][0], acc[1][0], 0, 0, 0); a_lo[0][1] = LDA2(T0, 1, 1); SB
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[1], b_hi[1][1], acc[1][1], 0, 0, 0); SB
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][1], b_lo[1][1], acc[1][1], 0, 0, 0); a_hi[0][2] = LDA2(T0, 0, 2); SB
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][1], b_hi[1][0], acc[1][0], 0, 0, 0); SB
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][1], b_hi[1][1], acc[1][1], 0, 0, 0); a_lo[0][2] = LDA2(T0, 1, 2); SB
+      a_sc[2] = a_hi[1][2] * k2048;
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[2], b_hi[1][0], acc[2][0], 0, 0, 0); SB
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][2], b_lo[1][0], acc[2][0], 0, 0, 0); a_hi[0][3] = LDA2(T0, 0, 3); SB
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[2], b_hi[1][1], acc[2][1], 0, 0, 0); SB
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][2], b_lo[1][1], acc[2][1], 0, 0, 0); a_lo[0][3] = LDA2(T0, 1, 3); SB
+      acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][2], b_hi[1][0], acc[2][0], 0, 0, 0); SB
+      acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][2], b_hi[1][1], acc[2][1], 0, 0, 0); b_hi[0][0] = LDB2(T0, 0, 0); SB
+      a_sc[3] = a_hi[1][3] * k2048;
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[3], b_hi[1][0], acc[3][0], 0, 0, 0); SB
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][3], b_lo[1][0], acc[3][0], 0, 0, 0); b_lo[0][0] = LDB2(T0, 1, 0); SB
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_sc[3], b_hi[1][1], acc[3][1], 0, 0, 0); SB
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][3], b_lo[1][1], acc[3][1], 0, 0, 0); b_hi[0][1] = LDB2(T0, 0, 1); SB
+      acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][3], b_hi[1][0], acc[3][0], 0, 0, 0); SB
+      acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][3], b_hi[1][1], acc[3][1], 0, 0, 0); b_lo[0][1] = LDB2(T0, 1, 1); SB
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[c][q][i] * (1.f / 2048.f);
+  }
   unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   if (lane == 0 && wave == 0 && blockIdx.x < 256) { g_clk[blockIdx.x * 4] = t1 - t0; g_clk[blockIdx.x * 4 + 1] = r1 - r0; }
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -218,18 +305,20 @@ int main() {
   };
   (void)hipFuncSetAttribute((const void*)k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   (void)hipFuncSetAttribute((const void*)k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+  (void)hipFuncSetAttribute((const void*)k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
   for (int mode = 1; mode >= 0; --mode) {
     for (auto& v : h) v = mode ? (rnd_half() | (rnd_half() << 16)) : 0u;
     (void)hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     const int chunks = 24 * 1200;
     for (int rep = 0; rep < 3; ++rep)
-      for (int shape = 0; shape < 2; ++shape) {
+      for (int shape = 0; shape < 3; ++shape) {
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
         auto launch = [&](int n) {
           if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), kLdsBytes, 0, din, dout, n);
-          else hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), kLdsBytes, 0, din, dout, n);
+          else if (shape == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), kLdsBytes, 0, din, dout, n);
+          else hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), kLdsBytes, 0, din, dout, n);
         };
         launch(chunks / 4);
         (void)hipDeviceSynchronize();
@@ -247,7 +336,7 @@ int main() {
         const double flop = 256.0 * 4 * chunks * 108.0 * 32768.0;
         printf("%s data, %s: %.2f ms, %.3f us per 16-channel chunk, %.0f TFLOP/s fp16 (= %.0f algorithmic), clock median %.3f GHz, "
                "cycles per chunk %.0f (ideal 3456)\n",
-               mode ? "random" : "zero  ", shape ? "16x16x32" : "32x32x16", ms, ms * 1e3 / chunks, flop / (ms * 1e-3) / 1e12,
+               mode ? "random" : "zero  ", shape == 0 ? "32x32x16" : (shape == 1 ? "16x16x32" : "32x32x16 one accumulator, 128x64 wave tile"), ms, ms * 1e3 / chunks, flop / (ms * 1e-3) / 1e12,
                flop / (ms * 1e-3) / 1e12 / 3, ghz[128], (double)c[0] / chunks);
       }
   }
