@@ -78,6 +78,7 @@ SIGNATURES = {
     "as_conv_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv_pack_size_split": (C.c_int64, [_i, _i, _i]),
     "as_conv_pack_weights_split": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "as_conv_pack_weights_split_t": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "as_conv7x7_c1_relu": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "as_conv3x3_to1": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "as_tap_shift_sum": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -436,7 +436,7 @@ class PointwiseLinear(torch.autograd.Function):
         d_x = d_w = d_b = None
         if ctx.needs_input_grad[0]:
             if weight.shape[0] >= 16:
-                pk = ctx.pack_b.get([weight], [None], transform=lambda w: w.t().contiguous())
+                pk = ctx.pack_b.get_dgrad(weight)
                 d_x = ops.conv2d_plain(d.view(b, -1, 1, q), pk).view(b, c, q)
             else:  # a handful of output channels (the 9 mask logits): not worth a K-padded MFMA launch
                 d_x = torch.matmul(weight.t(), d)
@@ -468,7 +468,7 @@ class Conv2dSame(torch.autograd.Function):
         k = weight.shape[2]
         d_x = d_w = d_b = None
         if ctx.needs_input_grad[0]:
-            pk = ctx.pack_b.get([weight], [None], transform=lambda w: w.transpose(0, 1).flip(2, 3).contiguous())
+            pk = ctx.pack_b.get_dgrad(weight)
             d_x = ops.conv2d_plain(d, pk)
         want_w, want_b = ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]
         if want_w or want_b:

@@ -415,6 +415,36 @@ class PackedConv:
             self._remember(ts)
         return self
 
+    def get_dgrad(self, weight: torch.Tensor):
+        """Pack of the DATA-GRADIENT convolution of `weight` [Cout, Cin, k, k] (or [Cout, Cin]): W' = W transposed over the channel
+        axes with flipped taps, no bias.  In split precision the pack kernel reads W in that order directly
+        (as_conv_pack_weights_split_t): no `transpose().flip().contiguous()` copies per layer and step."""
+        split = L.load().as_get_precision() == 1
+        key = ("dgrad", split, weight.data_ptr(), weight._version, weight.device)
+        if key != self._key or not self._alive([weight]):
+            w = weight.detach()
+            w = w.reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1)))
+            if not split:
+                self._build([w.transpose(0, 1).flip(2, 3).contiguous()], [None], split, key)
+            else:
+                w = w.contiguous().float()
+                _req(w, "conv weight")
+                cout_w, cin_w, ks, ks2 = w.shape
+                if ks != ks2:
+                    raise RuntimeError("PackedConv: non-square kernel")
+                cin, cout = cout_w, cin_w   # of the data-gradient convolution
+                n = L.load().as_conv_pack_size_split(cin, cout, ks)
+                if n <= 0:
+                    raise RuntimeError(f"PackedConv: unsupported conv Cin={cin} Cout={cout} K={ks}")
+                wp = torch.empty(n, device=w.device, dtype=torch.float16)
+                with _guard(w.device):
+                    L.check(L.load().as_conv_pack_weights_split_t(_p(w), _p(wp), cin, cout, ks, _stream()), "conv_pack_weights_split_t")
+                self.split, self.bias, self.wpack = True, None, wp
+                self.cin, self.cout, self.ks = cin, cout, ks
+                self._key = key
+            self._remember([weight])
+        return self
+
     def _build(self, ws, biases, split, key):
         ws = [w.reshape(w.shape[0], w.shape[1], *(w.shape[2:] if w.dim() == 4 else (1, 1))) for w in ws]
         w = torch.cat(ws, dim=0).contiguous().float() if len(ws) > 1 else ws[0].contiguous().float()

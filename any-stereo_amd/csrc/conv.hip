@@ -1709,8 +1709,10 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
 #undef AS_SPLIT_LDOPS
 
 // weight [Cout,Cin,KS,KS] fp32 -> split pack [chunk16][tap][comp][h][Cout_pad][8] fp16 (zero padded)
+// transposed != 0: pack of the data-gradient convolution's weight W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx] straight from W
+// ([Cin, Cout, K, K] as the caller passes Cin / Cout of W': W is then [Cout][Cin][K][K]) — no flipped / transposed copy in memory
 __global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int Cin, int Cout,
-                                          int Cout_pad, int ntap, long long total) {
+                                          int Cout_pad, int ntap, long long total, int transposed = 0) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int j = (int)(idx & 7);
@@ -1725,7 +1727,7 @@ __global__ void pack_weights_split_kernel(const float* __restrict__ w, _Float16*
   const int chunk = (int)(t / ntap);
   const int ci = chunk * kSplitKC + 8 * h + j;
   float v = 0.f;
-  if (co < Cout && ci < Cin) v = w[((long long)co * Cin + ci) * ntap + tap];
+  if (co < Cout && ci < Cin) v = transposed ? w[((long long)ci * Cout + co) * ntap + (ntap - 1 - tap)] : w[((long long)co * Cin + ci) * ntap + tap];
   as::fp16_saturate_mode();
   const _Float16 hi = (_Float16)v;
   wp[idx] = comp == 0 ? hi : (_Float16)((v - (float)hi) * 2048.f);
@@ -1946,12 +1948,21 @@ int64_t as_conv_pack_size_split(int Cin, int Cout, int KS) {
   return chunks * KS * KS * 4 * conv_cout_pad(Cout) * 8;  // fp16 elements
 }
 
+int as_conv_pack_weights_split_t(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream) {
+  AS_REQUIRE(weight && wpack, AS_ERR_BAD_ARG, "conv_pack_split_t: null pointer");
+  const int64_t total = as_conv_pack_size_split(Cin, Cout, KS);
+  AS_REQUIRE(total > 0, AS_ERR_BAD_ARG, "conv_pack_split_t: unsupported Cin=%d Cout=%d KS=%d", Cin, Cout, KS);
+  hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream),
+                     weight, (_Float16*)wpack, Cin, Cout, conv_cout_pad(Cout), KS * KS, (long long)total, 1);
+  return as::check_launch("conv_pack_weights_split_t");
+}
+
 int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream) {
   AS_REQUIRE(weight && wpack, AS_ERR_BAD_ARG, "conv_pack_split: null pointer");
   const int64_t total = as_conv_pack_size_split(Cin, Cout, KS);
   AS_REQUIRE(total > 0, AS_ERR_BAD_ARG, "conv_pack_split: unsupported Cin=%d Cout=%d KS=%d", Cin, Cout, KS);
   hipLaunchKernelGGL(pack_weights_split_kernel, dim3((unsigned)as::cdiv64(total, 256)), dim3(256), 0, as::as_stream(stream),
-                     weight, (_Float16*)wpack, Cin, Cout, conv_cout_pad(Cout), KS * KS, (long long)total);
+                     weight, (_Float16*)wpack, Cin, Cout, conv_cout_pad(Cout), KS * KS, (long long)total, 0);
   return as::check_launch("conv_pack_weights_split");
 }
 

@@ -228,6 +228,10 @@ int as_conv_pack_weights(const float* weight, float* wpack, int Cin, int Cout, i
 /* the split-precision pack (fp16 hi/lo, k-contiguous): element count is in fp16 units */
 int64_t as_conv_pack_size_split(int Cin, int Cout, int KS);
 int as_conv_pack_weights_split(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream);
+/* the pack of the DATA-GRADIENT convolution straight from the forward weight: weight is [Cout_w, Cin_w, KS, KS] with Cout_w = Cin and
+ * Cin_w = Cout of this call, packed as W'[ci][co][ky][kx] = W[co][ci][KS-1-ky][KS-1-kx] (transposed, taps flipped; autograd of
+ * update.py:16-92 and of every stride-1 convolution the library runs: no flipped / transposed copy of the weight in memory) */
+int as_conv_pack_weights_split_t(const float* weight, void* wpack, int Cin, int Cout, int KS, void* stream);
 
 /* direct (VALU) convolutions for the two shapes where an MFMA tile would be mostly padding:
  *   convd1: 7x7, 1 -> Cout, +bias, ReLU   (update.py:81,87);   conv2 of DispHead: 3x3, Cin -> 1, +bias (update.py:19,24)

@@ -2113,3 +2113,22 @@ def test_conv_frozen_bn_backward(cin, cout, ks, bias):
             assert err < tol, f"conv_frozen_bn {k_}: max err / max |ref| = {err:.2e} (limit {tol:g})"
     finally:
         ops.set_precision(prev)
+
+@pytest.mark.parametrize("cout,cin,ks", [(64, 48, 3), (100, 37, 3), (9, 64, 1), (256, 384, 3)])
+def test_dgrad_pack_equals_transposed_flipped_copy(cout, cin, ks):
+    """PackedConv.get_dgrad (as_conv_pack_weights_split_t: the data-gradient convolution's pack read straight from the forward weight)
+    is bit for bit the pack of `weight.transpose(0, 1).flip(2, 3)`; ragged channel counts, 1x1 and 3x3, a Linear's 2-D weight."""
+    from anystereo import ops
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        w = (U((cout, cin, ks, ks), 900 + cout) * 0.2).to(DEV)
+        a = ops.PackedConv().get_dgrad(w)
+        b = ops.PackedConv().get([w], [None], transform=lambda t: t.transpose(0, 1).flip(2, 3).contiguous())
+        assert (a.cin, a.cout, a.ks) == (b.cin, b.cout, b.ks) == (cout, cin, ks) and a.bias is None
+        assert torch.equal(a.wpack, b.wpack)
+        if ks == 1:
+            a2 = ops.PackedConv().get_dgrad(w.view(cout, cin))
+            assert torch.equal(a2.wpack, b.wpack)
+    finally:
+        ops.set_precision(prev)
