@@ -53,6 +53,7 @@ SIGNATURES = {
     "as_last_error_string": (C.c_char_p, []),
     "as_abi_version": (_i, []),
     "as_graph_replace_memsets": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "as_stamp": (_i, [_vp, _i, _vp]),
     "as_source_hash": (C.c_char_p, []),
     "as_device_count": (_i, []),
     "as_corr_sampler_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -68,6 +68,14 @@ class ContinuousStereoBase(nn.Module):
         for m in bns:
             m.eval()
 
+    # ---- timeline markers (measurement) ---------------------------------------------------------
+    stamps = None  # an ops.Stamps: markers at the phase boundaries of a pass become nodes of the captured forward (bench.py)
+
+    def _mark(self, name: str):
+        st = self.__dict__.get("stamps")
+        if st is not None:
+            st.mark(name)
+
     # ---- hot-path hooks (HIP) ------------------------------------------------------------------
     def _hot_update(self, net_list, inp_list, corr, disp, **flags):
         return self.update_block(net_list, inp_list, corr, disp, **flags)
@@ -207,7 +215,7 @@ class ContinuousStereoBase(nn.Module):
     def _forward_graphed(self, image1, image2, iters, hr_coord, scale):
         key = (tuple(image1.shape), tuple(hr_coord.shape), tuple(scale.shape), int(iters), image1.device.index,
                ops.get_precision(), ops.get_fast_fp16() or bool(getattr(self.args, "mixed_precision", False)),
-               self._weights_fingerprint())
+               self._weights_fingerprint(), id(self.__dict__.get("stamps")))
         graphs = self.__dict__.setdefault("_graphs", {})
         ent = graphs.pop(key, None)
         if ent is None:
@@ -411,8 +419,11 @@ class ContinuousStereoBase(nn.Module):
                 # run on a branch of their own beside the loop instead of in front of the tail kernel after it
                 liif.precompute_static([[stem_4x, net_list[0]] if stem_4x is not None else [net_list[0]], [stem_2x]], 1,
                                        ub._side_stream(disp.device, 2))
+            self._mark("loop_begin")
             disp = self._iterate_pipelined(lookup_fn, net_list, inp_list, disp, coords, iters)
+            self._mark("loop_end")
             disp_up = self.upsample_disp(disp, net_list[0], stem_4x, stem_2x, stem_1x, hr_coord=hr_coord, scale=scale)
+            self._mark("pass_end")
             if liif is not None and hasattr(liif, "clear_static"):
                 liif.clear_static()
             return disp, disp_up, [disp_up]

@@ -105,6 +105,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         """Estimate disparity between a pair of frames (images are 0..255 float)."""
         G.begin_forward()  # deferred-gradient anchors are scoped to this forward (grad.py)
         a = self.args
+        self._mark("pass_begin")
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda and not self._reduced_precision(image1)):
@@ -133,12 +134,16 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 with torch.cuda.stream(side):
                     if self.parallel_stems:
                         stem_1b, stem_2b, stem_4b = self._stems_fwd(both)
+                        self._mark("stems_end")
                         stems_done = torch.cuda.Event()
                         stems_done.record(side)
                     net_list, ctx_list = self._context(image1)
+                    self._mark("context_end")
             if fast:
                 if not (side is not None and self.trunk_first):
+                    self._mark("trunk_begin")
                     feats = self.feature(both)
+                    self._mark("trunk_end")
                 if side is not None and self.parallel_stems:
                     main.wait_event(stems_done)
                     stem_2b.record_stream(main)
@@ -171,6 +176,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
             else:
                 cost = B.conv3d_train(self.classifier, geo_encoding_volume)
             init_disp = self._hot_init_disp(cost.squeeze(1))
+            self._mark("cost_agg_end")
             del gwc_volume
             if side is None:
                 net_list, ctx_list = self._context(image1)

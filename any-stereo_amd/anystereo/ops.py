@@ -1518,6 +1518,31 @@ def graph_replace_memsets(graph: "torch.cuda.CUDAGraph"):
     return a.value, b.value
 
 
+class Stamps:
+    """Timeline markers of a forward pass (as_stamp): named slots of a device buffer that receive the device wall clock
+    (100 MHz) when the issuing stream reaches the marker.  `model.stamps = Stamps(device)` switches the markers of
+    models/base.py on (they become kernel nodes of the captured forward); `read()` -> {name: microseconds since the first
+    marker}.  Measurement only; the default forward issues none."""
+    TICK_US = 0.01  # wall_clock64 on gfx950: constant 100 MHz
+
+    def __init__(self, device, slots: int = 64):
+        self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
+        self.names = {}
+
+    def mark(self, name: str):
+        slot = self.names.setdefault(name, len(self.names))
+        if slot >= self.buf.numel():
+            raise ValueError("Stamps: out of slots")
+        with _guard(self.buf.device):
+            L.check(L.load().as_stamp(_p(self.buf), slot, _stream()), "stamp")
+
+    def read(self):
+        torch.cuda.synchronize(self.buf.device)
+        v = self.buf.cpu().tolist()
+        t0 = min(v[s] for s in self.names.values()) if self.names else 0
+        return {n: round((v[s] - t0) * self.TICK_US, 2) for n, s in self.names.items()}
+
+
 def split_overflow_count(reset: bool = True) -> int:
     """Split-precision range check: number of waves (since the last reset) in which a kernel met an operand with
     |x| >= 65504 (outside fp16) or NaN.  Such operands are SATURATED to +-65504 — results stay finite but are no longer the

@@ -93,7 +93,7 @@ int as_get_precision(void) { return as::precision_mode(); }
 
 const char* as_last_error_string(void) { return as::err_buf(); }
 
-int as_abi_version(void) { return 36; }
+int as_abi_version(void) { return 37; }
 
 int as_device_count(void) {
   int n = 0;

@@ -26,9 +26,23 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(unsigned char* dst, uns
   }
 }
 
+// one lane writes the device's constant-rate wall clock (100 MHz on gfx950) into its slot: a timeline marker that is an ordinary
+// kernel node of a captured graph, ordered like any other launch of its stream
+__global__ void stamp_kernel(unsigned long long* buf, int slot) { buf[slot] = wall_clock64(); }
+
 }  // namespace
 
 extern "C" {
+
+/* Timeline marker: buf[slot] = the device wall clock (wall_clock64: constant 100 MHz, 10 ns ticks) when the stream reaches this
+ * point.  A kernel launch like any other, so it can be captured into the forward's hipGraph: models/base.py places markers at the
+ * phase boundaries of a pass and bench.py reports the phases of a REPLAYED graph without a profiler attached (rocprofv3's queue
+ * interception changes how the graph's parallel branches are fed). */
+int as_stamp(unsigned long long* buf, int slot, void* stream) {
+  AS_REQUIRE(buf && slot >= 0, AS_ERR_BAD_ARG, "stamp: null buffer or negative slot");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), buf, slot);
+  return as::check_launch("stamp");
+}
 
 /* graph: the hipGraph_t of a finished stream capture, not yet instantiated (or to be instantiated again afterwards).
  * Replaces each memset node by a fill kernel node (same edges); counts what it replaced and the memset nodes it had to leave

@@ -48,6 +48,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16/bf16 MFMA dense peak 
 # against the nominal dense peak.
 MFMA_F16_RANDOM_DATA_TFLOPS = 1510.0
 INFINITY_CACHE_MB = 256
+TIMED_BLOCKS = 3  # `value` is the median of this many timed blocks of `--steps` steps each
 
 
 def parse(argv=None):
@@ -148,7 +149,7 @@ def _dist_init(backend_gpu: bool, local: int):
 def dry_main(a, rank, world):
     """No GPU visible: rehearse the N-rank protocol only (rendezvous, barrier, timed steps, MAX over ranks, gather of the
     per-rank values) over gloo.  Nothing of the hot path runs and no throughput is claimed (`value` is null)."""
-    td = _dist_init(False, 0) if world > 1 else None
+    td = _dist_init(False, 0) if (world > 1 or "RANK" in os.environ) else None
     x = torch.ones(64, 64)
     for _ in range(a.warmup):
         x = x @ x * 1e-3
@@ -172,9 +173,19 @@ def dry_main(a, rank, world):
         per_rank = [float(g.item()) for g in gathered]
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t.item())
+    # the training leg of an N-rank run, same code path as on the GPU (train_leg), on the stand-in module over gloo
+    train_mode = None
+    if td and not a.no_train_mode:
+        guard = _LegWatchdog(rank, float(os.environ.get("ANYSTEREO_TRAIN_LEG_TIMEOUT", "240")))
+        try:
+            train_mode = train_leg(a, rank, world, 0, td, None, dry=True)
+        except Exception as ex:
+            train_mode = {"error": repr(ex)[:300]} if rank == 0 else None
+        guard.done()
     if rank == 0:
         sys.stderr.write("bench.py: no GPU visible - dry run of the launch protocol over gloo; the hot path has no CPU fallback\n")
         print(json.dumps({"metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)", "value": None,
+                          "train_mode": train_mode,
                           "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
@@ -446,6 +457,242 @@ def train_mode_child(a, steps=5, warmup=4, timeout=420):
             "grad_bytes": d.get("grad_bytes"), "exchange_ms": d.get("exchange_ms"), "exchange_how": d.get("exchange_how"),
             "how": "child process `bench.py --mode train --train-quick`, inputs resident, graphed gradient half + eager clip/AdamW",
             "child_wall_s": round(time.perf_counter() - t0, 1)}
+
+
+class _DryStereo:
+    """Stand-in module of the no-GPU rehearsals: the reference's forward signature on a few parameters."""
+
+    @staticmethod
+    def build():
+        class DryStereo(torch.nn.Module):  # (image1, image2, iters=, hr_coord=, scale=) -> list of [B,1,Q] predictions
+            def __init__(self):
+                super().__init__()
+                self.conv = torch.nn.Conv2d(6, 8, 3, padding=1)
+                self.head = torch.nn.Linear(10, 1)
+
+            def freeze_bn(self):
+                pass
+
+            def forward(self, image1, image2, iters=2, hr_coord=None, scale=None, **_):
+                f = torch.relu(self.conv(torch.cat([image1, image2], 1) / 255.0)).mean((2, 3))  # [B,8]
+                x = torch.cat([f.unsqueeze(1).expand(-1, hr_coord.shape[1], -1), hr_coord], -1)  # [B,Q,10]
+                d = self.head(x).transpose(1, 2)
+                return [d * (i + 1) for i in range(iters)]
+        return DryStereo()
+
+
+class _LegWatchdog:
+    """Bounds the in-process training leg of an N-rank run.  `stash` (rank 0) is the line as far as it is known; if `done()` has
+    not been called `seconds` after construction, rank 0 prints the stashed line with train_mode = {"error": "timed out"} and
+    every rank ends its process (os._exit: a peer may be stuck inside a collective that will never complete)."""
+
+    def __init__(self, rank, seconds):
+        import threading
+        self.rank, self.stash, self._done = rank, None, False
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._t.start()
+        self.seconds = seconds
+
+    def rearm(self, stash):
+        self.stash = stash
+
+    def done(self):
+        self._done = True
+        self._t.cancel()
+
+    def _fire(self):
+        if self._done:
+            return
+        sys.stderr.write(f"bench.py: rank {self.rank}: the training leg did not finish within {self.seconds:.0f} s - leaving without it\n")
+        if self.rank == 0 and self.stash is not None:
+            line = dict(self.stash, train_mode={"error": f"training leg timed out after {self.seconds:.0f} s"})
+            print(json.dumps(line), flush=True)
+        os._exit(0 if (self.rank != 0 or self.stash is not None) else 3)
+
+
+TRAIN_LEG_KEYS = ("n_gpus", "global_batch", "value", "unit", "per_rank_samples_per_s", "ms_per_step", "exchange_ms", "ranks_seen",
+                  "one_rank_ms_per_step", "scaling", "steps", "warmup", "grad_bytes", "trainer", "loss_first_last", "loss_finite")
+
+
+def train_leg(a, rank, world, local, td, dev, dry=False):
+    """The N-rank TRAINING leg of `bench.py --gpus N` (north_star: 1 -> 8-GPU training throughput scaling; the reference shards its
+    batch with nn.DataParallel, train_continuous_IGEV.py:184,214-239).  Runs on the SAME ranks and process group as the
+    inference leg, after it (no new process, nothing re-executed): cfg 4 — 4 samples per rank at 160x320, 16 GRU iterations,
+    51 200 queries per sample — through `Trainer`: the gradient half of the step replayed as one captured hipGraph, ONE RCCL
+    all-reduce of the flat fp32 gradient vector, clip + AdamW.  Timed like the headline: barrier + synchronize on both sides of
+    K steps, MAX over ranks.  Then, reported only: the all-reduce alone at N ranks (HIP events), and K steps of every rank with
+    the exchange off (`one_rank_ms_per_step`; the ranks' weights diverge from there on, so it comes last) ->
+    scaling = N * mean(one-rank step) / N-rank step, an in-job estimate (the driver computes its own from its N=1 run).
+    dry=True (no GPU): the same protocol and the same keys over gloo on a stand-in module; no throughput is claimed.
+    Returns the `train_mode` object on rank 0, None elsewhere.  A failure on one rank is agreed on by all ranks (MIN all-reduce
+    of an ok flag between the phases) so nobody is left waiting in a collective."""
+    import math
+    from anystereo.harness.train import Trainer, synthetic_train_batch
+    t_leg = time.perf_counter()
+    steps = max(2, min(a.steps, 20))
+    warm = max(4, min(a.warmup, 6))  # 3 eager steps (solver search, packs, optimizer state) + the capture
+    bsz = a.batch_per_gpu
+    cdev = torch.device("cpu") if dry else dev
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    def agree(ok: bool) -> bool:
+        if td is None:
+            return ok
+        f = torch.tensor([1 if ok else 0], device=cdev, dtype=torch.int32)
+        td.all_reduce(f, op=td.ReduceOp.MIN)
+        return bool(f.item())
+
+    err = None
+    tr = batch = None
+    try:
+        if dry:
+            torch.manual_seed(100 + rank)  # every rank builds DIFFERENT weights: the Trainer must make them rank 0's
+            model = _DryStereo.build()
+            tr = Trainer(model, train_iters=2, max_disp=192, ddp_impl="flat", num_steps=100, force_ddp=td is not None)
+            g = torch.Generator().manual_seed(7 + rank)
+            q = 64
+            batch = (torch.rand(bsz, 3, 16, 32, generator=g) * 255, torch.rand(bsz, 3, 16, 32, generator=g) * 255,
+                     torch.rand(bsz, q, 2, generator=g) * 2 - 1, torch.rand(bsz, 1, q, generator=g) * 60 + 0.5, torch.ones(bsz, 1))
+            what = "training launch protocol only (no GPU visible; stand-in module)"
+        else:
+            from anystereo.harness.synthetic import fill_module_deterministic
+            from anystereo.models import __models__, default_args
+            targs = default_args("continuous_IGEVStereo")
+            model = __models__["continuous_IGEVStereo"](targs)
+            fill_module_deterministic(model, base_seed=1)
+            model = model.to(dev)
+            tr = Trainer(model, train_iters=a.train_iters, max_disp=targs.max_disp, force_ddp=td is not None)
+            batch = synthetic_train_batch(bsz, 160, 320, seed=rank, device=dev)
+            what = (f"cfg4 continuous_IGEVStereo training 160x320, {a.train_iters} GRU iters, LIIF every iter, "
+                    f"Q={batch[2].shape[1]} queries/sample, AdamW+OneCycleLR, clip 1.0")
+    except Exception as ex:
+        err = "setup: " + repr(ex)[:300]
+    if not agree(err is None):
+        return {"error": err or "another rank failed during setup"} if rank == 0 else None
+
+    losses = []
+
+    def timed(n, sync_grads=True):
+        sync()
+        if td is not None:
+            td.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss, _ = tr.step(batch, sync_grads=sync_grads)
+        sync()
+        own = time.perf_counter() - t0
+        if td is not None:
+            td.barrier()
+        sync()
+        return time.perf_counter() - t0, own, float(loss)
+
+    def gather(v):
+        if td is None:
+            return [v]
+        t = torch.tensor([v], device=cdev, dtype=torch.float64)
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        td.all_gather(outs, t)
+        return [float(o.item()) for o in outs]
+
+    try:
+        for _ in range(warm):
+            losses.append(float(tr.step(batch)[0]))
+    except Exception as ex:
+        err = "warm-up: " + repr(ex)[:300]
+    if not agree(err is None):
+        return {"error": err or "another rank failed during the warm-up steps"} if rank == 0 else None
+    try:
+        dt, own, loss = timed(steps)
+        losses.append(loss)
+    except Exception as ex:
+        err = "timed steps: " + repr(ex)[:300]
+    if not agree(err is None):
+        return {"error": err or "another rank failed during the timed steps"} if rank == 0 else None
+    dt = max(gather(dt))
+    per_rank_own = gather(own)
+    nparam = sum(p.numel() for p in tr.model.parameters() if p.requires_grad)
+    # the collective alone, at N ranks: what the flat exchange issues once per step
+    exchange_ms = None
+    exchange_how = "no process group (one rank without a launcher): nothing is exchanged"
+    if td is not None:
+        try:
+            flat = torch.zeros(nparam, device=cdev, dtype=torch.float32)
+            for _ in range(3):
+                td.all_reduce(flat)
+            sync()
+            reps = 20
+            if dry:
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    td.all_reduce(flat)
+                ms = (time.perf_counter() - t0) / reps * 1e3
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    td.all_reduce(flat)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / reps
+            exchange_ms = round(max(gather(ms)), 4)
+            exchange_how = (f"{reps} all-reduces of the {4 * nparam} B flat fp32 gradient vector over {td.get_backend()} at {world} rank(s), "
+                            + ("host clock" if dry else "HIP events on the collective's stream") + ", MAX over ranks")
+            del flat
+        except Exception as ex:
+            exchange_how = "unavailable: " + repr(ex)[:200]
+        if not agree(True):
+            return {"error": "a rank failed in the exchange probe"} if rank == 0 else None
+    # identity of the ranks' devices (a SCALE record must show N distinct GPUs)
+    seen = {"rank": rank, "local_rank": local, "host": socket.gethostname()}
+    if not dry:
+        pr = torch.cuda.get_device_properties(dev)
+        seen.update(device_index=dev.index, name=pr.name,
+                    pci="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                    uuid=str(getattr(pr, "uuid", "")) or None)
+    ranks_seen = [seen]
+    if td is not None:
+        ranks_seen = [None] * world
+        td.all_gather_object(ranks_seen, seen)
+    # every rank alone: the same steps with the exchange off (LAST: the ranks' parameters diverge from here on)
+    one_rank = None
+    try:
+        _, own_ns, _ = timed(steps, sync_grads=False)
+    except Exception as ex:
+        err = "no-exchange steps: " + repr(ex)[:300]
+    if agree(err is None):
+        one_rank = [round(v / steps * 1e3, 3) for v in gather(own_ns)]
+    if rank != 0:
+        return None
+    ms_step = dt / steps * 1e3
+    res = {"workload": what, "n_gpus": world, "global_batch": world * bsz, "metric": "train_samples_per_s",
+           "value": None if dry else round(world * bsz * steps / dt, 3), "unit": "samples/s",
+           "samples_per_s_protocol": round(world * bsz * steps / dt, 3) if dry else None,
+           "per_rank_samples_per_s": [round(bsz * steps / v, 3) for v in per_rank_own],
+           "ms_per_step": round(ms_step, 3), "steps": steps, "warmup": warm,
+           "grad_bytes": 4 * nparam, "exchange_ms": exchange_ms, "exchange_how": exchange_how,
+           "ranks_seen": ranks_seen,
+           "distinct_devices": len({(r_.get("host"), r_.get("pci") or r_.get("device_index") or r_.get("rank")) for r_ in ranks_seen}),
+           "one_rank_ms_per_step": one_rank,
+           "scaling": None if not one_rank else round(world * (sum(one_rank) / len(one_rank)) / ms_step, 3),
+           "scaling_how": "N x mean(one_rank_ms_per_step: every rank's own steps with the exchange off, all ranks running at once) / "
+                          "ms_per_step at N ranks; the driver's SCALE record divides by its own N=1 run instead",
+           "dtype": TRAIN_DTYPE, "dry_run": bool(dry),
+           "trainer": {"graph": bool(tr.use_graph), "graph_scope": tr.graph_scope if tr.use_graph else None,
+                       "gradient_exchange": tr.ddp_mode},
+           "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+           "loss_finite": all(math.isfinite(v) for v in losses),
+           "loss_scale": tr.loss_scale, "split_overflow_events": list(tr.overflow_events),
+           "how": "same ranks and process group as the inference leg, after it; inputs resident; graphed gradient half + one flat "
+                  "all-reduce + eager clip/AdamW; barrier + synchronize around the K steps, MAX over ranks",
+           "leg_wall_s": round(time.perf_counter() - t_leg, 1)}
+    if err:
+        res["error_no_exchange_steps"] = err
+    return res
 
 
 def train_main(a, rank, world, local):
@@ -843,7 +1090,7 @@ def roofline_table(kstats, alg, precision, traffic):
 
 
 def infer_main(a, rank, world, local):
-    dist = world > 1
+    dist = world > 1 or "RANK" in os.environ  # under a launcher even one rank joins a process group (RCCL): the training leg uses it
     td = _dist_init(True, local) if dist else None
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -875,26 +1122,43 @@ def infer_main(a, rank, world, local):
     from anystereo.harness import timing
     if not run.graph:
         timing.enable(True)       # HIP events around every hot-kernel launch, on the launch stream
-    telemetry = GpuTelemetry(local).start()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = run.step()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    telemetry = telemetry.stop()
+    # `value` = the MEDIAN of `TIMED_BLOCKS` timed blocks; each block times exactly `--steps` steps between barrier +
+    # synchronize on both sides and is reduced with MAX over the ranks.  Box-to-box and run-to-run spread of this workload is a
+    # few per cent (profiles/r05_bench_lease_spread.txt): one block is one sample of it, the line carries all of them.
+    block_dt, block_tel, block_own = [], [], []
+    for _ in range(TIMED_BLOCKS):
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        telemetry = GpuTelemetry(local).start()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = run.step()
+        torch.cuda.synchronize()
+        d_own = time.perf_counter() - t0   # this rank's own K steps (before it waits for the others)
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        d_blk = time.perf_counter() - t0
+        block_tel.append(telemetry.stop())
+        if dist:
+            t = torch.tensor([d_blk], device=dev, dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            d_blk = float(t.item())
+        block_dt.append(d_blk)
+        block_own.append(d_own)
+    order = sorted(range(TIMED_BLOCKS), key=lambda i: block_dt[i])
+    mid = order[TIMED_BLOCKS // 2]      # the same index on every rank: block_dt is the all-reduced figure
+    dt, telemetry = block_dt[mid], block_tel[mid]
     out_split = out.float().cpu() if precision == "split" else None
     out_this = out.float().cpu()
-    per_rank = [dt]
+    per_rank = [block_own[mid]]
     if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([block_own[mid]], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         td.all_gather(gathered, t)
         per_rank = [float(g.item()) for g in gathered]
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t.item())
     assert torch.isfinite(out).all()
     if run.graph:
         kstats, ksteps = kernel_stats(run, passes=2)
@@ -931,6 +1195,33 @@ def infer_main(a, rank, world, local):
         batched = {"pairs_per_gpu": nbb, "value": round(world * nbb * 3 / dtb, 4), "unit": "pairs/s",
                    "ms_per_step": round(dtb / 3 * 1e3, 3), "steps": 3}
         del rb
+
+    # The N-rank TRAINING leg (cfg 4) on the same ranks and process group, right after the inference leg: what lets a SCALE record
+    # (bench.py --gpus 1,2,4,8) answer north_star's training-scaling criterion.  One rank without a launcher keeps the child
+    # process of the default line (below).  A watchdog bounds the leg: if it has not returned in time, rank 0 prints the line it
+    # already has with train_mode = {"error": ...} and every rank leaves (nobody waits in a collective for a peer that died).
+    train_mode_n = None
+    leg_guard = None
+    if dist and not a.no_train_mode and wl.name == "cfg2":
+        leg_guard = _LegWatchdog(rank, float(os.environ.get("ANYSTEREO_TRAIN_LEG_TIMEOUT", "240")))
+        if rank == 0:  # the contract's fields of the headline, known before the leg starts: what the watchdog prints if it must
+            leg_guard.rearm({
+                "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",
+                "value": round(world * nb * a.steps / dt, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if precision == "fp32" else "f32 (3xf16 split-precision MFMA, fp32 accumulate)", "data": "synthetic",
+                "config": {"workload": f"{wl.what} (padded {run.wp}x{run.hp}), {wl.iters} GRU iters, scale {wl.scale}, Q={run.Q} queries, "
+                                       f"{nb} pair(s) per GPU, random-init weights", "name": wl.name, "pairs_per_gpu": nb,
+                           "parallelism": f"replicas x{world}", "gru_loop": "hipGraph" if run.graph else "eager"},
+                "per_rank_pairs_per_s": [round(nb * a.steps / v, 4) for v in per_rank],
+                "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
+                "roofline": None, "cpu_baseline": None, "truncated": "printed by the training leg's watchdog"})
+        try:
+            train_mode_n = train_leg(a, rank, world, local, td, dev)
+        except Exception as ex:  # a rank-local failure outside the agreed phases
+            train_mode_n = {"error": repr(ex)[:300]} if rank == 0 else None
+        leg_guard.done()
+        torch.cuda.empty_cache()
 
     if rank == 0:
         h4, w4 = run.hp // 4, run.wp // 4
@@ -1079,8 +1370,8 @@ def infer_main(a, rank, world, local):
                 del r1, m1, o1
             except Exception as ex:
                 others["cfg1"] = {"error": repr(ex)}
-        train_mode = None
-        if extras and world == 1 and wl.name == "cfg2" and not a.no_train_mode:
+        train_mode = train_mode_n
+        if train_mode is None and extras and not dist and wl.name == "cfg2" and not a.no_train_mode:
             # this process is idle on the GPU now: the child has the chip to itself
             torch.cuda.synchronize()
             try:
@@ -1091,6 +1382,13 @@ def infer_main(a, rank, world, local):
             "metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)",
             "value": round(world * nb * a.steps / dt, 4), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "timed_blocks": TIMED_BLOCKS,
+            "value_spread": {"how": f"`value` / `ms_per_step` = the median of {TIMED_BLOCKS} timed blocks of {a.steps} steps each (barrier + synchronize "
+                                    "on both sides of every block, MAX over ranks per block)",
+                             "pairs_per_s": [round(world * nb * a.steps / v, 4) for v in block_dt],
+                             "min": round(world * nb * a.steps / max(block_dt), 4), "max": round(world * nb * a.steps / min(block_dt), 4),
+                             "median": round(world * nb * a.steps / dt, 4),
+                             "telemetry_per_block": block_tel},
             "dtype": "f32" if precision == "fp32" else "f32 (3xf16 split-precision MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{wl.what} (padded {run.wp}x{run.hp}), {wl.iters} GRU iters, scale {wl.scale}, Q={run.Q} queries, "
                                    f"{nb} pair(s) per GPU, random-init weights", "name": wl.name, "pairs_per_gpu": nb,
@@ -1168,39 +1466,127 @@ def reduced_precision_run(run, alg, oracle_out, out_split):
     return res
 
 
+def host_cpu_info() -> dict:
+    """CPU model and core counts of this host: physical cores = distinct (physical id, core id) pairs of /proc/cpuinfo (the
+    BASELINE.md §4 thread count), next to what this process may actually use (affinity mask, cgroup v2 cpu.max quota)."""
+    model, pairs, logical = None, set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                k, _, v = ln.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "processor":
+                    logical += 1
+                    phys = core = None
+                elif k == "model name" and model is None:
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = round(float(q) / float(per), 2)
+    except (OSError, ValueError):
+        pass
+    physical = len(pairs) or None
+    usable = min(v for v in (physical or logical or 1, affinity, None if quota is None else max(1, int(quota))) if v)
+    return {"model": model, "logical_cpus": logical or (os.cpu_count() or 1), "physical_cores": physical, "affinity_cpus": affinity,
+            "cgroup_cpu_quota": quota, "threads_used": max(1, usable)}
+
+
+def _staged_oracle(cls):
+    """The CPU oracle with a wall-clock timer around each hot-path stage (build, lookup, update_block, LIIF):
+    the hooks oracle/model.py substitutes are the instrumentation points; everything else of a pass is `backbone_other`."""
+    class Staged(cls):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.__dict__["stage_s"] = {}
+
+        def _t(self, name, fn, *a, **k):
+            t = time.perf_counter()
+            r = fn(*a, **k)
+            st = self.__dict__["stage_s"]
+            st[name] = st.get(name, 0.0) + time.perf_counter() - t
+            return r
+
+        def _hot_gwc(self, *a, **k):
+            return self._t("build", super()._hot_gwc, *a, **k)
+
+        def _hot_init_disp(self, *a, **k):
+            return self._t("build", super()._hot_init_disp, *a, **k)
+
+        def _hot_lookup_fn(self, *a, **k):
+            fn = self._t("build", super()._hot_lookup_fn, *a, **k)
+            return lambda *la, **lk: self._t("lookup", fn, *la, **lk)
+
+        def _hot_update(self, *a, **k):
+            return self._t("update_block", super()._hot_update, *a, **k)
+
+        def _hot_upsample(self, *a, **k):
+            return self._t("liif", super()._hot_upsample, *a, **k)
+    return Staged
+
+
 def cpu_baseline(run):
-    """The CPU oracle (same weights) timed on this host: 1 pair of the same workload; if the machine is slow the GRU
-    iteration count of the sample is reduced and the full figure extrapolated.  Returns (record, oracle output or None):
-    the output of a full-length run is kept so the line can state this run's EPE against it."""
+    """The CPU oracle (same weights) timed on this host as BASELINE.md §4 states the protocol (the reference's only timing is the
+    perf_counter pair of evaluation.py:248-250): fp32, eval, no_grad, threads = physical cores this process may use, 1 warm-up +
+    3 timed full runs of 1 pair, the MEDIAN reported, ms per GRU iteration = (t32 - t8) / 24, and the per-stage split (build,
+    lookup, update_block, LIIF) from timers on the oracle's hot-path hooks.  A host too slow for 3 full runs inside the bound
+    gets fewer (stated in `sample`).  Returns (record, oracle output): the output of a full-length run is kept so the line can
+    state this run's EPE against it."""
     from oracle.model import OracleIGEV
     wl = run.wl
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    cpu = host_cpu_info()
+    threads = cpu["threads_used"]
     torch.set_num_threads(threads)
-    ref = OracleIGEV(run.args).eval()
+    ref = _staged_oracle(OracleIGEV)(run.args).eval()
     ref.load_state_dict({k: v.cpu() for k, v in run.model.state_dict().items()})
     i1, i2, coord, sc = run.cpu_inputs
 
     def go(iters):
+        ref.__dict__["stage_s"] = {}
         t = time.perf_counter()
         with torch.no_grad():
             o = ref(i1, i2, iters=iters, test_mode=True, hr_coord=coord.clone(), scale=sc)
-        return time.perf_counter() - t, o
+        dt = time.perf_counter() - t
+        st = dict(ref.__dict__["stage_s"])
+        st["backbone_other"] = max(0.0, dt - sum(st.values()))
+        return dt, o, st
     go(1)  # warm-up (thread pools, allocator)
-    t2, t6 = go(2)[0], go(6)[0]
-    per_iter = max((t6 - t2) / 4, 1e-6)
-    est_full = t2 + per_iter * (wl.iters - 2)
-    out = None
-    if est_full <= 45.0:
-        t_full, out = go(wl.iters)
-        sample = f"1 pair, full workload ({wl.iters} iters), fp32, {threads} threads"
-    else:
-        t_full = est_full
-        sample = (f"1 pair at 2 and 6 GRU iters ({t2:.1f}s, {t6:.1f}s), extrapolated to {wl.iters} iters, fp32, "
-                  f"{threads} threads")
+    lo = max(1, wl.iters // 4)
+    t_lo = go(lo)[0]
+    first = go(wl.iters)
+    runs = [first]
+    budget = 60.0  # seconds of full-length runs
+    while len(runs) < 3 and (len(runs) + 1) * first[0] <= budget:
+        runs.append(go(wl.iters))
+    runs.sort(key=lambda r: r[0])
+    t_full, out, stages = runs[len(runs) // 2]
+    per_iter = max((t_full - t_lo) / max(1, wl.iters - lo), 1e-6)
+    sample = (f"1 pair, full workload ({wl.iters} iters), fp32, eval, no_grad, {threads} threads; 1 warm-up + {len(runs)} timed runs, "
+              f"median (all: {', '.join('%.2f' % r[0] for r in runs)} s); ms per GRU iteration = (t{wl.iters} - t{lo}) / {wl.iters - lo}")
     return {"value": round(1.0 / t_full, 5), "unit": "pairs/s", "cores": threads, "kind": "port", "sample": sample,
-            "config": wl.name, "s_per_pair": round(t_full, 3), "ms_per_gru_iter": round(per_iter * 1e3, 2)}, \
-        (None if out is None else out.float())
+            "config": wl.name, "s_per_pair": round(t_full, 3), "runs_s": [round(r[0], 3) for r in runs],
+            "ms_per_gru_iter": round(per_iter * 1e3, 2),
+            "stage_split_s": {k: round(v, 3) for k, v in stages.items()},
+            "stage_split_note": "wall clock of the median run by hot-path stage: build = gwc volume + all-pairs / geometry pyramids + "
+                                "disparity regression, lookup = all iterations' pyramid lookups, update_block = all iterations' "
+                                "BasicMultiUpdateBlock, liif = the upsampler; backbone_other = the rest of the pass",
+            "host_cpu": cpu, "torch": torch.__version__}, out.float()
 
 
 def cpu_baseline_cfg1():
@@ -1212,7 +1598,8 @@ def cpu_baseline_cfg1():
     ref = OracleRAFT(args).eval()
     ref.load_state_dict(model.state_dict())
     i1, i2, coord, sc = WL.build_inputs(wl)
-    threads = torch.get_num_threads()
+    threads = host_cpu_info()["threads_used"]
+    torch.set_num_threads(threads)
 
     def go():
         t = time.perf_counter()

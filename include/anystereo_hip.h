@@ -77,6 +77,11 @@ int as_abi_version(void);        /* bumped on any signature change */
  * inside a ~5 000-node chain are not reliably ordered with their neighbours on this ROCm stack).  graph: the
  * hipGraph_t before (re-)instantiation; *replaced / *left (optional) count the converted nodes and the ones left alone. */
 int as_graph_replace_memsets(void* graph, int* replaced, int* left);
+
+/* Timeline marker (measurement, no reference counterpart: the reference's only timing is the host perf_counter pair of
+ * evaluation.py:248-250): buf[slot] = device wall clock (constant 100 MHz, 10 ns ticks) when `stream` reaches this launch.
+ * buf: device memory, >= slot + 1 unsigned 64-bit words.  Capturable: a marker is an ordinary kernel node of the forward's graph. */
+int as_stamp(unsigned long long* buf, int slot, void* stream);
 /* 16 hex digits: sha256 over the .hip / .h files of csrc and this header at build time (any-stereo_amd/build.py); the Python binding
  * recomputes it from the tree and refuses a library built from other sources */
 const char* as_source_hash(void);

@@ -211,6 +211,26 @@ def test_flat_exchange_broadcasts_rank0_state_and_overflow_is_collective_world2(
         assert gate is False and skipped == 1
 
 
+def _check_train_leg(d, world):
+    """`train_mode` of an N-rank `bench.py --gpus N` line: the training leg the same ranks run after the inference leg
+    (bench.train_leg) — every key a SCALE record needs to answer north_star's training-scaling criterion."""
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, root)
+    import bench
+    tm = d["train_mode"]
+    assert tm is not None and "error" not in tm, tm
+    assert set(bench.TRAIN_LEG_KEYS) <= set(tm), set(bench.TRAIN_LEG_KEYS) - set(tm)
+    assert tm["n_gpus"] == world and tm["global_batch"] == 4 * world
+    assert len(tm["per_rank_samples_per_s"]) == world and len(tm["one_rank_ms_per_step"]) == world
+    assert len(tm["ranks_seen"]) == world and sorted(r["rank"] for r in tm["ranks_seen"]) == list(range(world))
+    assert tm["distinct_devices"] == world
+    assert tm["exchange_ms"] is not None and tm["exchange_ms"] > 0 and tm["grad_bytes"] > 0
+    assert tm["scaling"] is not None and tm["scaling"] > 0 and tm["ms_per_step"] > 0
+    assert tm["trainer"]["gradient_exchange"].startswith("flat") and tm["loss_finite"] is True
+    return tm
+
+
 def test_bench_launcher_spawns_ranks_world2():
     """`python bench.py --gpus 2` without torchrun: the parent spawns 2 ranks itself (it never imports torch or touches a
     GPU), the ranks rendezvous on 127.0.0.1, and rank 0 prints ONE JSON line with n_gpus = 2 and one value per rank.  Here
@@ -229,6 +249,8 @@ def test_bench_launcher_spawns_ranks_world2():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None
     assert len(d["per_rank_step_s"]) == 2 and d["config"]["parallelism"] == "replicas x2"
+    tm = _check_train_leg(d, 2)  # the N-rank training leg rides in the same line
+    assert tm["dry_run"] is True and tm["value"] is None
     # every rank is bound to its own core set before torch starts a thread, and sizes its pools to it (bench.pin_rank)
     sets = d["per_rank_cpus"]
     avail = len(os.sched_getaffinity(0))
@@ -287,6 +309,25 @@ def test_bench_under_torch_distributed_run_world2():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["dry_run"] is True and len(d["per_rank_step_s"]) == 2
+    _check_train_leg(d, 2)
     sets = d["per_rank_cpus"]
     if len(os.sched_getaffinity(0)) >= 2:
         assert len(sets) == 2 and not set(sets[0]) & set(sets[1]), sets
+
+
+def test_bench_train_leg_watchdog_prints_stashed_line():
+    """The training leg of an N-rank run is bounded: a rank stuck in it (a peer died inside a collective) lets rank 0 print the
+    headline it already has, with train_mode = {"error": ...}, and every rank ends (bench._LegWatchdog)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = ("import sys, time; sys.path.insert(0, %r); sys.argv=['bench.py']; import bench\n"
+            "g = bench._LegWatchdog(0, 0.3); g.rearm({'metric': 'm', 'value': 1.5}); time.sleep(30)\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["value"] == 1.5 and "timed out" in d["train_mode"]["error"]
+    code2 = code.replace("_LegWatchdog(0, 0.3)", "_LegWatchdog(1, 0.3)")
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=60)
+    assert r2.returncode == 0 and r2.stdout.strip() == ""  # other ranks leave silently

@@ -739,3 +739,17 @@ def test_bench_command_under_the_drivers_launcher_one_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["unit"] == "pairs/s" and d["value"] > 0 and len(d["per_rank_pairs_per_s"]) == 1
     assert d["config"]["parallelism"] == "replicas x1" and d["library"]["matches_sources"] is True
+    assert d["timed_blocks"] >= 3 and len(d["value_spread"]["pairs_per_s"]) == d["timed_blocks"]
+    assert d["value_spread"]["min"] <= d["value"] <= d["value_spread"]["max"]
+    # the training leg of an N-rank run (bench.train_leg): the SAME rank, on the RCCL group the launcher gave it, runs graphed cfg-4
+    # steps with the flat gradient exchange after the inference leg and reports what a SCALE record needs
+    sys.path.insert(0, root)
+    import bench
+    tm = d["train_mode"]
+    assert tm is not None and "error" not in tm, tm
+    assert set(bench.TRAIN_LEG_KEYS) <= set(tm), set(bench.TRAIN_LEG_KEYS) - set(tm)
+    assert tm["n_gpus"] == 1 and tm["global_batch"] == 4 and tm["value"] > 0 and tm["ms_per_step"] > 0 and tm["dry_run"] is False
+    assert tm["trainer"]["graph"] is True and tm["trainer"]["gradient_exchange"].startswith("flat")
+    assert tm["exchange_ms"] > 0 and tm["grad_bytes"] > 4e7 and tm["loss_finite"] is True
+    assert len(tm["ranks_seen"]) == 1 and tm["ranks_seen"][0]["device_index"] == 0 and tm["distinct_devices"] == 1
+    assert len(tm["one_rank_ms_per_step"]) == 1 and 0.5 < tm["scaling"] < 1.5

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/anystereo_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     bound = _lib.load()
-    assert bound.as_abi_version() == 36
+    assert bound.as_abi_version() == 37
     assert bound.as_last_error_string() is not None
 
 
