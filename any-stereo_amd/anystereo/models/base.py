@@ -76,6 +76,8 @@ class ContinuousStereoBase(nn.Module):
         if st is not None:
             st.mark(name)
 
+    stamp_iters = (15, 16)  # GRU iterations whose inner stages are marked too (two consecutive ones: a full period)
+
     # ---- hot-path hooks (HIP) ------------------------------------------------------------------
     def _hot_update(self, net_list, inp_list, corr, disp, **flags):
         return self.update_block(net_list, inp_list, corr, disp, **flags)
@@ -212,6 +214,13 @@ class ContinuousStereoBase(nn.Module):
         return self._forward_impl(image1, image2, iters=iters, flow_init=flow_init, test_mode=test_mode,
                                   hr_coord=hr_coord, scale=scale, output_raw=output_raw)
 
+    def _forward_impl_marked(self, *a, **k):
+        ops.set_stamps(self.__dict__.get("stamps"))
+        try:
+            return self._forward_impl(*a, **k)
+        finally:
+            ops.set_stamps(None)
+
     def _forward_graphed(self, image1, image2, iters, hr_coord, scale):
         key = (tuple(image1.shape), tuple(hr_coord.shape), tuple(scale.shape), int(iters), image1.device.index,
                ops.get_precision(), ops.get_fast_fp16() or bool(getattr(self.args, "mixed_precision", False)),
@@ -227,14 +236,14 @@ class ContinuousStereoBase(nn.Module):
             with torch.cuda.stream(side):  # warm-up: MIOpen solver search, weight packing, allocator
                 for _ in range(2):
                     st[2].copy_(hr_coord)
-                    self._forward_impl(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
+                    self._forward_impl_marked(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize(image1.device)
             keep = os.environ.get("ANYSTEREO_INFER_GRAPH_KEEP", "1") != "0"  # 0 (diagnostics): instantiate at capture end, no node rewrite
             g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
             st[2].copy_(hr_coord)
             with torch.cuda.graph(g):
-                out = self._forward_impl(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
+                out = self._forward_impl_marked(st[0], st[1], iters=iters, test_mode=True, hr_coord=st[2], scale=st[3])
             # memset nodes (a library zero-filling through hipMemsetAsync) are not reliably ordered inside long graphs on this ROCm
             # stack (csrc/graph.hip): rewritten as fill kernel nodes before instantiation.  This library issues none
             # itself; the count is kept for inspection.
@@ -320,6 +329,11 @@ class ContinuousStereoBase(nn.Module):
         s16 = (main if serial else ub._side_stream(dev, 1)) if early else None
         net2_next = up16_next = None
         for itr in range(iters):
+            sink = ops._ACTIVE_STAMPS
+            if sink is not None:
+                sink.fine, sink.prefix = itr in self.stamp_iters, f"it{itr}."
+            mk = ops.mark_fine
+            mk("main_begin")
             pre = ub.gru04.pre_zr(net[0], *(inp[0])) if self.split_gate_conv else None
             if net2_next is None:
                 net[2] = ub.gru16(net[2], *(inp[2]), pool2x(net[1]))
@@ -334,6 +348,7 @@ class ContinuousStereoBase(nn.Module):
                 up16, up16_next = up16_next, None
                 (up16.t if isinstance(up16, ops.BS8) else up16).record_stream(main)
             net[1] = ub.gru08(net[1], *(inp[1]), pool2x(net[0]), up16)
+            mk("gru08_end")
             if early and itr + 1 < iters:
                 s16.wait_stream(main)  # net[1], net[2] of this iteration are final
                 with torch.cuda.stream(s16):
@@ -343,9 +358,12 @@ class ContinuousStereoBase(nn.Module):
                 net[1].record_stream(s16)
                 net[2].record_stream(s16)
             up = interp(net[1], net[0])
+            mk("interp08_end")
             main.wait_stream(side)  # motion features (and the disparity they were computed from) are ready
             mf.record_stream(main)
+            mk("gru04_begin")
             net[0] = ub.gru04(net[0], *(inp[0]), mf, up, pre_zr=pre)
+            mk("gru04_end")
             net[0].record_stream(side)
             twin = getattr(net[0], "_as_bs", None)  # blocked twin of the hidden state: read by the head on the side stream
             if twin is not None:
@@ -357,10 +375,14 @@ class ContinuousStereoBase(nn.Module):
                     mf, disp = ub.encoder.forward_front(ub.disp_head.taps(net[0]), ub.disp_head, disp, lookup_fn)
                 else:
                     disp = ub.disp_head(net[0], addend=disp)
+                    mk("head_end")
                     if itr + 1 < iters:
                         mf = enc(disp)
+                    mk("encoder_end")
         main.wait_stream(side)
         disp.record_stream(main)
+        if ops._ACTIVE_STAMPS is not None:
+            ops._ACTIVE_STAMPS.fine, ops._ACTIVE_STAMPS.prefix = False, ""
         return disp
 
     batched_train_upsample = os.environ.get("ANYSTEREO_BATCHED_TRAIN_LIIF", "1") != "0"

@@ -119,12 +119,23 @@ class _SearchedConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, cfg):
+        # Under autocast (the reference's training arithmetic, train_continuous_IGEV.py:206) the convolution runs in the autocast
+        # dtype, as nn.Conv3d would: operands are cast HERE (aten.convolution called directly would be cast by autocast's own
+        # wrapper, but the tensors saved for backward would keep their dtypes and convolution_backward refuses a mix); the
+        # gradients go back in the dtypes the inputs came in.
+        ctx.in_dtypes = (x.dtype, w.dtype, None if bias is None else bias.dtype)
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            x, w, bias = x.to(dt), w.to(dt), (None if bias is None else bias.to(dt))
+        elif x.dtype != w.dtype:
+            x = x.to(w.dtype)
         ctx.save_for_backward(x, w)
         ctx.cfg, ctx.bias_sizes = cfg, None if bias is None else list(bias.shape)
         prev = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = True
         try:
-            return torch.ops.aten.convolution(x, w, bias, *cfg)
+            with torch.autocast("cuda", enabled=False):
+                return torch.ops.aten.convolution(x, w, bias, *cfg)
         finally:
             torch.backends.cudnn.benchmark = prev
 
@@ -134,12 +145,14 @@ class _SearchedConv(torch.autograd.Function):
         prev = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = True
         try:
-            gx, gw, gb = torch.ops.aten.convolution_backward(
-                gy.contiguous(), x, w, ctx.bias_sizes, *ctx.cfg,
-                [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]])
+            with torch.autocast("cuda", enabled=False):
+                gx, gw, gb = torch.ops.aten.convolution_backward(
+                    gy.contiguous().to(x.dtype), x, w, ctx.bias_sizes, *ctx.cfg,
+                    [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]])
         finally:
             torch.backends.cudnn.benchmark = prev
-        return gx, gw, gb, None
+        dx, dw, db = ctx.in_dtypes
+        return (None if gx is None else gx.to(dx), None if gw is None else gw.to(dw), None if gb is None else gb.to(db), None)
 
 
 def conv3d_train(conv, x):

@@ -625,9 +625,11 @@ class liif_out_multi_scale_Training(nn.Module):
         """The first Linear layer's feature block of input i at low resolution under autograd: a 1x1 convolution on this library's
         kernels (forward, dgrad, wgrad — grad.Conv2dSame; the weight is a column block of the layer's matrix, autograd carries
         its gradient back into it), else the library's."""
-        if s.is_cuda and s.dtype == torch.float32 and s.shape[1] >= 16:
-            return G.conv2d_same(self, f"u{i}", s, w.contiguous(), None)
-        return F.conv2d(s, w)
+        if not s.is_cuda:
+            raise RuntimeError(f"anystereo liif first layer: expected a CUDA tensor (the hot path has no CPU fallback), got {s.device}")
+        if s.shape[1] >= 16:  # fp16 / bf16 inputs (autocast training) are cast for the kernel: fp32 result, as the MLP expects
+            return G.conv2d_same(self, f"u{i}", s if s.dtype == torch.float32 else s.float(), w.float().contiguous(), None)
+        return F.conv2d(s.float(), w.float())  # < 16 input channels (non-default option sets): below the MFMA kernel's K granularity
 
     def _mask_logits(self, sfs, coord, ctot, pre=None):
         b, q = coord.shape[:2]

@@ -82,6 +82,7 @@ class DispHead(nn.Module):
             with scope("disp_head_conv1"):
                 taps = ops.conv2d([_twin(_f(x))], self._p1.get([self.conv1.weight], [self.conv1.bias]), act=L.ACT_RELU,
                                   epilogue=L.EPI_RELU_TAPS, tap_w=self._tap_weights())
+            ops.mark_fine("head_conv1_end")
             with scope("disp_head_conv2"):
                 return ops.tap_shift_sum(taps, _f(self.conv2.bias.detach()), None if addend is None else _f(addend))
         with scope("disp_head_conv1"):
@@ -207,6 +208,7 @@ class ConvGRU(nn.Module):
             pzx = self._pzr_x.get([self.convz.weight, self.convr.weight], [None, None], transform=lambda w: w[:, hid:])
             with scope(self.tag + "_zr_conv"):
                 z, rh = ops.conv2d(xs, pzx, add=pre_zr, add_coff=0, epilogue=L.EPI_GRU_ZR, h=h, out_bs=rbs, bs_only=links)
+        ops.mark_fine(self.tag + "_zr_end")
         with scope(self.tag + "_q_conv"):
             out = ops.conv2d([rbs if links else rh] + xs, pq, add=ctx, add_coff=coff + 2 * hid, epilogue=L.EPI_GRU_Q, h=h, z=z,
                              out_bs=hbs)
@@ -325,12 +327,15 @@ class BasicMotionEncoder(nn.Module):
         # (Tried and removed: the 7x7 conv on a branch stream beside the fused lookup — both depend on `disp` only — forked
         # from the loop's side stream: capturing that nested fork into the forward's hipGraph crashed the process.)
         lookup_fn.lookup_convc1(disp, self._plc1.get(self.convc1.weight, self.convc1.bias), out_bs=cor)
+        ops.mark_fine("enc.lookup_end")
         with scope("enc_convd1"):
             ops.conv7x7_c1_relu(disp, self.convd1.weight, self.convd1.bias, out=d1, copy_out=out, copy_coff=127)
+        ops.mark_fine("enc.conv7x7_end")
         with scope("enc_convc2"):
             second = {"src": d1, "pack": self._pd2.get([self.convd2.weight], [self.convd2.bias]), "out_coff": 64, "out_bs_coff": 64}
             ops.conv2d([cor], self._pc2.get([self.convc2.weight], [self.convc2.bias]), act=L.ACT_RELU, out_bs=cd, out_bs_coff=0,
                        bs_only=True, dual=second)
+        ops.mark_fine("enc.dual_end")
         return self.merge(cd, disp, out)
 
     # The three pieces of forward(), exposed so the inference schedule (models/base.py::_iterate_pipelined) can run
@@ -391,20 +396,29 @@ class BasicMotionEncoder(nn.Module):
         return out
 
 
+def _hip_train_input(x, what):
+    """Training inputs of the resamplers: fp32 CUDA tensors go to the HIP forward / backward kernels as they are; fp16 / bf16
+    CUDA tensors (the reference's autocast training, train_continuous_IGEV.py:206,288) are cast to fp32 for the kernel and the
+    result is cast back; anything else is an error — the hot path has no library / CPU fallback."""
+    if not x.is_cuda:
+        raise RuntimeError(f"anystereo {what}: expected a CUDA tensor (the hot path has no CPU fallback), got {x.device}")
+    if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise RuntimeError(f"anystereo {what}: dtype {x.dtype} (float32, or float16 / bfloat16 under autocast)")
+    return x if x.dtype == torch.float32 else x.float()
+
+
 def pool2x(x):
-    if _train(x):
-        if x.is_cuda and x.dtype == torch.float32:
-            return G.Pool2x.apply(x)
-        return F.avg_pool2d(x, 3, stride=2, padding=1)  # update.py:94-95
+    if _train(x):  # update.py:94-95 (3x3 average pool, stride 2, zero padding 1 counted in the divisor)
+        with scope("pool2x"):
+            return G.Pool2x.apply(_hip_train_input(x, "pool2x")).to(x.dtype)
     with scope("pool2x"):
         return ops.pool2x_bs(_f(x)) if _links() else ops.pool2x(_f(x))  # the pooled / resized maps only feed GRU convs
 
 
 def interp(x, dest):
-    if _train(x):
-        if x.is_cuda and x.dtype == torch.float32:
-            return G.InterpBilinear.apply(x, dest.shape[2], dest.shape[3])
-        return F.interpolate(x, dest.shape[2:], mode="bilinear", align_corners=True)  # update.py:100-102
+    if _train(x):  # update.py:100-102 (bilinear resize to dest's size, align_corners=True)
+        with scope("interp"):
+            return G.InterpBilinear.apply(_hip_train_input(x, "interp"), dest.shape[2], dest.shape[3]).to(x.dtype)
     with scope("interp"):
         if _links():
             return ops.interp_bs(_f(x), dest.shape[2], dest.shape[3])

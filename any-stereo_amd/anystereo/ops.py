@@ -1525,11 +1525,15 @@ class Stamps:
     marker}.  Measurement only; the default forward issues none."""
     TICK_US = 0.01  # wall_clock64 on gfx950: constant 100 MHz
 
-    def __init__(self, device, slots: int = 64):
+    def __init__(self, device, slots: int = 128):
         self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
         self.names = {}
+        self.fine = False   # operator-level markers (nn/update.py) on: set by the loop for the iterations it wants resolved
+        self.prefix = ""    # prepended to operator-level marker names (the iteration they were issued in)
 
-    def mark(self, name: str):
+    def mark(self, name: str, prefixed: bool = False):
+        if prefixed:
+            name = self.prefix + name
         slot = self.names.setdefault(name, len(self.names))
         if slot >= self.buf.numel():
             raise ValueError("Stamps: out of slots")
@@ -1541,6 +1545,27 @@ class Stamps:
         v = self.buf.cpu().tolist()
         t0 = min(v[s] for s in self.names.values()) if self.names else 0
         return {n: round((v[s] - t0) * self.TICK_US, 2) for n, s in self.names.items()}
+
+
+_ACTIVE_STAMPS = None
+
+
+def set_stamps(st: Optional["Stamps"]):
+    """Make `st` the process-wide marker sink (None: off).  models/base.py does this for the duration of a forward whose model
+    has `stamps` set, so that operator-level code (nn/update.py) can place markers with `ops.mark` without holding the model."""
+    global _ACTIVE_STAMPS
+    _ACTIVE_STAMPS = st
+
+
+def mark(name: str):
+    if _ACTIVE_STAMPS is not None:
+        _ACTIVE_STAMPS.mark(name)
+
+
+def mark_fine(name: str):
+    """Operator-level marker: placed only while the active sink asks for them (`fine`), named with its current prefix."""
+    if _ACTIVE_STAMPS is not None and _ACTIVE_STAMPS.fine:
+        _ACTIVE_STAMPS.mark(name, prefixed=True)
 
 
 def split_overflow_count(reset: bool = True) -> int:

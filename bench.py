@@ -506,7 +506,9 @@ class _LegWatchdog:
             return
         sys.stderr.write(f"bench.py: rank {self.rank}: the training leg did not finish within {self.seconds:.0f} s - leaving without it\n")
         if self.rank == 0 and self.stash is not None:
-            line = dict(self.stash, train_mode={"error": f"training leg timed out after {self.seconds:.0f} s"})
+            line = dict(self.stash)
+            if getattr(self, "key", "train_mode") == "train_mode":
+                line["train_mode"] = {"error": f"training leg timed out after {self.seconds:.0f} s"}
             print(json.dumps(line), flush=True)
         os._exit(0 if (self.rank != 0 or self.stash is not None) else 3)
 
@@ -695,6 +697,41 @@ def train_leg(a, rank, world, local, td, dev, dry=False):
     return res
 
 
+def _exchange_probe(a, rank, dist, dev, nbytes):
+    """What the flat gradient exchange costs through RCCL on this box: 20 all-reduces of the flat fp32 vector, HIP events on the
+    collective's stream.  With a single rank that is the collective's launch + the in-place pass over the vector (no link traffic),
+    the floor under the N-rank figure (ring: + 2*(N-1)/N*bytes per link)."""
+    exchange = {"grad_bytes": nbytes, "exchange_ms": None, "how": None}
+    if not ((dist or rank == 0) and not a.no_extras):  # every rank of a group takes part in its collective
+        return exchange
+    try:
+        import torch.distributed as tdd
+        own_pg = not tdd.is_initialized()
+        if own_pg:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            tdd.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        flat = torch.zeros(nbytes // 4, device=dev, dtype=torch.float32)
+        for _ in range(3):
+            tdd.all_reduce(flat)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            tdd.all_reduce(flat)
+        e1.record()
+        torch.cuda.synchronize()
+        exchange["exchange_ms"] = round(e0.elapsed_time(e1) / 20, 4)
+        exchange["how"] = (f"20 all-reduces of the {nbytes} B flat fp32 gradient vector through RCCL, {tdd.get_world_size()} rank(s), "
+                           "HIP events on the collective's stream; what the Trainer's flat exchange issues once per step")
+        del flat
+        if own_pg:
+            tdd.destroy_process_group()
+    except Exception as ex:
+        exchange["how"] = "unavailable: " + repr(ex)[:200]
+    return exchange
+
+
 def train_main(a, rank, world, local):
     """SURVEY.md §8d cfg 4: IGEV training, 4 samples per GPU at 160x320 network input, 51 200 HR queries per sample, 16 GRU
     iterations with the LIIF upsampler every iteration, AdamW + OneCycleLR; one process per GPU, DDP over RCCL.  A step =
@@ -757,38 +794,6 @@ def train_main(a, rank, world, local):
         overlap = {"ms_per_step_with_allreduce": round(ms_sync, 2), "ms_per_step_no_sync": round(ms_nosync, 2),
                    "exposed_allreduce_ms": round(ms_sync - ms_nosync, 2), "gradient_bytes": nbytes,
                    "ddp": tr.ddp_mode}
-    # The two numbers an N-rank run is judged by: the size of the ONE flat gradient vector the graphed step
-    # exchanges, and what its all-reduce costs through RCCL on this box — with a single rank that is the collective's launch +
-    # the in-place pass over the vector (no link traffic), the floor under the 8-rank figure (ring: + 2*(7/8)*bytes per link).
-    nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
-    exchange = {"grad_bytes": nbytes, "exchange_ms": None, "how": None}
-    if (dist or rank == 0) and not a.no_extras:  # every rank of a group takes part in its collective
-        try:
-            import torch.distributed as tdd
-            own_pg = not tdd.is_initialized()
-            if own_pg:
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", str(_free_port()))
-                tdd.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            if True:
-                flat = torch.zeros(nbytes // 4, device=dev, dtype=torch.float32)
-                for _ in range(3):
-                    tdd.all_reduce(flat)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    tdd.all_reduce(flat)
-                e1.record()
-                torch.cuda.synchronize()
-                exchange["exchange_ms"] = round(e0.elapsed_time(e1) / 20, 4)
-                exchange["how"] = (f"20 all-reduces of the {nbytes} B flat fp32 gradient vector through RCCL, {tdd.get_world_size()} rank(s), "
-                                   "HIP events on the collective's stream; what the Trainer's flat exchange issues once per step")
-                del flat
-            if own_pg:
-                tdd.destroy_process_group()
-        except Exception as ex:
-            exchange["how"] = "unavailable: " + repr(ex)[:200]
     roof = cpu = eager = None
     if rank == 0 and world == 1 and a.train_quick:
         roof = train_roofline(a, batch, dev)
@@ -800,9 +805,10 @@ def train_main(a, rank, world, local):
         roof = train_roofline(a, batch, dev)
         if not a.no_cpu_baseline:
             cpu = train_cpu_baseline(a, args, model, batch)
+    line = None
     if rank == 0:
         nparam = sum(p.numel() for p in model.parameters())
-        print(json.dumps({
+        line = ({
             "metric": "train_samples_per_s", "value": round(world * a.batch_per_gpu * a.steps / dt, 3), "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": TRAIN_DTYPE, "data": "synthetic",
@@ -813,7 +819,7 @@ def train_main(a, rank, world, local):
             "host": {"cpus_per_rank": len(RANK_CPUS or []), "pinned": world > 1 and os.environ.get("ANYSTEREO_PIN", "1") != "0",
                      "torch_threads": torch.get_num_threads()},
             "allreduce_overlap": overlap,
-            "grad_bytes": exchange["grad_bytes"], "exchange_ms": exchange["exchange_ms"], "exchange_how": exchange["how"],
+            "grad_bytes": 4 * sum(p.numel() for p in model.parameters() if p.requires_grad), "exchange_ms": None, "exchange_how": None,
             "trainer": {"graph": bool(tr.use_graph), "graph_scope": tr.graph_scope if tr.use_graph else None,
                         "gradient_exchange": tr.ddp_mode},
             "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
@@ -826,7 +832,18 @@ def train_main(a, rank, world, local):
                                "saturated_waves_at_end": tr._poll_overflow() if tr._on_gpu() else None,
                                "events": tr.overflow_events, "skipped_steps": tr.skipped_steps},
             "eager_step": eager,
-            "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu}))
+            "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu})
+    # The exchange probe comes LAST and is bounded: with one rank and no launcher it creates a 1-rank RCCL group of its own; if
+    # that initialisation (or a collective) hangs on some box, rank 0 still prints the training line it already has
+    nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
+    guard = _LegWatchdog(rank, float(os.environ.get("ANYSTEREO_EXCHANGE_PROBE_TIMEOUT", "90")))
+    guard.rearm(None if line is None else dict(line, exchange_how="unavailable: the probe did not return in time"))
+    guard.key = "exchange_probe"
+    exchange = _exchange_probe(a, rank, dist, dev, nbytes)
+    guard.done()
+    if rank == 0:
+        line.update(exchange_ms=exchange["exchange_ms"], exchange_how=exchange["how"])
+        print(json.dumps(line))
     if dist:
         td.barrier()
         td.destroy_process_group()

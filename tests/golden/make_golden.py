@@ -320,6 +320,46 @@ def golden_model_options(RefIGEV, RefRAFT, rliif):
     save("model_opts", **outs)
 
 
+PRELOOP_SIZES = ((64, 128), (96, 160))  # the G7 size and a non-square one whose 1/32 map is 3 x 5 (odd in both dimensions)
+PRELOOP_STRIDE = 5                       # every 5th element of each flattened tensor is stored (plus fp64 sums of the whole)
+
+
+def golden_preloop(RefIGEV, rliif):
+    """Pre-loop tensors of the imported reference (continuous_IGEVstereo.py:245-276): the matching features, the geometry
+    encoding volume, the initial disparity, the hidden states and the context terms the GRU loop starts from — what the backbone
+    WIRING (stems, feature trunk, descriptor head, cost aggregation, context network, context_zqr_convs) produces.  The oracle's
+    whole-model check shares the product's backbone modules; these vectors pin that wiring against the reference itself, at two
+    shapes.  Captured with forward hooks (no edits to the reference)."""
+    outs = {}
+    for (H, W) in PRELOOP_SIZES:
+        args = default_args("continuous_IGEVStereo")
+        model = RefIGEV(args).eval()
+        fill_module_deterministic(model, base_seed=1)
+        img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+        cap = {"desc": [], "zqr": []}
+        hooks = [model.desc.register_forward_hook(lambda m, i, o: cap["desc"].append(o.detach().clone())),
+                 model.cost_agg.register_forward_hook(lambda m, i, o: cap.__setitem__("gev", o.detach().clone())),
+                 model.cnet.register_forward_hook(lambda m, i, o: cap.__setitem__("cnet", [[t.detach().clone() for t in lv] for lv in o]))]
+        hooks += [c.register_forward_hook(lambda m, i, o: cap["zqr"].append(o.detach().clone())) for c in model.context_zqr_convs]
+        coord = rliif.make_coord([H, W]).unsqueeze(0)
+        init_disp, preds = model(img1, img2, iters=1, test_mode=False, hr_coord=coord.clone(), scale=torch.tensor([[1.0]]))
+        for h_ in hooks:
+            h_.remove()
+        assert len(cap["desc"]) == 2 and len(cap["zqr"]) == 3 and len(cap["cnet"]) == 3
+        tensors = {"match_left": cap["desc"][0], "match_right": cap["desc"][1], "gev": cap["gev"], "init_disp": init_disp,
+                   "pred_0": preds[0]}
+        for i in range(3):
+            tensors[f"net{i}"] = torch.tanh(cap["cnet"][i][0])   # :271
+            tensors[f"ctx{i}"] = cap["zqr"][i]                   # :273 before the split into cz | cr | cq
+        key = f"{H}x{W}"
+        for n, t in tensors.items():
+            flat = t.reshape(-1)
+            outs[f"{key}.{n}"] = flat[::PRELOOP_STRIDE].clone()
+            outs[f"{key}.{n}.shape"] = np.array(t.shape)
+            outs[f"{key}.{n}.sums"] = np.array([float(flat.double().sum()), float(flat.double().abs().sum())])
+    save("preloop_igev", sizes=np.array(PRELOOP_SIZES), stride=PRELOOP_STRIDE, **outs)
+
+
 SENS_ARGS = {}
 MARGIN_ARGS = {}
 
@@ -380,6 +420,8 @@ def main(only=None):
         return gen_update()
     if only == "model_opts":
         return golden_model_options(RefIGEV, RefRAFT, rliif)
+    if only == "preloop":
+        return golden_preloop(RefIGEV, rliif)
     if only in ("train", "train_sens", "train_margin"):
         import ast
         import torch.nn.functional as F
@@ -483,6 +525,7 @@ def main(only=None):
     with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
         json.dump(sd_keys, f, indent=0, sort_keys=True)
     golden_model_options(RefIGEV, RefRAFT, rliif)
+    golden_preloop(RefIGEV, rliif)
 
     # ---- §8(f1): query grid of pad_for_multi_train (evaluation.py:67-89) ---------------------------
     # evaluation.py itself cannot be imported (missing tensorboardX / fvcore / a dangling model import,
@@ -543,7 +586,7 @@ def main(only=None):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["train", "train_sens", "train_margin", "update", "model_opts"], default=None,
+    ap.add_argument("--only", choices=["train", "train_sens", "train_margin", "update", "model_opts", "preloop"], default=None,
                     help="regenerate only the G8 training-step fixtures / their perturbation sensitivities / only the G5 flag-combination fixtures")
     ap.add_argument("--sens-seeds", type=int, default=32)
     ap.add_argument("--sens-rel", type=float, default=1e-6)

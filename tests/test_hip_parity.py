@@ -823,13 +823,26 @@ G8_FLOOR_NORM = 2e-3   # gradient norms, relative (worst observed / limit over t
 # the reference's value is rounding noise (1e-9 of the largest norm); required of the product: noise of that size, not its digits
 G8_ZERO_REF, G8_ZERO_GOT = 1e-7, 1e-6
 G8_CAP_ELEM, G8_CAP_NORM = 5e-2, 5e-2  # no fixture deviation buys more than this
+# Tensors the reference's own 128 perturbations move by LESS than G8_STABLE are stable in the reference: there the limit is the
+# reference's observed maximum itself (not 3x), floored by G8_STABLE_FLOOR_* — 10x below the general norm floor (the product's own
+# rounding differs from the reference's — split operands, summation order, MIOpen's per-box solver choice — so a limit below its
+# noise would test the box, not the code).  Measured margin (tools/g8_margins.py, profiles/r06_g8_margins.txt): over the 165
+# (IGEV) + 49 (RAFT) such tensors the product's worst relative norm deviation is 4.1e-5 (RAFT split), 2.1e-5 (IGEV fp32).
+G8_STABLE = 1e-4
+G8_STABLE_FLOOR_NORM = 2e-4
+G8_STABLE_FLOOR_ELEM = 3e-5
 
 
 def _g8_limits(name):
     import numpy as np
     s = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}_sens.npz"))
-    elem = {str(n): min(G8_CAP_ELEM, max(G8_FLOOR_ELEM, 3.0 * float(d))) for n, d in zip(s["full_names"], s["full_dev"])}
-    norm = {str(n): min(G8_CAP_NORM, max(G8_FLOOR_NORM, 3.0 * float(d))) for n, d in zip(s["names"], s["norm_dev"])}
+    def lim(d, floor, stable_floor, cap):
+        d = float(d)
+        if d < G8_STABLE:  # stable in the reference: its own observed maximum, not a multiple of it
+            return max(stable_floor, d)
+        return min(cap, max(floor, 3.0 * d))
+    elem = {str(n): lim(d, G8_FLOOR_ELEM, G8_STABLE_FLOOR_ELEM, G8_CAP_ELEM) for n, d in zip(s["full_names"], s["full_dev"])}
+    norm = {str(n): lim(d, G8_FLOOR_NORM, G8_STABLE_FLOOR_NORM, G8_CAP_NORM) for n, d in zip(s["names"], s["norm_dev"])}
     return elem, norm
 
 
@@ -888,13 +901,19 @@ def test_training_step_vs_reference(name, mode):
     print(f"[G8 {name} {mode}] loss rel {abs(loss.item() - float(z['loss'])) / abs(float(z['loss'])):.2e}; grad-norm rel max "
           f"{rel.max():.3e}, median {np.median(rel):.3e}; closest to their limits: "
           + ", ".join(f"{names[i]} {rel[i]:.2e} / {lim_n[names[i]]:.1e}" for i in order))
+    # the margin actually used, per class of tensor (stable in the reference / moved by its perturbations)
+    stable = np.array([lim_n[n] <= G8_STABLE_FLOOR_NORM for n in names]) & ~zero
+    for tag, sel in (("stable tensors (limit = the reference's own maximum, floor 2e-4)", stable), ("perturbation-sensitive tensors (limit 3x)", ~stable & ~zero)):
+        if sel.any():
+            k = int(np.argmax(np.where(sel, ratio, -1.0)))
+            print(f"[G8 {name} {mode}] {int(sel.sum())} {tag}: worst deviation / limit = {ratio[k]:.2f} at {names[k]} ({rel[k]:.2e} / {lim_n[names[k]]:.1e})")
     assert ratio.max() < 1.0, f"{name}: grad-norm mismatch {rel[int(ratio.argmax())]:.3e} at {names[int(ratio.argmax())]}"
     # element-wise, on one tensor per operator family, relative to the tensor's max
     for i, n in enumerate(str(x) for x in z["full_names"]):
         want = torch.from_numpy(z[f"g{i}"])
         got = grads[n].cpu()
         e = ((got - want).abs().max() / want.abs().max()).item()
-        print(f"[G8 {name} {mode}] {n}: max |d| / max |g| = {e:.2e} (limit {lim_e[n]:.1e})")
+        print(f"[G8 {name} {mode}] {n}: max |d| / max |g| = {e:.2e} (limit {lim_e[n]:.1e}, margin used {e / lim_e[n]:.2f})")
         close(got, want, rtol=lim_e[n], atol=1e-6 * want.abs().max().item(), what=n)
 
 
@@ -1030,6 +1049,64 @@ def test_conv7x7_c1_relu_backward_and_head_conv2():
         e = ((got.grad.cpu().double() - want.grad).abs().max() / want.grad.abs().max()).item()
         print(f"[head conv2 {nm}] max |d| / max |g| = {e:.2e}")
         assert e < 5e-5, (nm, e)
+
+
+def test_preloop_tensors_vs_reference(golden, precision):
+    """The pre-loop of the HIP path — fused backbone kernels, gwc volume, cost aggregation, context network: what the GRU loop
+    starts from — against the imported reference's own tensors (tests/golden/preloop_igev.npz) at 64x128 and at the non-square
+    96x160, eager and as the captured forward runs it (same code path), both matrix-core modes (round-5 review item 7: the
+    full-size oracle shares the product's module wiring; this pins that wiring against the reference at two shapes)."""
+    from _preloop import capture_preloop, check_preloop
+    from anystereo.harness.synthetic import fill_module_deterministic, synthetic_pair
+    from anystereo.models import __models__, default_args
+    g = golden("preloop_igev")
+    args = default_args("continuous_IGEVStereo")
+    model = __models__["continuous_IGEVStereo"](args).eval()
+    fill_module_deterministic(model, base_seed=1)
+    model = model.to(DEV)
+    for H, W in ((int(a), int(b)) for a, b in g["sizes"]):
+        img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+        coord = O.make_coord([H, W]).view(1, -1, 2)
+        cap = capture_preloop(model, img1.to(DEV), img2.to(DEV), coord.to(DEV), torch.tensor([[1.0]], device=DEV))
+        worst = check_preloop(cap, g, f"{H}x{W}", 5e-4, f"hip {precision}")
+        print(f"[preloop hip {precision} {H}x{W}] " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
+def test_autocast_training_step_keeps_resamplers_on_hip():
+    """The reference trains under autocast + GradScaler (train_continuous_IGEV.py:206,288).  One such step (args.mixed_precision,
+    Trainer(mixed_precision=True), eager) on a small problem: the loss is finite, and row a8 (pool2x / interp, update.py:94-102)
+    went through the HIP forward kernels — counted by the launch-stream timing hooks — whatever dtype autocast handed them;
+    there is no ATen branch left for them to take (nn/update.py::_hip_train_input raises for anything it does not serve)."""
+    import math
+    from anystereo.harness import timing
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer, synthetic_train_batch
+    from anystereo.models import __models__, default_args
+    from anystereo.nn import update as U
+    args = default_args("continuous_IGEVStereo", mixed_precision=True)
+    m = __models__["continuous_IGEVStereo"](args)
+    fill_module_deterministic(m, base_seed=1)
+    tr = Trainer(m.to(DEV), lr=2e-4, num_steps=1000, train_iters=3, max_disp=args.max_disp, mixed_precision=True, graph=False)
+    batch = synthetic_train_batch(2, 64, 128, n_query=3000, seed=1, device=DEV)
+    tr.step(batch)  # solver searches, packs
+    timing.enable(True)
+    loss, met = tr.step(batch)
+    ks = timing.collect()
+    timing.enable(False)
+    assert math.isfinite(float(loss)) and all(math.isfinite(float(v)) for v in met.values())
+    # per iteration: pool2x(net[1]), pool2x(net[0]), interp(net[2]), interp(net[1])  (update.py:118-128)
+    assert ks.get("pool2x", {}).get("count", 0) == 2 * 3 and ks.get("interp", {}).get("count", 0) == 2 * 3, {k: v["count"] for k, v in ks.items()}
+    # fp16 inputs are served by the kernels (cast in, cast back), not by a library fallback
+    x = torch.randn(1, 16, 12, 20, device=DEV, dtype=torch.float16, requires_grad=True)
+    y = U.pool2x(x)
+    assert y.dtype == torch.float16 and y.shape == (1, 16, 6, 10)
+    want = torch.nn.functional.avg_pool2d(x.float(), 3, stride=2, padding=1)
+    assert (y.float() - want).abs().max() < 2e-3
+    z = U.interp(x, torch.empty(1, 1, 24, 40))
+    want = torch.nn.functional.interpolate(x.float(), (24, 40), mode="bilinear", align_corners=True)
+    assert z.dtype == torch.float16 and (z.float() - want).abs().max() < 2e-3
+    (y.float().sum() + z.float().sum()).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
 
 
 @pytest.mark.parametrize("scope", ["grads", "step"])

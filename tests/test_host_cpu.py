@@ -74,6 +74,20 @@ def test_product_path_has_no_cpu_fallback():
         model(i1, i2, iters=1, test_mode=True, hr_coord=torch.zeros(1, 4, 2), scale=torch.ones(1, 1))
 
 
+def test_training_resamplers_have_no_library_fallback():
+    """Row a8 in training (pool2x / interp, update.py:94-102): a tensor the HIP path does not take is an ERROR, not a silent
+    ATen call (round-5 review item 8) — CPU tensors and integer dtypes are refused before any launch."""
+    from anystereo.nn import update as U
+    x = torch.randn(1, 8, 6, 10, requires_grad=True)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        U.pool2x(x)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        U.interp(x, torch.empty(1, 1, 12, 20))
+    src = open(os.path.join(ROOT, "any-stereo_amd", "anystereo", "nn", "update.py")).read()
+    body = src[src.index("def pool2x(x):"):src.index("class BasicMultiUpdateBlock")]
+    assert "F.avg_pool2d(" not in body and "F.interpolate(" not in body
+
+
 def test_state_dict_matches_reference(golden):
     """Parameter names and shapes are the reference's (captured by make_golden.py)."""
     import json

@@ -180,6 +180,22 @@ def test_whole_model_vs_reference(golden):
                 assert (p - g[f"pred_{i}"]).abs().mean().item() < 1e-3
 
 
+def test_preloop_tensors_vs_reference(golden):
+    """The tensors the GRU loop starts from — matching features, geometry encoding volume, initial disparity, hidden states, context
+    terms (continuous_IGEVstereo.py:245-276) — of the oracle model against the imported reference at 64x128 AND at 96x160 (a
+    non-square size whose 1/32 map is 3 x 5): pins the backbone WIRING the oracle shares with the product (oracle/model.py) at more
+    than one shape (round-5 review item 7)."""
+    from _preloop import capture_preloop, check_preloop
+    g = golden("preloop_igev")
+    model, synthetic_pair = _whole("igev")
+    for H, W in ((int(a), int(b)) for a, b in g["sizes"]):
+        img1, img2 = synthetic_pair(1, H, W, shift=6, seed=99)
+        coord = O.make_coord([H, W]).view(1, -1, 2)
+        cap = capture_preloop(model, img1, img2, coord, torch.tensor([[1.0]]))
+        worst = check_preloop(cap, g, f"{H}x{W}", 2e-4, "oracle")
+        print(f"[preloop oracle {H}x{W}] " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
 def test_model_options_vs_reference(golden):
     """The forward() branches evaluation.py can reach beyond the main G7 fixture (tests/golden/model_opts.npz, generated from the
     imported reference): `slow_fast_gru = True` (continuous_IGEVstereo.py:288-291, prune_raft_stereo.py:280-283), a `flow_init`

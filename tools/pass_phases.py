@@ -34,7 +34,14 @@ def phases(model, inputs, iters, reps=5):
     r = runs[len(runs) // 2]
     t0 = r["pass_begin"]
     r = {k: round(v - t0, 1) for k, v in r.items()}
-    out = {"markers_us": r, "pass_us": r["pass_end"], "pre_loop_us": r["loop_begin"], "loop_us": round(r["loop_end"] - r["loop_begin"], 1),
+    fine = sorted(((v, k) for k, v in r.items() if k.startswith("it")))
+    if fine:
+        f0 = fine[0][0]
+        print("loop stages (us since the first marked stage):", file=sys.stderr)
+        for v, k in fine:
+            print("  %8.1f  %s" % (v - f0, k), file=sys.stderr)
+    r = {k: v for k, v in r.items() if not k.startswith("it")}
+    out = {"loop_stages_us": {k: round(v - fine[0][0], 1) for v, k in fine} if fine else None, "markers_us": r, "pass_us": r["pass_end"], "pre_loop_us": r["loop_begin"], "loop_us": round(r["loop_end"] - r["loop_begin"], 1),
            "post_loop_us": round(r["pass_end"] - r["loop_end"], 1), "us_per_iter": round((r["loop_end"] - r["loop_begin"]) / iters, 2),
            "all_pass_us": [round(x["pass_end"] - x["pass_begin"], 1) for x in runs]}
     return out
