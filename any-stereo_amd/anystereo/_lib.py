@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("bs_only", C.c_int),
         ("tap_w", C.c_void_p), ("dual", C.c_int), ("src2", C.c_void_p), ("src2_bs", C.c_int), ("wpack2", C.c_void_p), ("bias2", C.c_void_p),
         ("out_coff2", C.c_int), ("out_bs_coff2", C.c_int),
+        ("h2", C.c_void_p), ("dual_act2", C.c_int), ("act2", C.c_int), ("out_b", C.c_void_p), ("out_bs_b", C.c_void_p),
     ]
 
 

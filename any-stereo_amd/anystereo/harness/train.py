@@ -303,7 +303,11 @@ class Trainer:
         # inside a capture
         graphs = self.__dict__.setdefault("_graphs", {})
         warm = self.__dict__.setdefault("_warm", {})
-        key = tuple(tuple(t.shape) if torch.is_tensor(t) else ("scalar", float(t)) for t in batch)
+        # ... and per state of the module's BUFFERS: a captured step holds constants derived from them (grad.conv_frozen_bn caches
+        # 1/sqrt(var + eps) of the frozen BatchNorm layers per buffer version), so load_state_dict() / a resume in the same process
+        # selects a fresh capture instead of replaying the old statistics.  Parameters are re-packed from live storage inside the
+        # graph and need no such key.  (Edits through `.data` bump no version counter: call `drop_graphs()` after those.)
+        key = tuple(tuple(t.shape) if torch.is_tensor(t) else ("scalar", float(t)) for t in batch) + (self._buffers_fingerprint(),)
         ent = graphs.pop(key, None)
         if ent is not None:
             graphs[key] = ent  # most recently used last
@@ -434,6 +438,25 @@ class Trainer:
                 self._graph = None
                 self.__dict__.get("_graphs", {}).clear()
         return out
+
+    def _buffers_fingerprint(self):
+        bufs = self.__dict__.get("_all_buffers")
+        if bufs is None:
+            # the FROZEN layers' statistics (BatchNorm2d, eval for the whole run: freeze_bn): the hourglass' BatchNorm3d layers
+            # normalise with batch statistics and update their running buffers every step — inside the graph once captured
+            bufs = self.__dict__["_all_buffers"] = [b for m in self.model.modules() if isinstance(m, torch.nn.BatchNorm2d)
+                                                    for b in (m.running_mean, m.running_var) if b is not None]
+        ver = ptr = 0
+        for i, t in enumerate(bufs):
+            ver += t._version
+            ptr ^= (t.data_ptr() + 0x9E3779B97F4A7C15 * i) & 0xFFFFFFFFFFFFFFFF
+        return (len(bufs), ver, ptr)
+
+    def drop_graphs(self):
+        """Forget every captured step (after edits the version counters do not see, e.g. through `.data`)."""
+        self._graph = None
+        self.__dict__.get("_graphs", {}).clear()
+        self.__dict__.get("_warm", {}).clear()
 
     def _on_gpu(self) -> bool:
         return next(self.model.parameters()).is_cuda

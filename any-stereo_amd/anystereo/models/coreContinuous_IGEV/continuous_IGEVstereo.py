@@ -96,9 +96,21 @@ class continuous_IGEVStereo(ContinuousStereoBase):
 
     def _context(self, image1):
         """Hidden-state initialisation and the per-level context terms (continuous_IGEVstereo.py:270-273)."""
-        cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
-        net_list = [torch.tanh(x[0]) for x in cnet_list]
-        inp_list = [torch.relu(x[1]) for x in cnet_list]
+        from ... import _lib as L
+        fuse = (B.fused_ok(image1, self.cnet) and getattr(self.cnet, "paired_heads", False)
+                and all(len(o) == 2 for o in (self.cnet.outputs04, self.cnet.outputs08, self.cnet.outputs16)))
+        if fuse:  # tanh (:271) and relu (:272) in the epilogue of the heads' last (paired) convolution
+            self.cnet.head_acts = (L.ACT_TANH, L.ACT_RELU)
+            try:
+                cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
+            finally:
+                self.cnet.head_acts = None
+            net_list = [x[0] for x in cnet_list]
+            inp_list = [x[1] for x in cnet_list]
+        else:
+            cnet_list = self.cnet(image1, num_layers=self.args.n_gru_layers)
+            net_list = [torch.tanh(x[0]) for x in cnet_list]
+            inp_list = [torch.relu(x[1]) for x in cnet_list]
         return net_list, [_plain_conv(self, conv, i) for i, conv in zip(inp_list, self.context_zqr_convs)]
 
     def _forward_impl(self, image1, image2, iters=12, flow_init=None, test_mode=False, hr_coord=None, scale=1.0, output_raw=None):

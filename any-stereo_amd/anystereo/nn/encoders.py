@@ -218,16 +218,65 @@ class MultiBasicEncoder(_Trunk):
             v = x
             x = x[: x.shape[0] // 2]
         tail = (v,) if dual_inp else ()
-        o04 = [self._head(f, x) for f in self.outputs04]
+        o04 = self._heads(self.outputs04, x)
         if num_layers == 1:
             return (o04,) + tail
         y = self.layer4(x)
-        o08 = [self._head(f, y) for f in self.outputs08]
+        o08 = self._heads(self.outputs08, y)
         if num_layers == 2:
             return (o04, o08) + tail
         z = self.layer5(y)
-        o16 = [self._head(f, z) for f in self.outputs16]
+        o16 = self._heads(self.outputs16, z)
         return (o04, o08, o16) + tail
+
+    # The two heads of a scale (hidden state | context, extractor.py:254-273) apply the same layer shapes to the same input: in
+    # inference each layer of the pair is ONE dual launch (as_conv_desc.dual with a residual and dense outputs per convolution)
+    # instead of two launches on the pre-loop's side branch — 7 launches per pass instead of 14, twice the blocks per launch on
+    # the 1/8 and 1/16 maps.  When the caller applies tanh / relu to the pair right away (continuous_IGEVstereo.py:271-272) the
+    # activations ride in the last launch's epilogue (`head_acts`).  Same arithmetic per convolution: results are bit-identical.
+    paired_heads = __import__("os").environ.get("ANYSTEREO_PAIRED_HEADS", "1") != "0"
+    head_acts = None  # (act of head 0, act of head 1) fused into the heads' last convolution, set by the caller for one forward
+
+    def _heads_plain(self, heads, x):
+        outs = [self._head(f, x) for f in heads]
+        if self.head_acts is not None:  # the caller asked for the activations: applied here when no epilogue can carry them
+            fn = {L.ACT_NONE: (lambda t: t), L.ACT_TANH: torch.tanh, L.ACT_RELU: torch.relu}
+            outs = [fn[a](o) for a, o in zip(self.head_acts, outs)]
+        return outs
+
+    def _heads(self, heads, x):
+        if not (self.paired_heads and len(heads) == 2 and _fused_ok(x, self) and ops.get_precision() == "split" and _bs_links()):
+            return self._heads_plain(heads, x)
+        fa, fb = heads
+        seq = isinstance(fa, nn.Sequential)
+        ca, cb = (fa[1], fb[1]) if seq else (fa, fb)
+        same = lambda m, n: (m.weight.shape == n.weight.shape and m.kernel_size == n.kernel_size and _conv_hip_ok(m) and _conv_hip_ok(n)
+                             and m.stride == (1, 1) and n.stride == (1, 1))
+        if isinstance(fa, nn.Sequential) != isinstance(fb, nn.Sequential) or not same(ca, cb):
+            return self._heads_plain(heads, x)
+        packs = self.__dict__.setdefault("_hip_packs", {})
+        pk = lambda c: packs.setdefault(id(c), ops.PackedConv())
+        x = x.contiguous()
+        b, _, hh, ww = x.shape
+        src_a = src_b = x
+        if seq:
+            ra, rb = fa[0], fb[0]
+            if not (isinstance(ra.norm1, nn.BatchNorm2d) and isinstance(rb.norm1, nn.BatchNorm2d) and ra.downsample is None
+                    and rb.downsample is None and same(ra.conv1, rb.conv1) and same(ra.conv2, rb.conv2)):
+                return self._heads_plain(heads, x)
+            c = ra.conv1.out_channels
+            ya, yb = ops.BS8.empty(b, c, hh, ww, x.device), ops.BS8.empty(b, c, hh, ww, x.device)
+            ops.conv2d([x], ra._pk1.get_folded(ra.conv1, ra.norm1), act=L.ACT_RELU, out_bs=ya, bs_only=True,
+                       dual={"src": x, "pack": rb._pk1.get_folded(rb.conv1, rb.norm1), "out_bs": yb})
+            za, zb = ops.BS8.empty(b, c, hh, ww, x.device), ops.BS8.empty(b, c, hh, ww, x.device)
+            # relu(x + relu(bn2(conv2 y))) per block; the blocks' results only feed the heads' last convolutions: blocked only
+            ops.conv2d([ya], ra._pk2.get_folded(ra.conv2, ra.norm2), act=L.ACT_RELU, h=x, out_bs=za, bs_only=True,
+                       dual={"src": yb, "pack": rb._pk2.get_folded(rb.conv2, rb.norm2), "h": x, "out_bs": zb})
+            src_a, src_b = za, zb
+        acts = self.head_acts or (L.ACT_NONE, L.ACT_NONE)
+        oa, ob = ops.conv2d([src_a], pk(ca).get([ca.weight], [ca.bias]), act=acts[0],
+                            dual={"src": src_b, "pack": pk(cb).get([cb.weight], [cb.bias]), "act": acts[1], "out": True})
+        return [oa, ob]
 
 
 def _plain_conv(mod: nn.Module, conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:

@@ -530,7 +530,10 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
     (LINEAR / GRU_Q: of out; GRU_ZR: of r*h) in channels [out_bs_coff, ...); with `bs_only` the fp32 form of that result is
     not written and None is returned in its place.
     dual = {"src": tensor | BS8, "pack": PackedConv, "out_coff": int, "out_bs_coff": int}: a second convolution of the same
-    shape in the same launch, writing its own channel window of out / out_bs (LINEAR epilogue, one source, no add / residual)."""
+    shape in the same launch, writing its own channel window of out / out_bs (LINEAR epilogue, one source, no add).
+    Optional keys: "h" (its residual; then `h` must be given too), "act" (its own activation), and "out" / "out_bs": DENSE outputs
+    of its own ([B,Cout,H,W] / BS8 of Cout channels, mirroring which of out / out_bs the first convolution writes) instead of a
+    channel window; with "out": True a fresh tensor is allocated.  Returns (out, out_second) then."""
     b, _, hin, win = srcs[0].shape
     if stride not in (1, 2):
         raise RuntimeError("conv2d: stride must be 1 or 2")
@@ -625,9 +628,38 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
         d.h, d.z, d.out = h.data_ptr(), z.data_ptr(), out.data_ptr()
     if dual is not None:
         s2, p2 = dual["src"], dual["pack"]
-        if (epilogue != L.EPI_LINEAR or len(srcs) != 1 or add is not None or h is not None or stride != 1
+        if (epilogue != L.EPI_LINEAR or len(srcs) != 1 or add is not None or stride != 1
                 or (p2.cin, p2.cout, p2.ks, p2.split) != (pack.cin, pack.cout, pack.ks, pack.split) or tuple(s2.shape) != tuple(srcs[0].shape)):
             raise RuntimeError("conv2d(dual): needs two LINEAR single-source convolutions of one shape")
+        h2 = dual.get("h")
+        if (h is None) != (h2 is None):
+            raise RuntimeError("conv2d(dual): a residual for both convolutions or for neither")
+        if h2 is not None:
+            _req(h2, "dual h")
+            if tuple(h2.shape) != (b, cout, hh, ww):
+                raise RuntimeError("conv2d(dual): residual h must be [B,Cout,H,W]")
+            d.h2 = h2.data_ptr()
+        if "act" in dual:
+            d.dual_act2, d.act2 = 1, int(dual["act"])
+        o2, obs2 = dual.get("out"), dual.get("out_bs")
+        if o2 is not None or obs2 is not None:
+            if (obs2 is not None) != (out_bs is not None) or (o2 is not None) != (out is not None):
+                raise RuntimeError("conv2d(dual): separate second outputs mirror the first convolution's (fp32 and / or blocked)")
+            if o2 is True:
+                o2 = torch.empty((b, cout, hh, ww), device=dev, dtype=torch.float32)
+            if o2 is not None:
+                _req(o2, "dual out")
+                if tuple(o2.shape) != (b, cout, hh, ww):
+                    raise RuntimeError("conv2d(dual): out must be [B,Cout,H,W]")
+                d.out_b = o2.data_ptr()
+            if obs2 is not None:
+                _req(obs2.t, "dual out_bs", torch.float16)
+                if tuple(obs2.shape) != (b, cout, hh, ww):
+                    raise RuntimeError("conv2d(dual): out_bs must hold [B,Cout,H,W]")
+                d.out_bs_b = obs2.t.data_ptr()
+            dual_second_out = o2
+        else:
+            dual_second_out = None
         if isinstance(s2, BS8):
             _req(s2.t, "dual src", torch.float16)
         else:
@@ -651,6 +683,8 @@ def conv2d(srcs: Sequence[torch.Tensor], pack: PackedConv, act: int = L.ACT_NONE
             d.ws, d.ws_elems = ws.data_ptr(), n_ws
     with _guard(dev):
         L.check(L.load().as_conv2d(C.byref(d), _stream()), "conv2d")
+    if dual is not None and (dual.get("out") is not None or dual.get("out_bs") is not None):
+        return out, dual_second_out
     return (out, out2) if epilogue == L.EPI_GRU_ZR else out
 
 

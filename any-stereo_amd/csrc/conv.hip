@@ -69,6 +69,14 @@ struct ConvParams {
   const float* wpack2;
   const float* bias2;
   int out_coff2, out_bs_coff8_2;
+  // ... optionally with its own residual (both convolutions or neither), activation and DENSE outputs of its own (dual_sep: out_b
+  // [B,Cout,H,W] / out_bs_b blocked, Cout channels) instead of a channel window of out / out_bs — the two heads of a context-network
+  // scale (extractor.py:254-273: same input, same shapes, different weights) as one launch per layer
+  const float* h2;
+  int act2;
+  int dual_sep;
+  float* out_b;
+  _Float16* out_bs_b;
   // AS_EPI_RELU_TAPS: [Cout][9] weights of a following 3x3, Cout -> 1 convolution whose per-tap channel reductions this
   // conv's epilogue accumulates instead of storing its own result (out = [B][n_tiles * 9][H][W])
   const float* tap_w;
@@ -118,6 +126,7 @@ __device__ __forceinline__ void as_bstore(__amdgpu_buffer_rsrc_t r, unsigned off
 struct EpiCtx {
   __amdgpu_buffer_rsrc_t r_add, r_out, r_h, r_z, r_bs, r_bsl;
   bool has_add, has_bs, skip_out;
+  int act;           // activation of this block's convolution (a dual launch's second one may have its own)
   int cvalid;        // valid output channels of this block's tile
   int cend;          // blocked copy: channels from the tile's first to the destination tensor's logical end (slots past it are zeroed;
                      // slots in [cvalid, cend) belong to another producer and are left untouched)
@@ -132,6 +141,8 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
   const int cvalid = min(p.Cout - n0, bn);
   const int recs = cvalid > 0 ? (int)((long long)cvalid * plane * 4) : 0;
   e.plane4 = (unsigned)(plane * 4);
+  e.act = second ? p.act2 : p.act;
+  const bool sep = second && p.dual_sep;  // the second convolution of a dual launch writes dense tensors of its own
   e.has_add = p.add != nullptr;
   const float* addp = p.add ? p.add + ((long long)b * p.add_ctot + p.add_coff + n0) * plane : p.out;
   e.r_add = __builtin_amdgcn_make_buffer_rsrc((void*)addp, 0, p.add ? recs : 0, 0x00020000);
@@ -145,10 +156,13 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
     e.r_h = e.r_out;
     e.r_z = e.r_out;
   } else if (EPI == AS_EPI_LINEAR) {
-    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + ((long long)b * p.out_ctot + (second ? p.out_coff2 : p.out_coff) + n0) * plane), 0, recs, 0x00020000);
+    float* outp = sep ? p.out_b + ((long long)b * p.Cout + n0) * plane
+                      : p.out + ((long long)b * p.out_ctot + (second ? p.out_coff2 : p.out_coff) + n0) * plane;
+    e.r_out = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, recs, 0x00020000);
     // optional residual (ResidualBlock tail, extractor.py:56-62): out = relu(h + act(...)); 0 records when absent
-    const float* res = p.h ? p.h + ((long long)b * p.Cout + n0) * plane : p.out;
-    e.r_h = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, p.h ? recs : 0, 0x00020000);
+    const float* hsel = second ? p.h2 : p.h;
+    const float* res = hsel ? hsel + ((long long)b * p.Cout + n0) * plane : outp;
+    e.r_h = __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, hsel ? recs : 0, 0x00020000);
     e.r_z = e.r_out;
   } else if (EPI == AS_EPI_GRU_ZR) {
     const int ch = p.Cout >> 1;
@@ -171,18 +185,19 @@ __device__ __forceinline__ EpiCtx make_epi_ctx(const ConvParams& p, int b, int n
   e.cend = cvalid;
   e.r_bs = e.r_out;
   e.r_bsl = e.r_out;
-  if (EPI != kEpiPartial && p.out_bs) {
+  if (EPI != kEpiPartial && (sep ? p.out_bs_b != nullptr : p.out_bs != nullptr)) {
     int c0 = n0;
     bool on = true;
     if (EPI == AS_EPI_GRU_ZR) { const int ch = p.Cout >> 1; on = n0 >= ch; c0 = n0 - ch; }
     if (on) {
       const int nblk = cvalid > 0 ? (cvalid + 7) / 8 : 0;
-      const int coff8 = second ? p.out_bs_coff8_2 : p.out_bs_coff8;
-      _Float16* dst = p.out_bs + (((long long)b * 2 * p.out_bs_c8tot + coff8 + (c0 >> 3)) * plane) * 8;
+      const int coff8 = sep ? 0 : (second ? p.out_bs_coff8_2 : p.out_bs_coff8);
+      const int c8tot = sep ? (p.Cout + 7) / 8 : p.out_bs_c8tot;
+      _Float16* dst = (sep ? p.out_bs_b : p.out_bs) + (((long long)b * 2 * c8tot + coff8 + (c0 >> 3)) * plane) * 8;
       e.r_bs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)((long long)nblk * plane * 16), 0x00020000);
-      e.r_bsl = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (long long)p.out_bs_c8tot * plane * 8), 0, (int)((long long)nblk * plane * 16), 0x00020000);
+      e.r_bsl = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (long long)c8tot * plane * 8), 0, (int)((long long)nblk * plane * 16), 0x00020000);
       e.has_bs = true;
-      e.cend = p.out_bs_ctot - (coff8 * 8 + c0);
+      e.cend = (sep ? p.Cout : p.out_bs_ctot) - (coff8 * 8 + c0);
       e.skip_out = p.bs_only != 0;
     }
   }
@@ -229,7 +244,7 @@ __device__ __forceinline__ void epi_finish(const ConvParams& p, const EpiCtx& e,
     if (EPI == kEpiPartial) {
       o = v[r];
     } else if (EPI == AS_EPI_LINEAR) {
-      o = act_apply(x, p.act);
+      o = act_apply(x, e.act);
       if (p.h) o = fmaxf(o + R.hv[i], 0.f);
     } else if (EPI == AS_EPI_GRU_ZR) {
       const float gte = 1.f / (1.f + expf(-x));
@@ -1639,7 +1654,7 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
         const float x = stage[col * BM + mt] + bias_s[col] + pav[k][j];
         float o;
         if (EPI == AS_EPI_LINEAR) {
-          o = act_apply(x, p.act);
+          o = act_apply(x, e.act);
           if (p.h) o = fmaxf(o + phv[k][j], 0.f);
         } else if (EPI == AS_EPI_GRU_ZR) {
           const float gte = 1.f / (1.f + expf(-x));
@@ -1902,6 +1917,11 @@ void conv_apply_dual(ConvParams& p, const as_conv_desc* d) {
   p.bias2 = d->bias2;
   p.out_coff2 = d->out_coff2;
   p.out_bs_coff8_2 = d->out_bs_coff2 / 8;
+  p.h2 = d->h2;
+  p.act2 = d->dual_act2 ? d->act2 : d->act;
+  p.dual_sep = (d->out_b || d->out_bs_b) ? 1 : 0;
+  p.out_b = d->out_b;
+  p.out_bs_b = reinterpret_cast<_Float16*>(d->out_bs_b);
 }
 
 }  // namespace
@@ -1984,14 +2004,27 @@ static int conv2d_dual_sequential(const as_conv_desc* d, void* stream) {
   if (rc != AS_OK) return rc;
   a.src[0] = d->src2; a.src_bs[0] = d->src2_bs; a.wpack = d->wpack2; a.bias = d->bias2;
   a.out_coff = d->out_coff2; a.out_bs_coff = d->out_bs_coff2;
+  a.h = d->h2;
+  if (d->dual_act2) a.act = d->act2;
+  if (d->out_b || d->out_bs_b) {  // dense outputs of its own
+    a.out = d->out_b; a.out_ctot = d->Cout; a.out_coff = 0;
+    a.out_bs = d->out_bs_b; a.out_bs_ctot = d->Cout; a.out_bs_coff = 0;
+    a.bs_only = (d->out_b == nullptr) ? 1 : 0;
+  }
+  a.h2 = nullptr; a.out_b = nullptr; a.out_bs_b = nullptr; a.dual_act2 = 0;
   return as_conv2d(&a, stream);
 }
 
 int as_conv2d(const as_conv_desc* d, void* stream) {
   AS_REQUIRE(d, AS_ERR_BAD_ARG, "conv2d: null descriptor");
   if (d->dual) {
-    AS_REQUIRE(d->n_src == 1 && d->epilogue == AS_EPI_LINEAR && !d->add && !d->h && (d->stride == 0 || d->stride == 1), AS_ERR_BAD_ARG,
-               "conv2d(dual): one source, LINEAR epilogue, no add / residual, stride 1");
+    AS_REQUIRE(d->n_src == 1 && d->epilogue == AS_EPI_LINEAR && !d->add && (d->stride == 0 || d->stride == 1), AS_ERR_BAD_ARG,
+               "conv2d(dual): one source, LINEAR epilogue, no add, stride 1");
+    AS_REQUIRE((d->h == nullptr) == (d->h2 == nullptr), AS_ERR_BAD_ARG, "conv2d(dual): a residual for both convolutions or for neither");
+    AS_REQUIRE(!d->dual_act2 || (d->act2 >= AS_ACT_NONE && d->act2 <= AS_ACT_LEAKY), AS_ERR_BAD_ARG, "conv2d(dual): act2=%d", d->act2);
+    AS_REQUIRE(!d->out_bs_b || (reinterpret_cast<uintptr_t>(d->out_bs_b) & 15) == 0, AS_ERR_BAD_ARG, "conv2d(dual): out_bs_b not 16-B aligned");
+    AS_REQUIRE(!(d->out_b || d->out_bs_b) || ((d->out_b != nullptr) == (d->out != nullptr && !d->bs_only) && (d->out_bs_b != nullptr) == (d->out_bs != nullptr)),
+               AS_ERR_BAD_ARG, "conv2d(dual): separate second outputs mirror the first convolution's (fp32 and / or blocked)");
     AS_REQUIRE(d->src2 && d->wpack2 && (reinterpret_cast<uintptr_t>(d->wpack2) & 15) == 0, AS_ERR_BAD_ARG, "conv2d(dual): null / misaligned src2 / wpack2");
     AS_REQUIRE(!d->src2_bs || (reinterpret_cast<uintptr_t>(d->src2) & 15) == 0, AS_ERR_BAD_ARG, "conv2d(dual): blocked src2 not 16-B aligned");
     AS_REQUIRE(d->out_coff2 >= 0 && d->out_bs_coff2 >= 0 && d->out_bs_coff2 % 8 == 0, AS_ERR_BAD_SHAPE, "conv2d(dual): bad second output window");

@@ -51,6 +51,29 @@ INFINITY_CACHE_MB = 256
 TIMED_BLOCKS = 3  # `value` is the median of this many timed blocks of `--steps` steps each
 
 
+_REAL_STDOUT = None  # the process's stdout as it was at start; fd 1 itself is pointed at stderr while the ranks work
+
+
+def claim_stdout():
+    """Rank 0 prints ONE JSON line on stdout — and nothing else may: RCCL writes a version banner to fd 1 when its first
+    communicator comes up, MIOpen / hipBLASLt may log there too.  fd 1 is therefore re-pointed at stderr for the life of the
+    process (native writes and stray prints end up in the log) and the line goes out through a duplicate of the original fd."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: dict):
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,7 +207,7 @@ def dry_main(a, rank, world):
         guard.done()
     if rank == 0:
         sys.stderr.write("bench.py: no GPU visible - dry run of the launch protocol over gloo; the hot path has no CPU fallback\n")
-        print(json.dumps({"metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)", "value": None,
+        emit(({"metric": "stereo pairs/sec (coreContinuous_IGEV inference, 32-iter GRU, 960x540)", "value": None,
                           "train_mode": train_mode,
                           "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                           "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -267,7 +290,7 @@ def dry_train_main(a, rank, world):
                    "exposed_allreduce_ms": round(ms_sync - ms_nosync, 3), "gradient_bytes": 4 * flat.numel(), "ddp": tr.ddp_mode}
     if rank == 0:
         sys.stderr.write("bench.py: no GPU visible - dry run of the training launch protocol over gloo; the hot path has no CPU fallback\n")
-        print(json.dumps({"metric": "train_samples_per_s", "value": None, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        emit(({"metric": "train_samples_per_s", "value": None, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": TRAIN_DTYPE, "data": "synthetic", "dry_run": True,
                           "config": {"workload": "training launch protocol only (no GPU visible; stand-in module)",
@@ -455,6 +478,7 @@ def train_mode_child(a, steps=5, warmup=4, timeout=420):
             "loss_finite": all(math.isfinite(v) for v in d["loss_first_last"]), "trainer": d["trainer"], "loss_scale": d["loss_scale"],
             "split_overflow_events": d["split_overflow"]["events"], "roofline": d["roofline"],
             "grad_bytes": d.get("grad_bytes"), "exchange_ms": d.get("exchange_ms"), "exchange_how": d.get("exchange_how"),
+            "reduced_precision": d.get("reduced_precision"),
             "how": "child process `bench.py --mode train --train-quick`, inputs resident, graphed gradient half + eager clip/AdamW",
             "child_wall_s": round(time.perf_counter() - t0, 1)}
 
@@ -509,7 +533,7 @@ class _LegWatchdog:
             line = dict(self.stash)
             if getattr(self, "key", "train_mode") == "train_mode":
                 line["train_mode"] = {"error": f"training leg timed out after {self.seconds:.0f} s"}
-            print(json.dumps(line), flush=True)
+            emit(line)
         os._exit(0 if (self.rank != 0 or self.stash is not None) else 3)
 
 
@@ -794,7 +818,12 @@ def train_main(a, rank, world, local):
         overlap = {"ms_per_step_with_allreduce": round(ms_sync, 2), "ms_per_step_no_sync": round(ms_nosync, 2),
                    "exposed_allreduce_ms": round(ms_sync - ms_nosync, 2), "gradient_bytes": nbytes,
                    "ddp": tr.ddp_mode}
-    roof = cpu = eager = None
+    roof = cpu = eager = reduced = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        try:
+            reduced = train_reduced_precision(a, args, batch, dev, losses)
+        except Exception as ex:  # never lose the headline line to the side measurement
+            reduced = {"error": repr(ex)[:300]}
     if rank == 0 and world == 1 and a.train_quick:
         roof = train_roofline(a, batch, dev)
     elif rank == 0 and world == 1 and not a.no_extras:
@@ -831,7 +860,7 @@ def train_main(a, rank, world, local):
             "split_overflow": {"policy": tr.overflow_policy, "check_every": tr.overflow_check_every,
                                "saturated_waves_at_end": tr._poll_overflow() if tr._on_gpu() else None,
                                "events": tr.overflow_events, "skipped_steps": tr.skipped_steps},
-            "eager_step": eager,
+            "eager_step": eager, "reduced_precision": reduced,
             "library": _lib.library_info(), "roofline": roof, "cpu_baseline": cpu})
     # The exchange probe comes LAST and is bounded: with one rank and no launcher it creates a 1-rank RCCL group of its own; if
     # that initialisation (or a collective) hangs on some box, rank 0 still prints the training line it already has
@@ -843,10 +872,43 @@ def train_main(a, rank, world, local):
     guard.done()
     if rank == 0:
         line.update(exchange_ms=exchange["exchange_ms"], exchange_how=exchange["how"])
-        print(json.dumps(line))
+        emit(line)
     if dist:
         td.barrier()
         td.destroy_process_group()
+
+
+def train_reduced_precision(a, args, batch, dev, split_losses):
+    """cfg 4 in the reference's OWN training arithmetic (it always trains under autocast + GradScaler,
+    train_continuous_IGEV.py:206,288: fp16 operands, fp32 accumulation): the same graphed step with the forward and data-gradient
+    convolutions in the one-MFMA mode (fp16 operands = the hi parts only, fp32 accumulate and storage; ops.fast_fp16), weight
+    gradients unchanged (bf16 hi + lo).  A second, labelled figure with its own tolerance (tests/test_hip_parity.py::
+    test_training_step_reduced_precision_vs_reference) — never the headline, whose split mode is WIDER than the reference's."""
+    from anystereo import ops
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.harness.train import Trainer
+    from anystereo.models import __models__
+    m = __models__["continuous_IGEVStereo"](args)
+    fill_module_deterministic(m, base_seed=1)
+    losses = []
+    with ops.fast_fp16(True):
+        tr = Trainer(m.to(dev), train_iters=a.train_iters, max_disp=args.max_disp)
+        for _ in range(max(4, a.warmup)):  # 3 eager steps + the capture, all inside the mode: the graph's launches carry it
+            losses.append(float(tr.step(batch)[0]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss, _ = tr.step(batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        losses.append(float(loss))
+    n = min(len(split_losses), len(losses)) - 1  # the warm-up steps both runs took from the same weights on the same batch
+    rel = [abs(x - y) / max(abs(y), 1e-12) for x, y in zip(losses[:n], split_losses[:n])]
+    return {"value": round(a.batch_per_gpu * a.steps / dt, 3), "unit": "samples/s", "ms_per_step": round(dt / a.steps * 1e3, 2), "steps": a.steps,
+            "dtype": "fp16 operands (1 MFMA per product) in forward + dgrad convolutions, fp32 accumulate and storage; wgrad 2-term bf16 split",
+            "graphed": bool(tr.use_graph), "loss_first_last": [round(losses[0], 4), round(losses[-1], 4)],
+            "max_rel_loss_diff_vs_split_over_warmup_steps": max(rel) if rel else None,
+            "note": "the reference's autocast arithmetic (train_continuous_IGEV.py:206,288); labelled second figure, never `value`"}
 
 
 def train_eager_step(a, args, batch, dev, n_cmp=6):
@@ -1432,7 +1494,7 @@ def infer_main(a, rank, world, local):
             "train_mode": train_mode,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        emit(line)
     if dist:
         td.barrier()
         td.destroy_process_group()
@@ -1637,6 +1699,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     global torch, RANK_CPUS
+    claim_stdout()
     RANK_CPUS = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))  # before torch / HIP start any thread
     import torch as _torch
     torch = _torch

@@ -223,6 +223,14 @@ typedef struct {
   const float* wpack2;
   const float* bias2;
   int out_coff2, out_bs_coff2;
+  /* Dual launch, round 6: the second convolution may carry its own residual (h2: both convolutions or neither), its own
+     activation (dual_act2 != 0: act2 instead of act) and DENSE outputs of its own — out_b [B,Cout,H,W] and / or out_bs_b (blocked,
+     Cout channels), mirroring which of out / out_bs the first one writes — instead of a channel window of out / out_bs: the two
+     heads of a context-network scale (extractor.py:254-273: ResidualBlock + conv per head on the same input) layer by layer. */
+  const float* h2;
+  int dual_act2, act2;
+  float* out_b;
+  void* out_bs_b;
 } as_conv_desc;
 int as_conv2d(const as_conv_desc* d, void* stream);
 /* floats of split-K scratch worth passing in as_conv_desc.ws for this problem (0: the problem is large enough) */

@@ -21,7 +21,7 @@ def pytest_configure(config):
 # Cheapest and most local first: kernel-level forward parity -> kernel-level backward / weight-gradient / fused-kernel parity ->
 # the torch.ops boundary -> the off-by-default upsampler variants -> whole-model and golden training steps -> the BASELINE
 # configurations at full size -> the tests that run bench.py as a child process.  (CPU tests keep their file order.)
-_WHOLE_MODEL = re.compile(r"test_(whole_model|training_step_vs_reference|training_step_is_bit_repeatable|training_batched_upsampler|"
+_WHOLE_MODEL = re.compile(r"test_(whole_model|training_step_vs_reference|training_step_reduced_precision|training_step_is_bit_repeatable|training_batched_upsampler|"
                           r"trainer_graphed_step|training_fused_liif_mlp_equals_layered|reduced_precision_mode|update_block_links_on_off)")
 _BACKWARD = re.compile(r"backward|wgrad|dgrad|deferred|training_fused_gates|mlp_tail_function|accumulates_over_iterations")
 _BENCH_CMD = re.compile(r"bench_command")

@@ -846,8 +846,9 @@ def _g8_limits(name):
     return elem, norm
 
 
-def _g8_run(name, mode):
-    """The G8 step of the product model: (loss, predictions, {parameter: gradient / loss scale}, model)."""
+def _g8_run(name, mode, fast16=False):
+    """The G8 step of the product model: (loss, predictions, {parameter: gradient / loss scale}, model).
+    fast16: the one-MFMA mode of the forward / dgrad convolutions (fp16 operands: the reference's autocast arithmetic)."""
     from anystereo import ops
     from anystereo.harness.metrics import sequence_loss_multiscale
     from anystereo.harness.synthetic import fill_module_deterministic, tiny_train_case
@@ -864,12 +865,13 @@ def _g8_run(name, mode):
     ls = 4096.0 if mode == "split" else 1.0
     try:
         ops.set_precision(mode)
-        res = model(img1.to(DEV), img2.to(DEV), iters=3, hr_coord=coord.to(DEV), scale=scale.to(DEV))
-        preds = res[1] if name == "igev" else res
-        gtd = gt.to(DEV)
-        loss, _ = sequence_loss_multiscale(preds, gtd, ((gtd < 512) & (gtd > 0)).float(), max_disp=args.max_disp)
-        (loss * ls).backward()
-        torch.cuda.synchronize()
+        with ops.fast_fp16(bool(fast16)):
+            res = model(img1.to(DEV), img2.to(DEV), iters=3, hr_coord=coord.to(DEV), scale=scale.to(DEV))
+            preds = res[1] if name == "igev" else res
+            gtd = gt.to(DEV)
+            loss, _ = sequence_loss_multiscale(preds, gtd, ((gtd < 512) & (gtd > 0)).float(), max_disp=args.max_disp)
+            (loss * ls).backward()
+            torch.cuda.synchronize()
     finally:
         torch.backends.cudnn.deterministic = prev
         ops.set_precision(prev_mode)
@@ -915,6 +917,33 @@ def test_training_step_vs_reference(name, mode):
         e = ((got - want).abs().max() / want.abs().max()).item()
         print(f"[G8 {name} {mode}] {n}: max |d| / max |g| = {e:.2e} (limit {lim_e[n]:.1e}, margin used {e / lim_e[n]:.2f})")
         close(got, want, rtol=lim_e[n], atol=1e-6 * want.abs().max().item(), what=n)
+
+
+@pytest.mark.parametrize("name", ["igev", "raft"])
+def test_training_step_reduced_precision_vs_reference(name):
+    """The G8 step in the REFERENCE's own training arithmetic (autocast: fp16 operands, fp32 accumulation;
+    train_continuous_IGEV.py:206,288) = the one-MFMA mode of the forward and data-gradient convolutions (ops.fast_fp16), against
+    the fp32 fixture of the imported reference.  A second arithmetic mode with its own, stated tolerance — what bench.py's
+    `train_mode.reduced_precision` leg runs; never the parity mode.  Tolerances: loss 5e-3 relative, last prediction 5e-2 px (the
+    inference mode's bar), gradient norms: median 2e-2 relative, and no tensor off by more than 0.1 of its norm unless the fp32
+    reference itself moves it under its own eps-level perturbations (G8 sensitivity > 1e-3)."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}.npz"))
+    s = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"train_{name}_sens.npz"))
+    loss, preds, grads = _g8_run(name, "split", fast16=True)
+    lrel = abs(loss.item() - float(z["loss"])) / abs(float(z["loss"]))
+    epe = (preds[-1].cpu() - torch.from_numpy(z["last_pred"])).abs().mean().item()
+    names = [str(n) for n in z["names"]]
+    assert sorted(grads) == names
+    norms = np.array([float(grads[n].double().norm()) for n in names])
+    live = z["norms"] >= 1e-6 * z["norms"].max()
+    rel = np.abs(norms - z["norms"])[live] / z["norms"][live]
+    stable = np.array([float(d) < 1e-3 for d in s["norm_dev"]])[live]
+    print(f"[G8 {name} reduced precision] loss rel {lrel:.2e}; last prediction EPE {epe:.2e} px; grad-norm rel: median {np.median(rel):.2e}, "
+          f"max over reference-stable tensors {rel[stable].max():.2e}, max {rel.max():.2e}")
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    assert lrel < 5e-3 and epe < 5e-2, (lrel, epe)
+    assert np.median(rel) < 2e-2 and rel[stable].max() < 0.1, (np.median(rel), rel[stable].max())
 
 
 @pytest.mark.parametrize("name", ["igev", "raft"])
@@ -1720,6 +1749,66 @@ def test_conv_dual_launch_equals_two_launches(h, w, precision):
         assert torch.equal(bs_got.t, bs_ref.t)
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 9, 14), (2, 17, 30), (1, 136, 240)])  # sequential fallback (split-K) / batch 2 / the fused grid
+def test_conv_dual_launch_residual_act_separate_outputs(b, h, w, precision):
+    """as_conv_desc.dual, round-6 form: the second convolution with its own residual (h2), its own activation (act2) and DENSE
+    outputs of its own (out_b / out_bs_b) == the two single launches, bit for bit — fp32 outputs, blocked outputs, same and
+    different sources: the paired heads of a context-network scale (nn/encoders.py::MultiBasicEncoder._heads)."""
+    from anystereo import _lib as Lb, ops
+    c = 128
+    x, xb = U((b, c, h, w), 511).to(DEV), U((b, c, h, w), 512).to(DEV)
+    pa = ops.PackedConv().get([(U((c, c, 3, 3), 513) * 0.05).to(DEV)], [U((c,), 514).to(DEV)])
+    pb = ops.PackedConv().get([(U((c, c, 3, 3), 515) * 0.05).to(DEV)], [U((c,), 516).to(DEV)])
+    ha, hb = U((b, c, h, w), 517).to(DEV), U((b, c, h, w), 518).to(DEV)
+    # (1) same source, residual on both, fp32 outputs, different activations
+    ra = ops.conv2d([x], pa, act=Lb.ACT_RELU, h=ha)
+    rb = ops.conv2d([x], pb, act=Lb.ACT_NONE, h=hb)
+    ga, gb = ops.conv2d([x], pa, act=Lb.ACT_RELU, h=ha, dual={"src": x, "pack": pb, "h": hb, "act": Lb.ACT_NONE, "out": True})
+    assert torch.equal(ga, ra) and torch.equal(gb, rb)
+    # (2) tanh | relu without residual, two sources (the heads' last convolutions)
+    ra, rb = ops.conv2d([x], pa, act=Lb.ACT_TANH), ops.conv2d([xb], pb, act=Lb.ACT_RELU)
+    ga, gb = ops.conv2d([x], pa, act=Lb.ACT_TANH, dual={"src": xb, "pack": pb, "act": Lb.ACT_RELU, "out": True})
+    assert torch.equal(ga, ra) and torch.equal(gb, rb)
+    close(ga, torch.tanh(ops.conv2d([x], pa)), 0, 5e-7, "tanh epilogue vs ATen tanh")
+    if precision == "split":
+        # (3) blocked outputs only, blocked second source, residual
+        xbb = ops.BS8.empty(b, c, h, w, DEV)
+        pid = ops.PackedConv().get([torch.eye(c, device=DEV).view(c, c, 1, 1).contiguous()], [None])
+        ops.conv2d([xb], pid, out_bs=xbb, bs_only=True)
+        ra_bs, rb_bs, ga_bs, gb_bs = (ops.BS8.empty(b, c, h, w, DEV) for _ in range(4))
+        ops.conv2d([x], pa, act=Lb.ACT_RELU, h=ha, out_bs=ra_bs, bs_only=True)
+        ops.conv2d([xbb], pb, act=Lb.ACT_RELU, h=hb, out_bs=rb_bs, bs_only=True)
+        ops.conv2d([x], pa, act=Lb.ACT_RELU, h=ha, out_bs=ga_bs, bs_only=True, dual={"src": xbb, "pack": pb, "h": hb, "out_bs": gb_bs})
+        assert torch.equal(ga_bs.t, ra_bs.t) and torch.equal(gb_bs.t, rb_bs.t)
+    with pytest.raises(RuntimeError, match="residual"):
+        ops.conv2d([x], pa, h=ha, dual={"src": x, "pack": pb, "out": True})
+
+
+def test_context_heads_paired_equals_separate():
+    """MultiBasicEncoder's heads per scale as dual launches (with tanh | relu in the last epilogue) == head by head with ATen's
+    tanh / relu behind them: the convolutions bit-identical, tanh within 1 ulp-scale of ATen's."""
+    from anystereo import _lib as Lb
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn.encoders import MultiBasicEncoder
+    net = MultiBasicEncoder(output_dim=[[128, 128, 128], [128, 128, 128]], norm_fn="batch", downsample=2).eval()
+    fill_module_deterministic(net, base_seed=3)
+    net = net.to(DEV)
+    x = (U((1, 3, 64, 96), 521) * 2).to(DEV)
+    with torch.no_grad():
+        net.paired_heads = False
+        want = net(x, num_layers=3)
+        net.paired_heads = True
+        got = net(x, num_layers=3)
+        net.head_acts = (Lb.ACT_TANH, Lb.ACT_RELU)
+        got_act = net(x, num_layers=3)
+        net.head_acts = None
+    for lv, (w_, g_, ga_) in enumerate(zip(want, got, got_act)):
+        for k in range(2):
+            assert torch.equal(g_[k], w_[k]), (lv, k)
+        close(ga_[0], torch.tanh(w_[0]), 0, 5e-7, f"hidden head, level {lv}")
+        assert torch.equal(ga_[1], torch.relu(w_[1]))
+
+
 @pytest.mark.parametrize("b,cin,cout,h,w", [(1, 128, 256, 136, 240), (2, 32, 100, 9, 14), (1, 16, 64, 24, 40)])
 def test_conv_relu_taps_epilogue(b, cin, cout, h, w):
     """AS_EPI_RELU_TAPS + as_tap_shift_sum(groups) == conv3x3(relu(conv3x3(x))) with a 1-channel second conv (DispHead)."""
@@ -2144,7 +2233,8 @@ def test_dwconv3x3_backward(b, c, h, w, stride):
     assert torch.equal(wt.grad, g1), "dwconv3x3 weight gradient is not bit-repeatable"
 
 @pytest.mark.parametrize("cin,cout,ks,bias", [(64, 64, 3, True), (32, 96, 1, False)])
-def test_conv_frozen_bn_backward(cin, cout, ks, bias):
+@pytest.mark.parametrize("mean_scale", [1.0, 30.0])
+def test_conv_frozen_bn_backward(cin, cout, ks, bias, mean_scale):
     """relu(bn(conv(x))) with a FROZEN BatchNorm2d under autograd (grad.conv_frozen_bn: the context network's residual blocks in the
     training step, extractor.py:10-62 with train_continuous_IGEV.py:189): the affine map folded into the convolution's weights by
     differentiable weight-sized operations — output and the gradients of x, W, bias, gamma, beta against the fp64 modules."""
@@ -2162,7 +2252,10 @@ def test_conv_frozen_bn_backward(cin, cout, ks, bias):
             if bias:
                 conv.bias.copy_(U((cout,), 811).to(DEV))
             bn.weight.copy_(U((cout,), 812, 0.5, 1.5).to(DEV)), bn.bias.copy_(U((cout,), 813).to(DEV))
-            bn.running_mean.copy_(U((cout,), 814).to(DEV)), bn.running_var.copy_(U((cout,), 815, 0.5, 2.0).to(DEV))
+            # mean_scale 30: |running_mean| / std up to ~40 — the regime in which the fold's gamma gradient,
+            # rs * (sum(dW' * W) - mean * sum(dy)), is a difference of two activation-sized sums |mean| / std times larger than
+            # itself (advisor, round 5): its error grows by that ratio over the ~5e-6 of the weight-gradient kernel
+            bn.running_mean.copy_((U((cout,), 814) * mean_scale).to(DEV)), bn.running_var.copy_(U((cout,), 815, 0.5, 2.0).to(DEV))
         holder = nn.Module()
         x = U((b, cin, h, w), 816).to(DEV).requires_grad_(True)
         gout = U((b, cout, h, w), 817).to(DEV)
@@ -2183,10 +2276,11 @@ def test_conv_frozen_bn_backward(cin, cout, ks, bias):
         want = {"y": yd, "d_x": xd.grad, "d_w": convd.weight.grad, "d_gamma": bnd.weight.grad, "d_beta": bnd.bias.grad}
         if bias:
             want["d_bias"] = convd.bias.grad
-        for k_, tol in (("y", 5e-6), ("d_x", 1e-5), ("d_w", 1e-4), ("d_gamma", 1e-4), ("d_beta", 1e-4), ("d_bias", 1e-4)):
+        for k_, tol in (("y", 5e-6), ("d_x", 1e-5), ("d_w", 1e-4), ("d_gamma", 1e-4 * max(1.0, mean_scale / 3.0)), ("d_beta", 1e-4), ("d_bias", 1e-4)):
             if k_ not in got:
                 continue
             err = (got[k_].double() - want[k_]).abs().max().item() / max(want[k_].abs().max().item(), 1e-30)
+            print(f"[conv_frozen_bn {cin}->{cout} k{ks} mean x{mean_scale:g}] {k_}: {err:.2e} (limit {tol:g})")
             assert err < tol, f"conv_frozen_bn {k_}: max err / max |ref| = {err:.2e} (limit {tol:g})"
     finally:
         ops.set_precision(prev)
