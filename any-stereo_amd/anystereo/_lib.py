@@ -114,10 +114,11 @@ SIGNATURES = {
     "as_liif_lowres_cl": (_i, [_pp, C.POINTER(C.c_int), _i, _vp, _vp, _i, _i, _i, _vp]),
     "as_liif_tail_image_bytes": (C.c_int64, []),
     "as_liif_tail_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "as_liif_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_tail": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "as_liif_query_rows": (_i, [_vp, _i, _i, _vp, _vp]),
     "as_liif_rows_pitch": (_i, []),
     "as_liif_rows_cl": (_i, [_pp, C.POINTER(C.c_int), _i, _vp, _i, _i, _i, _vp]),
-    "as_liif_tail_direct": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_liif_tail_direct": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "as_liif_mlp_bwd_image_bytes": (C.c_int64, []),
     "as_liif_mlp_bwd_pack": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "as_liif_mlp_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

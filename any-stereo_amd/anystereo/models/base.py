@@ -440,7 +440,7 @@ class ContinuousStereoBase(nn.Module):
                 # the stem_2x input of the upsampler does not change during the loop: its affinity + low-resolution first layer
                 # run on a branch of their own beside the loop instead of in front of the tail kernel after it
                 liif.precompute_static([[stem_4x, net_list[0]] if stem_4x is not None else [net_list[0]], [stem_2x]], 1,
-                                       ub._side_stream(disp.device, 2))
+                                       ub._side_stream(disp.device, 2), coord=hr_coord)
             self._mark("loop_begin")
             disp = self._iterate_pipelined(lookup_fn, net_list, inp_list, disp, coords, iters)
             self._mark("loop_end")

@@ -453,7 +453,7 @@ class liif_out_multi_scale_Training(nn.Module):
         with scope("liif_mlp_lowres"):
             return ops.liif_lowres_cl(parts + [aff], pk)
 
-    def precompute_static(self, feats_parts, slot, stream):
+    def precompute_static(self, feats_parts, slot, stream, coord=None):
         """Affinity + first MLP layer at low resolution of input `slot`, whose maps do not change during the GRU loop (stem_2x):
         issued on `stream` BEFORE the loop, so the post-loop upsampler only has the hidden-state input's chain in front of the
         tail kernel.  feats_parts as in `upsample_fused` (the other inputs are read for their channel counts only).  The result
@@ -480,11 +480,17 @@ class liif_out_multi_scale_Training(nn.Module):
             with scope("structure_feature"):
                 aff = ops.liif_affinity(parts)
             u = self._input_rows(slot, parts, aff, pk.get(w1, o_, c))
+            # the tail's query-order hint (ops.liif_query_rows) depends on the coordinates alone: found here, off the tail's path
+            row_len = None
+            if (coord is not None and ops.PATCH_ORDER and coord.is_cuda and coord.dtype == torch.float32 and coord.is_contiguous()
+                    and coord.dim() == 3):
+                row_len = ops.liif_query_rows(coord)
             done = torch.cuda.Event()
             done.record(stream)
         for t_ in parts:
             t_.record_stream(stream)
-        self.__dict__["_early_static"] = {"slot": slot, "src": src, "parts": parts, "u": u, "done": done, "pack": pk.get(w1, o_, c)}
+        self.__dict__["_early_static"] = {"slot": slot, "src": src, "parts": parts, "u": u, "done": done, "pack": pk.get(w1, o_, c),
+                                          "row_len": row_len, "coord": coord if row_len is not None else None}
 
     def clear_static(self):
         """Drop the early rows; JOINS their branch into the current stream (a forked branch that nobody waited for would leave a
@@ -522,6 +528,7 @@ class liif_out_multi_scale_Training(nn.Module):
             if (early is not None and i == early["slot"] and len(parts) == len(early["parts"])
                     and all(a is b_ for a, b_ in zip(early["src"], feats_parts[i])) and early["pack"] is pk):
                 main.wait_event(early["done"])
+                early["joined"] = True
                 early["u"].record_stream(main)
                 us.append(early["u"])
                 sizes.append(tuple(parts[0].shape[2:]))
@@ -550,9 +557,15 @@ class liif_out_multi_scale_Training(nn.Module):
             self._tail_pack = ops.LiifTailPack()
         pack = self._tail_pack.get(lin, rel_cols)
         direct1 = prep[1][2] if (len(prep) > 1 and self._direct_slot(1, prep[1][1])) else None
+        row_len = None
+        if early is not None and early.get("joined") and early.get("coord") is coord and early.get("row_len") is not None:
+            row_len = early["row_len"]  # its branch was joined above (main.wait_event(early["done"]))
+            row_len.record_stream(main)
+        elif ops.PATCH_ORDER:
+            row_len = ops.liif_query_rows(coord)
         with scope("liif_tail"):
             return ops.liif_tail(us[0], us[1] if len(us) > 1 else None, sizes, coord, pack, disp, scale_vec,
-                                 clamp_inplace=True, want_logits=want_logits, direct1=direct1)
+                                 clamp_inplace=True, want_logits=want_logits, direct1=direct1, row_len=row_len)
 
     def _mask_logits_train(self, feats, coord):
         """Differentiable form (liif.py:652-678).  With <= 2 sources the first Linear layer is applied at LOW resolution

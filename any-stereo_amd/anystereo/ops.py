@@ -1411,8 +1411,20 @@ class LiifTailPack:
         return self
 
 
+PATCH_ORDER = os.environ.get("ANYSTEREO_LIIF_PATCH_ORDER", "1") != "0"  # A/B: 0 = 32-query runs of one row (round-5 order)
+
+
+def liif_query_rows(coord: torch.Tensor) -> torch.Tensor:
+    """Device int32 [1]: the row length of a raster-ordered query grid [B,Q,2] (0: none) — as_liif_query_rows; no host sync."""
+    _req(coord, "coord")
+    out = torch.empty(1, device=coord.device, dtype=torch.int32)
+    with _guard(coord.device):
+        L.check(L.load().as_liif_query_rows(_p(coord), coord.shape[0], coord.shape[1], _p(out), _stream()), "liif_query_rows")
+    return out
+
+
 def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_inplace=True, want_logits=False,
-              direct1: Optional[LiifLowresPack] = None):
+              direct1: Optional[LiifLowresPack] = None, row_len: Optional[torch.Tensor] = None):
     """The per-query tail: gather + first-layer finish + MLP + softmax + convex upsampling -> [B,1,Q] (and the mask logits
     [B,9,Q] when asked).  u0 / u1: liif_lowres_cl results; sizes = [(H0,W0)] or [(H0,W0),(H1,W1)].
     direct1 = the LiifLowresPack of the second input's columns: u1 then is liif_rows_cl's [B, H1*W1, 48] raw rows and the tail
@@ -1434,14 +1446,18 @@ def liif_tail(u0, u1, sizes, coord, pack: LiifTailPack, disp, scale=None, clamp_
             raise RuntimeError("liif_tail: scale must hold one value per batch element")
     out = torch.empty((b, 1, q), device=coord.device, dtype=torch.float32)
     logits = torch.empty((b, 9, q), device=coord.device, dtype=torch.float32) if want_logits else None
+    if row_len is None and PATCH_ORDER:
+        row_len = liif_query_rows(coord)  # order hint only (reads the coordinates before the tail clamps them in place)
+    if row_len is not None and (row_len.dtype != torch.int32 or not row_len.is_cuda):
+        raise RuntimeError("liif_tail: row_len must be a CUDA int32 tensor")
     with _guard(coord.device):
         if direct1 is not None:
             L.check(L.load().as_liif_tail_direct(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(direct1.image), _p(disp), _p(scale),
                                                  _p(out), _p(logits), b, q, h0, w0, h1, w1, disp.shape[2], disp.shape[3],
-                                                 1 if clamp_inplace else 0, _stream()), "liif_tail_direct")
+                                                 1 if clamp_inplace else 0, _p(row_len), _stream()), "liif_tail_direct")
         else:
             L.check(L.load().as_liif_tail(_p(u0), _p(u1), _p(coord), _p(pack.image), _p(disp), _p(scale), _p(out), _p(logits), b, q,
-                                          h0, w0, h1, w1, disp.shape[2], disp.shape[3], 1 if clamp_inplace else 0, _stream()),
+                                          h0, w0, h1, w1, disp.shape[2], disp.shape[3], 1 if clamp_inplace else 0, _p(row_len), _stream()),
                     "liif_tail")
     return (out, logits) if want_logits else out
 

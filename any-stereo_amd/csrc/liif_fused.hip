@@ -484,6 +484,12 @@ struct TailParams {
   // > 0: u[1] holds B1 batch elements and query batch b reads element b % B1 (training: the loop-invariant second input is
   // shared by the n evaluations (iteration, sample) of one batched call, models/base.py::_upsample_batched)
   int B1;
+  // Query ORDER hint (device memory, may be null): the row length R of a raster-ordered query grid (as_liif_query_rows).  With a
+  // sensible R the waves of a block take the SAME 32-column tile of consecutive query rows (a 4- or 8-row x 32-column patch per
+  // block step) instead of 32-query runs of one row each: the rows of the low-resolution tables a patch shares (one 1/4-resolution
+  // row per 4 query rows at scale 1) are fetched once per block step instead of once per block that happens to pass by.  Any
+  // value is a valid order — every query is processed exactly once either way — so the hint cannot change a result.
+  const int* row_len;
 };
 constexpr int kDirectCP = 48;                       // row pitch (floats) of a direct source: 3 k-steps
 constexpr int kDirectKS = kDirectCP / 16;
@@ -633,9 +639,30 @@ __global__ __launch_bounds__(DIRECT1 ? 512 : 256, DIRECT1 ? 1 : 2) void liif_tai
   float* __restrict__ outp = p.out;
   float* __restrict__ logitsp = p.logits;
 
-  const long long tile0 = gw * p.tpw;
-  if (tile0 >= p.tiles) return;
-  const int ntile = (int)min((long long)p.tpw, (long long)p.tiles - tile0);
+  // order of the queries over (block, wave, step): raster patches when the caller's hint describes a grid, 32-query runs else.
+  // All of it is wave-uniform 32-bit scalar arithmetic: one division per wave, then increments.
+  constexpr int G = NT / 64;  // waves per block = query rows per patch
+  int R = 0, rows = 0, ct_n = 1, rg = 0, ct = 0;
+  if (p.row_len) R = __builtin_amdgcn_readfirstlane(*p.row_len);
+  const bool patch = R >= 32 && R <= (1 << 20) && p.total < (1ll << 31) && (int)p.total % R == 0;
+  long long tile0;
+  int ntile;
+  if (patch) {
+    rows = (int)p.total / R;
+    ct_n = (R + 31) >> 5;
+    const int steps_total = ((rows + G - 1) / G) * ct_n;           // patches of G rows x 32 columns, row-major
+    const int per = (steps_total + nb - 1) / nb;                   // consecutive patches per block
+    const int s0 = mapped * per;
+    if (s0 >= steps_total) return;
+    ntile = min(per, steps_total - s0);
+    rg = s0 / ct_n;
+    ct = s0 - rg * ct_n;
+    tile0 = 0;
+  } else {
+    tile0 = gw * p.tpw;
+    if (tile0 >= p.tiles) return;
+    ntile = (int)min((long long)p.tpw, (long long)p.tiles - tile0);
+  }
   for (int ti = 0; ti < ntile; ++ti) {
     // the weight image is re-read from LDS for every tile: an opaque zero offset keeps the compiler from hoisting the 56
     // fragment reads (224 registers) out of the tile loop
@@ -646,8 +673,17 @@ __global__ __launch_bounds__(DIRECT1 ? 512 : 256, DIRECT1 ? 1 : 2) void liif_tai
     const float* bias = reinterpret_cast<const float*>(smem + kFragBlocks * 1024) + opaque;
     TileCtx cur;
     {
-      long long t = (tile0 + ti) * 32 + c;
-      const bool valid = t < p.total;
+      long long t;
+      bool valid;
+      if (patch) {
+        const int row = rg * G + wave, col = ct * 32 + c;
+        valid = row < rows && col < R;
+        t = (long long)row * R + col;
+        if (++ct == ct_n) { ct = 0; ++rg; }
+      } else {
+        t = (tile0 + ti) * 32 + c;
+        valid = t < p.total;
+      }
       if (!valid) t = p.total - 1;
       tile_prepare<NSRC, DIRECT1>(p, u0p, u1p, dispp, t, valid, coordp[t * 2], coordp[t * 2 + 1], half, amax, cur);
       tile_first_gather<NSRC, DIRECT1>(cur, amax);
@@ -1199,6 +1235,30 @@ __global__ __launch_bounds__(256) void liif_rows_cl_kernel(RowsParams p) {
   *reinterpret_cast<float4*>(p.out + pix * kDirectCP + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// The row length of a raster-ordered query grid, found on the device (no host synchronisation; capturable): the first index at
+// which the row coordinate changes, accepted when the column coordinate restarts there and the row repeats with that period.
+// 0 = no such structure (random / sorted training queries).  One block; scans at most the first 2^16 queries.
+__global__ __launch_bounds__(256) void liif_query_rows_kernel(const float* __restrict__ coord, long long total, int* __restrict__ out) {
+  __shared__ int first;
+  if (threadIdx.x == 0) first = 0x7FFFFFFF;
+  __syncthreads();
+  const float r0 = coord[0];
+  const long long lim = total < 65536 ? total : 65536;
+  for (long long i = 1 + threadIdx.x; i < lim; i += 256)
+    if (coord[2 * i] != r0) { atomicMin(&first, (int)i); break; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int R = first == 0x7FFFFFFF ? 0 : first;
+    if (R > 0) {
+      const bool restarts = coord[2ll * R + 1] == coord[1];                                   // column of row 1 = column of row 0
+      const bool periodic = 2ll * R >= total || coord[2ll * (2ll * R)] != coord[2ll * R];     // row 2 differs from row 1
+      const bool whole = 2ll * R - 1 >= total || coord[2ll * (2ll * R - 1)] == coord[2ll * R];  // row 1 lasts R queries
+      if (!(restarts && periodic && whole)) R = 0;
+    }
+    *out = R;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1317,24 +1377,31 @@ int as_liif_rows_cl(const float* const* srcs, const int* channels, int n_src, fl
 
 static int liif_tail_impl(const float* u0, const float* u1, float* coord, const void* image, const void* image1, const float* disp,
                           const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
-                          int clamp_inplace, void* stream);
+                          int clamp_inplace, const int* row_len, void* stream);
 
 int as_liif_tail(const float* u0, const float* u1, float* coord, const void* image, const float* disp, const float* scale,
                  float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd, int clamp_inplace,
-                 void* stream) {
-  return liif_tail_impl(u0, u1, coord, image, nullptr, disp, scale, out, logits, B, Q, H0, W0, H1, W1, Hd, Wd, clamp_inplace, stream);
+                 const int* row_len, void* stream) {
+  return liif_tail_impl(u0, u1, coord, image, nullptr, disp, scale, out, logits, B, Q, H0, W0, H1, W1, Hd, Wd, clamp_inplace, row_len, stream);
 }
 
 int as_liif_tail_direct(const float* u0, const float* rows1, float* coord, const void* image, const void* image1, const float* disp,
                         const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
-                        int clamp_inplace, void* stream) {
+                        int clamp_inplace, const int* row_len, void* stream) {
   AS_REQUIRE(rows1 && image1, AS_ERR_BAD_ARG, "liif_tail_direct: null rows / fragment image of the second input");
-  return liif_tail_impl(u0, rows1, coord, image, image1, disp, scale, out, logits, B, Q, H0, W0, H1, W1, Hd, Wd, clamp_inplace, stream);
+  return liif_tail_impl(u0, rows1, coord, image, image1, disp, scale, out, logits, B, Q, H0, W0, H1, W1, Hd, Wd, clamp_inplace, row_len, stream);
+}
+
+int as_liif_query_rows(const float* coord, int B, int Q, int* row_len, void* stream) {
+  AS_REQUIRE(coord && row_len, AS_ERR_BAD_ARG, "liif_query_rows: null pointer");
+  AS_REQUIRE(B > 0 && Q > 0, AS_ERR_BAD_ARG, "liif_query_rows: non-positive size");
+  hipLaunchKernelGGL(liif_query_rows_kernel, dim3(1), dim3(256), 0, as::as_stream(stream), coord, (long long)B * Q, row_len);
+  return as::check_launch("liif_query_rows");
 }
 
 static int liif_tail_impl(const float* u0, const float* u1, float* coord, const void* image, const void* image1, const float* disp,
                           const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
-                          int clamp_inplace, void* stream) {
+                          int clamp_inplace, const int* row_len, void* stream) {
   AS_REQUIRE(u0 && coord && image && disp && out, AS_ERR_BAD_ARG, "liif_tail: null pointer");
   AS_REQUIRE(B > 0 && Q > 0 && H0 > 0 && W0 > 0 && Hd > 0 && Wd > 0, AS_ERR_BAD_ARG, "liif_tail: non-positive size");
   AS_REQUIRE(!u1 || (H1 > 0 && W1 > 0), AS_ERR_BAD_ARG, "liif_tail: second source without a size");
@@ -1352,6 +1419,7 @@ static int liif_tail_impl(const float* u0, const float* u1, float* coord, const 
   AS_REQUIRE(tiles < 2147483647ll, AS_ERR_BAD_SHAPE, "liif_tail: too many queries");
   p.tiles = (int)tiles;
   p.image1 = (const _Float16*)image1;
+  p.row_len = row_len;
   // 2 blocks of 4 waves per CU (LDS: 2 x 66 KB weight images) — or one block of 8 waves around one 90 KB image pair (direct
   // second input); a wave walks `tpw` consecutive tiles
   const long long waves = 256ll * 2 * 4;

@@ -1449,6 +1449,18 @@ def infer_main(a, rank, world, local):
                 del r1, m1, o1
             except Exception as ex:
                 others["cfg1"] = {"error": repr(ex)}
+        pass_phases = None
+        if extras and run.graph:
+            # where a replayed pass spends its time, from marker kernels inside the graph (no profiler: rocprofv3's interception
+            # serialises the pre-loop's two branches and reports 5.6 ms for what takes 3.9 ms, profiles/r06_pass_phases_preloop_ab.txt)
+            try:
+                from anystereo.harness.phases import phases
+                ph = phases(model, (run.i1, run.i2, run.coord, run.scale), wl.iters, reps=5)
+                pass_phases = {"pre_loop_wall_ms": round(ph["pre_loop_us"] / 1e3, 3), "loop_ms": round(ph["loop_us"] / 1e3, 3),
+                               "post_loop_ms": round(ph["post_loop_us"] / 1e3, 3), "ms_per_gru_iter_in_graph": round(ph["us_per_iter"] / 1e3, 4),
+                               "pass_ms": round(ph["pass_us"] / 1e3, 3), "markers_us": ph["markers_us"], "how": ph["how"]}
+            except Exception as ex:
+                pass_phases = {"error": repr(ex)[:300]}
         train_mode = train_mode_n
         if train_mode is None and extras and not dist and wl.name == "cfg2" and not a.no_train_mode:
             # this process is idle on the GPU now: the child has the chip to itself
@@ -1477,6 +1489,7 @@ def infer_main(a, rank, world, local):
                      "torch_threads": torch.get_num_threads(), **telemetry},
             "library": _lib.library_info(),
             "ms_per_gru_iter": None if ms_iter is None else round(ms_iter, 4),
+            "pass_phases": pass_phases,
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "roofline_source": ("HIP events on the launch stream around each hot-kernel launch, " +
                                 ("2 eager passes of the same workload right after the timed hipGraph replays" if run.graph

@@ -379,12 +379,18 @@ int as_liif_tail_pack(const float* wrel, const float* b1, const float* w2, const
                       const float* w4, const float* b4, int n_src, void* image, void* stream);
 int as_liif_tail(const float* u0, const float* u1, float* coord, const void* image, const float* disp, const float* scale,
                  float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd, int clamp_inplace,
-                 void* stream);
+                 const int* row_len, void* stream);
+/* Query ORDER hint for as_liif_tail / as_liif_tail_direct (round 6): *row_len (device memory) = the row length of a raster-ordered
+ * query grid (make_coord, liif.py:27-45, flattened row-major as evaluation.py:67-89 builds hr_coord), found on the device without a
+ * host synchronisation — the first index where the row coordinate changes, accepted when the grid structure repeats — or 0.  The
+ * tail then walks 4 (8) query rows x 32 columns per block step, so the low-resolution rows a patch shares are fetched once
+ * (HBM-side traffic of the tail at 960x540: 200 -> ~100 MB).  row_len may be NULL.  Any value yields the same results. */
+int as_liif_query_rows(const float* coord, int B, int Q, int* row_len, void* stream);
 int as_liif_rows_pitch(void);
 int as_liif_rows_cl(const float* const* srcs, const int* channels, int n_src, float* out, int B, int H, int W, void* stream);
 int as_liif_tail_direct(const float* u0, const float* rows1, float* coord, const void* image, const void* image1, const float* disp,
                         const float* scale, float* out, float* logits, int B, int Q, int H0, int W0, int H1, int W1, int Hd, int Wd,
-                        int clamp_inplace, void* stream);
+                        int clamp_inplace, const int* row_len, void* stream);
 
 /* Training of the per-query MLP (liif.py:9-25, :644-678 under autograd; train_continuous_IGEV.py:214-239) without per-query
  * activations saved by the forward.

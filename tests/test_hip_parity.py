@@ -1961,6 +1961,46 @@ def test_liif_fused_tail_vs_staged(two, b, h, w, s, nq):
     up.float().to(DEV)
 
 
+@pytest.mark.parametrize("b,h,w,s", [(1, 17, 29, 1.0), (2, 9, 13, 2.95), (1, 24, 40, 1.5), (3, 8, 10, 1.0), (1, 34, 60, 2.0)])
+def test_liif_tail_patch_order_is_bit_identical(b, h, w, s, monkeypatch):
+    """The tail's raster-patch query order (as_liif_query_rows: row length found on the device; waves of a block share a 32-column
+    tile of consecutive query rows) against the round-5 order (32-query runs): every query is processed once either way and a
+    query's result depends on its own operand column only, so disparities and logits must be BIT-identical — ragged row lengths
+    (R % 32 != 0), row counts that do not fill the last patch, batch > 1 (patches straddling batch elements), both tail forms.
+    Random / permuted queries: the detector answers 0 and the old order runs."""
+    from anystereo import ops
+    up = _liif_module(seed=17, two=True)
+    x4 = U((b, 176, h, w), 221, -1.5, 1.5).to(DEV)
+    x2 = U((b, 32, 2 * h, 2 * w), 222, -1.5, 1.5).to(DEV)
+    hq, wq = round(4 * h * s), round(4 * w * s)
+    grid = O.make_coord([hq, wq])
+    disp = U((b, 1, h, w), 224, 0.0, 40.0).to(DEV)
+    sv = torch.full((b,), float(s), device=DEV)
+    parts = [[x4[:, :48].contiguous(), x4[:, 48:].contiguous()], [x2]]
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        with torch.no_grad():
+            coord = grid.view(1, -1, 2).repeat(b, 1, 1).contiguous().to(DEV)
+            assert int(ops.liif_query_rows(coord).item()) == wq
+            cropped = grid.view(hq, wq, 2)[2:-1, 3:-2].reshape(1, -1, 2).repeat(b, 1, 1).contiguous().to(DEV)  # pad_for_multi_train's crop
+            assert int(ops.liif_query_rows(cropped).item()) == wq - 5
+            perm = torch.argsort(U((hq * wq,), 225, 0.0, 1.0))
+            shuffled = grid.reshape(-1, 2)[perm].view(1, -1, 2).repeat(b, 1, 1).contiguous().to(DEV)
+            assert int(ops.liif_query_rows(shuffled).item()) in (0, 1)  # no raster structure (1: a single-query "row", never used)
+            for direct in (False, True):
+                up.direct_second_input = direct
+                for cd in (coord, cropped, shuffled):
+                    monkeypatch.setattr(ops, "PATCH_ORDER", True)
+                    o1, l1 = up.upsample_fused(parts, cd.clone(), disp, sv, want_logits=True)
+                    monkeypatch.setattr(ops, "PATCH_ORDER", False)
+                    o0, l0 = up.upsample_fused(parts, cd.clone(), disp, sv, want_logits=True)
+                    assert torch.equal(o1, o0) and torch.equal(l1, l0), (direct, tuple(cd.shape))
+    finally:
+        up.direct_second_input = False
+        ops.set_precision(prev)
+
+
 @pytest.mark.parametrize("b,h,w,s,nq", [(1, 17, 29, 1.0, None), (2, 9, 13, 2.95, 777), (1, 24, 40, 1.5, None)])
 def test_liif_tail_direct_second_input(b, h, w, s, nq):
     """The tail with the second input handed over as raw channels-last rows (its first-layer product taken per query,
