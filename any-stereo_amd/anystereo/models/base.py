@@ -78,6 +78,23 @@ class ContinuousStereoBase(nn.Module):
 
     stamp_iters = (15, 16)  # GRU iterations whose inner stages are marked too (two consecutive ones: a full period)
 
+    def _pixel_grid(self, b, h, w, device):
+        """The reference's `coords` argument of the lookup (x index of every pixel, continuous_IGEVstereo.py:279): a constant of
+        the shape — built once per (shape, device) OUTSIDE a capture (the forward's eager warm-up passes) and reused, so the
+        replayed graph carries no arange / cast / repeat launches between the cost aggregation and the loop.  The HIP lookup
+        regenerates the grid itself (`_as_pixel_grid`); callers that substitute their own lookup read the tensor."""
+        cache = self.__dict__.setdefault("_pixel_grids", {})
+        key = (b, h, w, str(device))
+        g = cache.get(key)
+        if g is None:
+            g = torch.arange(w, device=device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
+            g._as_pixel_grid = True  # the kernels regenerate this grid: mark it so the lookup need not compare it
+            if not (g.is_cuda and torch.cuda.is_current_stream_capturing()):  # a capture's allocations belong to its graph
+                if len(cache) > 8:
+                    cache.clear()
+                cache[key] = g
+        return g
+
     # ---- hot-path hooks (HIP) ------------------------------------------------------------------
     def _hot_update(self, net_list, inp_list, corr, disp, **flags):
         return self.update_block(net_list, inp_list, corr, disp, **flags)
@@ -193,6 +210,7 @@ class ContinuousStereoBase(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._drop_graphs()
+        self.__dict__.pop("_pixel_grids", None)
         return super()._apply(fn, *a, **k)
 
     def _reduced_precision(self, image1) -> bool:

@@ -87,6 +87,12 @@ class continuous_IGEVStereo(ContinuousStereoBase):
     # which branch of the forked pre-loop is ISSUED first (the feature trunk on the main stream, or the stems + context network on
     # the side stream): same kernels, same dependencies, bit-identical results — only the node order of the captured graph
     trunk_first = os.environ.get("ANYSTEREO_TRUNK_FIRST", "0") != "0"
+    # (with trunk_first) the context network — the branch's heavy full-resolution convolutions — starts only when the feature trunk
+    # is done: the trunk's ~60 short dependent launches then run beside the light stems only, the context network beside the
+    # cost aggregation.  Measured: see DESIGN.md §0 (round 6)
+    context_after_trunk = os.environ.get("ANYSTEREO_CONTEXT_AFTER_TRUNK", "0") != "0"
+    # ... or when the trunk has passed one of its stages (nn/encoders.py::Feature.forward: "block0" .. "deconv16_8"): "" = no wait
+    context_after_stage = os.environ.get("ANYSTEREO_CONTEXT_AFTER_STAGE", "")
 
     def _stems_fwd(self, image):
         """(stem_1x | None, stem_2x, stem_4x) of one image batch (continuous_IGEVstereo.py:247-256)."""
@@ -118,16 +124,20 @@ class continuous_IGEVStereo(ContinuousStereoBase):
         G.begin_forward()  # deferred-gradient anchors are scoped to this forward (grad.py)
         a = self.args
         self._mark("pass_begin")
-        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        fast = B.fused_ok(image1, self) and image2.dtype == image1.dtype and image2.shape == image1.shape
+        if fast:
+            # inference: left and right image as ONE batch through the (per-sample) feature net, stems and descriptor head — same
+            # arithmetic per sample, half the launches, twice the blocks per launch.  The pair is concatenated FIRST and normalised
+            # once, in place ((x / 255) * 2 - 1 per element, the reference's operations, :242-243): 4 launches instead of 7 in front
+            # of both pre-loop branches
+            n = image1.shape[0]
+            both = torch.cat((image1, image2), 0).div_(255.0).mul_(2).sub_(1.0)
+            image1, image2 = both[:n], both[n:]
+        else:
+            image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+            image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         with torch.autocast("cuda", enabled=bool(a.mixed_precision) and image1.is_cuda and not self._reduced_precision(image1)):
-            fast = B.fused_ok(image1, self)
             side = None
-            if fast:
-                # inference: left and right image as ONE batch through the (per-sample) feature net, stems and
-                # descriptor head — same arithmetic per sample, half the launches, twice the blocks per launch
-                n = image1.shape[0]
-                both = torch.cat((image1, image2), 0)
             if fast and self.parallel_context and image1.is_cuda:
                 # the stems and the context network do not depend on the feature trunk, and most of the trunk / cost-aggregation
                 # kernels at 1/8 .. 1/32 resolution leave CUs idle: run them on the second stream (captured as a parallel
@@ -139,7 +149,20 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                     # short kernels go first, the second branch forks off the point BEFORE them (an event, not wait_stream)
                     forked = torch.cuda.Event()
                     forked.record(main)
-                    feats = self.feature(both)
+                    self._mark("trunk_begin")
+                    stage_ev = {}
+
+                    def on_stage(name, want=self.context_after_stage):
+                        if name == want:
+                            stage_ev[name] = torch.cuda.Event()
+                            stage_ev[name].record(main)
+                            self._mark("trunk_" + name)
+                    feats = self.feature(both, on_stage=on_stage if self.context_after_stage else None)
+                    self._mark("trunk_end")
+                    trunk_done = stage_ev.get(self.context_after_stage)
+                    if trunk_done is None:
+                        trunk_done = torch.cuda.Event()
+                        trunk_done.record(main)
                     side.wait_event(forked)
                 else:
                     side.wait_stream(main)
@@ -149,6 +172,8 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                         self._mark("stems_end")
                         stems_done = torch.cuda.Event()
                         stems_done.record(side)
+                    if self.trunk_first and (self.context_after_trunk or self.context_after_stage):
+                        side.wait_event(trunk_done)
                     net_list, ctx_list = self._context(image1)
                     self._mark("context_end")
             if fast:
@@ -202,8 +227,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
 
         geo_fn = self._hot_lookup_fn(match_left, match_right, geo_encoding_volume)
         b, c, h, w = match_left.shape
-        coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
-        coords._as_pixel_grid = True  # the kernels regenerate this grid: mark it so the lookup need not compare it
+        coords = self._pixel_grid(b, h, w, match_left.device)
         disp, disp_up, disp_preds = self._iterate(geo_fn, net_list, inp_list, init_disp.float(), coords, iters, test_mode,
                                                   stem_4x, stem_2x, hr_coord, scale, stem_1x=stem_1x)
         if test_mode:

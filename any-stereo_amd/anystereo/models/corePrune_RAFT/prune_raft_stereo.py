@@ -110,8 +110,7 @@ class continuous_RaftStereo(ContinuousStereoBase):
 
         corr_fn = self._hot_lookup_fn(match_left, match_right)
         b, c, h, w = match_left.shape
-        coords = torch.arange(w, device=match_left.device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
-        coords._as_pixel_grid = True  # the kernels regenerate this grid: mark it so the lookup need not compare it
+        coords = self._pixel_grid(b, h, w, match_left.device)
         disp0 = match_left.new_zeros((b, 1, h, w), dtype=torch.float32)
         disp, disp_up, disp_preds = self._iterate(corr_fn, net_list, inp_list, disp0, coords, iters, test_mode,
                                                   stem_4x, stem_2x, hr_coord, scale, stem_1x=self.__dict__.pop("_stem_1x", None))

@@ -104,7 +104,50 @@ def deconv3d_fused(mod: nn.Module, conv: nn.ConvTranspose3d, bn, x: torch.Tensor
     return ops.deconv3d_k4s2(x.contiguous(), w, b, act)
 
 
+# Small stride-1 3x3x3 layers of the hourglass (continuous_IGEVstereo.py:22-89) on the MFMA convolution kernel: out[:, d] =
+# sum_kd conv2d(x[:, d + kd - 1], W[:, :, kd]) is ONE 2-D convolution with batch = D over the un-materialised channel concat of
+# three depth-shifted views of a depth-major copy of x with a zero slice at both ends (ops.conv2d's multi-source input).  The
+# direct kernel (as_conv3d_k3, VALU) is latency-bound on these volumes (48 -> 48 at 6x17x30: 83 us for 0.4 GFLOP); the implicit
+# GEMM with its split-K takes ~15 us, plus the two layout copies.  ANYSTEREO_CONV3D_MFMA=0 keeps the direct kernel.
+_CONV3D_MFMA = __import__("os").environ.get("ANYSTEREO_CONV3D_MFMA", "1") != "0"
+_CONV3D_MFMA_MAX_VOXELS = int(__import__("os").environ.get("ANYSTEREO_CONV3D_MFMA_MAX_VOXELS", "40000"))
+
+
+def conv3d_mfma_ok(conv: nn.Conv3d, x: torch.Tensor) -> bool:
+    return (_CONV3D_MFMA and ops.get_precision() == "split" and conv.stride == (1, 1, 1) and x.shape[0] == 1
+            and conv.in_channels % 16 == 0 and conv.out_channels >= 16 and x.shape[2] * x.shape[3] * x.shape[4] <= _CONV3D_MFMA_MAX_VOXELS)
+
+
+def _conv3d_pack2d(mod, conv, bn):
+    """PackedConv of the layer as a 2-D convolution over [x(d-1) | x(d) | x(d+1)] channels, BatchNorm folded (fp64 fold, as for
+    every other folded layer); rebuilt when the folded weight changes (FoldedConv's key)."""
+    cache = mod.__dict__.setdefault("_c3d_cache", {})
+    fc = cache.setdefault(("fold2d", id(conv)), ops.FoldedConv())
+    w, b = fc.get(conv, bn)  # [Cout, Cin, 3, 3, 3] (module layout), bias | None
+    ent = cache.get(("pack2d", id(conv)))
+    if ent is None or ent[0] is not w:
+        co, ci = w.shape[:2]
+        w2 = w.permute(0, 2, 1, 3, 4).reshape(co, 3 * ci, 3, 3).contiguous()  # channel index = kd * Cin + c
+        pk = ops.PackedConv()
+        ent = (w, pk, w2, b)
+        cache[("pack2d", id(conv))] = ent
+    _, pk, w2, b = ent
+    return pk.get([w2], [b])
+
+
+def conv3d_mfma(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
+    _, c, d, h, w = x.shape
+    xp = x.new_empty((d + 2, c, h, w))
+    xp[0].zero_()
+    xp[d + 1].zero_()
+    xp[1:d + 1].copy_(x[0].transpose(0, 1))  # depth-major copy: slice d of the volume is a dense [C, H, W] image
+    y = ops.conv2d([xp[0:d], xp[1:d + 1], xp[2:d + 2]], _conv3d_pack2d(mod, conv, bn), act=act)  # [D, Cout, H, W]
+    return y.transpose(0, 1).unsqueeze(0).contiguous()
+
+
 def conv3d_fused(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
+    if conv3d_mfma_ok(conv, x):
+        return conv3d_mfma(mod, conv, bn, x.contiguous(), act)
     cache = mod.__dict__.setdefault("_c3d_cache", {})
     fc = cache.setdefault(id(conv), ops.FoldedConv("c3d"))
     w, b = fc.get(conv, bn)

@@ -395,7 +395,10 @@ class Feature(nn.Module):
         self.deconv8_4 = Conv2x_IN(chans[2] * 2, chans[1], deconv=True, concat=True)
         self.conv4 = BasicConv_IN(chans[1] * 2, chans[1] * 2, kernel_size=3, stride=1, padding=1)
 
-    def forward(self, x):
+    def forward(self, x, on_stage=None):
+        """on_stage (optional callable(name)): called after each stage of the trunk ("stem", "block0" .. "block4", "deconv32_16",
+        "deconv16_8") — the inference schedule records events there (the other pre-loop branch may wait for one of them)."""
+        stage = on_stage or (lambda name: None)
         if _fused_ok(x, self) and isinstance(self.bn1, nn.BatchNorm2d):
             if not hasattr(self, "_f_stem"):
                 self._f_stem = ops.FoldedConv()
@@ -412,12 +415,20 @@ class Feature(nn.Module):
                 x = nn.functional.conv2d(x, w, b, self.conv_stem.stride, self.conv_stem.padding).clamp_(0.0, 6.0)
         else:
             x = self.act1(self.bn1(self.conv_stem(x)))
+        stage("stem")
         x2 = self.block0(x)
+        stage("block0")
         x4 = self.block1(x2)
+        stage("block1")
         x8 = self.block2(x4)
+        stage("block2")
         x16 = self.block3(x8)
+        stage("block3")
         x32 = self.block4(x16)
+        stage("block4")
         x16 = self.deconv32_16(x32, x16)
+        stage("deconv32_16")
         x8 = self.deconv16_8(x16, x8)
+        stage("deconv16_8")
         x4 = self.conv4(self.deconv8_4(x8, x4))
         return [x4, x8, x16, x32]

@@ -361,6 +361,38 @@ def test_conv3d_k3(b, cin, cout, d, h, w, stride, act):
     close(out, ref, 2e-6, 2e-6, "conv3d_k3")
 
 
+@pytest.mark.parametrize("cin,cout,d,h,w,relu", [(32, 32, 12, 34, 60, True), (48, 48, 6, 17, 30, True), (16, 16, 5, 9, 14, False),
+                                                  (32, 48, 1, 7, 33, True), (64, 32, 3, 8, 16, True)])
+def test_conv3d_on_the_mfma_kernel(cin, cout, d, h, w, relu, monkeypatch):
+    """§8 f4: the small stride-1 3x3x3 layers of the hourglass (continuous_IGEVstereo.py:22-89) as ONE 2-D convolution with
+    batch = depth over three depth-shifted views of a zero-padded depth-major copy (nn/blocks.py::conv3d_mfma) — against the
+    fp64 module (BatchNorm3d eval + LeakyReLU) and against the direct VALU kernel it replaces; D = 1 (both neighbours are the
+    zero slices), ragged planes, Cin != Cout."""
+    from anystereo import ops
+    from anystereo.nn import blocks as B
+    from anystereo.harness.synthetic import fill_module_deterministic
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        m = B.BasicConv(cin, cout, is_3d=True, bn=True, relu=relu, kernel_size=3, stride=1, padding=1).eval()
+        fill_module_deterministic(m, base_seed=31)
+        with torch.no_grad():
+            m.bn.running_mean.copy_(U((cout,), 191) * 0.3), m.bn.running_var.copy_(U((cout,), 192, 0.5, 2.0))
+        x = U((1, cin, d, h, w), 190, -2, 2)
+        want = m.double()(x.double())
+        m = m.float().to(DEV)
+        with torch.no_grad():
+            assert B.conv3d_mfma_ok(m.conv, x.to(DEV))
+            got = m(x.to(DEV))
+            monkeypatch.setattr(B, "_CONV3D_MFMA", False)
+            direct = m(x.to(DEV))
+        assert got.shape == want.shape and got.is_contiguous()
+        close(got, want, 1e-5, 1e-5, "conv3d on the MFMA kernel vs fp64")
+        close(got, direct, 1e-5, 1e-5, "conv3d on the MFMA kernel vs the direct kernel")
+    finally:
+        ops.set_precision(prev)
+
+
 @pytest.mark.parametrize("b,cin,cout,d,h,w,act", [(1, 16, 8, 4, 6, 70, 0), (2, 8, 16, 3, 5, 33, 5), (1, 5, 3, 2, 3, 9, 1),
                                                   (1, 8, 8, 2, 3, 62, 0), (1, 8, 8, 2, 3, 63, 5), (1, 8, 8, 2, 2, 125, 0)])
 def test_deconv3d_k4s2(b, cin, cout, d, h, w, act):
