@@ -13,7 +13,7 @@ import torch
 from .. import ops
 
 
-def phases(model, inputs, iters, reps=5, fine=False, verbose=False):
+def phases(model, inputs, iters, reps=5, fine=False, verbose=False, stages=False):
     """-> {"pre_loop_us", "loop_us", "post_loop_us", "us_per_iter", "pass_us", "markers_us", "loop_stages_us", "all_pass_us"} of
     the median of `reps` replays of the captured forward of `model` on `inputs` = (image1, image2, hr_coord, scale).
     fine=True also places the operator-level markers of two consecutive GRU iterations (models/base.py::stamp_iters: head,
@@ -24,6 +24,7 @@ def phases(model, inputs, iters, reps=5, fine=False, verbose=False):
     keep_iters = model.stamp_iters
     model.stamp_iters = type(model).stamp_iters if fine else ()
     model.stamps = ops.Stamps(i1.device)
+    model.stamps.stages = bool(stages)  # + a marker after every stage of the feature trunk
     model.enable_graph(True)
     runs = []
     try:

@@ -94,6 +94,31 @@ class continuous_IGEVStereo(ContinuousStereoBase):
     # ... or when the trunk has passed one of its stages (nn/encoders.py::Feature.forward: "block0" .. "deconv16_8"): "" = no wait
     context_after_stage = os.environ.get("ANYSTEREO_CONTEXT_AFTER_STAGE", "")
 
+    # The six feature-attention gates of the cost aggregation (submodule.py:328-341 via continuous_IGEVstereo.py:60-88) depend on
+    # the 2-D features only: in inference they are computed on a branch stream right behind the feature trunk, in the order the
+    # cost aggregation consumes them, instead of as 12 small launches inside its serial chain (each FeatureAtt waits for its own).
+    early_gates = os.environ.get("ANYSTEREO_EARLY_GATES", "1") != "0"
+
+    def _early_gates(self, features_left, image1):
+        if not (self.early_gates and image1.is_cuda and B.fused_ok(features_left[0], self)):
+            return
+        h = self.cost_agg
+        order = [(self.corr_feature_att, 0), (h.feature_att_8, 1), (h.feature_att_16, 2), (h.feature_att_32, 3),
+                 (h.feature_att_up_16, 2), (h.feature_att_up_8, 1)]
+        if not all(isinstance(m, B.FeatureAtt) and m.gate_ok(features_left[i]) for m, i in order):
+            return
+        main = torch.cuda.current_stream(image1.device)
+        br = self.update_block._side_stream(image1.device, 2)
+        br.wait_stream(main)
+        with torch.cuda.stream(br):
+            for m, i in order:
+                g = m.gate(features_left[i])
+                ev = torch.cuda.Event()
+                ev.record(br)
+                m.early = (g, ev)
+        for f in features_left:
+            f.record_stream(br)
+
     def _stems_fwd(self, image):
         """(stem_1x | None, stem_2x, stem_4x) of one image batch (continuous_IGEVstereo.py:247-256)."""
         s1 = self.stem_1(image) if hasattr(self, "stem_1") else None
@@ -179,7 +204,8 @@ class continuous_IGEVStereo(ContinuousStereoBase):
             if fast:
                 if not (side is not None and self.trunk_first):
                     self._mark("trunk_begin")
-                    feats = self.feature(both)
+                    st = self.__dict__.get("stamps")
+                    feats = self.feature(both, on_stage=(lambda name: self._mark("trunk_" + name)) if (st is not None and st.stages) else None)
                     self._mark("trunk_end")
                 if side is not None and self.parallel_stems:
                     main.wait_event(stems_done)
@@ -204,6 +230,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 features_right[0] = torch.cat((features_right[0], stem_4y), 1)
                 match_left = _plain_conv(self, self.desc, self.conv(features_left[0]))
                 match_right = _plain_conv(self, self.desc, self.conv(features_right[0]))
+            self._early_gates(features_left, image1)
             gwc_volume = self._hot_gwc(match_left, match_right)
             gwc_volume = self.corr_stem(gwc_volume)
             gwc_volume = self.corr_feature_att(gwc_volume, features_left[0])

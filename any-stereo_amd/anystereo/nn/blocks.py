@@ -408,12 +408,29 @@ class FeatureAtt(nn.Module):
         self.feat_att = nn.Sequential(BasicConv(feat_chan, feat_chan // 2, kernel_size=1, stride=1, padding=0),
                                       nn.Conv2d(feat_chan // 2, cv_chan, 1))
 
+    def gate_ok(self, feat) -> bool:
+        return _FOLD_POINTWISE and fused_ok(feat, self) and conv2d_hip_ok(self.feat_att[1])
+
+    def gate(self, feat):
+        """sigmoid(feat_att(feat)) [B, cv_chan, H, W]: depends on the 2-D features only, so the inference schedule computes all
+        gates of a pass on a branch of their own beside the cost aggregation (`early`, set per forward by the model)."""
+        c = self.feat_att[1]  # 1x1 + bias with the sigmoid in the epilogue
+        pk = self.__dict__.setdefault("_pk_gate", ops.PackedConv())
+        return ops.conv2d([self.feat_att[0](feat).contiguous()], pk.get([c.weight], [c.bias]), act=L.ACT_SIGMOID)
+
+    early = None  # (gate tensor, event recorded behind it on the branch stream) for the next forward() call, or None
+
     def forward(self, cv, feat):
-        if _FOLD_POINTWISE and fused_ok(feat, self) and conv2d_hip_ok(self.feat_att[1]):
-            c = self.feat_att[1]  # 1x1 + bias with the sigmoid in the epilogue
-            pk = self.__dict__.setdefault("_pk_gate", ops.PackedConv())
-            gate = ops.conv2d([self.feat_att[0](feat).contiguous()], pk.get([c.weight], [c.bias]), act=L.ACT_SIGMOID)
-            return gate.unsqueeze(2) * cv
+        if self.gate_ok(feat):
+            ent = self.__dict__.pop("early", None)
+            if ent is not None:
+                g, ev = ent
+                cur = torch.cuda.current_stream(cv.device)
+                cur.wait_event(ev)
+                g.record_stream(cur)
+            else:
+                g = self.gate(feat)
+            return g.unsqueeze(2) * cv
         return torch.sigmoid(self.feat_att(feat).unsqueeze(2)) * cv
 
 

@@ -1578,6 +1578,7 @@ class Stamps:
     def __init__(self, device, slots: int = 128):
         self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
         self.names = {}
+        self.stages = False  # markers after every stage of the feature trunk / cost aggregation (pre-loop diagnosis)
         self.fine = False   # operator-level markers (nn/update.py) on: set by the loop for the iterations it wants resolved
         self.prefix = ""    # prepended to operator-level marker names (the iteration they were issued in)
 

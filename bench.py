@@ -60,9 +60,13 @@ def claim_stdout():
     process (native writes and stray prints end up in the log) and the line goes out through a duplicate of the original fd."""
     global _REAL_STDOUT
     if _REAL_STDOUT is None:
-        sys.stdout.flush()
-        _REAL_STDOUT = os.dup(1)
-        os.dup2(2, 1)
+        try:
+            sys.stdout.flush()
+            fd = os.dup(1)
+            os.dup2(2, 1)
+            _REAL_STDOUT = fd
+        except OSError:  # stdout / stderr closed by the launcher: print through sys.stdout as before
+            _REAL_STDOUT = None
 
 
 def emit(line: dict):

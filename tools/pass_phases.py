@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--stages", action="store_true", help="also a marker after every stage of the feature trunk")
     ap.add_argument("--fine", action="store_true", help="also the operator-level markers of two GRU iterations")
     a = ap.parse_args()
     _lib.load()
@@ -27,7 +28,7 @@ def main():
     wl = WL.WORKLOADS[a.config]
     model, _ = WL.build_model(wl, device=dev)
     inputs = WL.build_inputs(wl, seed=1234, device=dev)
-    print(json.dumps(phases(model, inputs, wl.iters, a.reps, fine=a.fine, verbose=True)))
+    print(json.dumps(phases(model, inputs, wl.iters, a.reps, fine=a.fine, verbose=True, stages=a.stages)))
 
 
 if __name__ == "__main__":
