@@ -55,6 +55,9 @@ SIGNATURES = {
     "as_abi_version": (_i, []),
     "as_graph_replace_memsets": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "as_stamp": (_i, [_vp, _i, _vp]),
+    "as_ir_block_pack_bytes": (C.c_int64, [_i, _i, _i]),
+    "as_ir_block_pack": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "as_ir_block": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_source_hash": (C.c_char_p, []),
     "as_device_count": (_i, []),
     "as_corr_sampler_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -85,7 +85,7 @@ class ContinuousStereoBase(nn.Module):
         regenerates the grid itself (`_as_pixel_grid`); callers that substitute their own lookup read the tensor."""
         cache = self.__dict__.setdefault("_pixel_grids", {})
         key = (b, h, w, str(device))
-        g = cache.get(key)
+        g = cache.get(key) if os.environ.get("ANYSTEREO_GRID_CACHE", "1") != "0" else None
         if g is None:
             g = torch.arange(w, device=device).float().reshape(1, 1, w, 1).repeat(b, h, 1, 1)
             g._as_pixel_grid = True  # the kernels regenerate this grid: mark it so the lookup need not compare it

@@ -332,8 +332,17 @@ class _InvRes(nn.Module):
         self.res = stride == 1 and cin == cout
 
         self._fdw, self._pk1, self._pk3 = ops.FoldedConv(), ops.PackedConv(), ops.PackedConv()
+        self._irpk = ops.IrBlockPack()
+
+    # inference: the whole block as ONE launch with the 6x-expanded tensor in LDS (csrc/irblock.hip) instead of pw / dw / pwl
+    # launches with that tensor through HBM; ANYSTEREO_FUSED_IR=0 keeps the three launches
+    fused_ir = __import__("os").environ.get("ANYSTEREO_FUSED_IR", "1") != "0"
 
     def forward(self, x):
+        if (_fused_ok(x, self) and self.fused_ir and ops.get_precision() == "split" and self.conv_pwl.out_channels <= 160
+                and self.conv_pw.in_channels <= 256 and self.conv_dw.stride[0] in (1, 2)):
+            return ops.ir_block(x.contiguous(), self._irpk.get(self.conv_pw, self.bn1, self.conv_dw, self.bn2, self.conv_pwl, self.bn3),
+                                self.conv_dw.stride[0], self.res)
         if _fused_ok(x, self):
             # pw (+bn1, ReLU6) and pwl (+bn3, + skip) on the implicit-GEMM kernel, dw (+bn2, ReLU6) on the direct one
             x = x.contiguous()

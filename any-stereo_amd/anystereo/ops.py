@@ -784,6 +784,59 @@ def conv3x3_few(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
     return out
 
 
+class IrBlockPack:
+    """Fragments + fp32 parameters of one MobileNetV2 inverted-residual block for as_ir_block (csrc/irblock.hip), BatchNorm folded
+    in fp64 (fold_bn); rebuilt when any of the block's 15 tensors changes (object identity + version)."""
+
+    def __init__(self):
+        self._key, self._refs = None, None
+        self.pack = self.fparams = None
+        self.dims = None
+
+    def get(self, conv_pw, bn1, conv_dw, bn2, conv_pwl, bn3):
+        ts = [conv_pw.weight, conv_dw.weight, conv_pwl.weight]
+        for bn in (bn1, bn2, bn3):
+            ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple((t.data_ptr(), t._version, t.device) for t in ts)
+        alive = self._refs is not None and all(r() is t for r, t in zip(self._refs, ts))
+        if key != self._key or not alive:
+            with torch.no_grad():
+                w1, b1 = fold_bn(conv_pw, bn1)
+                wd, b2 = fold_bn(conv_dw, bn2)
+                w3, b3 = fold_bn(conv_pwl, bn3)
+                mid, cin = w1.shape[:2]
+                cout = w3.shape[0]
+                mp = (mid + 31) // 32 * 32
+                f = torch.zeros(11 * mp + cout, device=w1.device, dtype=torch.float32)
+                f[:mid] = b1
+                f[mp:mp + mid] = b2
+                f[2 * mp:2 * mp + 9 * mid] = wd.reshape(mid, 9).reshape(-1)
+                f[11 * mp:] = b3
+                lib = L.load()
+                pack = torch.empty(int(lib.as_ir_block_pack_bytes(cin, mid, cout)), device=w1.device, dtype=torch.uint8)
+                w1c, w3c = w1.reshape(mid, cin).contiguous(), w3.reshape(cout, mid).contiguous()
+                with _guard(w1.device):
+                    L.check(lib.as_ir_block_pack(_p(w1c), _p(w3c), cin, mid, cout, pack.data_ptr(), _stream()), "ir_block_pack")
+            self.pack, self.fparams, self.dims = pack, f, (cin, mid, cout)
+            self._key, self._refs = key, [weakref.ref(t) for t in ts]
+        return self
+
+
+def ir_block(x: torch.Tensor, pk: "IrBlockPack", stride: int, residual: bool) -> torch.Tensor:
+    """One MobileNetV2 inverted-residual block (extractor.py:327-342) as ONE launch: expand 1x1 + ReLU6 -> depthwise 3x3 + ReLU6 ->
+    project 1x1 (+ x), eval-mode BatchNorm folded; the expanded tensor never leaves LDS (as_ir_block)."""
+    _req(x, "x")
+    b, c, h, w = x.shape
+    cin, mid, cout = pk.dims
+    if c != cin:
+        raise RuntimeError(f"ir_block: input has {c} channels, the block expects {cin}")
+    out = torch.empty((b, cout, (h - 1) // stride + 1, (w - 1) // stride + 1), device=x.device, dtype=torch.float32)
+    with _guard(x.device):
+        L.check(L.load().as_ir_block(_p(x), pk.pack.data_ptr(), _p(pk.fparams), _p(out), b, cin, mid, cout, h, w, stride,
+                                     1 if residual else 0, _stream()), "ir_block")
+    return out
+
+
 class Stem7x7Pack:
     """MFMA fragments of a [64,3,7,7] weight (csrc/stem7x7.hip), rebuilt when the weight tensor object or its version changes."""
 

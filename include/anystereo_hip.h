@@ -287,6 +287,17 @@ int as_interp_bilinear_ac_bs(const float* x, void* out_bs, int B, int C, int H, 
  * ------------------------------------------------------------------------------------------- */
 int as_dwconv3x3(const float* x, const float* weight, const float* bias, const float* residual, float* out,
                  int B, int C, int H, int W, int stride, int act, void* stream);
+
+/* f4 (round 6)  One launch per MobileNetV2 inverted-residual block of Feature (extractor.py:327-342 = timm mobilenetv2_100
+ *   InvertedResidual, eval): relu6(bn1(conv_pw x)) -> relu6(bn2(conv_dw .)) (3x3, padding 1, stride 1|2) -> bn3(conv_pwl .) [+ x when
+ *   stride 1 and Cin == Cout].  The 6x-expanded tensor stays in LDS.  BatchNorm is folded by the caller:
+ *   as_ir_block_pack: w1 [mid][Cin], w3 [Cout][mid] -> MFMA fragments (as_ir_block_pack_bytes bytes, 16-B aligned);
+ *   fparams [11 * mid_pad + Cout] fp32 = b1 [mid_pad] | b2 [mid_pad] | wd [mid_pad][9] | b3 [Cout], mid_pad = ceil(mid/32)*32, padding 0.
+ *   x [B,Cin,H,W] -> out [B,Cout,(H-1)/stride+1,(W-1)/stride+1].  Cin <= 256, Cout <= 160.  Split-precision arithmetic. */
+int64_t as_ir_block_pack_bytes(int Cin, int mid, int Cout);
+int as_ir_block_pack(const float* w1, const float* w3, int Cin, int mid, int Cout, void* pack, void* stream);
+int as_ir_block(const float* x, const void* pack, const float* fparams, float* out, int B, int Cin, int mid, int Cout, int H, int W,
+                int stride, int residual, void* stream);
 int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* out,
                  int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
 /*   as_deconv3d_k4s2: ConvTranspose3d kernel 4, stride 2, padding 1 (all dims) — the hourglass up-convolutions

@@ -479,6 +479,39 @@ def test_backbone_blocks_fused_inference(precision):
         _fused_vs_plain(mod, U(shape, 190 + k, -2, 2), 3e-5, f"fused block {k}")
 
 
+@pytest.mark.parametrize("cin,cout,stride,b,h,w", [(16, 24, 2, 2, 34, 60), (24, 24, 1, 2, 17, 37), (24, 32, 2, 1, 19, 33), (32, 32, 1, 1, 9, 21),
+                                                    (32, 64, 2, 2, 10, 18), (64, 64, 1, 2, 5, 9), (64, 96, 1, 1, 8, 8), (96, 96, 1, 1, 7, 10),
+                                                    (96, 160, 2, 2, 9, 15), (160, 160, 1, 1, 5, 8), (160, 160, 1, 2, 17, 30)])
+def test_ir_block_one_launch(cin, cout, stride, b, h, w, monkeypatch):
+    """§8 f4: every (Cin, Cout, stride) of the MobileNetV2 trunk's inverted-residual blocks (extractor.py:327-342) as ONE launch
+    (csrc/irblock.hip: expand -> ReLU6 -> depthwise -> ReLU6 -> project [+ x], BatchNorm folded, the expanded tensor in LDS) against
+    the fp64 module and against the three-launch path it replaces; odd planes (ragged tiles, the zero padding of the EXPANDED
+    tensor at every border), batch 2, the 144-channel expansion (4.5 chunks), activations that saturate ReLU6."""
+    from anystereo import ops
+    from anystereo.harness.synthetic import fill_module_deterministic
+    from anystereo.nn.encoders import _InvRes
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        mod = _InvRes(cin, cout, stride).eval()
+        fill_module_deterministic(mod, 50 + cin + cout)
+        _randomize_bn(mod, 900 + cin)
+        x = U((b, cin, h, w), 950 + cout, -3, 3)
+        with torch.enable_grad():  # grad mode keeps the plain PyTorch path
+            want = mod.double()(x.double()).detach()
+        mod = mod.float().to(DEV)
+        with torch.no_grad():
+            monkeypatch.setattr(_InvRes, "fused_ir", True)
+            got = mod(x.to(DEV))
+            monkeypatch.setattr(_InvRes, "fused_ir", False)
+            three = mod(x.to(DEV))
+        assert got.shape == want.shape
+        close(got, want, 2e-5, 2e-5, "ir_block vs fp64")
+        close(got, three, 2e-5, 2e-5, "ir_block vs the three-launch path")
+    finally:
+        ops.set_precision(prev)
+
+
 def test_norm_kernels():
     from anystereo import _lib as L
     from anystereo import ops
@@ -673,7 +706,15 @@ def test_model_options_vs_reference(name, golden, precision):
         base = model(img1, img2, iters=3, test_mode=True, hr_coord=coord, scale=sc)
         assert (base.cpu() - g[f"{name}_base"]).abs().mean().item() < 1e-3
         with_fi = model(img1, img2, iters=3, flow_init=g[f"{name}_flow_init"].to(DEV), test_mode=True, hr_coord=coord, scale=sc)
-        assert torch.equal(with_fi, base), "flow_init must not change the result (the reference never reads it)"
+        # the reference never reads flow_init: the result must not move.  Checked to 1e-4 px (an argument that WAS read would move
+        # it by pixels: the fixture's flow_init is U(0, 20)); run-to-run bit equality of two eager forwards is a separate property
+        # (test_training_step_is_bit_repeatable) — on one MI355X lease of round 6 two identical RAFT forwards differed by one ulp
+        # of the output (7.6e-6 px) in every precision mode while IGEV's were bit-equal, on six other leases both were bit-equal
+        # (DESIGN.md §2 "run-to-run")
+        d_fi = (with_fi - base).abs().max().item()
+        if d_fi != 0.0:
+            print(f"[model_opts {name} {precision}] two forwards differ by {d_fi:.1e} px (not bit-equal on this box)")
+        assert d_fi < 1e-4, f"flow_init must not change the result (the reference never reads it): {d_fi:.2e} px"
         raw = model(img1, img2, iters=3, test_mode=True, hr_coord=coord, scale=sc, output_raw=True)
         if name == "raft":
             assert isinstance(raw, tuple) and len(raw) == 2
