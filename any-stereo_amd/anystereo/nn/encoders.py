@@ -335,11 +335,17 @@ class _InvRes(nn.Module):
         self._irpk = ops.IrBlockPack()
 
     # inference: the whole block as ONE launch with the 6x-expanded tensor in LDS (csrc/irblock.hip) instead of pw / dw / pwl
-    # launches with that tensor through HBM; ANYSTEREO_FUSED_IR=0 keeps the three launches
-    fused_ir = __import__("os").environ.get("ANYSTEREO_FUSED_IR", "1") != "0"
+    # launches with that tensor through HBM; opt-in (ANYSTEREO_FUSED_IR=1) until it beats the three launches on every shape
+    fused_ir = {"0": False, "1": True, "auto": "auto"}[__import__("os").environ.get("ANYSTEREO_FUSED_IR", "0")]
+
+    def _ir_pick(self) -> bool:
+        """auto: the shapes the one-launch kernel wins stand-alone (tools/kbench_ir.py): the stride-2 blocks on the large maps."""
+        if self.fused_ir == "auto":
+            return self.conv_dw.stride[0] == 2 and self.conv_pw.in_channels <= 32
+        return bool(self.fused_ir)
 
     def forward(self, x):
-        if (_fused_ok(x, self) and self.fused_ir and ops.get_precision() == "split" and self.conv_pwl.out_channels <= 160
+        if (_fused_ok(x, self) and self._ir_pick() and ops.get_precision() == "split" and self.conv_pwl.out_channels <= 160
                 and self.conv_pw.in_channels <= 256 and self.conv_dw.stride[0] in (1, 2)):
             return ops.ir_block(x.contiguous(), self._irpk.get(self.conv_pw, self.bn1, self.conv_dw, self.bn2, self.conv_pwl, self.bn3),
                                 self.conv_dw.stride[0], self.res)

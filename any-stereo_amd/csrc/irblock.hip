@@ -84,16 +84,32 @@ __global__ __launch_bounds__(256) void ir_block_kernel(IrParams p) {
   const long long plane = (long long)p.H * p.W;
   const float* __restrict__ xb = p.x + (long long)b * p.Cin * plane;
 
-  // ---- 1. input tile -> split fp16, pixel-major (q fastest over the threads: runs of PW pixels of one channel row) ----
-  for (int idx = tid; idx < p.Cin_pad * G::NP; idx += 256) {
-    const int c = idx / G::NP, q = idx - c * G::NP;
-    const int qy = q / G::PW, qx = q - qy * G::PW;
-    const int gy = iy0 + qy, gx = ix0 + qx;
-    float v = 0.f;
-    if (q < G::PIN && c < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = xb[(long long)c * plane + (long long)gy * p.W + gx];
-    const _Float16 h = (_Float16)v;
-    xs_hi[q * XP + c] = h;
-    xs_lo[q * XP + c] = (_Float16)((v - (float)h) * 2048.f);
+  // ---- 1. input tile -> split fp16, pixel-major (q fastest over the threads: runs of PW pixels of one channel row).  Eight
+  //         loads per thread are in flight before the first is consumed (one exposed round trip per 2048 elements, not per 256)
+  {
+    const int total = p.Cin_pad * G::NP;
+    for (int base = tid; base < total; base += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = base + 256 * k;
+        const int c = idx / G::NP, q = idx - c * G::NP;
+        const int qy = q / G::PW, qx = q - qy * G::PW;
+        const int gy = iy0 + qy, gx = ix0 + qx;
+        const bool ok = idx < total && q < G::PIN && c < p.Cin && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        v[k] = ok ? xb[(long long)c * plane + (long long)gy * p.W + gx] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = base + 256 * k;
+        if (idx < total) {
+          const int c = idx / G::NP, q = idx - c * G::NP;
+          const _Float16 h = (_Float16)v[k];
+          xs_hi[q * XP + c] = h;
+          xs_lo[q * XP + c] = (_Float16)((v[k] - (float)h) * 2048.f);
+        }
+      }
+    }
   }
   for (int i = tid; i < p.mid_pad; i += 256) { b1s[i] = p.b1[i]; b2s[i] = p.b2[i]; }
 
