@@ -1147,6 +1147,12 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
   const int su = mt >> 7, m = mt & 127;                                                                \
   const int gy = ((NSUB > 1 && su) ? sy0[NSUB - 1] : sy0[0]) + m / TW, gx = ((NSUB > 1 && su) ? sx0[NSUB - 1] : sx0[0]) + m % TW; \
   const unsigned poff = (gy < p.H && gx < p.W) ? (unsigned)(((long long)gy * p.W + gx) * 4) : 0x7FFFFFF0u;
+// INVARIANT (loader prefetch, all-DMA path): one AS_EPI_LOADK(K) issues EXACTLY 8 * EOPS buffer loads (8 channels x {add, h[, z]}),
+// and the loader's counted wait `s_waitcnt vmcnt(8 * EOPS)` behind it relies on that count: it must cover the unit's LDS-DMA and every
+// older load and leave only this block's loads in flight, because the barrier that follows is a bare s_barrier.  An edit (or a
+// compiler) that merges, drops or predicates one of these loads turns that wait into a silent race on the LDS image; use
+// vmcnt(0) there when in doubt (one exposed round trip per unit).  Round 5's advisor checked the build's disassembly by hand
+// (16 / 24 loads per branch, no spills); `llvm-objdump --offloading` + `-d` on build/conv.o reproduces it.
 #define AS_EPI_LOADK(K)                                                                               \
   _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                      \
     const int col = (cg * ENB8 + (K)) * 8 + j;                                                        \

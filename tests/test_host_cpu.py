@@ -58,6 +58,16 @@ def test_argument_validation_without_gpu():
     assert lib.as_conv_pack_size(162, 64, 1) == 6 * 1 * 32 * 64
     assert lib.as_conv_pack_size(384, 256, 3) == 48 * 9 * 8 * 256
     assert lib.as_conv_pack_size(8, 8, 5) == -1
+    # round-6 entry points: argument checks come before any launch
+    assert lib.as_stamp(None, 0, None) == -1 and lib.as_stamp(one, -1, None) == -1
+    assert lib.as_liif_query_rows(None, 1, 8, one, None) == -1 and lib.as_liif_query_rows(one, 1, 0, one, None) == -1
+    assert lib.as_ir_block_pack_bytes(16, 96, 24) == (3 * 1 * 2 + 3 * 1 * 2 * 2) * 64 * 8 * 2
+    assert lib.as_ir_block_pack_bytes(24, 144, 24) == (5 * 2 * 2 + 5 * 1 * 2 * 2) * 64 * 8 * 2   # 144 -> 160 expanded channels, Cin 24 -> 32
+    assert lib.as_ir_block_pack_bytes(0, 96, 24) == -1
+    assert lib.as_ir_block(None, one, one, one, 1, 16, 96, 24, 8, 8, 1, 0, None) == -1
+    assert lib.as_ir_block(one, one, one, one, 1, 16, 96, 24, 8, 8, 3, 0, None) == -1          # stride
+    assert lib.as_ir_block(one, one, one, one, 1, 16, 96, 24, 8, 8, 1, 1, None) == -1          # residual needs Cin == Cout
+    assert lib.as_ir_block(one, one, one, one, 1, 16, 96, 200, 8, 8, 1, 0, None) == -2         # Cout <= 160
     d = _lib.ConvDesc()
     assert lib.as_conv2d(ctypes.byref(d), None) == -1
 
