@@ -128,6 +128,8 @@ class continuous_IGEVStereo(ContinuousStereoBase):
     def _context(self, image1):
         """Hidden-state initialisation and the per-level context terms (continuous_IGEVstereo.py:270-273)."""
         from ... import _lib as L
+        st = self.__dict__.get("stamps")
+        self.cnet.on_stage = (lambda name: self._mark("cnet_" + name)) if (st is not None and st.stages) else None
         fuse = (B.fused_ok(image1, self.cnet) and getattr(self.cnet, "paired_heads", False)
                 and all(len(o) == 2 for o in (self.cnet.outputs04, self.cnet.outputs08, self.cnet.outputs16)))
         if fuse:  # tanh (:271) and relu (:272) in the epilogue of the heads' last (paired) convolution

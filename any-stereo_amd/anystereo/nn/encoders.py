@@ -156,7 +156,8 @@ class _Trunk(nn.Module):
             self._pk_stem = ops.Stem7x7Pack()
         return self._pk_stem
 
-    def trunk(self, x):
+    def trunk(self, x, stage=None):
+        stage = stage or (lambda name: None)
         if _fused_ok(x, self) and isinstance(self.norm1, nn.BatchNorm2d):
             if not hasattr(self, "_f_stem"):
                 self._f_stem = ops.FoldedConv()
@@ -173,7 +174,14 @@ class _Trunk(nn.Module):
             x = ops.instance_norm_act(y, self.norm1.eps, L.ACT_RELU)
         else:
             x = self.relu1(self.norm1(self.conv1(x)))
-        return self.layer3(self.layer2(self.layer1(x)))
+        stage("stem")
+        x = self.layer1(x)
+        stage("layer1")
+        x = self.layer2(x)
+        stage("layer2")
+        x = self.layer3(x)
+        stage("layer3")
+        return x
 
 
 class BasicEncoder(_Trunk):
@@ -212,21 +220,27 @@ class MultiBasicEncoder(_Trunk):
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init_encoder(self)
 
+    on_stage = None  # optional callable(name): timeline markers of the inference schedule (set per forward by the model)
+
     def forward(self, x, dual_inp=False, num_layers=3):
-        x = self.trunk(x)
+        stage = self.on_stage or (lambda name: None)
+        x = self.trunk(x, stage)
         if dual_inp:
             v = x
             x = x[: x.shape[0] // 2]
         tail = (v,) if dual_inp else ()
         o04 = self._heads(self.outputs04, x)
+        stage("heads04")
         if num_layers == 1:
             return (o04,) + tail
         y = self.layer4(x)
         o08 = self._heads(self.outputs08, y)
+        stage("heads08")
         if num_layers == 2:
             return (o04, o08) + tail
         z = self.layer5(y)
         o16 = self._heads(self.outputs16, z)
+        stage("heads16")
         return (o04, o08, o16) + tail
 
     # The two heads of a scale (hidden state | context, extractor.py:254-273) apply the same layer shapes to the same input: in
