@@ -138,8 +138,8 @@ def _conv3d_pack2d(mod, conv, bn):
 def conv3d_mfma(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
     _, c, d, h, w = x.shape
     xp = x.new_empty((d + 2, c, h, w))
-    xp[0].zero_()
-    xp[d + 1].zero_()
+    xp[0].fill_(0.0)      # fill_ is a kernel; zero_() on a contiguous slice is a hipMemsetAsync = a memset NODE under capture
+    xp[d + 1].fill_(0.0)
     xp[1:d + 1].copy_(x[0].transpose(0, 1))  # depth-major copy: slice d of the volume is a dense [C, H, W] image
     y = ops.conv2d([xp[0:d], xp[1:d + 1], xp[2:d + 2]], _conv3d_pack2d(mod, conv, bn), act=act)  # [D, Cout, H, W]
     return y.transpose(0, 1).unsqueeze(0).contiguous()
