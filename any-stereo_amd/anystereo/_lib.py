@@ -92,6 +92,7 @@ SIGNATURES = {
     "as_interp_bilinear_ac_bs": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_dwconv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "as_conv3d_k3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "as_conv3d_k3_gated": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_deconv3d_k4s2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "as_instance_norm_ws_bytes": (C.c_int64, [_i]),
     "as_instance_norm_act": (_i, [_vp, _vp, _vp, _vp, _i, C.c_int64, C.c_float, _i, _vp]),

@@ -234,8 +234,7 @@ class continuous_IGEVStereo(ContinuousStereoBase):
                 match_right = _plain_conv(self, self.desc, self.conv(features_right[0]))
             self._early_gates(features_left, image1)
             gwc_volume = self._hot_gwc(match_left, match_right)
-            gwc_volume = self.corr_stem(gwc_volume)
-            gwc_volume = self.corr_feature_att(gwc_volume, features_left[0])
+            gwc_volume = self.corr_feature_att.after(self.corr_stem, gwc_volume, features_left[0])
             geo_encoding_volume = self.cost_agg(gwc_volume, features_left)
             if B.fused_ok(geo_encoding_volume, self) and B.conv3d_k3_ok(self.classifier):
                 cost = B.conv3d_fused(self, self.classifier, None, geo_encoding_volume, 0)

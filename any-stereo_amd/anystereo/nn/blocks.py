@@ -135,23 +135,27 @@ def _conv3d_pack2d(mod, conv, bn):
     return pk.get([w2], [b])
 
 
-def conv3d_mfma(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
+def conv3d_mfma(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int, gate=None) -> torch.Tensor:
     _, c, d, h, w = x.shape
     xp = x.new_empty((d + 2, c, h, w))
     xp[0].fill_(0.0)      # fill_ is a kernel; zero_() on a contiguous slice is a hipMemsetAsync = a memset NODE under capture
     xp[d + 1].fill_(0.0)
     xp[1:d + 1].copy_(x[0].transpose(0, 1))  # depth-major copy: slice d of the volume is a dense [C, H, W] image
     y = ops.conv2d([xp[0:d], xp[1:d + 1], xp[2:d + 2]], _conv3d_pack2d(mod, conv, bn), act=act)  # [D, Cout, H, W]
-    return y.transpose(0, 1).unsqueeze(0).contiguous()
+    if gate is None:
+        return y.transpose(0, 1).unsqueeze(0).contiguous()
+    out = y.new_empty((1, y.shape[1], d, h, w))  # the layout copy back and FeatureAtt's gate in one pass
+    return torch.mul(y.transpose(0, 1).unsqueeze(0), gate.unsqueeze(2), out=out)
 
 
-def conv3d_fused(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int) -> torch.Tensor:
+def conv3d_fused(mod: nn.Module, conv: nn.Conv3d, bn, x: torch.Tensor, act: int, gate=None) -> torch.Tensor:
+    """gate [B, Cout, Ho, Wo] (FeatureAtt, submodule.py:328-341): the result times the gate, in the producing launch."""
     if conv3d_mfma_ok(conv, x):
-        return conv3d_mfma(mod, conv, bn, x.contiguous(), act)
+        return conv3d_mfma(mod, conv, bn, x.contiguous(), act, gate)
     cache = mod.__dict__.setdefault("_c3d_cache", {})
     fc = cache.setdefault(id(conv), ops.FoldedConv("c3d"))
     w, b = fc.get(conv, bn)
-    return ops.conv3d_k3(x.contiguous(), w, b, conv.stride[0], act)
+    return ops.conv3d_k3(x.contiguous(), w, b, conv.stride[0], act, gate=None if gate is None else gate.contiguous())
 
 
 class _SearchedConv(torch.autograd.Function):
@@ -232,7 +236,14 @@ class _ConvNormAct(nn.Module):
     def _make_norm(self, c, is_3d):
         raise NotImplementedError
 
-    def forward(self, x):
+    def forward(self, x, gate=None):
+        """gate (inference, 3-D blocks): FeatureAtt's channel gate [B, Cout, H, W] applied to the block's result — in the
+        convolution's own launch where that is the fused 3x3x3 path, as a separate multiply otherwise."""
+        if gate is not None:
+            norm = getattr(self, self.norm_attr) if self.use_norm else None
+            if fused_ok(x, self) and (norm is None or isinstance(norm, nn.BatchNorm3d)) and conv3d_k3_ok(self.conv):
+                return conv3d_fused(self, self.conv, norm, x, L.ACT_LEAKY if self.relu else L.ACT_NONE, gate=gate)
+            return gate.unsqueeze(2) * self.forward(x)
         norm = getattr(self, self.norm_attr) if self.use_norm else None
         if fused_ok(x, self) and (norm is None or isinstance(norm, nn.BatchNorm3d)):
             if conv3d_k3_ok(self.conv):
@@ -420,18 +431,37 @@ class FeatureAtt(nn.Module):
 
     early = None  # (gate tensor, event recorded behind it on the branch stream) for the next forward() call, or None
 
+    def take_gate(self, feat):
+        """The gate for this forward: the one the model computed early on its branch stream (joined here), or computed now."""
+        ent = self.__dict__.pop("early", None)
+        if ent is None:
+            return self.gate(feat)
+        g, ev = ent
+        cur = torch.cuda.current_stream(feat.device)
+        cur.wait_event(ev)
+        g.record_stream(cur)
+        return g
+
     def forward(self, cv, feat):
         if self.gate_ok(feat):
-            ent = self.__dict__.pop("early", None)
-            if ent is not None:
-                g, ev = ent
-                cur = torch.cuda.current_stream(cv.device)
-                cur.wait_event(ev)
-                g.record_stream(cur)
-            else:
-                g = self.gate(feat)
-            return g.unsqueeze(2) * cv
+            return self.take_gate(feat).unsqueeze(2) * cv
         return torch.sigmoid(self.feat_att(feat).unsqueeze(2)) * cv
+
+    # inference: the gate rides in the launch that produces the cost volume it multiplies (BasicConv.forward(x, gate=))
+    fused_gate = __import__("os").environ.get("ANYSTEREO_FUSED_GATES", "1") != "0"
+
+    def after(self, block, x, feat):
+        """self(block(x), feat) with the multiply folded into `block`'s last 3-D convolution where possible."""
+        if not (self.fused_gate and self.gate_ok(feat) and fused_ok(x, self)):
+            return self(block(x), feat)
+        if isinstance(block, nn.Sequential):
+            for m in list(block)[:-1]:
+                x = m(x)
+            block = block[-1]
+        g = self.take_gate(feat)  # joined as late as possible: only the last convolution waits for the branch that computes the gates
+        if isinstance(block, _ConvNormAct):
+            return block(x, gate=g)
+        return g.unsqueeze(2) * block(x)
 
 
 class hourglass(nn.Module):
@@ -471,11 +501,9 @@ class hourglass(nn.Module):
         self.feature_att_up_8 = FeatureAtt(c * 2, 64)
 
     def forward(self, x, features):
-        c1 = self.feature_att_8(self.conv1(x), features[1])
-        c2 = self.feature_att_16(self.conv2(c1), features[2])
-        c3 = self.feature_att_32(self.conv3(c2), features[3])
-        c2 = self.agg_0(torch.cat((self.conv3_up(c3), c2), dim=1))
-        c2 = self.feature_att_up_16(c2, features[2])
-        c1 = self.agg_1(torch.cat((self.conv2_up(c2), c1), dim=1))
-        c1 = self.feature_att_up_8(c1, features[1])
+        c1 = self.feature_att_8.after(self.conv1, x, features[1])
+        c2 = self.feature_att_16.after(self.conv2, c1, features[2])
+        c3 = self.feature_att_32.after(self.conv3, c2, features[3])
+        c2 = self.feature_att_up_16.after(self.agg_0, torch.cat((self.conv3_up(c3), c2), dim=1), features[2])
+        c1 = self.feature_att_up_8.after(self.agg_1, torch.cat((self.conv2_up(c2), c1), dim=1), features[1])
         return self.conv1_up(c1)

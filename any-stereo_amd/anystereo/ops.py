@@ -988,8 +988,9 @@ def dwconv3x3_wgrad(x, d_out, stride: int):
     return (part[:, 0] if n == 1 else part.sum(dim=1)).view(c, 1, 3, 3)
 
 
-def conv3d_k3(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
-    """act(Conv3d 3x3x3(x, padding 1, stride) + bias); wpack = weight.permute(1,2,3,4,0) as [Cin,27,Cout]."""
+def conv3d_k3(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE, gate=None):
+    """act(Conv3d 3x3x3(x, padding 1, stride) + bias) [* gate [B,Cout,Ho,Wo] broadcast over depth: FeatureAtt, submodule.py:328-341];
+    wpack = weight.permute(1,2,3,4,0) as [Cin,27,Cout]."""
     _req(x, "x"), _req(wpack, "wpack")
     b, cin, d, h, w = x.shape
     if wpack.dim() != 3 or wpack.shape[0] != cin or wpack.shape[1] != 27:
@@ -999,8 +1000,12 @@ def conv3d_k3(x, wpack, bias=None, stride: int = 1, act: int = L.ACT_NONE):
         _req(bias, "bias")
     out = torch.empty((b, cout, (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1), device=x.device,
                       dtype=torch.float32)
+    if gate is not None:
+        _req(gate, "gate")
+        if tuple(gate.shape) != (b, cout, out.shape[3], out.shape[4]):
+            raise RuntimeError(f"conv3d_k3: gate must be [B,Cout,Ho,Wo] = {(b, cout, out.shape[3], out.shape[4])}, got {tuple(gate.shape)}")
     with _guard(x.device):
-        L.check(L.load().as_conv3d_k3(_p(x), _p(wpack), _p(bias), _p(out), b, cin, cout, d, h, w, stride, act, _stream()),
+        L.check(L.load().as_conv3d_k3_gated(_p(x), _p(wpack), _p(bias), _p(gate), _p(out), b, cin, cout, d, h, w, stride, act, _stream()),
                 "conv3d_k3")
     return out
 

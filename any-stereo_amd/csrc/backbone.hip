@@ -170,7 +170,7 @@ constexpr int kC3dCols = 62;  // outputs per wave of the shift-based kernels (64
 // ------------------------------------------------------------------------------------------------
 template <int S, int CT, int CO, int NR = 1>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        const float* __restrict__ bias, const float* __restrict__ gate, float* __restrict__ out,
                                                         int Cin, int Cout_rt, int D, int H, int W, int Do, int Ho, int Wo, int act) {
   // CO: Cout at compile time (0 = run time).  With a known weight row stride the 9 x CT scalar weights of a slab are
   // loads at immediate offsets from ONE running pointer; with a run-time stride each of the nine rows costs a 64-bit
@@ -257,8 +257,15 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(const float* __restrict_
     for (int n = 0; n < NR; ++n) {
       if (oy + n >= Ho) break;
       float* o = out + ((long long)b * Cout + g * CT) * ovol + ((long long)oz * Ho + oy + n) * Wo + ox;
+      if (gate) {  // FeatureAtt's channel gate [B, Cout, Ho, Wo], the same for every depth slice (submodule.py:328-341)
+        const long long oplane = (long long)Ho * Wo;
+        const float* gp = gate + ((long long)b * Cout + g * CT) * oplane + (long long)(oy + n) * Wo + ox;
 #pragma unroll
-      for (int j = 0; j < CT; ++j) o[j * ovol] = act_apply(acc[n][j], act);
+        for (int j = 0; j < CT; ++j) o[j * ovol] = act_apply(acc[n][j], act) * gp[j * oplane];
+      } else {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) o[j * ovol] = act_apply(acc[n][j], act);
+      }
     }
   }
 }
@@ -466,8 +473,16 @@ int as_conv3x3_few(const float* x, const float* wpack, const float* bias, float*
   return as::check_launch("conv3x3_few");
 }
 
+int as_conv3d_k3_gated(const float* x, const float* wpack, const float* bias, const float* gate, float* out,
+                       int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
+
 int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* out,
                  int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream) {
+  return as_conv3d_k3_gated(x, wpack, bias, nullptr, out, B, Cin, Cout, D, H, W, stride, act, stream);
+}
+
+int as_conv3d_k3_gated(const float* x, const float* wpack, const float* bias, const float* gate, float* out,
+                       int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream) {
   AS_REQUIRE(x && wpack && out, AS_ERR_BAD_ARG, "conv3d_k3: null pointer");
   AS_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && D > 0 && H > 0 && W > 0, AS_ERR_BAD_ARG, "conv3d_k3: non-positive size");
   AS_REQUIRE(stride == 1 || stride == 2, AS_ERR_BAD_ARG, "conv3d_k3: stride=%d (supported: 1, 2)", stride);
@@ -479,7 +494,7 @@ int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* o
   AS_REQUIRE(gz <= 65535, AS_ERR_BAD_SHAPE, "conv3d_k3: B*Do*groups=%lld exceeds the grid limit", gz);
   const dim3 grid((unsigned)as::cdiv(Wo, stride == 1 ? kC3dCols : 64), (unsigned)as::cdiv(Ho, 4), (unsigned)gz);
   hipStream_t s = as::as_stream(stream);
-#define AS_C3D(S_, CT_, CO_, NR_) hipLaunchKernelGGL((conv3d_k3_kernel<S_, CT_, CO_, NR_>), dim3(grid.x, (unsigned)as::cdiv(Ho, 4 * NR_), grid.z), dim3(256), 0, s, x, wpack, bias, out, Cin, Cout, D, H, W, Do, Ho, Wo, act)
+#define AS_C3D(S_, CT_, CO_, NR_) hipLaunchKernelGGL((conv3d_k3_kernel<S_, CT_, CO_, NR_>), dim3(grid.x, (unsigned)as::cdiv(Ho, 4 * NR_), grid.z), dim3(256), 0, s, x, wpack, bias, gate, out, Cin, Cout, D, H, W, Do, Ho, Wo, act)
 #define AS_C3D_CO(S_, NR_)                                     \
   switch (ct == 8 ? Cout : -1) {                               \
     case 8: AS_C3D(S_, 8, 8, NR_); break;                      \

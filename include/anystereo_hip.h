@@ -300,6 +300,11 @@ int as_ir_block(const float* x, const void* pack, const float* fparams, float* o
                 int stride, int residual, void* stream);
 int as_conv3d_k3(const float* x, const float* wpack, const float* bias, float* out,
                  int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
+/* as_conv3d_k3 with FeatureAtt's channel gate in the epilogue (round 6): out = act(conv + bias) * gate[b, co, y, x] for every depth
+ * slice — `torch.sigmoid(feat_att(feat).unsqueeze(2)) * cv` (submodule.py:328-341) without a pass over the volume.
+ * gate [B,Cout,Ho,Wo] or NULL (= as_conv3d_k3). */
+int as_conv3d_k3_gated(const float* x, const float* wpack, const float* bias, const float* gate, float* out,
+                       int B, int Cin, int Cout, int D, int H, int W, int stride, int act, void* stream);
 /*   as_deconv3d_k4s2: ConvTranspose3d kernel 4, stride 2, padding 1 (all dims) — the hourglass up-convolutions
  *     (continuous_IGEVstereo.py:43-51).  x [B,Cin,D,H,W]; wpack [Cin,4,4,4,Cout] (= weight [Cin,Cout,4,4,4] with
  *     Cout moved last); bias [Cout]|NULL -> out [B,Cout,2D,2H,2W]. */

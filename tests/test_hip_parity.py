@@ -361,6 +361,40 @@ def test_conv3d_k3(b, cin, cout, d, h, w, stride, act):
     close(out, ref, 2e-6, 2e-6, "conv3d_k3")
 
 
+@pytest.mark.parametrize("cin,cout,d,h,w,stride", [(8, 8, 6, 9, 33, 1), (8, 16, 6, 10, 34, 2), (32, 32, 4, 6, 21, 1), (16, 16, 24, 68, 120, 1)])
+def test_conv3d_with_feature_att_gate(cin, cout, d, h, w, stride, monkeypatch):
+    """FeatureAtt (submodule.py:328-341) folded into the launch that produces the volume it gates (as_conv3d_k3_gated; the MFMA
+    path's layout copy): FeatureAtt.after(block, x, feat) must equal FeatureAtt(block(x), feat) BIT for bit (one fp32 multiply
+    either way), on the direct kernel (stride 1 and 2, large volumes) and on the MFMA path, single blocks and Sequentials."""
+    from anystereo import ops
+    from anystereo.nn import blocks as B
+    from anystereo.harness.synthetic import fill_module_deterministic
+    prev = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        seq = torch.nn.Sequential(B.BasicConv(cin, cin, is_3d=True, bn=True, relu=True, kernel_size=3, stride=1, padding=1),
+                                  B.BasicConv(cin, cout, is_3d=True, bn=True, relu=True, kernel_size=3, stride=stride, padding=1)).eval()
+        att = B.FeatureAtt(cout, 64).eval()
+        for i, m in enumerate((seq, att)):
+            fill_module_deterministic(m, base_seed=41 + i)
+            _randomize_bn(m, 960 + 10 * i)
+        seq, att = seq.to(DEV), att.to(DEV)
+        x = U((1, cin, d, h, w), 970, -2, 2).to(DEV)
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        feat = U((1, 64, ho, wo), 971, -2, 2).to(DEV)
+        with torch.no_grad():
+            monkeypatch.setattr(B.FeatureAtt, "fused_gate", False)
+            want = att.after(seq, x, feat)
+            want1 = att.after(seq[1], seq[0](x), feat)
+            monkeypatch.setattr(B.FeatureAtt, "fused_gate", True)
+            got = att.after(seq, x, feat)
+            got1 = att.after(seq[1], seq[0](x), feat)
+        assert got.shape == want.shape and got.is_contiguous()
+        assert torch.equal(got, want) and torch.equal(got1, want1)
+    finally:
+        ops.set_precision(prev)
+
+
 @pytest.mark.parametrize("cin,cout,d,h,w,relu", [(32, 32, 12, 34, 60, True), (48, 48, 6, 17, 30, True), (16, 16, 5, 9, 14, False),
                                                   (32, 48, 1, 7, 33, True), (64, 32, 3, 8, 16, True)])
 def test_conv3d_on_the_mfma_kernel(cin, cout, d, h, w, relu, monkeypatch):
