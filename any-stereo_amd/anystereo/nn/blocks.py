@@ -16,6 +16,7 @@ from .. import ops
 
 # ANYSTEREO_FOLD_POINTWISE=0: BasicConv (2-D BatchNorm, 1x1x1 3-D) and the FeatureAtt gate back on MIOpen + separate norm / activation
 _FOLD_POINTWISE = __import__("os").environ.get("ANYSTEREO_FOLD_POINTWISE", "1") != "0"
+_CAT_FREE = __import__("os").environ.get("ANYSTEREO_CAT_FREE", "1") != "0"  # 0: materialise the skip concats (A/B)
 _NO_SEARCHED_CONV = __import__("os").environ.get("ANYSTEREO_NO_SEARCHED_CONV", "0") == "1"
 
 
@@ -236,6 +237,30 @@ class _ConvNormAct(nn.Module):
     def _make_norm(self, c, is_3d):
         raise NotImplementedError
 
+    def forward_cat(self, xs):
+        """self(torch.cat(xs, 1)) without the concatenation where the convolution kernel takes its sources one by one (inference:
+        the 1x1x1 blocks behind the hourglass' skip concats, the 3x3 blocks behind the feature decoder's): every source but the
+        last needs a multiple of 16 channels (the kernel's K chunk)."""
+        xs = list(xs)
+        norm = getattr(self, self.norm_attr) if self.use_norm else None
+        c = self.conv
+        ok = (_FOLD_POINTWISE and _CAT_FREE and len(xs) > 1 and all(fused_ok(t, self) for t in xs) and ops.get_precision() == "split"
+              and all(t.shape[1] % 16 == 0 for t in xs[:-1]) and c.groups == 1)
+        if ok and xs[0].dim() == 5 and (norm is None or isinstance(norm, nn.BatchNorm3d)) and c.kernel_size == (1, 1, 1) \
+                and c.stride == (1, 1, 1) and c.padding == (0, 0, 0) and c.dilation == (1, 1, 1):
+            b_, _, d_, h_, w_ = xs[0].shape
+            pk = self.__dict__.setdefault("_pk_fold", ops.PackedConv())
+            pack = pk.get_folded(c, norm) if norm is not None else pk.get([c.weight], [c.bias])
+            y = ops.conv2d([t.contiguous().view(b_, t.shape[1], 1, d_ * h_ * w_) for t in xs], pack,
+                           act=L.ACT_LEAKY if self.relu else L.ACT_NONE)
+            return y.view(b_, c.out_channels, d_, h_, w_)
+        if ok and xs[0].dim() == 4 and _plain_instance_norm(norm) and conv2d_hip_ok(c) and c.stride == (1, 1):
+            packs = self.__dict__.setdefault("_hip_packs", {})
+            pk = packs.setdefault(id(c), ops.PackedConv())
+            y = ops.conv2d([t.contiguous() for t in xs], pk.get([c.weight], [c.bias]))
+            return ops.instance_norm_act(y, norm.eps, L.ACT_LEAKY if self.relu else L.ACT_NONE)
+        return self(torch.cat(xs, 1))
+
     def forward(self, x, gate=None):
         """gate (inference, 3-D blocks): FeatureAtt's channel gate [B, Cout, H, W] applied to the block's result — in the
         convolution's own launch where that is the fused 3x3x3 path, as a separate multiply otherwise."""
@@ -323,8 +348,9 @@ class _Up2x(nn.Module):
         x = self.conv1(x)
         if x.shape != rem.shape:
             x = F.interpolate(x, size=rem.shape[-2:], mode="nearest")
-        x = torch.cat((x, rem), 1) if self.concat else x + rem
-        return self.conv2(x)
+        if self.concat:
+            return self.conv2.forward_cat((x, rem))  # the concat is never materialised where the kernel takes two sources
+        return self.conv2(x + rem)
 
 
 class Conv2x(_Up2x):
@@ -452,12 +478,20 @@ class FeatureAtt(nn.Module):
 
     def after(self, block, x, feat):
         """self(block(x), feat) with the multiply folded into `block`'s last 3-D convolution where possible."""
-        if not (self.fused_gate and self.gate_ok(feat) and fused_ok(x, self)):
-            return self(block(x), feat)
+        cat = isinstance(x, (tuple, list))  # a channel concat handed over as its parts (the hourglass' skip connections)
+        x0 = x[0] if cat else x
+        if not (self.fused_gate and self.gate_ok(feat) and fused_ok(x0, self)):
+            return self(block(torch.cat(x, 1) if cat else x), feat)
         if isinstance(block, nn.Sequential):
-            for m in list(block)[:-1]:
+            mods = list(block)
+            if cat:
+                x = mods[0].forward_cat(x) if isinstance(mods[0], _ConvNormAct) else mods[0](torch.cat(x, 1))
+                mods = mods[1:]
+            for m in mods[:-1]:
                 x = m(x)
-            block = block[-1]
+            block = mods[-1]
+        elif cat:
+            x = torch.cat(x, 1)
         g = self.take_gate(feat)  # joined as late as possible: only the last convolution waits for the branch that computes the gates
         if isinstance(block, _ConvNormAct):
             return block(x, gate=g)
@@ -504,6 +538,6 @@ class hourglass(nn.Module):
         c1 = self.feature_att_8.after(self.conv1, x, features[1])
         c2 = self.feature_att_16.after(self.conv2, c1, features[2])
         c3 = self.feature_att_32.after(self.conv3, c2, features[3])
-        c2 = self.feature_att_up_16.after(self.agg_0, torch.cat((self.conv3_up(c3), c2), dim=1), features[2])
-        c1 = self.feature_att_up_8.after(self.agg_1, torch.cat((self.conv2_up(c2), c1), dim=1), features[1])
+        c2 = self.feature_att_up_16.after(self.agg_0, (self.conv3_up(c3), c2), features[2])
+        c1 = self.feature_att_up_8.after(self.agg_1, (self.conv2_up(c2), c1), features[1])
         return self.conv1_up(c1)
