@@ -6,7 +6,11 @@
 
 One process per GPU over RCCL; every rank runs the same per-GPU workload on its own pair (independent units, no
 data-path collective: "replicas", weak scaling).  A step = one full forward pass (backbones on PyTorch-ROCm/MIOpen, hot path
-on libanystereo_hip.so) with inputs resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects on that line:
+on libanystereo_hip.so) with inputs resident in HBM.  `value` is the median of three timed blocks of --steps steps (`value_spread`).
+With a process group (N > 1, or any N under torch.distributed.run) the same ranks then run the cfg-4 TRAINING leg (`train_leg`:
+graphed steps, one flat RCCL all-reduce per step) and `train_mode` carries its N-rank figures; one rank without a launcher runs that
+leg as a child process.  Rank 0 prints ONE JSON line (stdout carries nothing else).  Extra objects on that line:
+  pass_phases     pre-loop / loop / upsampler wall time of a replayed pass from marker kernels inside the graph (no profiler)
   roofline        dominant kernel (by time), HIP events on its launch stream
   rooflines       the same figure for every hot kernel class; HBM-bound ones warm (working set in the Infinity Cache),
                   cold (operand sets rotated, > 256 MB) and co-scheduled inside the two-stream GRU loop
@@ -15,7 +19,10 @@ on libanystereo_hip.so) with inputs resident in HBM.  Rank 0 prints ONE JSON lin
   reduced_precision_mode  the same workload with fp16 operands / one MFMA per product (the reference's autocast path)
   other_configs   cfg 3 (KITTI x2.0), cfg 5 (Middlebury-F x1.5, 48 iterations) and cfg 1 (corePrune_RAFT, with its EPE vs the oracle)
                   pairs/s, N = 1 only
-  cpu_baseline    the CPU oracle (oracle/model.py) timed on this host's cores: cfg 2 (and cfg 1 under `also`)
+  train_mode      cfg 4: samples/s, ms per step, exchange_ms, ranks_seen, scaling (N ranks) | the 1-rank child's line + its
+                  reduced-precision leg (the reference's autocast arithmetic)
+  cpu_baseline    the CPU oracle (oracle/model.py) timed on this host as BASELINE.md §4 states: threads = usable physical cores, 1 warm-up
+                  + 3 runs, median, per-stage split; cfg 2 (and cfg 1 under `also`)
 `--mode train` = cfg 4 (DDP training step).  Without a visible GPU the launcher protocol alone runs (gloo, "dry_run").
 """
 from __future__ import annotations
