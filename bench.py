@@ -76,7 +76,15 @@ def claim_stdout():
             _REAL_STDOUT = None
 
 
+# Rehearsal of the N-rank protocol on a ONE-GPU box (ANYSTEREO_BENCH_ONE_GPU_REHEARSAL=1): every rank uses device 0 and the
+# process group is gloo (RCCL refuses two ranks on one device).  Everything else — the rank protocol, the Trainer, the flat
+# exchange, the agreement rounds, the watchdog — is the code an N-GPU node runs.  The line says so; its numbers are NOT a result.
+REHEARSAL = os.environ.get("ANYSTEREO_BENCH_ONE_GPU_REHEARSAL", "0") == "1"
+
+
 def emit(line: dict):
+    if REHEARSAL:
+        line = dict(line, rehearsal="all ranks on GPU 0 over gloo (ANYSTEREO_BENCH_ONE_GPU_REHEARSAL=1): protocol check, not a measurement")
     data = (json.dumps(line) + "\n").encode()
     if _REAL_STDOUT is None:
         sys.stdout.write(data.decode())
@@ -173,7 +181,7 @@ def pin_rank(local: int, local_world: int):
 def _dist_init(backend_gpu: bool, local: int):
     import torch.distributed as td
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if backend_gpu:
+    if backend_gpu and not REHEARSAL:
         td.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" IS RCCL on ROCm
     else:
         td.init_process_group("gloo")
@@ -1731,6 +1739,8 @@ def main():
         torch.set_num_threads(max(1, len(RANK_CPUS)))
     if not torch.cuda.is_available():
         return dry_train_main(a, rank, world) if a.mode == "train" else dry_main(a, rank, world)
+    if REHEARSAL:
+        local = 0
     if a.mode == "train":
         return train_main(a, rank, world, local)
     return infer_main(a, rank, world, local)
