@@ -892,6 +892,19 @@ struct MlpBwdParams {
 constexpr int kStageRow = 33;                                   // padded row of a wave's 32 x 32 staging tile (conflict-free column reads)
 constexpr int kStageFloats = 32 * kStageRow + 4 * 32;           // + the tile's relative coordinates [4][32]
 
+// Diagnostic builds only (tools/variant.sh liif_fused.hip <name> -DAS_ABL_BWD_NO_HD [-DAS_ABL_BWD_NO_ATOMICS]): timing of
+// liif_mlp_bwd_kernel without its activation / gradient stores (h1 h2 h3 d3 d2 [d1]) and without the first layer's scatter atomics
+// (results are wrong; tools/r06_bwd_ablation.sh).  Never defined in the product build.
+#ifdef AS_ABL_BWD_NO_HD
+#define AS_BWD_HD_STORE(V, R, VO, SO, AUX) ((void)(V))
+#else
+#define AS_BWD_HD_STORE(V, R, VO, SO, AUX) __builtin_amdgcn_raw_buffer_store_b32(V, R, VO, SO, AUX)
+#endif
+#ifdef AS_ABL_BWD_NO_ATOMICS
+#define AS_BWD_ATOMIC(V, R, VO, SO, AUX) ((void)(V))
+#else
+#define AS_BWD_ATOMIC(V, R, VO, SO, AUX) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(V, R, VO, SO, AUX)
+#endif
 template <bool FUSE1>
 __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
   constexpr int NT = 512;
@@ -1036,7 +1049,7 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           m1[t4] |= (v[j] > 0.f ? 1u : 0u) << (8 * s + j);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_h1, (int)vo128, (int)((32 * t4 + AS_ROW(8 * s + j)) * q4), 0);
+          AS_BWD_HD_STORE(__builtin_bit_cast(unsigned, v[j]), r_h1, (int)vo128, (int)((32 * t4 + AS_ROW(8 * s + j)) * q4), 0);
         }
         half8 bh, bl;
         split8_pos(v, bh, bl, imax);
@@ -1065,7 +1078,7 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         m2[mt] |= (v[j] > 0.f ? 1u : 0u) << (8 * s + j);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_h2, (int)vo64, (int)((32 * mt + AS_ROW(8 * s + j)) * q4), 0);
+        AS_BWD_HD_STORE(__builtin_bit_cast(unsigned, v[j]), r_h2, (int)vo64, (int)((32 * mt + AS_ROW(8 * s + j)) * q4), 0);
       }
       half8 bh, bl;
       split8_pos(v, bh, bl, imax);
@@ -1084,7 +1097,7 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
       for (int i = 0; i < 16; ++i) {
         const float v = relu_bits(fmaf(a3x[mt][i], 1.f / 2048.f, a3h[mt][i]));
         m3[mt] |= (v > 0.f ? 1u : 0u) << i;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_h3, (int)vo64, (int)((32 * mt + AS_ROW(i)) * q4), 0);
+        AS_BWD_HD_STORE(__builtin_bit_cast(unsigned, v), r_h3, (int)vo64, (int)((32 * mt + AS_ROW(i)) * q4), 0);
       }
     // ================= data-gradient chain =================
     // B operand of the first product: the 9 logit gradients of this lane's query in the chaining order of one k-step
@@ -1114,7 +1127,7 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
         for (int j = 0; j < 8; ++j) {
           const int i = 8 * s + j;
           v[j] = ((m3[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_d3, (int)vo64, (int)((32 * m + AS_ROW(i)) * q4), 0);
+          AS_BWD_HD_STORE(__builtin_bit_cast(unsigned, v[j]), r_d3, (int)vo64, (int)((32 * m + AS_ROW(i)) * q4), 0);
         }
         split8(v, f3h[2 * m + s], f3l[2 * m + s], amax);
       }
@@ -1137,7 +1150,7 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
         for (int j = 0; j < 8; ++j) {
           const int i = 8 * s + j;
           v[j] = ((m2[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), r_d2, (int)vo64, (int)((32 * m + AS_ROW(i)) * q4), 0);
+          AS_BWD_HD_STORE(__builtin_bit_cast(unsigned, v[j]), r_d2, (int)vo64, (int)((32 * m + AS_ROW(i)) * q4), 0);
         }
         split8(v, f2h[2 * m + s], f2l[2 * m + s], amax);
       }
@@ -1156,7 +1169,7 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float v = ((m1[m] >> i) & 1u) ? fmaf(gx[i], 1.f / 2048.f, gh[i]) : 0.f;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_d1, (int)vo128, (int)((32 * m + AS_ROW(i)) * q4), 0);
+          AS_BWD_HD_STORE(__builtin_bit_cast(unsigned, v), r_d1, (int)vo128, (int)((32 * m + AS_ROW(i)) * q4), 0);
         }
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous m-tile's column reads are done before the tile is overwritten
@@ -1173,8 +1186,8 @@ __global__ __launch_bounds__(512) void liif_mlp_bwd_kernel(MlpBwdParams P) {
           }
           // lanes that are not the head of a run carry an out-of-range offset: the atomic is dropped by the range check (a branch
           // around each of the 128 atomics of a tile costs 259 spilled registers)
-          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(s0, r_u0, (int)vo_u0, (int)((32 * m + AS_ROW(i)) * hw0 * 4u), 0);
-          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(s1, r_u1, (int)vo_u1, (int)((32 * m + AS_ROW(i)) * hw1 * 4u), 0);
+          AS_BWD_ATOMIC(s0, r_u0, (int)vo_u0, (int)((32 * m + AS_ROW(i)) * hw0 * 4u), 0);
+          AS_BWD_ATOMIC(s1, r_u1, (int)vo_u1, (int)((32 * m + AS_ROW(i)) * hw1 * 4u), 0);
           if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // two registers' shuffle chains in flight, not sixteen (register pressure)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile (and the tile's relative coordinates) have landed in LDS
