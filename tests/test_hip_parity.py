@@ -2450,3 +2450,41 @@ def test_dgrad_pack_equals_transposed_flipped_copy(cout, cin, ks):
             assert torch.equal(a2.wpack, b.wpack)
     finally:
         ops.set_precision(prev)
+
+
+KNOB_SETS = [
+    {"AS_CONV_LEAN": "0", "AS_CONV_XCD": "0", "AS_CONV_DMA": "0", "AS_POOL2X_EVEN": "0", "AS_LOOKUP_DIRECT": "0"},
+    {"AS_CONV_LEAN": "3", "AS_CONV_KSPLIT_MAX": "1", "AS_CONV_WIDE": "0", "AS_CONV_WIDE64": "0", "AS_CONV_SMALL_DMA": "0", "AS_LOOKUP_DIRECT": "2"},
+    {"AS_CONV_LEAN": "2", "AS_CONV_PREFER64": "1", "AS_CONV_XCD_STAGGER": "4", "AS_CONV_LEAN_OFFSET": "8", "AS_CONV_KSPLIT_MAX": "2"},
+]
+
+
+def test_schedule_knobs_keep_results(tmp_path):
+    """The AS_* environment knobs of csrc/conv.hip / lookup.hip (README: A/B switches of the kernel schedule — block shape, lean
+    blocks, XCD order and stagger, K split, staging path, resampler form) select HOW a launch is tiled, never WHAT it computes.  They
+    are read once per process, so each set runs tests/_knob_probe.py (the loop's launches at the cfg-2 sizes + two training-shaped
+    layers) in a child process; every result must agree with the default schedule's: bit for bit where the summation order is the
+    same, within 2e-6 of the tensor's range where a K split changes the order of the partial sums."""
+    import subprocess
+    import sys
+
+    import numpy as np
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_knob_probe.py")
+    base_env = {k: v for k, v in os.environ.items() if not k.startswith(("AS_CONV_", "AS_POOL2X", "AS_LOOKUP_"))}
+    outs = []
+    for i, knobs in enumerate([{}] + KNOB_SETS):
+        path = str(tmp_path / f"knobs{i}.npz")
+        r = subprocess.run([sys.executable, probe, path], env=dict(base_env, **knobs), capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, f"knob set {knobs}: child failed\n{r.stdout[-1000:]}\n{r.stderr[-3000:]}"
+        outs.append(dict(np.load(path)))
+    ref = outs[0]
+    assert len(ref) >= 20
+    for knobs, got in zip(KNOB_SETS, outs[1:]):
+        assert got.keys() == ref.keys()
+        exact = 0
+        for k, a in ref.items():
+            assert np.isfinite(got[k]).all(), (knobs, k)
+            d = float(np.abs(got[k] - a).max())
+            exact += d == 0.0
+            assert d <= 2e-6 * float(np.abs(a).max()) + 1e-9, f"{knobs}: {k} differs from the default schedule by {d:.3e} (range {np.abs(a).max():.3e})"
+        print(f"[knobs] {knobs}: {exact}/{len(ref)} results bit-identical to the default schedule")
