@@ -80,7 +80,7 @@ struct ConvParams {
   // AS_EPI_RELU_TAPS: [Cout][9] weights of a following 3x3, Cout -> 1 convolution whose per-tap channel reductions this
   // conv's epilogue accumulates instead of storing its own result (out = [B][n_tiles * 9][H][W])
   const float* tap_w;
-  int xcd_map;  // conv_split_kernel: XCD-aware block order (channel tiles of one pixel tile on the same XCD)
+  int xcd_map;  // conv_split_kernel: XCD-aware block order (1: channel tiles of one pixel tile on the same XCD; 2: + a contiguous band of pixel tiles per XCD)
   int fast16;   // conv_split_kernel: skip the two cross-term MFMAs (fp16 operands, fp32 accumulate: as_set_fast16)
   int ksplit;   // split-K factor (conv_split_kernel, EPI = kEpiPartial): blocks per output tile
   float* ws;    // [ksplit][B][Cout_pad][H][W] fp32 partial sums
@@ -1094,7 +1094,23 @@ __global__ __launch_bounds__(LEAN ? 256 : 512, 2) void conv_split_kernel(ConvPar
     ks = id / (T * p.n_tiles);   // K slice (0 unless split-K)
     id -= ks * T * p.n_tiles;
     int pt;
-    if (p.xcd_map) {
+    if (p.xcd_map == 2) {
+      // BANDED: XCD x (ids congruent to x mod 8) owns the contiguous run of pixel tiles [x T/8, (x+1) T/8) — about two tile rows of a
+      // 136x240 map — in raster order, the channel tiles of a pixel tile still 8 ids apart.  Neighbouring pixel tiles then share
+      // their halo rows and the 128-B lines that straddle a tile edge in ONE L2 instead of fetching them once per XCD
+      // (mode 1 puts pixel tile t on XCD t mod 8: horizontal neighbours never meet).  The T mod 8 last tiles are dealt as in mode 1.
+      const int a = T >> 3, full = a * 8 * p.n_tiles;
+      if (id < full) {
+        const int x = id & 7, j = id >> 3;
+        const int pl = j / p.n_tiles;
+        nt = j - pl * p.n_tiles;
+        pt = x * a + pl;
+      } else {
+        const int rem = id - full, bb = T - 8 * a;
+        nt = rem / bb;
+        pt = 8 * a + (rem - nt * bb);
+      }
+    } else if (p.xcd_map) {
       const int per = 8 * p.n_tiles;
       const int chunk = id / per, r = id - chunk * per;
       const int m = min(8, T - chunk * 8);  // pixel tiles in this chunk (the last one may be short)
@@ -1849,9 +1865,9 @@ int launch_conv_split_epi(const ConvParams& p, hipStream_t s) {
   }
   const long long groups = as::cdiv64((long long)p.tiles_x * p.tiles_y, NSUB);
   const dim3 grid((unsigned)((long long)p.B * groups * p.n_tiles * p.ksplit));
-  static const int xcd_mode = getenv("AS_CONV_XCD") ? atoi(getenv("AS_CONV_XCD")) : 1;
+  static const int xcd_mode = getenv("AS_CONV_XCD") ? atoi(getenv("AS_CONV_XCD")) : 2;  // 0 off | 1 channel tiles together | 2 + banded pixel tiles
   ConvParams q = p;
-  q.xcd_map = (xcd_mode && p.n_tiles > 1) ? 1 : 0;
+  q.xcd_map = xcd_mode == 2 ? 2 : ((xcd_mode && p.n_tiles > 1) ? 1 : 0);  // 2: banded pixel tiles per XCD (any channel-tile count)
   static const int stagger = getenv("AS_CONV_XCD_STAGGER") ? atoi(getenv("AS_CONV_XCD_STAGGER")) : 0;
   q.stagger = stagger;
   static const int lean_offset = getenv("AS_CONV_LEAN_OFFSET") ? atoi(getenv("AS_CONV_LEAN_OFFSET")) : 0;

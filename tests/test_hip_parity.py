@@ -2454,7 +2454,7 @@ def test_dgrad_pack_equals_transposed_flipped_copy(cout, cin, ks):
 
 KNOB_SETS = [
     {"AS_CONV_LEAN": "0", "AS_CONV_XCD": "0", "AS_CONV_DMA": "0", "AS_POOL2X_EVEN": "0", "AS_LOOKUP_DIRECT": "0"},
-    {"AS_CONV_LEAN": "3", "AS_CONV_KSPLIT_MAX": "1", "AS_CONV_WIDE": "0", "AS_CONV_WIDE64": "0", "AS_CONV_SMALL_DMA": "0", "AS_LOOKUP_DIRECT": "2"},
+    {"AS_CONV_XCD": "1", "AS_CONV_LEAN": "3", "AS_CONV_KSPLIT_MAX": "1", "AS_CONV_WIDE": "0", "AS_CONV_WIDE64": "0", "AS_CONV_SMALL_DMA": "0", "AS_LOOKUP_DIRECT": "2"},
     {"AS_CONV_LEAN": "2", "AS_CONV_PREFER64": "1", "AS_CONV_XCD_STAGGER": "4", "AS_CONV_LEAN_OFFSET": "8", "AS_CONV_KSPLIT_MAX": "2"},
 ]
 
